@@ -1,0 +1,192 @@
+/*
+ * nsfem.h -- C ABI of libnsfem_hip.so: MI355X (gfx950) implementation of the
+ * per-time-step Taylor-Hood (P2/P1) assembly + sparse solve that the reference
+ * (LKM-code-base/NavierStokes-with-Fenics) delegates to FEniCS/PETSc.
+ *
+ * Nothing like this interface exists in the reference (it is pure Python on top
+ * of dolfin).  Every entry point names the reference call it replaces; the
+ * Python binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns int (0 = ok, <0 = nsfem_status),
+ *     no C++ exception crosses the boundary; nsfem_last_error() gives the text.
+ *   - the caller owns every host buffer it passes (read during the call only);
+ *     the library owns all device memory; nothing returned outlives
+ *     nsfem_destroy().
+ *   - one context per process x device, one HIP stream per context; calls on a
+ *     context are not re-entrant (the reference is single threaded).
+ *   - all floating point data is fp64, all indices int32.
+ *   - velocity vectors are node-interleaved: index = 2 * p2_node + component;
+ *     "mixed" vectors are [velocity (2*n_p2) | pressure (n_p1)].
+ */
+#ifndef NSFEM_H
+#define NSFEM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsfem_ctx nsfem_ctx;
+
+enum nsfem_status {
+  NSFEM_OK = 0,
+  NSFEM_ERR_ARG = -1,         /* bad argument / wrong call order            */
+  NSFEM_ERR_HIP = -2,         /* HIP runtime error (no device, OOM, ...)     */
+  NSFEM_ERR_BREAKDOWN = -3,   /* Krylov breakdown (rho / omega = 0, NaN)     */
+  NSFEM_ERR_NOT_CONVERGED = -4, /* Newton / Krylov hit its iteration limit   */
+  NSFEM_ERR_COMM = -5         /* RCCL error                                  */
+};
+
+/* Mesh + dof maps: what dolfin.Mesh / FunctionSpace(mesh, P2^d x P1) hold in the
+ * reference (source/ns_solver_base.py:501-524).  Triangles only (dim = 2). */
+typedef struct {
+  int32_t dim;               /* 2                                             */
+  int32_t n_cells;
+  int32_t n_vertices;
+  int32_t n_p2;              /* scalar P2 nodes                               */
+  int32_t n_p1;              /* P1 nodes                                      */
+  const double* coords;      /* [n_vertices * dim]                            */
+  const int32_t* cells;      /* [n_cells * 3] vertex ids                      */
+  const int32_t* p2_dofmap;  /* [n_cells * 6] (v0,v1,v2,e12,e02,e01)          */
+  const int32_t* p1_dofmap;  /* [n_cells * 3]                                 */
+} nsfem_mesh_desc;
+
+/* state slots (device-resident vectors) */
+enum nsfem_slot {
+  NSFEM_U0 = 0,      /* velocity at t_{n+1}   (IPCS _velocities[0])   [2*n_p2] */
+  NSFEM_U1 = 1,      /* velocity at t_n                                       */
+  NSFEM_U2 = 2,      /* velocity at t_{n-1}                                   */
+  NSFEM_USTAR = 3,   /* IPCS _intermediate_velocity                           */
+  NSFEM_P = 4,       /* pressure                                    [n_p1]    */
+  NSFEM_P_OLD = 5,   /* IPCS _old_pressure / BDF pressure at t_n              */
+  NSFEM_BODY_FORCE = 6, /* nodal P2 interpolant of f               [2*n_p2]   */
+  NSFEM_TRACTION = 7,   /* assembled boundary traction vector      [2*n_p2]   */
+  NSFEM_P2_OLD = 8,  /* BDF: pressure at t_{n-1} (keeps _solutions[2] whole)  */
+  NSFEM_N_SLOTS = 9
+};
+
+/* fields for Dirichlet sets */
+enum nsfem_field { NSFEM_VELOCITY = 0, NSFEM_PRESSURE = 1 };
+
+/* operators that can be exported / applied (parity tests, _assemble_system) */
+enum nsfem_operator {
+  NSFEM_OP_MASS_P2 = 0,      /* scalar P2 mass               n_p2 x n_p2      */
+  NSFEM_OP_STIFF_P2 = 1,     /* scalar P2 stiffness                           */
+  NSFEM_OP_STIFF_P1 = 2,     /* (grad p, grad q)  ns_ipcs_solver.py:160       */
+  NSFEM_OP_MASS_P1 = 3,
+  NSFEM_OP_DIV = 4,          /* (div u, q)       n_p1 x 2 n_p2                */
+  NSFEM_OP_GRAD = 5,         /* (grad p, w)      2 n_p2 x n_p1                */
+  NSFEM_OP_DIVT = 6,         /* (p, div w)       2 n_p2 x n_p1                */
+  NSFEM_OP_MOMENTUM_JAC = 7, /* IPCS/BDF velocity block of the Newton matrix  */
+  NSFEM_OP_VISCOUS_EXTRA = 8 /* traction-form extra block (grad u^T : grad v) */
+};
+
+enum nsfem_system {
+  NSFEM_SYS_MOMENTUM = 0,    /* IPCS diffusion step  ns_ipcs_solver.py:106-147 */
+  NSFEM_SYS_POISSON = 1,     /* projection step      ns_ipcs_solver.py:149-171 */
+  NSFEM_SYS_CORRECTION = 2,  /* velocity correction  ns_ipcs_solver.py:173-196 */
+  NSFEM_SYS_MONOLITHIC = 3   /* BDF mixed system     ns_bdf_solver.py:36-100   */
+};
+
+typedef struct {
+  double rtol;          /* relative residual (to |b|) tolerance                */
+  double atol;          /* absolute residual tolerance                         */
+  int32_t max_iter;
+  int32_t precond;      /* 0 = Jacobi, 1 = multigrid (where available)         */
+  int32_t check_every;  /* host convergence check interval (>=1)               */
+  int32_t reserved;
+} nsfem_krylov_opts;
+
+typedef struct {
+  int32_t iterations;
+  int32_t converged;
+  double residual;      /* final |r|_2                                          */
+  double residual0;     /* initial |r|_2                                        */
+} nsfem_solve_info;
+
+typedef struct {
+  double newton_atol;   /* reference: tol (1e-10)   ns_ipcs_solver.py:144       */
+  double newton_rtol;   /* reference: 10 * tol                                  */
+  int32_t newton_max_iter; /* reference: 50                                     */
+  int32_t convective_form; /* 0 standard (others: NSFEM_ERR_ARG for now)        */
+  nsfem_krylov_opts momentum;   /* BiCGStab */
+  nsfem_krylov_opts poisson;    /* CG       */
+  nsfem_krylov_opts correction; /* CG       */
+} nsfem_step_opts;
+
+#define NSFEM_MAX_NEWTON 64
+typedef struct {
+  int32_t newton_iterations;
+  int32_t krylov_iterations_momentum;   /* summed over Newton iterations        */
+  int32_t krylov_iterations_poisson;
+  int32_t krylov_iterations_correction;
+  double newton_residuals[NSFEM_MAX_NEWTON]; /* |b| after 0,1,.. updates        */
+} nsfem_step_info;
+
+/* ---- life cycle: replaces FunctionSpace/Function construction
+ * (source/ns_solver_base.py:501-524,1018-1025; ns_ipcs_solver.py:66-82) ------ */
+int nsfem_create(const nsfem_mesh_desc* mesh, int device, nsfem_ctx** out);
+void nsfem_destroy(nsfem_ctx* ctx);
+const char* nsfem_last_error(const nsfem_ctx* ctx);   /* ctx may be NULL: last create error */
+int nsfem_version(void);
+
+/* ---- coefficients: replaces set_equation_coefficients (ns_solver_base.py:829-855)
+ * c = {convective, pressure, viscous, body_force, coriolis, euler}; NaN = None */
+int nsfem_set_coeffs(nsfem_ctx* ctx, const double c[6]);
+/* replaces _update_time_stepping_coefficients (ns_ipcs_solver.py:210-227) */
+int nsfem_set_bdf(nsfem_ctx* ctx, const double alpha[3], double k);
+/* replaces DirichletBC lists (ns_solver_base.py:546-660); re-callable each step
+ * (time dependent values, _set_time ns_solver_base.py:1033-1104).  dofs index the
+ * velocity (interleaved) or pressure vector; later entries win on duplicates. */
+int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const int32_t* dofs,
+                        const double* vals);
+/* viscous term form: 0 reduced, 1 traction (ns_solver_base.py:662-673) */
+int nsfem_set_viscous_form(nsfem_ctx* ctx, int traction_form);
+
+/* ---- state transfer: Function.vector() get/set ------------------------------ */
+int nsfem_set_state(nsfem_ctx* ctx, int slot, const double* host, int64_t n);
+int nsfem_get_state(nsfem_ctx* ctx, int slot, double* host, int64_t n);
+int64_t nsfem_state_size(const nsfem_ctx* ctx, int slot);
+void* nsfem_state_devptr(nsfem_ctx* ctx, int slot);   /* device pointer (plumbing) */
+
+/* ---- the explicit assembly seam (_assemble_system) ------------
+ * Assembles matrix and right-hand side / residual of one system from the current
+ * state; replaces the implicit dolfin assemble() inside *VariationalSolver.solve() */
+int nsfem_assemble(nsfem_ctx* ctx, int system, uint32_t flags);
+/* 2-norm of the assembled residual / rhs (Dirichlet rows: x_i - g_i for Newton) */
+int nsfem_residual_norm(nsfem_ctx* ctx, int system, double* out);
+int nsfem_get_rhs(nsfem_ctx* ctx, int system, double* host, int64_t n);
+/* Krylov solve of the assembled system; replaces PETSc LU */
+int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* opts,
+                nsfem_solve_info* info);
+
+/* ---- operator introspection for parity tests -------------------------------- */
+int nsfem_operator_shape(nsfem_ctx* ctx, int op, int64_t* n_rows, int64_t* n_cols,
+                         int64_t* nnz_scalar);
+/* scalar CSR copy (blocks expanded); arrays sized from nsfem_operator_shape */
+int nsfem_operator_export(nsfem_ctx* ctx, int op, int32_t* rowptr, int32_t* col, double* val);
+/* y = op * x on the device through the production SpMV kernel (host in/out) */
+int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y);
+
+/* ---- fused per-step drivers: replace _solve_time_step
+ * (ns_ipcs_solver.py:198-208, ns_bdf_solver.py:102-106) ------------------------ */
+int nsfem_default_step_opts(nsfem_step_opts* opts);
+int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info);
+int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info);
+/* replaces _advance_solution (ns_solver_base.py:1012-1016, ns_ipcs_solver.py:35-43) */
+int nsfem_advance(nsfem_ctx* ctx, int scheme /* 0 ipcs, 1 bdf */);
+/* mean-pressure shift (ns_solver_base.py:1190-1203): p -= (int p / |Omega| - target) */
+int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* mean_before);
+
+/* ---- measurement hooks (bench.py): time `reps` launches of the dominant SpMV
+ * with HIP events on the context's stream; ms per launch returned ------------- */
+int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
+                    int64_t* algorithmic_bytes);
+int nsfem_synchronize(nsfem_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSFEM_H */

@@ -1,0 +1,283 @@
+"""ctypes binding of libnsfem_hip.so (C ABI: include/nsfem.h).
+
+This is the only way the Python host code reaches the device.  There is NO CPU
+fallback: if the shared library is missing or no MI355X is visible, every entry
+point raises.  (The reference reaches its native layer -- DOLFIN/PETSc -- through
+pybind11 inside ``import dolfin``; this thin ctypes layer replaces that import.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsfem_hip.so")
+
+# ---- enums (mirror include/nsfem.h) ------------------------------------------
+OK, ERR_ARG, ERR_HIP, ERR_BREAKDOWN, ERR_NOT_CONVERGED, ERR_COMM = 0, -1, -2, -3, -4, -5
+U0, U1, U2, USTAR, P, P_OLD, BODY_FORCE, TRACTION, P2_OLD = range(9)
+VELOCITY, PRESSURE = 0, 1
+(OP_MASS_P2, OP_STIFF_P2, OP_STIFF_P1, OP_MASS_P1, OP_DIV, OP_GRAD, OP_DIVT,
+ OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA) = range(9)
+SYS_MOMENTUM, SYS_POISSON, SYS_CORRECTION, SYS_MONOLITHIC = range(4)
+MAX_NEWTON = 64
+
+EXPORTED_SYMBOLS = (
+    "nsfem_create", "nsfem_destroy", "nsfem_last_error", "nsfem_version",
+    "nsfem_set_coeffs", "nsfem_set_bdf", "nsfem_set_dirichlet", "nsfem_set_viscous_form",
+    "nsfem_set_state", "nsfem_get_state", "nsfem_state_size", "nsfem_state_devptr",
+    "nsfem_assemble", "nsfem_residual_norm", "nsfem_get_rhs", "nsfem_solve",
+    "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply",
+    "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
+    "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize",
+)
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_cells", C.c_int32), ("n_vertices", C.c_int32),
+                ("n_p2", C.c_int32), ("n_p1", C.c_int32),
+                ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
+                ("p2_dofmap", C.POINTER(C.c_int32)), ("p1_dofmap", C.POINTER(C.c_int32))]
+
+
+class KrylovOpts(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_iter", C.c_int32),
+                ("precond", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
+                ("residual", C.c_double), ("residual0", C.c_double)]
+
+
+class StepOpts(C.Structure):
+    _fields_ = [("newton_atol", C.c_double), ("newton_rtol", C.c_double),
+                ("newton_max_iter", C.c_int32), ("convective_form", C.c_int32),
+                ("momentum", KrylovOpts), ("poisson", KrylovOpts), ("correction", KrylovOpts)]
+
+
+class StepInfo(C.Structure):
+    _fields_ = [("newton_iterations", C.c_int32), ("krylov_iterations_momentum", C.c_int32),
+                ("krylov_iterations_poisson", C.c_int32),
+                ("krylov_iterations_correction", C.c_int32),
+                ("newton_residuals", C.c_double * MAX_NEWTON)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libnsfem_hip: %s (status %d)" % (message, code))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the shared library and declare the prototypes.  Raises loudly when
+    the library has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("libnsfem_hip.so is not built (%s): the HIP extension is mandatory, "
+                          "there is no CPU fallback; run __graft_entry__.build()" % path)
+    lib = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    protos = {
+        "nsfem_create": (C.c_int, [C.POINTER(MeshDesc), C.c_int, C.POINTER(vp)]),
+        "nsfem_destroy": (None, [vp]),
+        "nsfem_last_error": (C.c_char_p, [vp]),
+        "nsfem_version": (C.c_int, []),
+        "nsfem_set_coeffs": (C.c_int, [vp, pd]),
+        "nsfem_set_bdf": (C.c_int, [vp, pd, dbl]),
+        "nsfem_set_dirichlet": (C.c_int, [vp, C.c_int, i32, pi, pd]),
+        "nsfem_set_viscous_form": (C.c_int, [vp, C.c_int]),
+        "nsfem_set_state": (C.c_int, [vp, C.c_int, pd, i64]),
+        "nsfem_get_state": (C.c_int, [vp, C.c_int, pd, i64]),
+        "nsfem_state_size": (i64, [vp, C.c_int]),
+        "nsfem_state_devptr": (vp, [vp, C.c_int]),
+        "nsfem_assemble": (C.c_int, [vp, C.c_int, C.c_uint32]),
+        "nsfem_residual_norm": (C.c_int, [vp, C.c_int, pd]),
+        "nsfem_get_rhs": (C.c_int, [vp, C.c_int, pd, i64]),
+        "nsfem_solve": (C.c_int, [vp, C.c_int, C.POINTER(KrylovOpts), C.POINTER(SolveInfo)]),
+        "nsfem_operator_shape": (C.c_int, [vp, C.c_int, C.POINTER(i64), C.POINTER(i64),
+                                           C.POINTER(i64)]),
+        "nsfem_operator_export": (C.c_int, [vp, C.c_int, pi, pi, pd]),
+        "nsfem_operator_apply": (C.c_int, [vp, C.c_int, pd, pd]),
+        "nsfem_default_step_opts": (C.c_int, [C.POINTER(StepOpts)]),
+        "nsfem_step_ipcs": (C.c_int, [vp, C.POINTER(StepOpts), C.POINTER(StepInfo)]),
+        "nsfem_step_bdf": (C.c_int, [vp, C.POINTER(StepOpts), C.POINTER(StepInfo)]),
+        "nsfem_advance": (C.c_int, [vp, C.c_int]),
+        "nsfem_shift_mean_pressure": (C.c_int, [vp, dbl, pd]),
+        "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),
+        "nsfem_synchronize": (C.c_int, [vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)      # AttributeError = missing export: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class NsfemContext:
+    """RAII wrapper of one ``nsfem_ctx`` (one mesh, one GPU, one stream)."""
+
+    def __init__(self, coords, cells, p2_dofmap, p1_dofmap, n_p2, n_p1, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        p2 = np.ascontiguousarray(p2_dofmap, dtype=np.int32)
+        p1 = np.ascontiguousarray(p1_dofmap, dtype=np.int32)
+        assert coords.ndim == 2 and coords.shape[1] == 2
+        assert cells.shape == (p2.shape[0], 3) and p2.shape[1] == 6 and p1.shape == cells.shape
+        desc = MeshDesc(2, cells.shape[0], coords.shape[0], int(n_p2), int(n_p1),
+                        _dp(coords), _ip(cells), _ip(p2), _ip(p1))
+        rc = self._lib.nsfem_create(C.byref(desc), int(device), C.byref(self._h))
+        if rc != OK:
+            msg = self._lib.nsfem_last_error(None)
+            raise NativeError(rc, msg.decode() if msg else "nsfem_create failed")
+        self.n_p2, self.n_p1 = int(n_p2), int(n_p1)
+        self.n_velocity = 2 * self.n_p2
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nsfem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            msg = self._lib.nsfem_last_error(self._h)
+            raise NativeError(rc, msg.decode() if msg else "error")
+
+    # -- coefficients / BCs ---------------------------------------------------
+    def set_coeffs(self, convective, pressure, viscous, body_force=None, coriolis=None, euler=None):
+        c = np.array([np.nan if v is None else float(v)
+                      for v in (convective, pressure, viscous, body_force, coriolis, euler)])
+        self._check(self._lib.nsfem_set_coeffs(self._h, _dp(c)))
+
+    def set_bdf(self, alpha, k):
+        a = np.ascontiguousarray(alpha, dtype=np.float64)
+        assert a.shape == (3,)
+        self._check(self._lib.nsfem_set_bdf(self._h, _dp(a), float(k)))
+
+    def set_dirichlet(self, field, dofs, vals):
+        d = np.ascontiguousarray(dofs, dtype=np.int32)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        assert d.shape == v.shape and d.ndim == 1
+        self._check(self._lib.nsfem_set_dirichlet(self._h, field, d.size, _ip(d), _dp(v)))
+
+    def set_viscous_form(self, traction_form):
+        self._check(self._lib.nsfem_set_viscous_form(self._h, int(bool(traction_form))))
+
+    # -- state ------------------------------------------------------------------
+    def state_size(self, slot):
+        return int(self._lib.nsfem_state_size(self._h, slot))
+
+    def set_state(self, slot, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self._lib.nsfem_set_state(self._h, slot, _dp(v), v.size))
+
+    def get_state(self, slot):
+        out = np.empty(self.state_size(slot), dtype=np.float64)
+        self._check(self._lib.nsfem_get_state(self._h, slot, _dp(out), out.size))
+        return out
+
+    def state_devptr(self, slot):
+        return self._lib.nsfem_state_devptr(self._h, slot)
+
+    # -- assembly seam + solves -------------------------------------------------
+    def assemble(self, system, new_step=False):
+        self._check(self._lib.nsfem_assemble(self._h, system, 1 if new_step else 0))
+
+    def residual_norm(self, system):
+        out = C.c_double()
+        self._check(self._lib.nsfem_residual_norm(self._h, system, C.byref(out)))
+        return out.value
+
+    def get_rhs(self, system):
+        n = self.n_p1 if system == SYS_POISSON else self.n_velocity
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.nsfem_get_rhs(self._h, system, _dp(out), n))
+        return out
+
+    def solve(self, system, rtol=1e-12, atol=1e-14, max_iter=20000, precond=0, check_every=1):
+        o = KrylovOpts(rtol, atol, max_iter, precond, check_every, 0)
+        info = SolveInfo()
+        self._check(self._lib.nsfem_solve(self._h, system, C.byref(o), C.byref(info)))
+        return info
+
+    def default_step_opts(self):
+        o = StepOpts()
+        self._lib.nsfem_default_step_opts(C.byref(o))
+        return o
+
+    def step_ipcs(self, opts=None):
+        o = opts or self.default_step_opts()
+        info = StepInfo()
+        self._check(self._lib.nsfem_step_ipcs(self._h, C.byref(o), C.byref(info)))
+        return info
+
+    def step_bdf(self, opts=None):
+        o = opts or self.default_step_opts()
+        info = StepInfo()
+        self._check(self._lib.nsfem_step_bdf(self._h, C.byref(o), C.byref(info)))
+        return info
+
+    def advance(self, scheme=0):
+        self._check(self._lib.nsfem_advance(self._h, scheme))
+
+    def shift_mean_pressure(self, target):
+        out = C.c_double()
+        self._check(self._lib.nsfem_shift_mean_pressure(self._h, float(target), C.byref(out)))
+        return out.value
+
+    def synchronize(self):
+        self._check(self._lib.nsfem_synchronize(self._h))
+
+    # -- operator introspection ---------------------------------------------------
+    def operator_csr(self, op):
+        """scipy CSR copy of a device operator (parity tests)."""
+        import scipy.sparse as sp
+        nr, ncol, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.nsfem_operator_shape(self._h, op, C.byref(nr), C.byref(ncol),
+                                                   C.byref(nnz)))
+        rowptr = np.empty(nr.value + 1, dtype=np.int32)
+        col = np.empty(nnz.value, dtype=np.int32)
+        val = np.empty(nnz.value, dtype=np.float64)
+        self._check(self._lib.nsfem_operator_export(self._h, op, _ip(rowptr), _ip(col), _dp(val)))
+        return sp.csr_matrix((val, col, rowptr), shape=(nr.value, ncol.value))
+
+    def operator_apply(self, op, x):
+        nr, ncol, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.nsfem_operator_shape(self._h, op, C.byref(nr), C.byref(ncol),
+                                                   C.byref(nnz)))
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == ncol.value
+        y = np.empty(nr.value, dtype=np.float64)
+        self._check(self._lib.nsfem_operator_apply(self._h, op, _dp(x), _dp(y)))
+        return y
+
+    def time_spmv(self, op, reps=50):
+        ms = C.c_double()
+        nbytes = C.c_int64()
+        self._check(self._lib.nsfem_time_spmv(self._h, op, reps, C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value

@@ -1,0 +1,727 @@
+// C ABI of libnsfem_hip.so (declared in include/nsfem.h) and the per-step drivers.
+//
+// Step drivers restate, on device-resident state, what the reference does in
+//   IPCSSolver._solve_time_step            source/ns_ipcs_solver.py:198-208
+//   (diffusion Newton / projection / correction forms :106-196)
+//   InstationarySolverBase._advance_solution   source/ns_solver_base.py:1012-1016
+//   IPCSSolver._advance_solution               source/ns_ipcs_solver.py:35-43
+// with dolfin's NewtonSolver control (residual criterion, relaxation 1; parameters
+// from source/ns_ipcs_solver.py:143-147) and Krylov solves instead of sparse LU.
+#include "nsfem_internal.hpp"
+#include <algorithm>
+
+using namespace nsfem;
+
+static std::string g_create_error;
+
+#define API_BEGIN try {
+#define API_END(ctx)                                  \
+  }                                                   \
+  catch (const nsfem::Error& e) {                     \
+    if (ctx) (ctx)->err = e.what();                   \
+    else g_create_error = e.what();                   \
+    return e.code;                                    \
+  }                                                   \
+  catch (const std::exception& e) {                   \
+    if (ctx) (ctx)->err = e.what();                   \
+    else g_create_error = e.what();                   \
+    return NSFEM_ERR_ARG;                             \
+  }                                                   \
+  return NSFEM_OK;
+
+static inline int64_t nvel(const nsfem_ctx* c) { return 2 * (int64_t)c->mesh.n_p2; }
+static inline int64_t npre(const nsfem_ctx* c) { return (int64_t)c->mesh.n_p1; }
+
+static int64_t slot_size(const nsfem_ctx* c, int slot) {
+  switch (slot) {
+    case NSFEM_U0: case NSFEM_U1: case NSFEM_U2: case NSFEM_USTAR:
+    case NSFEM_BODY_FORCE: case NSFEM_TRACTION:
+      return nvel(c);
+    case NSFEM_P: case NSFEM_P_OLD: case NSFEM_P2_OLD:
+      return npre(c);
+    default:
+      return -1;
+  }
+}
+
+static void upload_pattern(hipStream_t s, HostPattern& h, Pattern& d) {
+  d.n_rows = h.n_rows;
+  d.n_cols = h.n_cols;
+  d.nr = h.nr;
+  d.nc = h.nc;
+  d.nnz = (int)h.col.size();
+  d.rowptr.upload(h.rowptr, s);
+  d.col.upload(h.col, s);
+  if (!h.diag.empty()) d.diag.upload(h.diag, s);
+  d.slot.upload(h.slot, s);
+  d.h_rowptr.swap(h.rowptr);
+  d.h_col.swap(h.col);
+  std::vector<int32_t>().swap(h.slot);
+}
+
+extern "C" int nsfem_version(void) { return 1; }
+
+extern "C" const char* nsfem_last_error(const nsfem_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** out) {
+  nsfem_ctx* ctx = nullptr;
+  nsfem_ctx* fresh = nullptr;
+  API_BEGIN
+  NSFEM_REQUIRE(m && out, "null argument");
+  *out = nullptr;
+  NSFEM_REQUIRE(m->dim == 2, "only 2D triangle meshes are supported");
+  NSFEM_REQUIRE(m->n_cells > 0 && m->n_vertices > 0 && m->n_p2 > 0 && m->n_p1 > 0, "empty mesh");
+  NSFEM_REQUIRE(m->coords && m->cells && m->p2_dofmap && m->p1_dofmap, "null mesh array");
+  int ndev = 0;
+  NSFEM_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) throw Error(NSFEM_ERR_HIP, "no such HIP device");
+  NSFEM_HIP(hipSetDevice(device));
+  fresh = new nsfem_ctx();
+  fresh->device = device;
+  NSFEM_HIP(hipStreamCreate(&fresh->stream));
+  hipStream_t s = fresh->stream;
+  const int nc = m->n_cells;
+  // ---- mesh arrays, SoA
+  {
+    std::vector<double> vx((size_t)6 * nc);
+    std::vector<int32_t> p2((size_t)6 * nc), p1((size_t)3 * nc);
+    double area = 0.0;
+    for (int c = 0; c < nc; ++c) {
+      double xy[3][2];
+      for (int v = 0; v < 3; ++v) {
+        const int vid = m->cells[(size_t)c * 3 + v];
+        NSFEM_REQUIRE(vid >= 0 && vid < m->n_vertices, "cell vertex id out of range");
+        for (int d = 0; d < 2; ++d) {
+          xy[v][d] = m->coords[(size_t)vid * 2 + d];
+          vx[(size_t)(2 * v + d) * nc + c] = xy[v][d];
+        }
+      }
+      const double det = (xy[1][0] - xy[0][0]) * (xy[2][1] - xy[0][1]) -
+                         (xy[2][0] - xy[0][0]) * (xy[1][1] - xy[0][1]);
+      NSFEM_REQUIRE(det != 0.0, "degenerate cell");
+      area += 0.5 * std::fabs(det);
+      for (int k = 0; k < 6; ++k) p2[(size_t)k * nc + c] = m->p2_dofmap[(size_t)c * 6 + k];
+      for (int k = 0; k < 3; ++k) p1[(size_t)k * nc + c] = m->p1_dofmap[(size_t)c * 3 + k];
+    }
+    fresh->area = area;
+    fresh->mesh.n_cells = nc;
+    fresh->mesh.n_p2 = m->n_p2;
+    fresh->mesh.n_p1 = m->n_p1;
+    fresh->mesh.n_vertices = m->n_vertices;
+    fresh->mesh.vx.upload(vx, s);
+    fresh->mesh.p2.upload(p2, s);
+    fresh->mesh.p1.upload(p1, s);
+  }
+  // ---- sparsity patterns + slot maps (host), then device copies
+  {
+    HostPattern h;
+    build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, 6, m->p2_dofmap, 6, true, h);
+    upload_pattern(s, h, fresh->p22);
+    build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, 3, m->p1_dofmap, 3, true, h);
+    upload_pattern(s, h, fresh->p11);
+    build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, 3, m->p2_dofmap, 6, false, h);
+    upload_pattern(s, h, fresh->p12);
+    build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, 6, m->p1_dofmap, 3, false, h);
+    upload_pattern(s, h, fresh->p21);
+  }
+  // ---- constant operators, integrated on the device
+  QuadTables qt;
+  fill_quad_tables(qt);
+  upload_quad_tables(qt);
+  fresh->M2.init(&fresh->p22, 1, 1, s);
+  fresh->K2.init(&fresh->p22, 1, 1, s);
+  fresh->L.init(&fresh->p22, 1, 1, s);
+  fresh->J.init(&fresh->p22, 2, 2, s);
+  fresh->Ap.init(&fresh->p11, 1, 1, s);
+  fresh->Mp.init(&fresh->p11, 1, 1, s);
+  fresh->Dv.init(&fresh->p12, 1, 2, s);
+  fresh->Gr.init(&fresh->p21, 2, 1, s);
+  fresh->DT.init(&fresh->p21, 2, 1, s);
+  launch_assemble_p2_scalar(s, fresh->mesh, fresh->p22, fresh->M2.vals.p, fresh->K2.vals.p);
+  launch_assemble_p1_scalar(s, fresh->mesh, fresh->p11, fresh->Ap.vals.p, fresh->Mp.vals.p);
+  launch_assemble_div_grad(s, fresh->mesh, fresh->p12, fresh->p21, fresh->Dv.vals.p,
+                           fresh->Gr.vals.p, fresh->DT.vals.p);
+  // ---- state + work vectors
+  for (int i = 0; i < NSFEM_N_SLOTS; ++i) {
+    fresh->state[i].alloc((size_t)slot_size(fresh, i));
+    fresh->state[i].zero(s);
+  }
+  const size_t nv = (size_t)nvel(fresh), np = (size_t)npre(fresh);
+  for (DevBuf<double>* b : {&fresh->rhs_v, &fresh->dx_v, &fresh->gconst, &fresh->tmp_v,
+                            &fresh->dinv_v, &fresh->dinv_m}) {
+    b->alloc(nv);
+    b->zero(s);
+  }
+  for (DevBuf<double>* b : {&fresh->rhs_p, &fresh->tmp_p, &fresh->dinv_p}) {
+    b->alloc(np);
+    b->zero(s);
+  }
+  fresh->mask_v.alloc(nv);
+  fresh->mask_v.zero(s);
+  fresh->mask_p.alloc(np);
+  fresh->mask_p.zero(s);
+  fresh->kw.ensure((int64_t)std::max(nv, np));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  *out = fresh;
+  fresh = nullptr;
+  }
+  catch (const nsfem::Error& e) {
+    g_create_error = e.what();
+    delete fresh;
+    return e.code;
+  }
+  catch (const std::exception& e) {
+    g_create_error = e.what();
+    delete fresh;
+    return NSFEM_ERR_ARG;
+  }
+  (void)ctx;
+  return NSFEM_OK;
+}
+
+extern "C" void nsfem_destroy(nsfem_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+}
+
+extern "C" int nsfem_synchronize(nsfem_ctx* ctx) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_set_coeffs(nsfem_ctx* ctx, const double c[6]) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && c, "null argument");
+  NSFEM_REQUIRE(std::isfinite(c[1]) && std::isfinite(c[2]), "pressure and viscous coefficients are required");
+  for (int i = 0; i < 6; ++i) ctx->coef[i] = c[i];
+  ctx->L_dirty = true;
+  API_END(ctx)
+}
+
+extern "C" int nsfem_set_bdf(nsfem_ctx* ctx, const double alpha[3], double k) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && alpha, "null argument");
+  NSFEM_REQUIRE(k > 0.0 && std::isfinite(k) && alpha[0] != 0.0, "bad BDF coefficients");
+  if (alpha[0] != ctx->alpha[0] || k != ctx->k) ctx->L_dirty = true;
+  for (int i = 0; i < 3; ++i) ctx->alpha[i] = alpha[i];
+  ctx->k = k;
+  API_END(ctx)
+}
+
+extern "C" int nsfem_set_viscous_form(nsfem_ctx* ctx, int traction_form) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  ctx->traction_form = traction_form ? 1 : 0;
+  if (ctx->traction_form && !ctx->have_E) {
+    ctx->E.init(&ctx->p22, 2, 2, ctx->stream);
+    launch_assemble_viscous_extra(ctx->stream, ctx->mesh, ctx->p22, ctx->E.vals.p);
+    ctx->have_E = true;
+  }
+  API_END(ctx)
+}
+
+extern "C" int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const int32_t* dofs,
+                                   const double* vals) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(field == NSFEM_VELOCITY || field == NSFEM_PRESSURE, "bad field");
+  NSFEM_REQUIRE(n >= 0 && (n == 0 || (dofs && vals)), "bad Dirichlet arrays");
+  const int64_t size = field == NSFEM_VELOCITY ? nvel(ctx) : npre(ctx);
+  // later entries win on duplicates (list order of dolfin bc.apply): dedupe on host
+  std::vector<int32_t> d;
+  std::vector<double> v;
+  {
+    std::vector<int32_t> last((size_t)size, -1);
+    for (int32_t i = 0; i < n; ++i) {
+      NSFEM_REQUIRE(dofs[i] >= 0 && dofs[i] < size, "Dirichlet dof out of range");
+      last[dofs[i]] = i;
+    }
+    for (int64_t k = 0; k < size; ++k)
+      if (last[k] >= 0) {
+        d.push_back((int32_t)k);
+        v.push_back(vals[last[k]]);
+      }
+  }
+  hipStream_t s = ctx->stream;
+  DevBuf<int32_t>& dd = field == NSFEM_VELOCITY ? ctx->bc_v_dofs : ctx->bc_p_dofs;
+  DevBuf<double>& dv = field == NSFEM_VELOCITY ? ctx->bc_v_vals : ctx->bc_p_vals;
+  DevBuf<uint8_t>& mask = field == NSFEM_VELOCITY ? ctx->mask_v : ctx->mask_p;
+  dd.upload(d, s);
+  dv.upload(v, s);
+  mask.zero(s);
+  launch_fill_mask(s, (int)d.size(), dd.p, mask.p);
+  if (field == NSFEM_VELOCITY) {
+    ctx->nbc_v = (int)d.size();
+    ctx->dinv_m_ready = false;
+  } else {
+    ctx->nbc_p = (int)d.size();
+    ctx->dinv_p_ready = false;
+  }
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int64_t nsfem_state_size(const nsfem_ctx* ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= NSFEM_N_SLOTS) return -1;
+  return slot_size(ctx, slot);
+}
+
+extern "C" void* nsfem_state_devptr(nsfem_ctx* ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= NSFEM_N_SLOTS) return nullptr;
+  return ctx->state[slot].p;
+}
+
+extern "C" int nsfem_set_state(nsfem_ctx* ctx, int slot, const double* host, int64_t n) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && host, "null argument");
+  NSFEM_REQUIRE(slot >= 0 && slot < NSFEM_N_SLOTS && n == slot_size(ctx, slot), "bad slot / size");
+  NSFEM_HIP(hipMemcpyAsync(ctx->state[slot].p, host, sizeof(double) * n, hipMemcpyHostToDevice,
+                           ctx->stream));
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  if (slot == NSFEM_BODY_FORCE) ctx->have_body_force = true;
+  if (slot == NSFEM_TRACTION) ctx->have_traction = true;
+  API_END(ctx)
+}
+
+extern "C" int nsfem_get_state(nsfem_ctx* ctx, int slot, double* host, int64_t n) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && host, "null argument");
+  NSFEM_REQUIRE(slot >= 0 && slot < NSFEM_N_SLOTS && n == slot_size(ctx, slot), "bad slot / size");
+  NSFEM_HIP(hipMemcpyAsync(host, ctx->state[slot].p, sizeof(double) * n, hipMemcpyDeviceToHost,
+                           ctx->stream));
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  API_END(ctx)
+}
+
+// ------------------------------------------------------------------ internals
+static void ensure_L(nsfem_ctx* c) {
+  if (!c->L_dirty) return;
+  // L = alpha0/k M + c_viscous K   (scalar P2; acts on both velocity components)
+  launch_scale_combine(c->stream, c->p22.nnz, c->alpha[0] / c->k, c->M2.vals.p, c->coef[2],
+                       c->K2.vals.p, c->L.vals.p);
+  c->L_dirty = false;
+}
+
+static double cc_of(const nsfem_ctx* c) { return std::isfinite(c->coef[0]) ? c->coef[0] : 0.0; }
+
+// time-step constant part of the momentum residual:
+//   g = M (a1 u1 + a2 u2) / k - c_p (p_old, div w) - c_b M f + traction
+static void momentum_begin_step(nsfem_ctx* c) {
+  hipStream_t s = c->stream;
+  const int64_t nv = nvel(c);
+  ensure_L(c);
+  const double a1 = c->alpha[1] / c->k, a2 = c->alpha[2] / c->k;
+  if (c->have_body_force) {
+    NSFEM_REQUIRE(std::isfinite(c->coef[3]), "body force set but body_force_term coefficient is None");
+    launch_lincomb3(s, nv, a1, c->state[NSFEM_U1].p, a2, c->state[NSFEM_U2].p, -c->coef[3],
+                    c->state[NSFEM_BODY_FORCE].p, c->tmp_v.p);
+  } else {
+    launch_axpby(s, nv, a1, c->state[NSFEM_U1].p, a2, c->state[NSFEM_U2].p, c->tmp_v.p);
+  }
+  launch_spmv(s, c->M2, 2, c->tmp_v.p, c->gconst.p, nullptr, MASK_NONE);
+  launch_spmv(s, c->DT, 1, c->state[NSFEM_P_OLD].p, c->tmp_v.p, nullptr, MASK_NONE);
+  launch_axpby(s, nv, 1.0, c->gconst.p, -c->coef[1], c->tmp_v.p, c->gconst.p);
+  if (c->have_traction)
+    launch_axpby(s, nv, 1.0, c->gconst.p, 1.0, c->state[NSFEM_TRACTION].p, c->gconst.p);
+}
+
+// b = L u* [+ c_v E u*] + g + c_c conv(u*) ;  Dirichlet rows: u*_i - g_i ;  returns |b|
+static double momentum_residual(nsfem_ctx* c) {
+  hipStream_t s = c->stream;
+  const int64_t nv = nvel(c);
+  double* u = c->state[NSFEM_USTAR].p;
+  launch_spmv(s, c->L, 2, u, c->rhs_v.p, nullptr, MASK_NONE);
+  launch_axpby(s, nv, 1.0, c->rhs_v.p, 1.0, c->gconst.p, c->rhs_v.p);
+  if (c->traction_form) {
+    launch_spmv(s, c->E, 1, u, c->tmp_v.p, nullptr, MASK_NONE);
+    launch_axpby(s, nv, 1.0, c->rhs_v.p, c->coef[2], c->tmp_v.p, c->rhs_v.p);
+  }
+  const double cc = cc_of(c);
+  if (cc != 0.0) launch_convection_residual(s, c->mesh, u, cc, c->rhs_v.p);
+  launch_set_bc_residual(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, c->rhs_v.p);
+  launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, c->kw.parts.p + 5 * kParts);
+  return std::sqrt(host_sum_parts(s, c->kw, 5));
+}
+
+static void momentum_jacobian(nsfem_ctx* c) {
+  hipStream_t s = c->stream;
+  launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, c->traction_form ? c->E.vals.p : nullptr,
+                       c->coef[2], c->J.vals.p);
+  const double cc = cc_of(c);
+  if (cc != 0.0)
+    launch_convection_jacobian(s, c->mesh, c->p22, c->state[NSFEM_USTAR].p, cc, c->J.vals.p);
+  launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
+}
+
+// J dx = b ; u* -= dx
+static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  hipStream_t s = c->stream;
+  c->dx_v.zero(s);
+  LinOp op;
+  op.A = &c->J;
+  op.nv = 1;
+  op.rowmask = c->mask_v.p;
+  op.maskmode = MASK_IDENTITY;
+  op.dinv = c->dinv_v.p;
+  int rc = bicgstab(s, c->kw, op, c->rhs_v.p, c->dx_v.p, o, info);
+  if (rc != NSFEM_OK) return rc;
+  double* u = c->state[NSFEM_USTAR].p;
+  launch_axpby(s, nvel(c), 1.0, u, -1.0, c->dx_v.p, u);
+  return NSFEM_OK;
+}
+
+// rhs = A_p p_old - alpha0/k D u* ; start vector p = p_old with Dirichlet values
+static void poisson_assemble(nsfem_ctx* c) {
+  hipStream_t s = c->stream;
+  const int64_t np = npre(c);
+  launch_spmv(s, c->Ap, 1, c->state[NSFEM_P_OLD].p, c->rhs_p.p, nullptr, MASK_NONE);
+  launch_spmv(s, c->Dv, 1, c->state[NSFEM_USTAR].p, c->tmp_p.p, nullptr, MASK_NONE);
+  launch_axpby(s, np, 1.0, c->rhs_p.p, -c->alpha[0] / c->k, c->tmp_p.p, c->rhs_p.p);
+  NSFEM_HIP(hipMemcpyAsync(c->state[NSFEM_P].p, c->state[NSFEM_P_OLD].p, sizeof(double) * np,
+                           hipMemcpyDeviceToDevice, s));
+  launch_set_values(s, c->nbc_p, c->bc_p_dofs.p, c->bc_p_vals.p, c->state[NSFEM_P].p);
+  if (!c->dinv_p_ready) {
+    launch_inv_diag(s, c->Ap, 1, c->mask_p.p, c->dinv_p.p);
+    c->dinv_p_ready = true;
+  }
+}
+
+static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  LinOp op;
+  op.A = &c->Ap;
+  op.nv = 1;
+  op.rowmask = c->mask_p.p;
+  op.maskmode = MASK_ZERO;
+  op.dinv = c->dinv_p.p;
+  return pcg(c->stream, c->kw, op, c->rhs_p.p, c->state[NSFEM_P].p, o, info, c->nbc_p == 0);
+}
+
+// rhs = M u* - k/alpha0 G (p - p_old) ; start vector u0 = u* with Dirichlet values
+static void correction_assemble(nsfem_ctx* c) {
+  hipStream_t s = c->stream;
+  const int64_t nv = nvel(c), np = npre(c);
+  launch_spmv(s, c->M2, 2, c->state[NSFEM_USTAR].p, c->rhs_v.p, nullptr, MASK_NONE);
+  launch_axpby(s, np, 1.0, c->state[NSFEM_P].p, -1.0, c->state[NSFEM_P_OLD].p, c->tmp_p.p);
+  launch_spmv(s, c->Gr, 1, c->tmp_p.p, c->tmp_v.p, nullptr, MASK_NONE);
+  launch_axpby(s, nv, 1.0, c->rhs_v.p, -c->k / c->alpha[0], c->tmp_v.p, c->rhs_v.p);
+  NSFEM_HIP(hipMemcpyAsync(c->state[NSFEM_U0].p, c->state[NSFEM_USTAR].p, sizeof(double) * nv,
+                           hipMemcpyDeviceToDevice, s));
+  launch_set_values(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, c->state[NSFEM_U0].p);
+  if (!c->dinv_m_ready) {
+    launch_inv_diag(s, c->M2, 2, c->mask_v.p, c->dinv_m.p);
+    c->dinv_m_ready = true;
+  }
+}
+
+static int correction_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  LinOp op;
+  op.A = &c->M2;
+  op.nv = 2;
+  op.rowmask = c->mask_v.p;
+  op.maskmode = MASK_ZERO;
+  op.dinv = c->dinv_m.p;
+  return pcg(c->stream, c->kw, op, c->rhs_v.p, c->state[NSFEM_U0].p, o, info, false);
+}
+
+// ------------------------------------------------------- assembly seam + solve
+extern "C" int nsfem_assemble(nsfem_ctx* ctx, int system, uint32_t flags) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  switch (system) {
+    case NSFEM_SYS_MOMENTUM:
+      if (flags & 1u) momentum_begin_step(ctx);
+      (void)momentum_residual(ctx);
+      momentum_jacobian(ctx);
+      break;
+    case NSFEM_SYS_POISSON:
+      poisson_assemble(ctx);
+      break;
+    case NSFEM_SYS_CORRECTION:
+      correction_assemble(ctx);
+      break;
+    default:
+      throw Error(NSFEM_ERR_ARG, "nsfem_assemble: system not available");
+  }
+  ctx->assembled_system = system;
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_residual_norm(nsfem_ctx* ctx, int system, double* out) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out, "null argument");
+  NSFEM_REQUIRE(system == ctx->assembled_system, "system not assembled");
+  const bool vel = (system != NSFEM_SYS_POISSON);
+  const double* b = vel ? ctx->rhs_v.p : ctx->rhs_p.p;
+  const int64_t n = vel ? nvel(ctx) : npre(ctx);
+  launch_dot(ctx->stream, n, b, b, ctx->kw.parts.p + 5 * kParts);
+  *out = std::sqrt(host_sum_parts(ctx->stream, ctx->kw, 5));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_get_rhs(nsfem_ctx* ctx, int system, double* host, int64_t n) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && host, "null argument");
+  const bool vel = (system != NSFEM_SYS_POISSON);
+  NSFEM_REQUIRE(n == (vel ? nvel(ctx) : npre(ctx)), "bad size");
+  NSFEM_HIP(hipMemcpyAsync(host, vel ? ctx->rhs_v.p : ctx->rhs_p.p, sizeof(double) * n,
+                           hipMemcpyDeviceToHost, ctx->stream));
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* opts,
+                           nsfem_solve_info* info) {
+  nsfem_solve_info local;
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && opts, "null argument");
+  NSFEM_REQUIRE(system == ctx->assembled_system, "system not assembled");
+  nsfem_solve_info& inf = info ? *info : local;
+  int rc = NSFEM_OK;
+  switch (system) {
+    case NSFEM_SYS_MOMENTUM: rc = momentum_solve_update(ctx, *opts, inf); break;
+    case NSFEM_SYS_POISSON: rc = poisson_solve(ctx, *opts, inf); break;
+    case NSFEM_SYS_CORRECTION: rc = correction_solve(ctx, *opts, inf); break;
+    default: throw Error(NSFEM_ERR_ARG, "nsfem_solve: system not available");
+  }
+  if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "Krylov breakdown");
+  if (rc == NSFEM_ERR_NOT_CONVERGED) throw Error(rc, "Krylov solver did not converge");
+  API_END(ctx)
+}
+
+extern "C" int nsfem_default_step_opts(nsfem_step_opts* o) {
+  if (!o) return NSFEM_ERR_ARG;
+  std::memset(o, 0, sizeof(*o));
+  o->newton_atol = 1e-10;
+  o->newton_rtol = 1e-9;
+  o->newton_max_iter = 50;
+  o->convective_form = 0;
+  nsfem_krylov_opts k;
+  k.rtol = 1e-12;
+  k.atol = 1e-14;
+  k.max_iter = 20000;
+  k.precond = 0;
+  k.check_every = 1;
+  k.reserved = 0;
+  o->momentum = k;
+  o->poisson = k;
+  o->correction = k;
+  return NSFEM_OK;
+}
+
+extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info) {
+  nsfem_step_info local;
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && opts, "null argument");
+  NSFEM_REQUIRE(opts->convective_form == 0, "only the standard convective form is implemented");
+  NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
+                "newton_max_iter out of range");
+  nsfem_step_info& inf = info ? *info : local;
+  std::memset(&inf, 0, sizeof(inf));
+  // ---- diffusion step: Newton (dolfin NewtonSolver, residual criterion)
+  momentum_begin_step(ctx);
+  double r = momentum_residual(ctx);
+  const double r0 = r;
+  inf.newton_residuals[0] = r;
+  int it = 0;
+  bool converged = r < opts->newton_atol;
+  while (!converged && it < opts->newton_max_iter) {
+    momentum_jacobian(ctx);
+    nsfem_solve_info si;
+    int rc = momentum_solve_update(ctx, opts->momentum, si);
+    inf.krylov_iterations_momentum += si.iterations;
+    if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the diffusion step");
+    if (rc == NSFEM_ERR_NOT_CONVERGED)
+      throw Error(rc, "BiCGStab did not converge in the diffusion step");
+    ++it;
+    r = momentum_residual(ctx);
+    inf.newton_residuals[it] = r;
+    if (!std::isfinite(r)) throw Error(NSFEM_ERR_BREAKDOWN, "Newton residual is not finite");
+    converged = (r / r0 < opts->newton_rtol) || (r < opts->newton_atol);
+  }
+  inf.newton_iterations = it;
+  if (!converged) throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
+  // ---- projection step
+  {
+    poisson_assemble(ctx);
+    nsfem_solve_info si;
+    int rc = poisson_solve(ctx, opts->poisson, si);
+    inf.krylov_iterations_poisson = si.iterations;
+    if (rc != NSFEM_OK) throw Error(rc, "CG failed in the projection step");
+  }
+  // ---- velocity correction step
+  {
+    correction_assemble(ctx);
+    nsfem_solve_info si;
+    int rc = correction_solve(ctx, opts->correction, si);
+    inf.krylov_iterations_correction = si.iterations;
+    if (rc != NSFEM_OK) throw Error(rc, "CG failed in the velocity correction step");
+  }
+  ctx->assembled_system = -1;
+  API_END(ctx)
+}
+
+extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts*, nsfem_step_info*) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  throw Error(NSFEM_ERR_ARG, "nsfem_step_bdf: monolithic step not built yet");
+  API_END(ctx)
+}
+
+extern "C" int nsfem_advance(nsfem_ctx* ctx, int scheme) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  hipStream_t s = ctx->stream;
+  // u2 <- u1 (pointer swap), u1 <- u0 (copy; u0 keeps its value as in the reference)
+  std::swap(ctx->state[NSFEM_U2].p, ctx->state[NSFEM_U1].p);
+  NSFEM_HIP(hipMemcpyAsync(ctx->state[NSFEM_U1].p, ctx->state[NSFEM_U0].p,
+                           sizeof(double) * nvel(ctx), hipMemcpyDeviceToDevice, s));
+  if (scheme == 0) {
+    NSFEM_HIP(hipMemcpyAsync(ctx->state[NSFEM_P_OLD].p, ctx->state[NSFEM_P].p,
+                             sizeof(double) * npre(ctx), hipMemcpyDeviceToDevice, s));
+  } else {
+    std::swap(ctx->state[NSFEM_P2_OLD].p, ctx->state[NSFEM_P_OLD].p);
+    NSFEM_HIP(hipMemcpyAsync(ctx->state[NSFEM_P_OLD].p, ctx->state[NSFEM_P].p,
+                             sizeof(double) * npre(ctx), hipMemcpyDeviceToDevice, s));
+  }
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* mean_before) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  hipStream_t s = ctx->stream;
+  const int64_t np = npre(ctx);
+  // int p dx = 1^T M_p p
+  launch_spmv(s, ctx->Mp, 1, ctx->state[NSFEM_P].p, ctx->tmp_p.p, nullptr, MASK_NONE);
+  launch_axpby(s, np, 0.0, ctx->tmp_p.p, 0.0, nullptr, ctx->rhs_p.p);
+  launch_add_scalar(s, np, 1.0, ctx->rhs_p.p);
+  launch_dot(s, np, ctx->tmp_p.p, ctx->rhs_p.p, ctx->kw.parts.p + 5 * kParts);
+  const double mean = host_sum_parts(s, ctx->kw, 5) / ctx->area;
+  if (mean_before) *mean_before = mean;
+  launch_add_scalar(s, np, -(mean - target), ctx->state[NSFEM_P].p);
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+// ----------------------------------------------------------- operator access
+static const BlockMat* get_op(nsfem_ctx* c, int op, int* nv_apply) {
+  *nv_apply = 1;
+  switch (op) {
+    case NSFEM_OP_MASS_P2: return &c->M2;
+    case NSFEM_OP_STIFF_P2: return &c->K2;
+    case NSFEM_OP_STIFF_P1: return &c->Ap;
+    case NSFEM_OP_MASS_P1: return &c->Mp;
+    case NSFEM_OP_DIV: return &c->Dv;
+    case NSFEM_OP_GRAD: return &c->Gr;
+    case NSFEM_OP_DIVT: return &c->DT;
+    case NSFEM_OP_MOMENTUM_JAC: return &c->J;
+    case NSFEM_OP_VISCOUS_EXTRA:
+      NSFEM_REQUIRE(c->have_E, "traction-form block not assembled (nsfem_set_viscous_form)");
+      return &c->E;
+    default: throw Error(NSFEM_ERR_ARG, "unknown operator id");
+  }
+}
+
+extern "C" int nsfem_operator_shape(nsfem_ctx* ctx, int op, int64_t* n_rows, int64_t* n_cols,
+                                    int64_t* nnz_scalar) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  int nv;
+  const BlockMat* A = get_op(ctx, op, &nv);
+  if (n_rows) *n_rows = (int64_t)A->pat->n_rows * A->br;
+  if (n_cols) *n_cols = (int64_t)A->pat->n_cols * A->bc;
+  if (nnz_scalar) *nnz_scalar = (int64_t)A->pat->nnz * A->br * A->bc;
+  API_END(ctx)
+}
+
+extern "C" int nsfem_operator_export(nsfem_ctx* ctx, int op, int32_t* rowptr, int32_t* col,
+                                     double* val) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && rowptr && col && val, "null argument");
+  int nv;
+  const BlockMat* A = get_op(ctx, op, &nv);
+  const Pattern& p = *A->pat;
+  const int br = A->br, bc = A->bc;
+  std::vector<double> v((size_t)p.nnz * br * bc);
+  NSFEM_HIP(hipMemcpyAsync(v.data(), A->vals.p, sizeof(double) * v.size(), hipMemcpyDeviceToHost,
+                           ctx->stream));
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t pos = 0;
+  for (int R = 0; R < p.n_rows; ++R)
+    for (int r = 0; r < br; ++r) {
+      rowptr[(size_t)R * br + r] = (int32_t)pos;
+      for (int k = p.h_rowptr[R]; k < p.h_rowptr[R + 1]; ++k)
+        for (int cc = 0; cc < bc; ++cc) {
+          col[pos] = p.h_col[k] * bc + cc;
+          val[pos] = v[(size_t)k * br * bc + r * bc + cc];
+          ++pos;
+        }
+    }
+  rowptr[(size_t)p.n_rows * br] = (int32_t)pos;
+  API_END(ctx)
+}
+
+extern "C" int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && x && y, "null argument");
+  int nv;
+  const BlockMat* A = get_op(ctx, op, &nv);
+  const Pattern& p = *A->pat;
+  const size_t nx = (size_t)p.n_cols * A->bc, ny = (size_t)p.n_rows * A->br;
+  DevBuf<double> dx, dy;
+  dx.alloc(nx);
+  dy.alloc(ny);
+  hipStream_t s = ctx->stream;
+  NSFEM_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, s));
+  launch_spmv(s, *A, 1, dx.p, dy.p, nullptr, MASK_NONE);
+  NSFEM_HIP(hipMemcpyAsync(y, dy.p, sizeof(double) * ny, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
+                               int64_t* algorithmic_bytes) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && reps > 0 && ms_per_launch, "bad argument");
+  int nv;
+  const BlockMat* A = get_op(ctx, op, &nv);
+  const Pattern& p = *A->pat;
+  // scalar P2 operators act on both velocity components in the solver
+  const int nvv = (op == NSFEM_OP_MASS_P2 || op == NSFEM_OP_STIFF_P2) ? 2 : 1;
+  const size_t nx = (size_t)p.n_cols * A->bc * nvv, ny = (size_t)p.n_rows * A->br * nvv;
+  DevBuf<double> dx, dy;
+  dx.alloc(nx);
+  dy.alloc(ny);
+  hipStream_t s = ctx->stream;
+  std::vector<double> hx(nx);
+  for (size_t i = 0; i < nx; ++i) hx[i] = std::sin((double)i);
+  NSFEM_HIP(hipMemcpyAsync(dx.p, hx.data(), sizeof(double) * nx, hipMemcpyHostToDevice, s));
+  for (int i = 0; i < 3; ++i) launch_spmv(s, *A, nvv, dx.p, dy.p, nullptr, MASK_NONE);
+  hipEvent_t e0, e1;
+  NSFEM_HIP(hipEventCreate(&e0));
+  NSFEM_HIP(hipEventCreate(&e1));
+  NSFEM_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; ++i) launch_spmv(s, *A, nvv, dx.p, dy.p, nullptr, MASK_NONE);
+  NSFEM_HIP(hipEventRecord(e1, s));
+  NSFEM_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  NSFEM_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / reps;
+  if (algorithmic_bytes)
+    *algorithmic_bytes = (int64_t)p.nnz * (8 * A->br * A->bc + 4) + (int64_t)(p.n_rows + 1) * 4 +
+                         (int64_t)(nx + ny) * 8;
+  API_END(ctx)
+}

@@ -1,0 +1,219 @@
+// Internal declarations of libnsfem_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/nsfem.h"
+
+namespace nsfem {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define NSFEM_HIP(expr)                                                              \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess)                                                            \
+      throw ::nsfem::Error(NSFEM_ERR_HIP, std::string(#expr) + ": " +                \
+                                              hipGetErrorString(e_));                \
+  } while (0)
+
+#define NSFEM_REQUIRE(cond, msg)                                                     \
+  do {                                                                               \
+    if (!(cond)) throw ::nsfem::Error(NSFEM_ERR_ARG, std::string(msg));              \
+  } while (0)
+
+// number of partial sums every reduction kernel emits (= its grid size); the
+// consumer kernels re-reduce them in a fixed order => bitwise reproducible dots.
+constexpr int kParts = 512;
+constexpr int kBlock = 256;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) NSFEM_HIP(hipMalloc(&p, count * sizeof(T)));
+  }
+  void upload(const T* host, size_t count, hipStream_t s) {
+    if (count != n) alloc(count);
+    if (count) NSFEM_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T>& v, hipStream_t s) {
+    upload(v.data(), v.size(), s);
+    NSFEM_HIP(hipStreamSynchronize(s));   // host vector may die after the call
+  }
+  void zero(hipStream_t s) {
+    if (n) NSFEM_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+};
+
+// ---- host-built sparsity pattern (CSR over block rows/cols) + slot map ---------
+struct HostPattern {
+  int n_rows = 0, n_cols = 0, nr = 0, nc = 0;   // nr/nc: local rows/cols per cell
+  std::vector<int32_t> rowptr, col, diag;       // diag only for square patterns
+  std::vector<int32_t> slot;                    // SoA: [nr*nc][n_cells]
+};
+void build_pattern(int n_rows, int n_cols, int n_cells, const int32_t* rowmap, int nr,
+                   const int32_t* colmap, int nc, bool want_diag, HostPattern& out);
+
+struct Pattern {
+  int n_rows = 0, n_cols = 0, nnz = 0, nr = 0, nc = 0;
+  DevBuf<int32_t> rowptr, col, diag, slot;
+  std::vector<int32_t> h_rowptr, h_col;   // kept for export
+};
+
+// block matrix on a pattern; vals[nnz][BR][BC] row-major blocks
+struct BlockMat {
+  const Pattern* pat = nullptr;
+  int br = 1, bc = 1;
+  DevBuf<double> vals;
+  void init(const Pattern* p, int br_, int bc_, hipStream_t s) {
+    pat = p; br = br_; bc = bc_;
+    vals.alloc((size_t)p->nnz * br * bc);
+    vals.zero(s);
+  }
+};
+
+// reference-element tables (7-point degree-5 rule)
+struct QuadTables {
+  double w[7];
+  double phi2[7][6];
+  double dphi2[7][6][2];
+  double phi1[7][3];
+  // dphi1 is constant: (-1,-1), (1,0), (0,1)
+};
+void fill_quad_tables(QuadTables& t);
+void upload_quad_tables(const QuadTables& t);
+
+// SpMV row-mask modes
+enum MaskMode { MASK_NONE = 0, MASK_IDENTITY = 1, MASK_ZERO = 2 };
+
+// -------------------------- kernel launch wrappers ------------------------------
+// y = A x.  nv = number of interleaved right-hand sides the scalar blocks act on
+// (scalar P2 matrices applied to both velocity components use br=bc=1, nv=2).
+void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
+                 const uint8_t* rowmask, int maskmode);
+// y = b - A x  (same arguments + b)
+void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
+                     const double* b, double* y, const uint8_t* rowmask, int maskmode);
+
+// element kernels
+struct MeshDev {
+  int n_cells = 0, n_p2 = 0, n_p1 = 0, n_vertices = 0;
+  DevBuf<double> vx;        // SoA vertex coords per cell: [6][n_cells] (x0,y0,x1,y1,x2,y2)
+  DevBuf<int32_t> p2;       // SoA [6][n_cells]
+  DevBuf<int32_t> p1;       // SoA [3][n_cells]
+};
+void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p22,
+                               double* mass, double* stiff);
+void launch_assemble_p1_scalar(hipStream_t s, const MeshDev& m, const Pattern& p11,
+                               double* stiff, double* mass);
+void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p12,
+                              const Pattern& p21, double* div, double* grad, double* divT);
+void launch_assemble_viscous_extra(hipStream_t s, const MeshDev& m, const Pattern& p22,
+                                   double* extra);
+// J(2x2 blocks) = L (scalar) (x) I_2 [+ cv_extra * E]  then  += cc * conv'(u)
+void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double* E,
+                          double cvE, double* J);
+void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
+                                const double* u, double cc, double* J);
+void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
+                                double* b);
+// diag extraction: d[(i,a)] = 1 / A_ii[a][a]  (mask rows -> 1)
+void launch_inv_diag(hipStream_t s, const BlockMat& A, int nv, const uint8_t* rowmask,
+                     double* dinv);
+
+// vector kernels (n = number of doubles)
+void launch_axpby(hipStream_t s, int64_t n, double a, const double* x, double b, const double* y,
+                  double* z);                                     // z = a x + b y
+void launch_lincomb3(hipStream_t s, int64_t n, double a, const double* x, double b,
+                     const double* y, double c, const double* z, double* out);
+void launch_scale_combine(hipStream_t s, int nnz, double a, const double* A, double b,
+                          const double* B, double* C);            // C = a A + b B (values)
+void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, double* parts);
+void launch_set_bc_residual(hipStream_t s, int nbc, const int32_t* dofs, const double* g,
+                            const double* x, double* b);          // b[d] = x[d] - g[d]
+void launch_set_values(hipStream_t s, int nbc, const int32_t* dofs, const double* g, double* x);
+void launch_fill_mask(hipStream_t s, int nbc, const int32_t* dofs, uint8_t* mask);
+void launch_mask_zero(hipStream_t s, int64_t n, const uint8_t* mask, double* x);
+void launch_add_scalar(hipStream_t s, int64_t n, double a, double* x);
+
+// Krylov scratch + drivers
+struct KrylovWork {
+  int64_t n = 0;
+  DevBuf<double> r, rhat, p, v, s, t, phat, shat, z, q;
+  DevBuf<double> parts;     // [8][kParts]
+  DevBuf<double> scal;      // device scalars
+  double* h_parts = nullptr;   // pinned host [8][kParts]
+  void ensure(int64_t n_);
+  ~KrylovWork();
+};
+
+struct LinOp {
+  const BlockMat* A = nullptr;
+  int nv = 1;
+  const uint8_t* rowmask = nullptr;
+  int maskmode = MASK_NONE;
+  const double* dinv = nullptr;     // Jacobi
+};
+
+// Jacobi-preconditioned BiCGStab; x holds the initial guess on entry
+int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
+             const nsfem_krylov_opts& o, nsfem_solve_info& info);
+// Jacobi-preconditioned CG (rowmask in MASK_ZERO mode => symmetric elimination);
+// project_mean: remove the mean of residuals (singular Neumann problem)
+int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
+        const nsfem_krylov_opts& o, nsfem_solve_info& info, bool project_mean);
+
+double host_sum_parts(hipStream_t s, KrylovWork& w, int which);   // sync + sum
+
+}  // namespace nsfem
+
+// the context
+struct nsfem_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  nsfem::MeshDev mesh;
+  nsfem::Pattern p22, p11, p12, p21;
+  nsfem::BlockMat M2, K2, Ap, Mp, Dv, Gr, DT, L, J, E;   // constant + per-step operators
+  bool have_E = false;
+  int traction_form = 0;
+  double coef[6] = {1.0, 1.0, 1.0, NAN, NAN, NAN};
+  double alpha[3] = {1.0, -1.0, 0.0};
+  double k = 1.0;
+  bool L_dirty = true;
+  nsfem::DevBuf<double> state[NSFEM_N_SLOTS];
+  bool have_body_force = false, have_traction = false;
+  // Dirichlet data
+  int nbc_v = 0, nbc_p = 0;
+  nsfem::DevBuf<int32_t> bc_v_dofs, bc_p_dofs;
+  nsfem::DevBuf<double> bc_v_vals, bc_p_vals;
+  nsfem::DevBuf<uint8_t> mask_v, mask_p;
+  // per-system work vectors
+  nsfem::DevBuf<double> rhs_v, rhs_p, dx_v, gconst, tmp_v, tmp_p, dinv_v, dinv_p, dinv_m;
+  bool dinv_p_ready = false, dinv_m_ready = false;
+  nsfem::KrylovWork kw;
+  int assembled_system = -1;
+  double area = 0.0;
+};

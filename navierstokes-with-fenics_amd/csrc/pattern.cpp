@@ -1,0 +1,113 @@
+// Host-side sparsity pattern + slot-map construction (what dolfin's
+// SparsityPatternBuilder / TensorLayout do inside FunctionSpace assembly in the
+// reference: implicit in every dlfn.*VariationalSolver, e.g.
+// source/ns_ipcs_solver.py:136-147).  Runs once per mesh at nsfem_create().
+#include "nsfem_internal.hpp"
+#include <algorithm>
+#include <numeric>
+
+namespace nsfem {
+
+void build_pattern(int n_rows, int n_cols, int n_cells, const int32_t* rowmap, int nr,
+                   const int32_t* colmap, int nc, bool want_diag, HostPattern& out) {
+  out.n_rows = n_rows;
+  out.n_cols = n_cols;
+  out.nr = nr;
+  out.nc = nc;
+  // 1. count candidate columns per row
+  std::vector<int64_t> start((size_t)n_rows + 1, 0);
+  for (int c = 0; c < n_cells; ++c)
+    for (int i = 0; i < nr; ++i) {
+      int r = rowmap[(size_t)c * nr + i];
+      if (r < 0 || r >= n_rows) throw Error(NSFEM_ERR_ARG, "dof map entry out of range (rows)");
+      start[(size_t)r + 1] += nc;
+    }
+  for (int r = 0; r < n_rows; ++r) start[r + 1] += start[r];
+  std::vector<int32_t> cand((size_t)start[n_rows]);
+  std::vector<int64_t> fill(start.begin(), start.end() - 1);
+  for (int c = 0; c < n_cells; ++c)
+    for (int i = 0; i < nr; ++i) {
+      int r = rowmap[(size_t)c * nr + i];
+      int64_t& f = fill[r];
+      for (int j = 0; j < nc; ++j) {
+        int cc = colmap[(size_t)c * nc + j];
+        if (cc < 0 || cc >= n_cols) throw Error(NSFEM_ERR_ARG, "dof map entry out of range (cols)");
+        cand[f++] = cc;
+      }
+    }
+  // 2. sort + unique per row
+  out.rowptr.assign((size_t)n_rows + 1, 0);
+  for (int r = 0; r < n_rows; ++r) {
+    auto b = cand.begin() + start[r], e = cand.begin() + start[r + 1];
+    std::sort(b, e);
+    auto u = std::unique(b, e);
+    out.rowptr[r + 1] = (int32_t)(u - b);
+  }
+  int64_t total = 0;
+  for (int r = 0; r < n_rows; ++r) {
+    int32_t len = out.rowptr[r + 1];
+    out.rowptr[r] = (int32_t)total;
+    total += len;
+    if (total > INT32_MAX) throw Error(NSFEM_ERR_ARG, "pattern exceeds int32 nnz");
+  }
+  out.rowptr[n_rows] = (int32_t)total;
+  out.col.resize((size_t)total);
+  for (int r = 0; r < n_rows; ++r) {
+    int32_t len = out.rowptr[r + 1] - out.rowptr[r];
+    std::copy(cand.begin() + start[r], cand.begin() + start[r] + len,
+              out.col.begin() + out.rowptr[r]);
+  }
+  std::vector<int32_t>().swap(cand);
+  // 3. diagonal positions
+  out.diag.clear();
+  if (want_diag) {
+    out.diag.assign((size_t)n_rows, -1);
+    for (int r = 0; r < n_rows; ++r) {
+      auto b = out.col.begin() + out.rowptr[r], e = out.col.begin() + out.rowptr[r + 1];
+      auto it = std::lower_bound(b, e, r);
+      if (it != e && *it == r) out.diag[r] = (int32_t)(it - out.col.begin());
+    }
+  }
+  // 4. slot map, SoA [nr*nc][n_cells]
+  out.slot.resize((size_t)n_cells * nr * nc);
+  for (int c = 0; c < n_cells; ++c)
+    for (int i = 0; i < nr; ++i) {
+      int r = rowmap[(size_t)c * nr + i];
+      auto b = out.col.begin() + out.rowptr[r], e = out.col.begin() + out.rowptr[r + 1];
+      for (int j = 0; j < nc; ++j) {
+        int cc = colmap[(size_t)c * nc + j];
+        auto it = std::lower_bound(b, e, cc);
+        out.slot[(size_t)(i * nc + j) * n_cells + c] = (int32_t)(it - out.col.begin());
+      }
+    }
+}
+
+// 7-point, degree-5 Radon rule on the reference triangle (weights sum to 1/2) and
+// the P2 / P1 Lagrange tables at its points.
+void fill_quad_tables(QuadTables& t) {
+  const double s15 = std::sqrt(15.0);
+  const double a1 = (6.0 - s15) / 21.0, a2 = (6.0 + s15) / 21.0;
+  const double w1 = (155.0 - s15) / 2400.0, w2 = (155.0 + s15) / 2400.0;
+  const double pts[7][2] = {{1.0 / 3.0, 1.0 / 3.0},
+                            {a1, a1}, {1.0 - 2.0 * a1, a1}, {a1, 1.0 - 2.0 * a1},
+                            {a2, a2}, {1.0 - 2.0 * a2, a2}, {a2, 1.0 - 2.0 * a2}};
+  const double wts[7] = {9.0 / 80.0, w1, w1, w1, w2, w2, w2};
+  const double dl[3][2] = {{-1.0, -1.0}, {1.0, 0.0}, {0.0, 1.0}};
+  const int pr[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+  for (int q = 0; q < 7; ++q) {
+    t.w[q] = wts[q];
+    double l[3] = {1.0 - pts[q][0] - pts[q][1], pts[q][0], pts[q][1]};
+    for (int i = 0; i < 3; ++i) {
+      t.phi1[q][i] = l[i];
+      t.phi2[q][i] = l[i] * (2.0 * l[i] - 1.0);
+      for (int d = 0; d < 2; ++d) t.dphi2[q][i][d] = (4.0 * l[i] - 1.0) * dl[i][d];
+    }
+    for (int e = 0; e < 3; ++e) {
+      int a = pr[e][0], b = pr[e][1];
+      t.phi2[q][3 + e] = 4.0 * l[a] * l[b];
+      for (int d = 0; d < 2; ++d) t.dphi2[q][3 + e][d] = 4.0 * (l[a] * dl[b][d] + l[b] * dl[a][d]);
+    }
+  }
+}
+
+}  // namespace nsfem

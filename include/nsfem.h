@@ -177,6 +177,12 @@ int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info
 int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info);
 /* replaces _advance_solution (ns_solver_base.py:1012-1016, ns_ipcs_solver.py:35-43) */
 int nsfem_advance(nsfem_ctx* ctx, int scheme /* 0 ipcs, 1 bdf */);
+/* L2 projection solve  M x = b  (no Dirichlet rows) on the velocity (field 0, both
+ * components, b/x node-interleaved) or pressure (field 1) space; replaces the
+ * mass-matrix LU inside dlfn.project (ns_solver_base.py:1151,1168).  b = int f phi_i
+ * is supplied by the caller. */
+int nsfem_mass_solve(nsfem_ctx* ctx, int field, const double* b, double* x,
+                     const nsfem_krylov_opts* opts, nsfem_solve_info* info);
 /* mean-pressure shift (ns_solver_base.py:1190-1203): p -= (int p / |Omega| - target) */
 int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* mean_before);
 

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_assemble", "nsfem_residual_norm", "nsfem_get_rhs", "nsfem_solve",
     "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply",
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
-    "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize",
+    "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
 )
 
 
@@ -113,6 +113,8 @@ def load_library(path=None):
         "nsfem_shift_mean_pressure": (C.c_int, [vp, dbl, pd]),
         "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),
         "nsfem_synchronize": (C.c_int, [vp]),
+        "nsfem_mass_solve": (C.c_int, [vp, C.c_int, pd, pd, C.POINTER(KrylovOpts),
+                                       C.POINTER(SolveInfo)]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)      # AttributeError = missing export: fail loudly
@@ -249,6 +251,15 @@ class NsfemContext:
         out = C.c_double()
         self._check(self._lib.nsfem_shift_mean_pressure(self._h, float(target), C.byref(out)))
         return out.value
+
+    def mass_solve(self, field, b, rtol=1e-13, max_iter=2000):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.empty_like(b)
+        o = KrylovOpts(rtol, 0.0, max_iter, 0, 1, 0)
+        info = SolveInfo()
+        self._check(self._lib.nsfem_mass_solve(self._h, field, _dp(b), _dp(x), C.byref(o),
+                                               C.byref(info)))
+        return x
 
     def synchronize(self):
         self._check(self._lib.nsfem_synchronize(self._h))

@@ -1,0 +1,96 @@
+"""Dimensionless numbers -> equation coefficients.
+
+Restates ``EquationCoefficientHandler`` of the reference
+(source/auxiliary_classes.py:167-406; arithmetic at :251-306): convective 1,
+pressure 1, viscous 1/Re (or Ek/Ro, Ek, 1 in rotating frames), body force 1/Fr^2,
+Coriolis/Euler 1/Ro, 1/(Ek Re) or 1.  Pure host arithmetic.
+"""
+import math
+
+
+class EquationCoefficientHandler:
+    _names = (("Re", "Reynolds"), ("Fr", "Froude"), ("Ro", "Rossby"), ("Ek", "Ekman"))
+
+    def __init__(self, **kwargs):
+        self._dimensionless_numbers = dict()
+        for key, long_name in self._names:
+            assert not (key in kwargs and long_name in kwargs)
+            value = kwargs.get(key, kwargs.get(long_name))
+            if value is not None:
+                self._store(key, value)
+        self._closed = False
+
+    def _store(self, key, value):
+        assert math.isfinite(value) and value > 0.0
+        self._dimensionless_numbers[key] = value
+
+    def _compute_equation_coefficients(self):
+        n = self._dimensionless_numbers
+        rotating = "Ro" in n or "Ek" in n
+        if not rotating:
+            if "Re" not in n:  # pragma: no cover
+                raise RuntimeError()
+            rotation, viscous = None, 1.0 / n["Re"]
+        else:
+            if all(k in n for k in ("Ek", "Re", "Ro")):  # pragma: no cover
+                raise RuntimeError("Overconstrained parameter set.")
+            if "Ro" in n and "Re" in n:
+                rotation, viscous = 1.0 / n["Ro"], 1.0 / n["Re"]
+            elif "Ro" in n and "Ek" in n:
+                rotation, viscous = 1.0 / n["Ro"], n["Ek"] / n["Ro"]
+            elif "Ek" in n and "Re" in n:
+                rotation, viscous = 1.0 / (n["Ek"] * n["Re"]), 1.0 / n["Re"]
+            elif "Ek" in n:
+                rotation, viscous = 1.0, n["Ek"]
+            else:
+                rotation, viscous = 1.0 / n["Ro"], 1.0
+        self._equation_coefficients = dict(
+            convective_term=1.0, coriolis_term=rotation, euler_term=rotation, pressure_term=1.0,
+            viscous_term=viscous,
+            body_force_term=(1.0 / n["Fr"] ** 2 if "Fr" in n else None))
+
+    @property
+    def equation_coefficients(self):
+        self._compute_equation_coefficients()
+        return self._equation_coefficients
+
+    def close(self):
+        self._closed = True
+
+    def clear(self):
+        self._closed = False
+        self._dimensionless_numbers.clear()
+        if hasattr(self, "_equation_coefficients"):
+            self._equation_coefficients.clear()
+
+    def modify_dimensionless_number(self, key, value):
+        assert key in self._dimensionless_numbers
+        assert isinstance(value, float)
+        self._store(key, value)
+
+    def get_file_suffix(self):
+        assert len(self._dimensionless_numbers) > 0
+        return "".join("_" + k + "{:1.3e}".format(v) for k, v in self._dimensionless_numbers.items())
+
+    def __str__(self):
+        lines = ["dimensionless numbers:"]
+        lines += ["  {:4} = {:.3e}".format(k, v) for k, v in self._dimensionless_numbers.items()]
+        lines.append("equation coefficients:")
+        for k, v in self.equation_coefficients.items():
+            lines.append("  {:16} = {}".format(k, "None" if v is None else "{:.3e}".format(v)))
+        return "\n".join(lines)
+
+
+def _number_property(key):
+    def getter(self):
+        return self._dimensionless_numbers.get(key)
+
+    def setter(self, value):
+        assert self._closed is False
+        assert isinstance(value, float)
+        self._store(key, value)
+    return property(getter, setter)
+
+
+for _key in ("Re", "Fr", "Ek", "Ro"):
+    setattr(EquationCoefficientHandler, _key, _number_property(_key))

@@ -597,6 +597,34 @@ extern "C" int nsfem_advance(nsfem_ctx* ctx, int scheme) {
   API_END(ctx)
 }
 
+extern "C" int nsfem_mass_solve(nsfem_ctx* ctx, int field, const double* b, double* x,
+                                const nsfem_krylov_opts* opts, nsfem_solve_info* info) {
+  nsfem_solve_info local;
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && b && x && opts, "null argument");
+  NSFEM_REQUIRE(field == NSFEM_VELOCITY || field == NSFEM_PRESSURE, "bad field");
+  nsfem_solve_info& inf = info ? *info : local;
+  hipStream_t s = ctx->stream;
+  const bool vel = field == NSFEM_VELOCITY;
+  const int64_t n = vel ? nvel(ctx) : npre(ctx);
+  DevBuf<double> db, dx, dinv;
+  db.alloc((size_t)n);
+  dx.alloc((size_t)n);
+  dinv.alloc((size_t)n);
+  NSFEM_HIP(hipMemcpyAsync(db.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  dx.zero(s);
+  LinOp op;
+  op.A = vel ? &ctx->M2 : &ctx->Mp;
+  op.nv = vel ? 2 : 1;
+  launch_inv_diag(s, *op.A, op.nv, nullptr, dinv.p);
+  op.dinv = dinv.p;
+  int rc = pcg(s, ctx->kw, op, db.p, dx.p, *opts, inf, false);
+  if (rc != NSFEM_OK) throw Error(rc, "CG failed in the mass (projection) solve");
+  NSFEM_HIP(hipMemcpyAsync(x, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
 extern "C" int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* mean_before) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");

@@ -1,0 +1,90 @@
+"""``dolfin.Function``-like views on device-resident state.
+
+The reference hands ``dolfin.Function`` objects around (``solver.solution``,
+``.split()``, ``.vector()``; source/ns_solver_base.py:1205-1207,
+source/ns_ipcs_solver.py:241-247).  Here the values live in HBM inside the
+``nsfem_ctx``; these objects are handles that copy to/from the host on demand.
+"""
+import numpy as np
+
+
+class DeviceFunction:
+    """One field (velocity: node-interleaved P2^2, or pressure: P1) in one state slot."""
+
+    def __init__(self, solver, field, slot, name=None):
+        self._solver = solver
+        self.field = field            # "velocity" | "pressure"
+        self.slot = slot
+        self._name = name or field
+
+    def name(self):
+        return self._name
+
+    def rename(self, name, label=""):
+        self._name = name
+
+    def vector(self):
+        """Host copy of the coefficient vector."""
+        return self._solver._ctx.get_state(self.slot)
+
+    def assign(self, values):
+        if isinstance(values, DeviceFunction):
+            values = values.vector()
+        self._solver._ctx.set_state(self.slot, np.asarray(values, dtype=np.float64))
+
+    def dof_coordinates(self):
+        dm = self._solver._dofmap
+        return dm.p2_coords if self.field == "velocity" else dm.p1_coords
+
+    def nodal_values(self):
+        v = self.vector()
+        return v.reshape(-1, 2) if self.field == "velocity" else v
+
+    def __call__(self, point):
+        """Point evaluation (host side, brute-force cell search; for tests/diagnostics)."""
+        dm = self._solver._dofmap
+        mesh = dm.mesh
+        p = np.asarray(point, dtype=np.float64)[:2]
+        x = mesh.coords[mesh.cells.astype(np.int64)]
+        d = x[:, 1:] - x[:, :1]
+        det = d[:, 0, 0] * d[:, 1, 1] - d[:, 0, 1] * d[:, 1, 0]
+        r = p[None, :] - x[:, 0]
+        xi = (r[:, 0] * d[:, 1, 1] - r[:, 1] * d[:, 1, 0]) / det
+        eta = (-r[:, 0] * d[:, 0, 1] + r[:, 1] * d[:, 0, 0]) / det
+        inside = np.nonzero((xi > -1e-12) & (eta > -1e-12) & (xi + eta < 1.0 + 1e-12))[0]
+        if inside.size == 0:
+            raise RuntimeError("point outside of the mesh")
+        c = int(inside[0])
+        l = np.array([1.0 - xi[c] - eta[c], xi[c], eta[c]])
+        if self.field == "pressure":
+            return float(l @ self.vector()[dm.p1_dofmap[c]])
+        N = np.array([l[0] * (2 * l[0] - 1), l[1] * (2 * l[1] - 1), l[2] * (2 * l[2] - 1),
+                      4 * l[1] * l[2], 4 * l[0] * l[2], 4 * l[0] * l[1]])
+        return N @ self.nodal_values()[dm.p2_dofmap[c]]
+
+
+class MixedFunction:
+    """(velocity, pressure) pair standing in for a Function on the mixed space."""
+
+    def __init__(self, solver, velocity_slot, pressure_slot, name="solution"):
+        self._solver = solver
+        self._name = name
+        self._parts = (DeviceFunction(solver, "velocity", velocity_slot),
+                       DeviceFunction(solver, "pressure", pressure_slot))
+
+    def name(self):
+        return self._name
+
+    def split(self, deepcopy=False):
+        return self._parts
+
+    def sub(self, i):
+        return self._parts[i]
+
+    def vector(self):
+        """[velocity (node-interleaved) | pressure] host copy."""
+        return np.concatenate([p.vector() for p in self._parts])
+
+    def assign(self, other):
+        for mine, theirs in zip(self._parts, other.split()):
+            mine.assign(theirs)

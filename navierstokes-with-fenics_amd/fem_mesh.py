@@ -44,6 +44,9 @@ class Mesh:
         self.cell_edges = inv.reshape(-1, 3).astype(np.int32)
         self.edges = np.stack([ukey // nv, ukey % nv], axis=1).astype(np.int32)     # [ne, 2]
         self.edge_on_boundary = counts == 1
+        # one adjacent cell per edge (the only one for boundary edges)
+        self.edge_cell = np.empty(self.edges.shape[0], dtype=np.int32)
+        self.edge_cell[self.cell_edges.ravel()] = np.repeat(np.arange(c.shape[0], dtype=np.int32), 3)
         self._dim = 2
 
     # -- the slice of the dolfin.Mesh API the reference touches -----------------
@@ -67,6 +70,19 @@ class Mesh:
 
     def edge_midpoints(self):
         return 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])
+
+    def edge_normals(self, edge_ids):
+        """Unit normals of the given edges pointing away from their adjacent cell
+        (outward for boundary edges)."""
+        e = self.edges[edge_ids].astype(np.int64)
+        t = self.coords[e[:, 1]] - self.coords[e[:, 0]]
+        n = np.stack([t[:, 1], -t[:, 0]], axis=1)
+        n /= np.linalg.norm(n, axis=1)[:, None]
+        centroid = self.coords[self.cells[self.edge_cell[edge_ids]].astype(np.int64)].mean(axis=1)
+        mid = 0.5 * (self.coords[e[:, 0]] + self.coords[e[:, 1]])
+        flip = ((centroid - mid) * n).sum(axis=1) > 0.0
+        n[flip] *= -1.0
+        return n
 
     def hmin(self):
         e = self.coords[self.edges[:, 1]] - self.coords[self.edges[:, 0]]

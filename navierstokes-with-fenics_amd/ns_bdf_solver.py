@@ -1,0 +1,52 @@
+"""Monolithic fully implicit BDF-2 Taylor-Hood step on the MI355X.
+
+Same class name, constructor and hooks as the reference's
+``source/ns_bdf_solver.py`` (:8-126): Newton on the mixed residual
+
+  F = 1/k sum_i alpha_i (u_i, w) + c_c ((grad u) u, w) - c_p (p, div w)
+      + c_v (grad u, grad w) - c_p (div u, q) [+ tractions - body force]   (:68-85)
+
+with the exact Jacobian (:88) and dolfin's NewtonSolver control (:96-100).
+"""
+import _native as nat
+from bdf_time_stepping import BDFTimeStepping
+from ns_solver_base import InstationarySolverBase, WeakFormConvectiveTerm
+
+
+class ImplicitBDFSolver(InstationarySolverBase):
+    # NB: the reference writes ("_solver") -- a string, so its _setup_problem re-runs
+    # every step; a real tuple is used here.
+    _required_objects = ("_solver",)
+    _scheme_id = 1
+
+    def __init__(self, mesh, boundary_markers, form_convective_term, time_stepping, tol=1e-10,
+                 max_iter=50, device=0):
+        assert isinstance(time_stepping, BDFTimeStepping)
+        super().__init__(mesh, boundary_markers, form_convective_term, time_stepping, tol,
+                         max_iter, device=device)
+        self.last_step_info = None
+
+    def _setup_problem(self):
+        if not all(hasattr(self, attr) for attr in ("_Wh", "_solutions")):  # pragma: no cover
+            self._setup_function_spaces()
+        if self._form_convective_term is not WeakFormConvectiveTerm.standard_form:
+            raise NotImplementedError("only the standard convective form has device kernels")
+        if not all(hasattr(self, attr) for attr in ("_next_step_size", "_alpha")):
+            self._update_time_stepping_coefficients()
+        self._setup_boundary_conditions()
+        self._solver = nat.SYS_MONOLITHIC
+
+    def _step_options(self):
+        o = self._ctx.default_step_opts()
+        o.newton_atol = self._tol
+        o.newton_rtol = 10.0 * self._tol
+        o.newton_max_iter = self._maxiter
+        o.momentum.rtol = self.krylov_rtol
+        o.momentum.max_iter = self.krylov_max_iter
+        return o
+
+    def _solve_time_step(self):
+        try:
+            self.last_step_info = self._ctx.step_bdf(self._step_options())
+        except nat.NativeError as err:
+            raise RuntimeError(str(err))

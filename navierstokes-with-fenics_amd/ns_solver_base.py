@@ -1,0 +1,486 @@
+"""Solver surface of the MI355X implementation.
+
+Mirrors the classes and call order of the reference's ``source/ns_solver_base.py``
+(``SolverBase`` :59-870 and ``InstationarySolverBase`` :991-1207): the same
+constructor arguments, ``set_*`` methods with the same validity checks, the same
+boundary-condition tuples and enums, ``solve()`` / ``advance_time()`` /
+``solution`` / ``_solve_time_step()`` hooks -- but no UFL form is built.  The
+weak forms of the reference (terms :121-191, :370-399, :662-673) are integrated by
+the HIP element kernels behind the ctypes C ABI (``_native.py``,
+``include/nsfem.h``); ``_assemble_system()`` is the new explicit seam to them
+(SURVEY.md D1).  The device library is mandatory: no CPU fallback exists.
+"""
+import math
+from enum import Enum, auto
+
+import numpy as np
+
+import _native as nat
+import dlfn_compat as dlfn
+import fem_host
+from discrete_time import DiscreteTime
+from fem_function import MixedFunction
+from fem_mesh import FacetMarkers, Mesh, TaylorHoodDofMap
+
+
+class VelocityBCType(Enum):
+    no_slip = auto()
+    no_normal_flux = auto()
+    no_tangential_flux = auto()
+    constant = auto()
+    constant_component = auto()
+    function = auto()
+    function_component = auto()
+
+
+class PressureBCType(Enum):
+    constant = auto()
+    function = auto()
+    mean_value = auto()
+
+
+class TractionBCType(Enum):
+    constant = auto()
+    constant_component = auto()
+    function = auto()
+    function_component = auto()
+    free = auto()
+
+
+class WeakFormConvectiveTerm(Enum):
+    standard_form = auto()
+    rotational_form = auto()
+    divergence_form = auto()
+    skew_symmetric_form = auto()
+
+
+class WeakFormViscousTerm(Enum):
+    reduced_form = auto()
+    traction_form = auto()
+
+
+_CONVECTIVE = {"standard": WeakFormConvectiveTerm.standard_form,
+               "rotational": WeakFormConvectiveTerm.rotational_form,
+               "divergence": WeakFormConvectiveTerm.divergence_form,
+               "skew_symmetric": WeakFormConvectiveTerm.skew_symmetric_form}
+_VISCOUS = {"standard": WeakFormViscousTerm.reduced_form,
+            "reduced": WeakFormViscousTerm.reduced_form,
+            "traction": WeakFormViscousTerm.traction_form}
+_EXPRESSION_TYPES = (dlfn.Expression, dlfn.UserExpression)
+_COEFFICIENT_KEYS = ("convective_term", "coriolis_term", "euler_term", "pressure_term",
+                     "viscous_term", "body_force_term")
+
+
+class SolverBase:
+    """P2-P1 Taylor-Hood discretisation of the incompressible Navier-Stokes
+    equations; state, operators and solves live on one MI355X."""
+
+    _sub_space_association = {0: "velocity", 1: "pressure"}
+    _field_association = {value: key for key, value in _sub_space_association.items()}
+
+    def __init__(self, mesh, boundary_markers, form_convective_term="standard",
+                 form_viscous_term="reduced", device=0):
+        assert isinstance(mesh, Mesh)
+        assert isinstance(boundary_markers, FacetMarkers)
+        assert isinstance(form_convective_term, str) and form_convective_term.lower() in _CONVECTIVE
+        assert isinstance(form_viscous_term, str) and form_viscous_term.lower() in _VISCOUS
+        self._mesh = mesh
+        self._boundary_markers = boundary_markers
+        self._space_dim = mesh.geometry().dim()
+        assert boundary_markers.dim() == self._space_dim - 1
+        self._n_cells = mesh.num_cells()
+        self._form_convective_term = _CONVECTIVE[form_convective_term.lower()]
+        self._form_viscous_term = _VISCOUS[form_viscous_term.lower()]
+        self._p_deg = 1
+        self._device = device
+
+    # ------------------------------------------------------------------ setters
+    def set_equation_coefficients(self, input_coefficients):
+        """Coefficients of the PDE terms; may be called again to update the values
+        (reference: source/ns_solver_base.py:829-855)."""
+        assert isinstance(input_coefficients, dict)
+        assert all(key in _COEFFICIENT_KEYS for key in input_coefficients)
+        if not hasattr(self, "_equation_coefficients"):
+            self._equation_coefficients = {key: None for key in _COEFFICIENT_KEYS}
+            for key, value in input_coefficients.items():
+                if value is not None:
+                    assert isinstance(value, float) and math.isfinite(value) and value > 0.0
+                self._equation_coefficients[key] = value
+        else:
+            for key, value in self._equation_coefficients.items():
+                assert key in input_coefficients
+                if value is not None:
+                    assert input_coefficients[key] is not None
+                    self._equation_coefficients[key] = float(input_coefficients[key])
+        self._push_coefficients()
+
+    def set_body_force(self, body_force):
+        assert isinstance(body_force, _EXPRESSION_TYPES + (dlfn.Constant,))
+        assert body_force.value_rank() == 1
+        if isinstance(body_force, dlfn.Constant):
+            assert body_force.ufl_shape[0] == self._space_dim
+        self._body_force = body_force
+        self._body_force.rename("body_force", "")
+
+    def set_angular_velocity(self, angular_velocity):
+        raise NotImplementedError("rotating frames (Coriolis / Euler terms) are outside the "
+                                  "hot-path scope of this build (SURVEY.md section 8f N3)")
+
+    def set_periodic_boundary_conditions(self, constrained_domain, constrained_boundary_ids):
+        assert isinstance(constrained_domain, dlfn.SubDomain)
+        assert isinstance(constrained_boundary_ids, (tuple, list))
+        assert all(isinstance(i, int) for i in constrained_boundary_ids)
+        self._constrained_domain = constrained_domain
+        self._constrained_boundary_ids = constrained_boundary_ids
+
+    def _check_boundary_condition_format(self, bc, internal_constraint=False):
+        assert isinstance(bc, (list, tuple)) and len(bc) >= 2
+        assert isinstance(bc[0], (VelocityBCType, PressureBCType, TractionBCType))
+        rank = 0 if isinstance(bc[0], PressureBCType) else 1
+        if bc[0] is not PressureBCType.mean_value:
+            assert isinstance(bc[1], int)
+            known = self._boundary_markers.ids(boundary_only=not internal_constraint)
+            assert bc[1] in known, "Boundary id {0} was not found in the boundary markers.".format(bc[1])
+        if rank == 0:
+            assert isinstance(bc[2], _EXPRESSION_TYPES + (float,)) or bc[2] is None
+            if isinstance(bc[2], _EXPRESSION_TYPES):
+                assert bc[2].value_rank() == 0
+        elif len(bc) == 3:
+            assert isinstance(bc[2], _EXPRESSION_TYPES + (tuple, list)) or bc[2] is None
+            if isinstance(bc[2], _EXPRESSION_TYPES):
+                assert bc[2].value_rank() == 1
+            elif isinstance(bc[2], (tuple, list)):
+                assert len(bc[2]) == self._space_dim and all(isinstance(x, float) for x in bc[2])
+        elif len(bc) == 4:
+            assert isinstance(bc[2], int) and bc[2] < self._space_dim
+            assert isinstance(bc[3], _EXPRESSION_TYPES + (float,)) or bc[3] is None
+            if isinstance(bc[3], _EXPRESSION_TYPES):
+                assert bc[3].value_rank() == 0
+
+    def set_boundary_conditions(self, bcs, internal_constraints=None):
+        """``bcs = [(Type, boundary_id, value), (Type, boundary_id, component, value)]``
+        with the validity / conflict rules of source/ns_solver_base.py:722-827."""
+        assert isinstance(bcs, (list, tuple))
+        for bc in bcs:
+            self._check_boundary_condition_format(bc)
+        groups = {VelocityBCType: [], TractionBCType: [], PressureBCType: []}
+        ids = {VelocityBCType: set(), TractionBCType: set(), PressureBCType: set()}
+        for bc in bcs:
+            if hasattr(self, "_constrained_domain"):
+                assert bc[1] not in self._constrained_boundary_ids
+            groups[type(bc[0])].append(bc)
+            ids[type(bc[0])].add(bc[1])
+        velocity_bcs, traction_bcs, pressure_bcs = (groups[VelocityBCType], groups[TractionBCType],
+                                                    groups[PressureBCType])
+        if not hasattr(self, "_constrained_domain"):
+            assert len(velocity_bcs) > 0
+        # velocity and traction on one boundary part: different components only
+        component_velocity = (VelocityBCType.no_normal_flux, VelocityBCType.no_tangential_flux,
+                              VelocityBCType.constant_component, VelocityBCType.function_component)
+        component_traction = (TractionBCType.constant_component, TractionBCType.function_component)
+        for bndry_id in ids[VelocityBCType] & ids[TractionBCType]:
+            vbc = next(bc for bc in velocity_bcs if bc[1] == bndry_id)
+            tbc = next(bc for bc in traction_bcs if bc[1] == bndry_id)
+            assert vbc[0] in component_velocity and tbc[0] in component_traction
+            assert tbc[2] != vbc[2]
+        if internal_constraints is not None:
+            assert isinstance(internal_constraints, (list, tuple))
+            taken = ids[VelocityBCType] | ids[TractionBCType] | ids[PressureBCType]
+            for bc in internal_constraints:
+                self._check_boundary_condition_format(bc, True)
+                assert bc[1] not in taken
+                if isinstance(bc[0], VelocityBCType):
+                    velocity_bcs.append(bc)
+                elif isinstance(bc[0], PressureBCType):
+                    pressure_bcs.append(bc)
+                else:  # pragma: no cover
+                    raise NotImplementedError()
+        self._velocity_bcs = velocity_bcs
+        if traction_bcs:
+            self._traction_bcs = traction_bcs
+            self._form_viscous_term = WeakFormViscousTerm.traction_form
+        if pressure_bcs:
+            self._pressure_bcs = pressure_bcs
+
+    # ------------------------------------------------------------- device setup
+    def _setup_function_spaces(self):
+        """Taylor-Hood dof maps + device context (reference: :501-524)."""
+        if hasattr(self, "_constrained_domain"):
+            raise NotImplementedError("periodic constraints are not built yet "
+                                      "(SURVEY.md section 8f N3)")
+        self._dofmap = TaylorHoodDofMap(self._mesh)
+        dm = self._dofmap
+        self._ctx = nat.NsfemContext(self._mesh.coords, self._mesh.cells, dm.p2_dofmap,
+                                     dm.p1_dofmap, dm.n_p2, dm.n_p1, device=self._device)
+        self._n_dofs = dm.n_dofs
+        self._Wh = dm
+        print("Number of cells {0}, number of DoFs: {1}".format(self._n_cells, self._n_dofs))
+        self._push_coefficients()
+
+    def _push_coefficients(self):
+        if hasattr(self, "_ctx") and hasattr(self, "_equation_coefficients"):
+            c = self._equation_coefficients
+            self._ctx.set_coeffs(c["convective_term"], c["pressure_term"], c["viscous_term"],
+                                 c["body_force_term"], c["coriolis_term"], c["euler_term"])
+
+    # Dirichlet sets -------------------------------------------------------------
+    def _velocity_dirichlet_arrays(self):
+        """(dofs, values) of all velocity conditions at the current expression time;
+        list order is kept so that later conditions win at shared nodes."""
+        dm = self._dofmap
+        dofs, vals = [], []
+
+        def add(nodes, comp, v):
+            dofs.append(2 * nodes + comp)
+            vals.append(np.broadcast_to(v, nodes.shape).astype(np.float64))
+
+        for bc in getattr(self, "_velocity_bcs", []):
+            bc_type, bndry_id = bc[0], bc[1]
+            nodes = np.unique(dm.facet_p2_nodes(self._boundary_markers.facets_with_id(bndry_id)))
+            X = dm.p2_coords[nodes]
+            if bc_type is VelocityBCType.no_slip:
+                for comp in range(2):
+                    add(nodes, comp, 0.0)
+            elif bc_type in (VelocityBCType.no_normal_flux, VelocityBCType.no_tangential_flux):
+                normal = np.array(fem_host.boundary_normal(self._mesh, self._boundary_markers, bndry_id))
+                k = int(np.abs(normal).argmax())
+                assert abs(abs(normal[k]) - 1.0) < 5.0e-14, "boundary must be axis aligned"
+                comps = (k,) if bc_type is VelocityBCType.no_normal_flux else tuple(
+                    d for d in range(2) if d != k)
+                for comp in comps:
+                    add(nodes, comp, 0.0)
+            elif bc_type is VelocityBCType.constant:
+                assert isinstance(bc[2], (tuple, list))
+                for comp in range(2):
+                    add(nodes, comp, bc[2][comp])
+            elif bc_type is VelocityBCType.constant_component:
+                assert isinstance(bc[3], float)
+                add(nodes, bc[2], bc[3])
+            elif bc_type is VelocityBCType.function:
+                v = dlfn.evaluate(bc[2], X)
+                for comp in range(2):
+                    add(nodes, comp, v[:, comp])
+            elif bc_type is VelocityBCType.function_component:
+                add(nodes, bc[2], dlfn.evaluate(bc[3], X))
+            else:  # pragma: no cover
+                raise RuntimeError()
+        if not dofs:
+            return np.zeros(0, dtype=np.int32), np.zeros(0)
+        return np.concatenate(dofs).astype(np.int32), np.concatenate(vals)
+
+    def _pressure_dirichlet_arrays(self):
+        dm = self._dofmap
+        dofs, vals = [], []
+        for bc in getattr(self, "_pressure_bcs", []):
+            assert len(bc) == 3
+            bc_type, bndry_id, value = bc
+            if bc_type is PressureBCType.mean_value:
+                assert bndry_id is None and isinstance(value, float)
+                self._mean_pressure_value = value
+                continue
+            nodes = np.unique(dm.facet_p1_nodes(self._boundary_markers.facets_with_id(bndry_id)))
+            if bc_type is PressureBCType.constant:
+                assert isinstance(value, float)
+            v = dlfn.evaluate(value, dm.p1_coords[nodes])
+            dofs.append(nodes)
+            vals.append(v)
+        if not dofs:
+            return np.zeros(0, dtype=np.int32), np.zeros(0)
+        return np.concatenate(dofs).astype(np.int32), np.concatenate(vals)
+
+    def _setup_boundary_conditions(self):
+        """Builds the Dirichlet dof sets and ships them to the device
+        (reference: DirichletBC lists, :526-660)."""
+        assert hasattr(self, "_ctx")
+        vd, vv = self._velocity_dirichlet_arrays()
+        pd, pv = self._pressure_dirichlet_arrays()
+        if vd.size == 0 and pd.size == 0:
+            assert hasattr(self, "_constrained_domain")
+        self._dirichlet_bcs = {"velocity": (vd, vv), "pressure": (pd, pv)}
+        self._ctx.set_dirichlet(nat.VELOCITY, vd, vv)
+        self._ctx.set_dirichlet(nat.PRESSURE, pd, pv)
+        self._ctx.set_viscous_form(self._form_viscous_term is WeakFormViscousTerm.traction_form)
+        self._push_natural_terms()
+
+    def _push_natural_terms(self):
+        """Body force (nodal P2 interpolant) and boundary tractions -> device vectors
+        (reference: _add_body_forces :158-171, _add_boundary_tractions :121-156)."""
+        dm = self._dofmap
+        if hasattr(self, "_body_force"):
+            assert self._equation_coefficients["body_force_term"] is not None
+            f = dlfn.evaluate(self._body_force, dm.p2_coords)
+            self._ctx.set_state(nat.BODY_FORCE, np.ascontiguousarray(f).ravel())
+        if hasattr(self, "_traction_bcs"):
+            total = np.zeros(dm.n_velocity)
+            for bc in self._traction_bcs:
+                bc_type, bndry_id = bc[0], bc[1]
+                if bc_type is TractionBCType.free:
+                    continue
+                facets = self._boundary_markers.facets_with_id(bndry_id)
+
+                def nodal(X, bc=bc, bc_type=bc_type):
+                    out = np.zeros((X.shape[0], 2))
+                    if bc_type in (TractionBCType.constant, TractionBCType.function):
+                        out[:] = dlfn.evaluate(bc[2], X)
+                    else:
+                        out[:, bc[2]] = dlfn.evaluate(bc[3], X)
+                    return out
+                total += fem_host.traction_vector(dm, facets, nodal)
+            self._ctx.set_state(nat.TRACTION, total)
+
+    # ----------------------------------------------------------------- accessors
+    @property
+    def field_association(self):
+        return self._field_association
+
+    @property
+    def sub_space_association(self):
+        return self._sub_space_association
+
+    @property
+    def solution(self):
+        return self._solution
+
+    def solve(self):  # pragma: no cover
+        raise NotImplementedError("You are calling a purely virtual method.")
+
+
+class InstationarySolverBase(SolverBase):
+    """Time-dependent solver base: owns the time levels and the per-step driver
+    (reference: source/ns_solver_base.py:991-1207)."""
+
+    _scheme_id = 0     # 0: IPCS slot rotation, 1: monolithic BDF
+
+    def __init__(self, mesh, boundary_markers, form_convective_term, time_stepping, tol=1e-10,
+                 max_iter=50, device=0):
+        super().__init__(mesh, boundary_markers, form_convective_term, device=device)
+        assert isinstance(max_iter, int) and max_iter > 0
+        assert isinstance(tol, float) and tol > 0.0
+        assert isinstance(time_stepping, DiscreteTime)
+        assert hasattr(time_stepping, "n_levels")
+        self._time_stepping = time_stepping
+        self._tol = tol
+        self._maxiter = max_iter
+        # Krylov options of the device solves (the reference uses sparse LU instead)
+        self.krylov_rtol = 1.0e-12
+        self.krylov_max_iter = 20000
+
+    # -- state ------------------------------------------------------------------
+    def _setup_function_spaces(self):
+        super()._setup_function_spaces()
+        levels = ((nat.U0, nat.P), (nat.U1, nat.P_OLD), (nat.U2, nat.P2_OLD))
+        self._solutions = []
+        for i in range(self._time_stepping.n_levels() + 1):
+            name = i * "old" + (i > 0) * "_" + "solution"
+            self._solutions.append(MixedFunction(self, *levels[i], name=name))
+
+    def _advance_solution(self):
+        """solutions[2] <- solutions[1] <- solutions[0] on the device."""
+        self._ctx.advance(self._scheme_id)
+
+    def _setup_problem(self):  # pragma: no cover
+        raise NotImplementedError("You are calling a purely virtual method.")
+
+    def _solve_time_step(self):  # pragma: no cover
+        raise NotImplementedError("You are calling a purely virtual method.")
+
+    def _update_time_stepping_coefficients(self):
+        """alpha (first derivative) and the step size k -> device
+        (reference: source/ns_ipcs_solver.py:210-227, source/ns_bdf_solver.py:108-126)."""
+        self._next_step_size = self._time_stepping.get_next_step_size()
+        self._alpha = list(self._time_stepping.coefficients(derivative=1))
+        assert len(self._alpha) == 3
+        self._ctx.set_bdf(self._alpha, self._next_step_size)
+
+    def _assemble_system(self, system, new_step=False):
+        """Explicit assembly seam (new): integrates matrix and residual /
+        right-hand side of ``system`` from the current device state.  The reference
+        does this implicitly inside ``dolfin.*VariationalSolver.solve()``."""
+        self._ctx.assemble(system, new_step)
+
+    def _set_time(self, next_time=None, current_time=None):
+        """Move every time-dependent Expression (boundary values, tractions, body
+        force) to t_{n+1} and refresh the device copies of their values
+        (reference: :1033-1104)."""
+        next_time = self._time_stepping.next_time if next_time is None else next_time
+        current_time = self._time_stepping.current_time if current_time is None else current_time
+        assert isinstance(next_time, float) and isinstance(current_time, float)
+        assert next_time > current_time
+        touched = []
+
+        def move(value):
+            if dlfn.is_time_dependent(value):
+                if "time" in value._params:
+                    value.time = next_time
+                else:
+                    value.t = next_time
+                touched.append(value)
+
+        for name in ("_velocity_bcs", "_pressure_bcs", "_traction_bcs"):
+            for bc in getattr(self, name, []):
+                move(bc[-1])
+        if hasattr(self, "_body_force"):
+            move(self._body_force)
+        if touched:
+            vd, vv = self._velocity_dirichlet_arrays()
+            pd, pv = self._pressure_dirichlet_arrays()
+            self._dirichlet_bcs = {"velocity": (vd, vv), "pressure": (pd, pv)}
+            self._ctx.set_dirichlet(nat.VELOCITY, vd, vv)
+            self._ctx.set_dirichlet(nat.PRESSURE, pd, pv)
+            self._push_natural_terms()
+
+    def advance_time(self):
+        self._advance_solution()
+
+    def _project(self, condition, field):
+        """L2 projection onto P2^2 / P1: host quadrature of the load vector, mass solve
+        on the device (reference: dlfn.project at :1151,1168)."""
+        dm = self._dofmap
+        if field == "velocity":
+            if isinstance(condition, (tuple, list)):
+                assert len(condition) == self._space_dim and all(isinstance(x, float) for x in condition)
+                return np.tile(np.asarray(condition, dtype=np.float64), dm.n_p2)
+            assert condition.value_rank() == 1
+            b = fem_host.load_vector(self._mesh, dm.p2_dofmap, dm.n_p2,
+                                     lambda X: dlfn.evaluate(condition, X), degree=2, n_comp=2)
+            return self._ctx.mass_solve(nat.VELOCITY, b)
+        if isinstance(condition, float):
+            return np.full(dm.n_p1, condition)
+        assert condition.value_rank() == 0
+        b = fem_host.load_vector(self._mesh, dm.p1_dofmap, dm.n_p1,
+                                 lambda X: dlfn.evaluate(condition, X), degree=1, n_comp=1)
+        return self._ctx.mass_solve(nat.PRESSURE, b)
+
+    def set_initial_conditions(self, initial_conditions):
+        """``{"velocity": tuple | Expression, "pressure": float | Expression}``; both
+        the new and the old time level are initialised (reference: :1123-1171)."""
+        assert isinstance(initial_conditions, dict) and "velocity" in initial_conditions
+        if not all(hasattr(self, attr) for attr in ("_Wh", "_solutions")):
+            self._setup_function_spaces()
+        velocity_condition = initial_conditions["velocity"]
+        assert isinstance(velocity_condition, _EXPRESSION_TYPES + (tuple, list))
+        u0 = self._project(velocity_condition, "velocity")
+        for level in (0, 1):
+            self._solutions[level].sub(0).assign(u0)
+        if "pressure" in initial_conditions:
+            pressure_condition = initial_conditions["pressure"]
+            assert isinstance(pressure_condition, _EXPRESSION_TYPES + (float,))
+            p0 = self._project(pressure_condition, "pressure")
+            for level in (0, 1):
+                self._solutions[level].sub(1).assign(p0)
+
+    def solve(self):
+        """One time step (reference call order, :1174-1203)."""
+        if not all(hasattr(self, attr) for attr in self._required_objects):
+            self._setup_problem()
+        self._set_time()
+        # the reference tests a bound method here (always true): refresh every step
+        self._update_time_stepping_coefficients()
+        self._solve_time_step()
+        if hasattr(self, "_mean_pressure_value"):
+            # p <- p - (mean(p) - target); exact for the reference's P1 projection
+            self._last_mean_pressure = self._ctx.shift_mean_pressure(self._mean_pressure_value)
+
+    @property
+    def solution(self):
+        return self._solutions[0]

@@ -1,0 +1,264 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, plus size-independent properties at BASELINE.json's full size.
+
+Tolerances (north_star): 1e-10 relative for linear (Stokes) steps, 1e-6 relative after
+the nonlinear loop; operators and residuals are compared to round-off (1e-13 relative).
+The Krylov solves use rtol 1e-12/1e-13, the oracle sparse LU.
+"""
+import numpy as np
+import pytest
+
+import _native as nat
+import fem_oracle as fo
+from gpu_common import box, cavity_bc, context, rel, velocity_bc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup16():
+    mesh, dm, marks = box(16, 12, p1=(1.5, 1.0))
+    ctx = context(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    yield mesh, dm, marks, ctx, s
+    ctx.close()
+
+
+def test_constant_operators_match_oracle(setup16):
+    _, _, _, ctx, s = setup16
+    pairs = [(nat.OP_MASS_P2, s.mass_p2()), (nat.OP_STIFF_P2, s.stiffness_p2()),
+             (nat.OP_STIFF_P1, s.stiffness_p1()), (nat.OP_MASS_P1, s.mass_p1()),
+             (nat.OP_DIV, s.divergence()), (nat.OP_GRAD, s.pressure_gradient()),
+             (nat.OP_DIVT, s.divergence().T.tocsr())]
+    for op, ref in pairs:
+        A = ctx.operator_csr(op)
+        assert A.shape == ref.shape
+        assert abs(A - ref).max() <= 1e-13 * abs(ref).max(), op
+    ctx.set_viscous_form(True)
+    E = ctx.operator_csr(nat.OP_VISCOUS_EXTRA)
+    K = fo.sp.kron(s.stiffness_p2(), fo.sp.identity(2))
+    ref = s.vector_stiffness(traction_form=True) - K
+    assert abs(E - ref).max() <= 1e-13 * abs(K).max()
+    ctx.set_viscous_form(False)
+
+
+def test_spmv_kernels_match_scipy(setup16):
+    _, dm, _, ctx, s = setup16
+    rng = np.random.default_rng(11)
+    for op, ref in [(nat.OP_DIV, s.divergence()), (nat.OP_GRAD, s.pressure_gradient()),
+                    (nat.OP_STIFF_P1, s.stiffness_p1()), (nat.OP_MASS_P2, s.mass_p2())]:
+        x = rng.standard_normal(ref.shape[1])
+        y = ctx.operator_apply(op, x)
+        assert rel(y, ref @ x) < 1e-13
+    # linearity of the production kernel
+    x1, x2 = rng.standard_normal(dm.n_p1), rng.standard_normal(dm.n_p1)
+    y = ctx.operator_apply(nat.OP_GRAD, 2.0 * x1 - 3.0 * x2)
+    assert rel(y, 2.0 * ctx.operator_apply(nat.OP_GRAD, x1) - 3.0 * ctx.operator_apply(nat.OP_GRAD, x2)) < 1e-13
+
+
+def test_momentum_residual_and_jacobian_match_oracle(setup16):
+    mesh, dm, marks, ctx, s = setup16
+    rng = np.random.default_rng(5)
+    Re, k, alpha = 50.0, 0.02, (1.5, -2.0, 0.5)
+    u = [rng.standard_normal(dm.n_velocity) for _ in range(4)]
+    p_old = rng.standard_normal(dm.n_p1)
+    f = rng.standard_normal(dm.n_velocity)
+    ctx.set_coeffs(1.0, 1.0, 1.0 / Re, 0.7)
+    ctx.set_bdf(alpha, k)
+    bd, bv = cavity_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    for slot, v in ((nat.U1, u[1]), (nat.U2, u[2]), (nat.USTAR, u[3]), (nat.P_OLD, p_old),
+                    (nat.BODY_FORCE, f)):
+        ctx.set_state(slot, v)
+    ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+    M, K, D = s.vector_mass(), s.vector_stiffness(), s.divergence()
+    L = alpha[0] / k * M + K / Re
+    b = L @ u[3] + M @ (alpha[1] * u[1] + alpha[2] * u[2]) / k - D.T @ p_old - 0.7 * (M @ f) \
+        + s.convection_residual(u[3])
+    b[bd] = u[3][bd] - bv
+    assert rel(ctx.get_rhs(nat.SYS_MOMENTUM), b) < 1e-13
+    assert abs(ctx.residual_norm(nat.SYS_MOMENTUM) - np.linalg.norm(b)) < 1e-12 * np.linalg.norm(b)
+    J = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
+    Jref = L + s.convection_jacobian(u[3])
+    assert abs(J - Jref).max() <= 1e-13 * abs(Jref).max()
+    # one Newton update through the device BiCGStab vs sparse LU
+    ctx.solve(nat.SYS_MOMENTUM, rtol=1e-13)
+    dx = fo.spla.splu(fo.apply_dirichlet_rows(Jref, bd).tocsc()).solve(b)
+    assert rel(ctx.get_state(nat.USTAR), u[3] - dx) < 1e-10
+    ctx.set_coeffs(1.0, 1.0, 1.0 / Re)
+
+
+def _run_ipcs(ctx, orc, nsteps, k, vbc, pbc, rtol=1e-13, body_force=None):
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, *pbc)
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = rtol
+    out = []
+    for step in range(nsteps):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, k)
+        info = ctx.step_ipcs(opts)
+        orc.step(alpha, k, vbc, pbc)
+        out.append((info, ctx.get_state(nat.USTAR), ctx.get_state(nat.U0), ctx.get_state(nat.P)))
+        ctx.advance(0)
+        orc.advance()
+    return out
+
+
+def test_ipcs_cavity_steps_match_oracle():
+    """Config-1-sized lid-driven cavity (n = 16 here so that the LU oracle is instant),
+    Re = 100: Newton residual histories, u*, u and p (modulo a constant: the reference's
+    Poisson problem is singular)."""
+    mesh, dm, marks = box(16, 16)
+    ctx = context(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    vbc = cavity_bc(dm, marks)
+    pbc = (np.zeros(0, np.int64), np.zeros(0))
+    res = _run_ipcs(ctx, orc, 4, 0.01, vbc, pbc)
+    for step, (info, us, u, p) in enumerate(res):
+        hist = orc.newton_history[step]
+        assert info.newton_iterations == orc.newton_its[step]
+        for i, r in enumerate(hist[:-1]):          # last entry is at round-off level
+            assert abs(info.newton_residuals[i] - r) <= 1e-6 * r + 1e-12 * hist[0]
+    # final state after 4 nonlinear steps: north_star tolerance 1e-6, achieved ~1e-11
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    assert rel(ctx.get_state(nat.USTAR), orc.ustar) < 1e-9
+    pg, po = ctx.get_state(nat.P_OLD), orc.p_old
+    assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
+    ctx.close()
+
+
+def test_ipcs_stokes_channel_linear_steps_1e10():
+    """Linear (convective term None) channel steps with a pressure Dirichlet outlet --
+    the reference's tests/test_ipcs_solver.py case; north_star tolerance 1e-10."""
+    mesh, dm, marks = box(30, 3, p1=(10.0, 1.0))
+    ctx = context(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=None, pressure_term=1.0, viscous_term=0.1, body_force_term=None)
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    ctx.set_coeffs(None, 1.0, 0.1)
+    zero = lambda X: np.zeros((X.shape[0], 2))
+    inlet = lambda X: np.stack([6.0 * X[:, 1] * (1.0 - X[:, 1]), 0.0 * X[:, 1]], axis=1)
+    vbc = velocity_bc(dm, marks, [(1, inlet), (3, zero), (4, zero)])
+    pn = np.unique(dm.facet_p1_nodes(marks.facets_with_id(2)))
+    pbc = (pn, np.zeros(pn.size))
+    res = _run_ipcs(ctx, orc, 3, 0.002, vbc, pbc, rtol=1e-14)
+    assert all(info.newton_iterations == 1 for info, *_ in res)
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-10
+    assert rel(ctx.get_state(nat.P_OLD), orc.p_old) < 1e-10
+    ctx.close()
+
+
+def test_ipcs_body_force_and_traction_form():
+    mesh, dm, marks = box(10, 10)
+    ctx = context(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.02, body_force_term=1.0)
+    orc = fo.IPCSOracle(s, coef, traction_form=True, refactor_every_step=False)
+    X = dm.p2_coords
+    f = np.stack([np.sin(np.pi * X[:, 1]), -1.0 + X[:, 0]], axis=1).ravel()
+    orc.body_force = f
+    facets = marks.facets_with_id(2)
+    nodes = dm.facet_p2_nodes(facets)
+    tvals = np.stack([0.3 * X[nodes, 1], -0.1 + 0.0 * X[nodes, 1]], axis=2)
+    orc.traction = s.traction_vector(nodes, tvals)
+    ctx.set_coeffs(1.0, 1.0, 0.02, 1.0)
+    ctx.set_viscous_form(True)
+    ctx.set_state(nat.BODY_FORCE, f)
+    ctx.set_state(nat.TRACTION, orc.traction)
+    zero = lambda X: np.zeros((X.shape[0], 2))
+    vbc = velocity_bc(dm, marks, [(1, zero), (3, zero), (4, zero)])
+    # open boundary 2 carries the traction; the pressure is pinned there (otherwise the
+    # Poisson problem of the scheme is singular AND incompatible: ill-posed)
+    pn = np.unique(dm.facet_p1_nodes(facets))
+    pbc = (pn, 0.2 * np.ones(pn.size))
+    _run_ipcs(ctx, orc, 2, 0.05, vbc, pbc)
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    assert rel(ctx.get_state(nat.P_OLD), orc.p_old) < 1e-9
+    ctx.close()
+
+
+def test_mass_projection_and_mean_pressure():
+    mesh, dm, marks = box(8, 8)
+    ctx = context(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal(dm.n_velocity)
+    x = ctx.mass_solve(nat.VELOCITY, b)
+    assert rel(s.vector_mass() @ x, b) < 1e-11
+    p = rng.standard_normal(dm.n_p1)
+    ctx.set_state(nat.P, p)
+    mean = ctx.shift_mean_pressure(0.25)
+    ref_mean = (s.mass_p1() @ p).sum() / 1.0
+    assert abs(mean - ref_mean) < 1e-13
+    assert np.abs(ctx.get_state(nat.P) - (p - (ref_mean - 0.25))).max() < 1e-13
+    ctx.close()
+
+
+def test_error_paths_are_loud():
+    mesh, dm, marks = box(4, 4)
+    ctx = context(mesh, dm)
+    with pytest.raises(nat.NativeError):
+        ctx.set_state(nat.P, np.zeros(3))                       # wrong size
+    with pytest.raises(nat.NativeError):
+        ctx.set_dirichlet(nat.VELOCITY, np.array([10 ** 6]), np.array([0.0]))
+    with pytest.raises(nat.NativeError):
+        ctx.solve(nat.SYS_POISSON)                              # nothing assembled
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    ctx.set_dirichlet(nat.VELOCITY, *cavity_bc(dm, marks))
+    ctx.set_bdf((1.0, -1.0, 0.0), 0.01)
+    opts = ctx.default_step_opts()
+    opts.momentum.max_iter = 1                                  # Krylov cannot converge
+    with pytest.raises(nat.NativeError) as err:
+        ctx.step_ipcs(opts)
+    assert err.value.code == nat.ERR_NOT_CONVERGED
+    ctx.close()
+    with pytest.raises(nat.NativeError):                         # bad dof map entry
+        nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap + 10 ** 6, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+
+
+def test_full_size_properties_n512():
+    """BASELINE config 2 size (n = 512, 2,364,419 dofs): properties that need no oracle."""
+    mesh, dm, marks = box(512, 512)
+    assert dm.n_dofs == 2364419
+    ctx = context(mesh, dm)
+    rng = np.random.default_rng(0)
+    ones2, ones1 = np.ones(dm.n_p2), np.ones(dm.n_p1)
+    # K 1 = 0, sum(M) = |Omega|, A_p 1 = 0
+    assert np.abs(ctx.operator_apply(nat.OP_STIFF_P2, ones2)).max() < 1e-9
+    assert abs(ctx.operator_apply(nat.OP_MASS_P2, ones2).sum() - 1.0) < 1e-12
+    assert np.abs(ctx.operator_apply(nat.OP_STIFF_P1, ones1)).max() < 1e-9
+    # adjointness  y . (D x) = x . (D^T y)  between the independently integrated D and D^T
+    x, y = rng.standard_normal(dm.n_velocity), rng.standard_normal(dm.n_p1)
+    lhs = y @ ctx.operator_apply(nat.OP_DIV, x)
+    rhs = x @ ctx.operator_apply(nat.OP_DIVT, y)
+    assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), 1.0)
+    # divergence of a linear field integrates exactly: sum_i (D u)_i = |Omega| tr(A)
+    X = dm.p2_coords
+    ulin = np.stack([0.3 * X[:, 0] + 0.1 * X[:, 1], -0.2 * X[:, 0] + 0.5 * X[:, 1]], axis=1).ravel()
+    assert abs(ctx.operator_apply(nat.OP_DIV, ulin).sum() - 0.8) < 1e-11
+    # two IPCS steps of the cavity: Newton converges, boundary values hold, the corrected
+    # velocity is discretely closer to divergence free than u*, mass CG needs O(10) its
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    bd, bv = cavity_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-10
+    for step in range(2):
+        ctx.set_bdf(fo.bdf_alpha(step, 1.0), 1e-3)
+        info = ctx.step_ipcs(opts)
+        assert 1 <= info.newton_iterations <= 6
+        assert info.newton_residuals[info.newton_iterations] < max(
+            1e-10, 1e-9 * info.newton_residuals[0])
+        assert info.krylov_iterations_correction < 60
+        u, us = ctx.get_state(nat.U0), ctx.get_state(nat.USTAR)
+        assert np.abs(u[bd] - bv).max() == 0.0
+        assert np.isfinite(u).all() and np.isfinite(ctx.get_state(nat.P)).all()
+        ctx.advance(0)
+    ctx.close()

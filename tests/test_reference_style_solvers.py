@@ -1,0 +1,137 @@
+"""The reference's own solver tests, re-stated against the dolfin-free modules with the
+problem classes kept as close to the originals as the missing ``dolfin`` import allows:
+tests/test_ipcs_solver.py:12-54 (IPCS channel, pressure outlet) and the lid-driven cavity
+of demo/cavity_flow.py:21-29 run as a transient IPCS problem (BASELINE config shape).
+Like the reference they are smoke tests (they pass iff Newton/Krylov converge), plus a
+parity check of the final fields against the oracle driven with the same inputs."""
+import numpy as np
+import pytest
+
+import dlfn_compat as dlfn
+import fem_oracle as fo
+from auxiliary_classes import EquationCoefficientHandler
+from grid_generator import HyperCubeBoundaryMarkers, HyperRectangleBoundaryMarkers, hyper_cube, hyper_rectangle
+from ns_ipcs_solver import IPCSSolver
+from ns_problem import InstationaryProblem, PressureBCType, VelocityBCType
+
+pytestmark = pytest.mark.gpu
+dlfn.set_log_level(30)
+
+
+class ChannelFlowProblem(InstationaryProblem):
+    def __init__(self, n_points, main_dir=None):
+        super().__init__(main_dir, start_time=0.0, end_time=1.0,
+                         desired_start_time_step=0.002, n_max_steps=10)
+        self._n_points = n_points
+        self._problem_name = "ChannelFlow"
+        self._output_frequency = 1
+        self._postprocessing_frequency = 1
+        self.set_solver_class(IPCSSolver)
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_rectangle((0.0, 0.0), (10.0, 1.0),
+                                                             (10 * self._n_points, self._n_points))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=10.0)
+
+    def set_initial_conditions(self):
+        self._initial_conditions = dict()
+        self._initial_conditions["velocity"] = (0.0, 0.0)
+        self._initial_conditions["pressure"] = 0.0
+
+    def set_boundary_conditions(self):
+        inlet_velocity = dlfn.Expression(("6.0*x[1]/h*(1.0-x[1]/h)", "0.0"), h=1.0, degree=2)
+        Markers = HyperRectangleBoundaryMarkers
+        self._bcs = ((PressureBCType.constant, Markers.right.value, 0.0),
+                     (VelocityBCType.function, Markers.left.value, inlet_velocity),
+                     (VelocityBCType.no_slip, Markers.bottom.value, None),
+                     (VelocityBCType.no_slip, Markers.top.value, None))
+
+    def postprocess_solution(self):
+        self._add_to_field_output(self._compute_pressure_gradient())
+        self._add_to_field_output(self._compute_vorticity())
+
+
+class CavityProblem(InstationaryProblem):
+    def __init__(self, n_points, n_steps=5):
+        super().__init__(None, start_time=0.0, end_time=1.0, desired_start_time_step=0.01,
+                         n_max_steps=n_steps)
+        self._n_points = n_points
+        self._output_frequency = 0
+        self._postprocessing_frequency = 0
+        self.set_solver_class(IPCSSolver)
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_cube(2, self._n_points)
+
+    def set_boundary_conditions(self):
+        no_slip, constant = VelocityBCType.no_slip, VelocityBCType.constant
+        BoundaryMarkers = HyperCubeBoundaryMarkers
+        self._bcs = ((no_slip, BoundaryMarkers.left.value, None),
+                     (no_slip, BoundaryMarkers.right.value, None),
+                     (no_slip, BoundaryMarkers.bottom.value, None),
+                     (constant, BoundaryMarkers.top.value, (1.0, 0.0)))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=100.0)
+
+    def set_initial_conditions(self):
+        self._initial_conditions = {"velocity": (0.0, 0.0), "pressure": 0.0}
+
+
+def _oracle_replay(solver, n_steps, k):
+    """Drive the CPU oracle with the Dirichlet arrays the solver shipped to the device."""
+    dm = solver._dofmap
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.IPCSOracle(s, solver._equation_coefficients, refactor_every_step=False)
+    vd, vv = solver._dirichlet_bcs["velocity"]
+    _, first = np.unique(vd[::-1], return_index=True)
+    keep = len(vd) - 1 - first
+    vbc = (vd[keep].astype(np.int64), vv[keep])
+    pbc = tuple(np.asarray(a) for a in solver._dirichlet_bcs["pressure"])
+    for step in range(n_steps):
+        orc.step(fo.bdf_alpha(step, 1.0), k, vbc, pbc)
+        orc.advance()
+    return orc
+
+
+def test_channel_flow():
+    channel_flow = ChannelFlowProblem(5)
+    channel_flow.solve_problem()
+    solver = channel_flow._get_solver()
+    assert channel_flow._time_stepping.step_number == 10
+    velocity, pressure = solver.solution.split()
+    orc = _oracle_replay(solver, 10, 0.002)
+    # after advance_time() the device levels U0 (kept) and U1 both hold the last velocity
+    assert np.linalg.norm(velocity.vector() - orc.vel[1]) < 1e-6 * np.linalg.norm(orc.vel[1])
+    assert np.linalg.norm(pressure.vector() - orc.p_old) < 1e-6 * np.linalg.norm(orc.p_old)
+    # point evaluation on the inlet profile
+    assert abs(velocity((0.0, 0.5))[0] - 1.5) < 1e-12
+
+
+def test_transient_cavity_fused_and_explicit_seam_agree():
+    a = CavityProblem(12)
+    a.solve_problem()
+    b = CavityProblem(12)
+    b.setup_mesh()
+    # same problem, Newton driven from Python through _assemble_system()
+    from bdf_time_stepping import BDFTimeStepping
+    ts = BDFTimeStepping(0.0, 1.0, desired_start_time_step=0.01)
+    solver = IPCSSolver(b._mesh, b._boundary_markers, "standard", ts)
+    solver.fused_step = False
+    b.set_boundary_conditions()
+    solver.set_equation_coefficients(EquationCoefficientHandler(Re=100.0).equation_coefficients)
+    solver.set_boundary_conditions(b._bcs)
+    solver.set_initial_conditions({"velocity": (0.0, 0.0), "pressure": 0.0})
+    for _ in range(5):
+        ts.update_coefficients()
+        solver.solve()
+        ts.advance_time()
+        solver.advance_time()
+    ua = a._get_solver().solution.split()[0].vector()
+    ub = solver.solution.split()[0].vector()
+    # same kernels; fp64 atomics in the convection scatter reorder sums -> last-bit noise
+    assert np.linalg.norm(ua - ub) <= 1e-12 * np.linalg.norm(ub)
+    orc = _oracle_replay(solver, 5, 0.01)
+    assert np.linalg.norm(ub - orc.vel[1]) < 1e-6 * np.linalg.norm(orc.vel[1])

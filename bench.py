@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--krylov-rtol", type=float, default=1.0e-10)
     ap.add_argument("--cpu-sample-n", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-multigrid", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,9 +111,13 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     mesh, dm, ctx, nat = cavity_setup(args.n, local_rank)
+    from multigrid import attach_hierarchy
+    mg_levels = attach_hierarchy(ctx, mesh) if not args.no_multigrid else None
     opts = ctx.default_step_opts()
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = args.krylov_rtol
+    if mg_levels is not None:
+        opts.momentum.precond = opts.poisson.precond = 1
 
     def one_step(i):
         ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), args.dt)
@@ -155,6 +160,7 @@ def main():
                                "(%d dofs), IPCS, BDF-2, dt=%g, zero initial state" % (
                                    args.n, args.n, dm.n_dofs, args.dt),
                    "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "preconditioner": "jacobi" if mg_levels is None else "geometric multigrid V(2,2) Chebyshev, %d coarse P1 levels" % mg_levels,
                    "parallelism": "1 GPU" if world == 1 else "%d independent replicas" % world,
                    "newton_its_per_step": newton / args.steps,
                    "bicgstab_its_per_step": kry / args.steps},

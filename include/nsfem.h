@@ -170,6 +170,30 @@ int nsfem_operator_export(nsfem_ctx* ctx, int op, int32_t* rowptr, int32_t* col,
 /* y = op * x on the device through the production SpMV kernel (host in/out) */
 int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y);
 
+/* ---- multigrid hierarchy (optional).  Coarse P1 levels are added finest-first; each
+ * carries its mesh and the prolongation P (CSR, rows = nodes of the previous finer P1
+ * level, n_fine of them; cols = nodes of this level).  Spaces must be nested (every
+ * coarse node coincides with a finer node: a row of P with the single entry 1).  The
+ * library integrates the coarse operators on the device, adds the P2 <- P1 transfer of
+ * the fine mesh itself and builds two V-cycle preconditioners: pressure Poisson and
+ * alpha0/k M + c_v K.  Selected per solve with nsfem_krylov_opts.precond = 1. */
+typedef struct {
+  int32_t n_vertices, n_cells;
+  const double* coords;      /* [n_vertices * 2] */
+  const int32_t* cells;      /* [n_cells * 3]    */
+  int32_t n_fine;
+  const int32_t* p_rowptr;   /* [n_fine + 1]     */
+  const int32_t* p_col;
+  const double* p_val;
+} nsfem_mg_level_desc;
+typedef struct {
+  int32_t smoother_degree;   /* Chebyshev steps per pre/post smoothing (default 2) */
+  int32_t coarse_dense_max;  /* dense coarse solve up to this many unknowns (1200)  */
+  double eig_ratio;          /* smoothing interval [lmax/ratio, lmax] (default 4)   */
+} nsfem_mg_opts;
+int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* level);
+int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* opts /* may be NULL */);
+
 /* ---- fused per-step drivers: replace _solve_time_step
  * (ns_ipcs_solver.py:198-208, ns_bdf_solver.py:102-106) ------------------------ */
 int nsfem_default_step_opts(nsfem_step_opts* opts);

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply",
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
+    "nsfem_mg_add_level", "nsfem_mg_finalize",
 )
 
 
@@ -61,6 +62,18 @@ class StepInfo(C.Structure):
                 ("krylov_iterations_poisson", C.c_int32),
                 ("krylov_iterations_correction", C.c_int32),
                 ("newton_residuals", C.c_double * MAX_NEWTON)]
+
+
+class MgLevelDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("n_cells", C.c_int32),
+                ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
+                ("n_fine", C.c_int32), ("p_rowptr", C.POINTER(C.c_int32)),
+                ("p_col", C.POINTER(C.c_int32)), ("p_val", C.POINTER(C.c_double))]
+
+
+class MgOpts(C.Structure):
+    _fields_ = [("smoother_degree", C.c_int32), ("coarse_dense_max", C.c_int32),
+                ("eig_ratio", C.c_double)]
 
 
 class NativeError(RuntimeError):
@@ -113,6 +126,8 @@ def load_library(path=None):
         "nsfem_shift_mean_pressure": (C.c_int, [vp, dbl, pd]),
         "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),
         "nsfem_synchronize": (C.c_int, [vp]),
+        "nsfem_mg_add_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
+        "nsfem_mg_finalize": (C.c_int, [vp, C.POINTER(MgOpts)]),
         "nsfem_mass_solve": (C.c_int, [vp, C.c_int, pd, pd, C.POINTER(KrylovOpts),
                                        C.POINTER(SolveInfo)]),
     }
@@ -260,6 +275,20 @@ class NsfemContext:
         self._check(self._lib.nsfem_mass_solve(self._h, field, _dp(b), _dp(x), C.byref(o),
                                                C.byref(info)))
         return x
+
+    def mg_add_level(self, coords, cells, p_rowptr, p_col, p_val):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        rp = np.ascontiguousarray(p_rowptr, dtype=np.int32)
+        pc = np.ascontiguousarray(p_col, dtype=np.int32)
+        pv = np.ascontiguousarray(p_val, dtype=np.float64)
+        d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
+                        _ip(rp), _ip(pc), _dp(pv))
+        self._check(self._lib.nsfem_mg_add_level(self._h, C.byref(d)))
+
+    def mg_finalize(self, degree=2, eig_ratio=4.0, coarse_dense_max=1200):
+        o = MgOpts(int(degree), int(coarse_dense_max), float(eig_ratio))
+        self._check(self._lib.nsfem_mg_finalize(self._h, C.byref(o)))
 
     def synchronize(self):
         self._check(self._lib.nsfem_synchronize(self._h))

@@ -106,6 +106,9 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
       for (int k = 0; k < 3; ++k) p1[(size_t)k * nc + c] = m->p1_dofmap[(size_t)c * 3 + k];
     }
     fresh->area = area;
+    fresh->h_p2map.assign(m->p2_dofmap, m->p2_dofmap + (size_t)6 * nc);
+    fresh->h_p1map.assign(m->p1_dofmap, m->p1_dofmap + (size_t)3 * nc);
+    fresh->mom_prec.c = fresh;
     fresh->mesh.n_cells = nc;
     fresh->mesh.n_p2 = m->n_p2;
     fresh->mesh.n_p1 = m->n_p1;
@@ -259,13 +262,16 @@ extern "C" int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const i
   dv.upload(v, s);
   mask.zero(s);
   launch_fill_mask(s, (int)d.size(), dd.p, mask.p);
+  std::vector<int32_t>& prev = field == NSFEM_VELOCITY ? ctx->h_bc_v : ctx->h_bc_p;
+  const bool changed = prev != d;
   if (field == NSFEM_VELOCITY) {
     ctx->nbc_v = (int)d.size();
-    ctx->dinv_m_ready = false;
+    if (changed) { ctx->dinv_m_ready = false; ctx->mg_v_dirty = true; }
   } else {
     ctx->nbc_p = (int)d.size();
-    ctx->dinv_p_ready = false;
+    if (changed) { ctx->dinv_p_ready = false; ctx->mg_p_dirty = true; }
   }
+  prev.swap(d);
   NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
 }
@@ -306,9 +312,39 @@ extern "C" int nsfem_get_state(nsfem_ctx* ctx, int slot, double* host, int64_t n
 static void ensure_L(nsfem_ctx* c) {
   if (!c->L_dirty) return;
   // L = alpha0/k M + c_viscous K   (scalar P2; acts on both velocity components)
-  launch_scale_combine(c->stream, c->p22.nnz, c->alpha[0] / c->k, c->M2.vals.p, c->coef[2],
-                       c->K2.vals.p, c->L.vals.p);
+  const double a = c->alpha[0] / c->k, b = c->coef[2];
+  launch_scale_combine(c->stream, c->p22.nnz, a, c->M2.vals.p, b, c->K2.vals.p, c->L.vals.p);
+  if (c->mg_built) {
+    launch_scale_combine(c->stream, c->p11.nnz, a, c->Mp.vals.p, b, c->Ap.vals.p, c->Lc0.vals.p);
+    for (nsfem_ctx::P1Level* lv : c->coarse)
+      launch_scale_combine(c->stream, lv->pat.nnz, a, lv->M.vals.p, b, lv->K.vals.p, lv->Lc.vals.p);
+    c->mg_v_dirty = true;
+  }
   c->L_dirty = false;
+}
+
+// (re)build masks / smoother data / coarse inverse of a hierarchy when its inputs changed
+static void mg_refresh(nsfem_ctx* c, bool momentum) {
+  if (momentum) {
+    ensure_L(c);
+    if (!c->mg_v_dirty) return;
+    std::vector<uint8_t> m((size_t)nvel(c), 0);
+    for (int32_t d : c->h_bc_v) m[d] = 1;
+    c->mg_v.refresh(c->stream, m, false);
+    c->mg_v_dirty = false;
+  } else {
+    if (!c->mg_p_dirty) return;
+    std::vector<uint8_t> m((size_t)npre(c), 0);
+    for (int32_t d : c->h_bc_p) m[d] = 1;
+    c->mg_p.refresh(c->stream, m, c->h_bc_p.empty());
+    c->mg_p_dirty = false;
+  }
+}
+
+void nsfem_ctx::MomentumPrec::apply(hipStream_t s, const double* r, double* z) {
+  c->mg_v.apply(s, r, z);
+  // Newton rows of Dirichlet dofs are identity rows: the preconditioner must be too
+  launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, r, z);
 }
 
 static double cc_of(const nsfem_ctx* c) { return std::isfinite(c->coef[0]) ? c->coef[0] : 0.0; }
@@ -372,6 +408,11 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
   op.rowmask = c->mask_v.p;
   op.maskmode = MASK_IDENTITY;
   op.dinv = c->dinv_v.p;
+  if (o.precond == 1) {
+    NSFEM_REQUIRE(c->mg_built, "multigrid requested but no hierarchy was set (nsfem_mg_finalize)");
+    mg_refresh(c, true);
+    op.prec = &c->mom_prec;
+  }
   int rc = bicgstab(s, c->kw, op, c->rhs_v.p, c->dx_v.p, o, info);
   if (rc != NSFEM_OK) return rc;
   double* u = c->state[NSFEM_USTAR].p;
@@ -402,6 +443,11 @@ static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_i
   op.rowmask = c->mask_p.p;
   op.maskmode = MASK_ZERO;
   op.dinv = c->dinv_p.p;
+  if (o.precond == 1) {
+    NSFEM_REQUIRE(c->mg_built, "multigrid requested but no hierarchy was set (nsfem_mg_finalize)");
+    mg_refresh(c, false);
+    op.prec = &c->mg_p;
+  }
   return pcg(c->stream, c->kw, op, c->rhs_p.p, c->state[NSFEM_P].p, o, info, c->nbc_p == 0);
 }
 
@@ -495,6 +541,115 @@ extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* 
   }
   if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "Krylov breakdown");
   if (rc == NSFEM_ERR_NOT_CONVERGED) throw Error(rc, "Krylov solver did not converge");
+  API_END(ctx)
+}
+
+extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && d, "null argument");
+  NSFEM_REQUIRE(!ctx->mg_built, "hierarchy already finalized");
+  NSFEM_REQUIRE(d->n_vertices > 0 && d->n_cells > 0 && d->coords && d->cells && d->p_rowptr &&
+                    d->p_col && d->p_val, "bad level description");
+  const int n_fine = ctx->coarse.empty() ? ctx->mesh.n_p1 : ctx->coarse.back()->n;
+  NSFEM_REQUIRE(d->n_fine == n_fine, "prolongation rows must match the previous level");
+  hipStream_t s = ctx->stream;
+  nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
+  ctx->coarse.push_back(lv);
+  const int nc = d->n_cells;
+  lv->n = d->n_vertices;
+  std::vector<double> vx((size_t)6 * nc);
+  std::vector<int32_t> p1((size_t)3 * nc);
+  for (int c = 0; c < nc; ++c)
+    for (int v = 0; v < 3; ++v) {
+      const int vid = d->cells[(size_t)c * 3 + v];
+      NSFEM_REQUIRE(vid >= 0 && vid < d->n_vertices, "coarse cell vertex id out of range");
+      p1[(size_t)v * nc + c] = vid;
+      for (int k = 0; k < 2; ++k) vx[(size_t)(2 * v + k) * nc + c] = d->coords[(size_t)vid * 2 + k];
+    }
+  lv->mesh.n_cells = nc;
+  lv->mesh.n_p1 = lv->mesh.n_vertices = d->n_vertices;
+  lv->mesh.vx.upload(vx, s);
+  lv->mesh.p1.upload(p1, s);
+  HostPattern h;
+  build_pattern(d->n_vertices, d->n_vertices, nc, d->cells, 3, d->cells, 3, true, h);
+  upload_pattern(s, h, lv->pat);
+  lv->K.init(&lv->pat, 1, 1, s);
+  lv->M.init(&lv->pat, 1, 1, s);
+  lv->Lc.init(&lv->pat, 1, 1, s);
+  launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+  lv->to_finer.build(s, n_fine, d->n_vertices, d->p_rowptr, d->p_col, d->p_val);
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(!ctx->mg_built, "hierarchy already finalized");
+  hipStream_t s = ctx->stream;
+  // P2 <- P1 on the fine mesh: identity at vertices, average at edge midpoints
+  {
+    const int n2 = ctx->mesh.n_p2, nc = ctx->mesh.n_cells;
+    std::vector<int32_t> a((size_t)n2, -1), b((size_t)n2, -1);
+    const int ends[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+    for (int c = 0; c < nc; ++c) {
+      const int32_t* p2 = &ctx->h_p2map[(size_t)c * 6];
+      const int32_t* p1 = &ctx->h_p1map[(size_t)c * 3];
+      for (int v = 0; v < 3; ++v) { a[p2[v]] = p1[v]; b[p2[v]] = -1; }
+      for (int e = 0; e < 3; ++e) {
+        a[p2[3 + e]] = std::min(p1[ends[e][0]], p1[ends[e][1]]);
+        b[p2[3 + e]] = std::max(p1[ends[e][0]], p1[ends[e][1]]);
+      }
+    }
+    std::vector<int32_t> rp((size_t)n2 + 1, 0), col;
+    std::vector<double> val;
+    for (int i = 0; i < n2; ++i) {
+      NSFEM_REQUIRE(a[i] >= 0, "P2 node not referenced by any cell");
+      if (b[i] < 0 || b[i] == a[i]) { col.push_back(a[i]); val.push_back(1.0); }
+      else { col.push_back(a[i]); val.push_back(0.5); col.push_back(b[i]); val.push_back(0.5); }
+      rp[i + 1] = (int32_t)col.size();
+    }
+    ctx->t_p2p1.build(s, n2, ctx->mesh.n_p1, rp.data(), col.data(), val.data());
+  }
+  ctx->Lc0.init(&ctx->p11, 1, 1, s);
+  const int degree = (o && o->smoother_degree > 0) ? o->smoother_degree : 2;
+  const double ratio = (o && o->eig_ratio > 1.0) ? o->eig_ratio : 4.0;
+  const int dense_max = (o && o->coarse_dense_max > 0) ? o->coarse_dense_max : 1200;
+  // pressure Poisson hierarchy: P1 fine -> coarse P1 levels
+  {
+    Multigrid& mg = ctx->mg_p;
+    mg.nv = 1; mg.degree = degree; mg.eig_ratio = ratio; mg.coarse_dense_max = dense_max;
+    mg.lv.clear();
+    mg.lv.resize(1 + ctx->coarse.size());
+    mg.lv[0].A = &ctx->Ap; mg.lv[0].n = ctx->mesh.n_p1; mg.lv[0].mask = ctx->mask_p.p;
+    for (size_t l = 0; l < ctx->coarse.size(); ++l) {
+      nsfem_ctx::P1Level* c = ctx->coarse[l];
+      mg.lv[l].P = &c->to_finer.P; mg.lv[l].R = &c->to_finer.R; mg.lv[l].h_inj = &c->to_finer.h_inj;
+      mg.lv[l + 1].A = &c->K; mg.lv[l + 1].n = c->n;
+    }
+    mg.setup_work(s);
+  }
+  // momentum hierarchy: P2 fine -> P1 fine -> coarse P1 levels, operator a M + b K
+  {
+    Multigrid& mg = ctx->mg_v;
+    mg.nv = 2; mg.degree = degree; mg.eig_ratio = ratio; mg.coarse_dense_max = dense_max;
+    mg.lv.clear();
+    mg.lv.resize(2 + ctx->coarse.size());
+    mg.lv[0].A = &ctx->L; mg.lv[0].n = ctx->mesh.n_p2; mg.lv[0].mask = ctx->mask_v.p;
+    mg.lv[0].P = &ctx->t_p2p1.P; mg.lv[0].R = &ctx->t_p2p1.R; mg.lv[0].h_inj = &ctx->t_p2p1.h_inj;
+    mg.lv[1].A = &ctx->Lc0; mg.lv[1].n = ctx->mesh.n_p1;
+    for (size_t l = 0; l < ctx->coarse.size(); ++l) {
+      nsfem_ctx::P1Level* c = ctx->coarse[l];
+      mg.lv[l + 1].P = &c->to_finer.P; mg.lv[l + 1].R = &c->to_finer.R;
+      mg.lv[l + 1].h_inj = &c->to_finer.h_inj;
+      mg.lv[l + 2].A = &c->Lc; mg.lv[l + 2].n = c->n;
+    }
+    mg.setup_work(s);
+  }
+  ctx->mg_built = true;
+  ctx->mg_p_dirty = ctx->mg_v_dirty = true;
+  ctx->L_dirty = true;       // (re)compute the coarse momentum operators
+  NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
 }
 

@@ -24,13 +24,29 @@
 namespace nsfem {
 
 // ------------------------------------------------------------------- SpMV
-template <int BR, int BC, int NV, int G, bool RESID>
+// One kernel body, four epilogues:
+//   EPI_STORE  y = A x                     EPI_RESID  y = b - A x
+//   EPI_ACCUM  y += A x  (prolongation)    EPI_CHEB   Chebyshev/Jacobi smoother step:
+//                                            d = c1 d + c2 dinv (b - A x); y = x + d
+// Row masks (Dirichlet dofs): identity rows (dolfin's non-symmetric bc.apply) or zero
+// rows (symmetric elimination on vectors that vanish on the constrained dofs).
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_ACCUM = 2, EPI_CHEB = 3 };
+
+struct SpmvArgs {
+  const double* x;
+  const double* b;
+  double* y;
+  const uint8_t* mask;
+  int maskmode;
+  const double* dinv;
+  double* d;
+  double c1, c2;
+};
+
+template <int BR, int BC, int NV, int G, int EPI>
 __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restrict__ rowptr,
                                               const int32_t* __restrict__ col,
-                                              const double* __restrict__ vals,
-                                              const double* __restrict__ x,
-                                              const double* __restrict__ b, double* __restrict__ y,
-                                              const uint8_t* __restrict__ mask, int maskmode) {
+                                              const double* __restrict__ vals, SpmvArgs a) {
   constexpr int NO = BR * NV;            // outputs per block row
   constexpr int RPB = 256 / G;           // block rows per workgroup
   // XCD-aware remap: workgroups b, b+8, ... share an XCD (round-robin dispatch);
@@ -40,15 +56,16 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
   const int row = lb * RPB + threadIdx.x / G;
   if (row >= n_rows) return;
   const int lane = threadIdx.x % G;
+  const double* __restrict__ x = a.x;
   double acc[NO];
 #pragma unroll
   for (int o = 0; o < NO; ++o) acc[o] = 0.0;
   const int s = rowptr[row], e = rowptr[row + 1];
   for (int k = s + lane; k < e; k += G) {
     const int c = col[k];
-    double a[BR * BC], xv[BC * NV];
+    double av[BR * BC], xv[BC * NV];
 #pragma unroll
-    for (int t = 0; t < BR * BC; ++t) a[t] = vals[(size_t)k * (BR * BC) + t];
+    for (int t = 0; t < BR * BC; ++t) av[t] = vals[(size_t)k * (BR * BC) + t];
 #pragma unroll
     for (int t = 0; t < BC * NV; ++t) xv[t] = x[(size_t)c * (BC * NV) + t];
 #pragma unroll
@@ -56,7 +73,7 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int cc = 0; cc < BC; ++cc) acc[r * NV + v] += a[r * BC + cc] * xv[cc * NV + v];
+        for (int cc = 0; cc < BC; ++cc) acc[r * NV + v] += av[r * BC + cc] * xv[cc * NV + v];
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1)
@@ -68,31 +85,42 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
     for (int o = 1; o < NO; ++o)
       if (lane == o) val = acc[o];
     const size_t idx = (size_t)row * NO + lane;
-    const bool m = (maskmode != MASK_NONE) && mask[idx];
-    if (RESID) {
-      // y = b - A x ; identity rows: b - x ; zero rows: 0
+    const bool m = (a.maskmode != MASK_NONE) && a.mask[idx];
+    if (EPI == EPI_RESID) {
+      // identity rows: b - x ; zero rows: 0
       if (m)
-        val = (maskmode == MASK_IDENTITY) ? b[idx] - x[idx] : 0.0;
+        val = (a.maskmode == MASK_IDENTITY) ? a.b[idx] - x[idx] : 0.0;
       else
-        val = b[idx] - val;
+        val = a.b[idx] - val;
+      a.y[idx] = val;
+    } else if (EPI == EPI_ACCUM) {
+      a.y[idx] = m ? 0.0 : a.y[idx] + val;
+    } else if (EPI == EPI_CHEB) {
+      double dn = 0.0, xn = 0.0;
+      if (!m) {
+        dn = a.c2 * a.dinv[idx] * (a.b[idx] - val);
+        if (a.c1 != 0.0) dn += a.c1 * a.d[idx];
+        xn = x[idx] + dn;
+      }
+      a.d[idx] = dn;
+      a.y[idx] = xn;
     } else {
-      if (m) val = (maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
+      if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
+      a.y[idx] = val;
     }
-    y[idx] = val;
   }
 }
 
-template <bool RESID>
-static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const double* x,
-                          const double* b, double* y, const uint8_t* mask, int maskmode) {
+template <int EPI>
+static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvArgs& a) {
   const Pattern& p = *A.pat;
   constexpr int G = 8;
   const int rpb = 256 / G;
   int grid = (p.n_rows + rpb - 1) / rpb;
   grid = (grid + 7) & ~7;
-#define NSFEM_SPMV(BR, BC, NV)                                                             \
-  hipLaunchKernelGGL((k_spmv<BR, BC, NV, G, RESID>), dim3(grid), dim3(256), 0, s, p.n_rows, \
-                     p.rowptr.p, p.col.p, A.vals.p, x, b, y, mask, maskmode)
+#define NSFEM_SPMV(BR, BC, NV)                                                           \
+  hipLaunchKernelGGL((k_spmv<BR, BC, NV, G, EPI>), dim3(grid), dim3(256), 0, s, p.n_rows, \
+                     p.rowptr.p, p.col.p, A.vals.p, a)
   if (A.br == 2 && A.bc == 2 && nv == 1) NSFEM_SPMV(2, 2, 1);
   else if (A.br == 1 && A.bc == 1 && nv == 2) NSFEM_SPMV(1, 1, 2);
   else if (A.br == 1 && A.bc == 1 && nv == 1) NSFEM_SPMV(1, 1, 1);
@@ -103,13 +131,33 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const double
   NSFEM_HIP(hipGetLastError());
 }
 
+static SpmvArgs make_args(const double* x, const double* b, double* y, const uint8_t* mask,
+                          int maskmode) {
+  SpmvArgs a;
+  a.x = x; a.b = b; a.y = y; a.mask = mask;
+  a.maskmode = mask ? maskmode : MASK_NONE;
+  a.dinv = nullptr; a.d = nullptr; a.c1 = 0.0; a.c2 = 0.0;
+  return a;
+}
+
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
                  const uint8_t* rowmask, int maskmode) {
-  spmv_dispatch<false>(s, A, nv, x, nullptr, y, rowmask, rowmask ? maskmode : MASK_NONE);
+  spmv_dispatch<EPI_STORE>(s, A, nv, make_args(x, nullptr, y, rowmask, maskmode));
 }
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                      double* y, const uint8_t* rowmask, int maskmode) {
-  spmv_dispatch<true>(s, A, nv, x, b, y, rowmask, rowmask ? maskmode : MASK_NONE);
+  spmv_dispatch<EPI_RESID>(s, A, nv, make_args(x, b, y, rowmask, maskmode));
+}
+void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
+                            const uint8_t* rowmask) {
+  spmv_dispatch<EPI_ACCUM>(s, A, nv, make_args(x, nullptr, y, rowmask, MASK_ZERO));
+}
+void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
+                      const double* dinv, double* d, double c1, double c2, double* xout,
+                      const uint8_t* rowmask) {
+  SpmvArgs a = make_args(x, b, xout, rowmask, MASK_ZERO);
+  a.dinv = dinv; a.d = d; a.c1 = c1; a.c2 = c2;
+  spmv_dispatch<EPI_CHEB>(s, A, nv, a);
 }
 
 // ---------------------------------------------------------- reductions helpers
@@ -251,6 +299,17 @@ void launch_set_values(hipStream_t s, int nbc, const int32_t* dofs, const double
 void launch_fill_mask(hipStream_t s, int nbc, const int32_t* dofs, uint8_t* mask) {
   if (nbc) LAUNCH(k_fill_mask, vgrid(nbc), s, nbc, dofs, mask);
 }
+__global__ __launch_bounds__(256) void k_copy_at(int n, const int32_t* __restrict__ dofs,
+                                                 const double* __restrict__ r,
+                                                 double* __restrict__ z) {
+  GRID_STRIDE(i, n) {
+    const int d = dofs[i];
+    z[d] = r[d];
+  }
+}
+void launch_copy_at(hipStream_t s, int n, const int32_t* dofs, const double* r, double* z) {
+  if (n) LAUNCH(k_copy_at, vgrid(n), s, n, dofs, r, z);
+}
 void launch_mask_zero(hipStream_t s, int64_t n, const uint8_t* mask, double* x) {
   LAUNCH(k_mask_zero, vgrid(n), s, n, mask, x);
 }
@@ -335,7 +394,7 @@ __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, int first, const doub
   GRID_STRIDE(i, n) {
     const double pi = first ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
     p[i] = pi;
-    phat[i] = dinv[i] * pi;
+    if (dinv) phat[i] = dinv[i] * pi;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_RHO] = rho;
 }
@@ -354,7 +413,7 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restr
   GRID_STRIDE(i, n) {
     const double si = r[i] - alpha * v[i];
     sv[i] = si;
-    shat[i] = dinv[i] * si;
+    if (dinv) shat[i] = dinv[i] * si;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_ALPHA] = alpha;
 }
@@ -436,11 +495,14 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   const int check = o.check_every > 0 ? o.check_every : 1;
   int it = 0;
   while (!info.converged && it < o.max_iter) {
-    LAUNCH(k_bicg_p, kParts, s, n, it == 0 ? 1 : 0, w.r.p, w.v.p, op.dinv, w.p.p, w.phat.p, parts,
-           scal);
+    LAUNCH(k_bicg_p, kParts, s, n, it == 0 ? 1 : 0, w.r.p, w.v.p, op.prec ? nullptr : op.dinv,
+           w.p.p, w.phat.p, parts, scal);
+    if (op.prec) op.prec->apply(s, w.p.p, w.phat.p);
     launch_spmv(s, *op.A, op.nv, w.phat.p, w.v.p, op.rowmask, op.maskmode);
     launch_dot(s, n, w.rhat.p, w.v.p, parts + P_RTV * kParts);
-    LAUNCH(k_bicg_s, kParts, s, n, w.r.p, w.v.p, op.dinv, w.s.p, w.shat.p, parts, scal);
+    LAUNCH(k_bicg_s, kParts, s, n, w.r.p, w.v.p, op.prec ? nullptr : op.dinv, w.s.p, w.shat.p,
+           parts, scal);
+    if (op.prec) op.prec->apply(s, w.s.p, w.shat.p);
     launch_spmv(s, *op.A, op.nv, w.shat.p, w.t.p, op.rowmask, op.maskmode);
     LAUNCH(k_dot_ts_tt, kParts, s, n, w.t.p, w.s.p, parts);
     LAUNCH(k_bicg_xr, kParts, s, n, w.phat.p, w.shat.p, w.s.p, w.t.p, w.rhat.p, x, w.r.p, parts,
@@ -471,7 +533,7 @@ __global__ __launch_bounds__(256) void k_cg_start(int64_t n, const double* __res
   double rz = 0.0, rr = 0.0;
   GRID_STRIDE(i, n) {
     const double ri = r[i];
-    const double zi = dinv[i] * ri;
+    const double zi = dinv ? dinv[i] * ri : p[i];      // general preconditioner: p holds z
     p[i] = zi;
     rz += ri * zi;
     rr += ri * ri;
@@ -501,16 +563,18 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n, const double* __re
     x[i] += alpha * p[i];
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
-    const double zi = dinv[i] * ri;
-    z[i] = zi;
-    rz += ri * zi;
+    if (dinv) {
+      const double zi = dinv[i] * ri;
+      z[i] = zi;
+      rz += ri * zi;
+    }
     rr += ri * ri;
   }
   rz = block_sum(rz, sh);
   rr = block_sum(rr, sh);
   __syncthreads();
   if (threadIdx.x == 0) {
-    parts[rz_next * kParts + blockIdx.x] = rz;
+    if (dinv) parts[rz_next * kParts + blockIdx.x] = rz;
     parts[P_RR * kParts + blockIdx.x] = rr;
   }
 }
@@ -543,7 +607,8 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   }
   launch_residual(s, *op.A, op.nv, x, rhs, w.r.p, op.rowmask, op.maskmode);
   int cur = P_RZ0, nxt = P_RZ1;
-  LAUNCH(k_cg_start, kParts, s, n, w.r.p, op.dinv, w.p.p, parts, cur);
+  if (op.prec) op.prec->apply(s, w.r.p, w.p.p);
+  LAUNCH(k_cg_start, kParts, s, n, w.r.p, op.prec ? nullptr : op.dinv, w.p.p, parts, cur);
   double rr = host_sum_parts(s, w, P_RR);
   const double r0 = std::sqrt(rr);
   launch_dot(s, n, rhs, rhs, parts + P_TT * kParts);
@@ -558,7 +623,12 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   while (!info.converged && it < o.max_iter) {
     launch_spmv(s, *op.A, op.nv, w.p.p, w.q.p, op.rowmask, op.maskmode);
     launch_dot(s, n, w.p.p, w.q.p, parts + P_PQ * kParts);
-    LAUNCH(k_cg_update, kParts, s, n, w.p.p, w.q.p, op.dinv, x, w.r.p, w.z.p, parts, cur, nxt);
+    LAUNCH(k_cg_update, kParts, s, n, w.p.p, w.q.p, op.prec ? nullptr : op.dinv, x, w.r.p, w.z.p,
+           parts, cur, nxt);
+    if (op.prec) {
+      op.prec->apply(s, w.r.p, w.z.p);
+      launch_dot(s, n, w.r.p, w.z.p, parts + nxt * kParts);
+    }
     LAUNCH(k_cg_p, kParts, s, n, w.z.p, w.p.p, parts, cur, nxt);
     std::swap(cur, nxt);
     ++it;

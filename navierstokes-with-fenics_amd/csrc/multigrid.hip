@@ -1,0 +1,306 @@
+// Geometric multigrid preconditioners for the IPCS pressure Poisson problem and the
+// constant part L = alpha0/k M + c_v K of the momentum operator.
+//
+// The reference solves every system with sparse LU (PETSc): the Krylov
+// solvers and their preconditioners are new functionality, judged on converged results.
+//
+// Hierarchy: [P2 on the fine mesh ->] P1 on the fine mesh -> P1 on nested coarser meshes.
+// All spaces are nested, so the Galerkin coarse operators equal the operators assembled
+// on the coarse meshes: they are integrated on the device by the same P1 element kernel
+// as the fine ones (no sparse triple products).  Smoother: Chebyshev-accelerated Jacobi,
+// fused into the SpMV kernel (EPI_CHEB epilogue: one launch per smoothing step);
+// transfers are SpMVs with explicit P and R = P^T; Dirichlet dofs are handled by row
+// masks propagated to the coarse levels by injection; the coarsest problem (<= ~1000
+// unknowns) is solved by one dense mat-vec with a host-computed (pseudo-)inverse.
+#include "nsfem_internal.hpp"
+#include <algorithm>
+
+namespace nsfem {
+
+// -------------------------------------------------------------------- kernels
+__global__ __launch_bounds__(256) void k_cheb_first(int64_t n, const double* __restrict__ b,
+                                                    const double* __restrict__ dinv,
+                                                    const uint8_t* __restrict__ mask, double c2,
+                                                    double* __restrict__ d,
+                                                    double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (mask && mask[i]) ? 0.0 : c2 * dinv[i] * b[i];
+    d[i] = v;
+    x[i] = v;
+  }
+}
+
+// x[(row, v)] = sum_c Ainv[v][c][row] b[(c, v)]   (Ainv symmetric, stored per component)
+__global__ __launch_bounds__(256) void k_dense_apply(int n, int nv,
+                                                     const double* __restrict__ Ainv,
+                                                     const double* __restrict__ b,
+                                                     double* __restrict__ x) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * nv) return;
+  const int v = idx / n, row = idx % n;
+  const double* A = Ainv + (size_t)v * n * n;
+  double acc = 0.0;
+  for (int c = 0; c < n; ++c) acc += A[(size_t)c * n + row] * b[(size_t)c * nv + v];
+  x[(size_t)row * nv + v] = acc;
+}
+
+// Gershgorin bound of D^{-1} A over unmasked rows: max_i dinv_i sum_j |a_ij|
+__global__ __launch_bounds__(256) void k_gershgorin(int n_rows, int nv,
+                                                    const int32_t* __restrict__ rowptr,
+                                                    const double* __restrict__ vals,
+                                                    const uint8_t* __restrict__ mask,
+                                                    const double* __restrict__ dinv,
+                                                    double* __restrict__ parts) {
+  __shared__ double sh[256];
+  double best = 0.0;
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows;
+       row += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) s += fabs(vals[k]);
+    for (int v = 0; v < nv; ++v) {
+      const size_t i = (size_t)row * nv + v;
+      if (!(mask && mask[i])) best = fmax(best, s * dinv[i]);
+    }
+  }
+  sh[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
+}
+
+// --------------------------------------------------------------- host helpers
+// transfer matrix from CSR triplets (rows = finer level, cols = coarser level) + R = P^T
+void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* rowptr,
+                     const int32_t* col, const double* val) {
+  const int nnz = rowptr[n_fine];
+  patP.n_rows = n_fine; patP.n_cols = n_coarse; patP.nnz = nnz;
+  patP.h_rowptr.assign(rowptr, rowptr + n_fine + 1);
+  patP.h_col.assign(col, col + nnz);
+  for (int k = 0; k < nnz; ++k)
+    NSFEM_REQUIRE(col[k] >= 0 && col[k] < n_coarse, "prolongation column out of range");
+  patP.rowptr.upload(patP.h_rowptr, s);
+  patP.col.upload(patP.h_col, s);
+  P.pat = &patP; P.br = P.bc = 1;
+  P.vals.upload(val, (size_t)nnz, s);
+  NSFEM_HIP(hipStreamSynchronize(s));
+  // transpose
+  std::vector<int32_t> rp((size_t)n_coarse + 1, 0), rc((size_t)nnz);
+  std::vector<double> rv((size_t)nnz);
+  for (int k = 0; k < nnz; ++k) rp[col[k] + 1]++;
+  for (int j = 0; j < n_coarse; ++j) rp[j + 1] += rp[j];
+  std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+  h_inj.assign((size_t)n_coarse, -1);
+  for (int i = 0; i < n_fine; ++i)
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const int j = col[k];
+      rc[fill[j]] = i;
+      rv[fill[j]] = val[k];
+      fill[j]++;
+      if (rowptr[i + 1] - rowptr[i] == 1 && std::fabs(val[k] - 1.0) < 1e-14) h_inj[j] = i;
+    }
+  for (int j = 0; j < n_coarse; ++j)
+    NSFEM_REQUIRE(h_inj[j] >= 0, "coarse node without a coinciding fine node (spaces not nested)");
+  patR.n_rows = n_coarse; patR.n_cols = n_fine; patR.nnz = nnz;
+  patR.h_rowptr = rp; patR.h_col = rc;
+  patR.rowptr.upload(rp, s);
+  patR.col.upload(rc, s);
+  R.pat = &patR; R.br = R.bc = 1;
+  R.vals.upload(rv, s);
+}
+
+static void invert_dense(std::vector<double>& a, int n) {
+  // Gauss-Jordan with partial pivoting, in place
+  std::vector<int> piv(n);
+  std::vector<double> inv((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+  for (int c = 0; c < n; ++c) {
+    int p = c;
+    double best = std::fabs(a[(size_t)c * n + c]);
+    for (int r = c + 1; r < n; ++r)
+      if (std::fabs(a[(size_t)r * n + c]) > best) { best = std::fabs(a[(size_t)r * n + c]); p = r; }
+    if (best == 0.0) throw Error(NSFEM_ERR_BREAKDOWN, "singular coarse multigrid matrix");
+    if (p != c)
+      for (int k = 0; k < n; ++k) {
+        std::swap(a[(size_t)p * n + k], a[(size_t)c * n + k]);
+        std::swap(inv[(size_t)p * n + k], inv[(size_t)c * n + k]);
+      }
+    const double d = 1.0 / a[(size_t)c * n + c];
+    for (int k = 0; k < n; ++k) { a[(size_t)c * n + k] *= d; inv[(size_t)c * n + k] *= d; }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = a[(size_t)r * n + c];
+      if (f == 0.0) continue;
+      for (int k = 0; k < n; ++k) {
+        a[(size_t)r * n + k] -= f * a[(size_t)c * n + k];
+        inv[(size_t)r * n + k] -= f * inv[(size_t)c * n + k];
+      }
+    }
+  }
+  a.swap(inv);
+}
+
+// ------------------------------------------------------------------ Multigrid
+void Multigrid::setup_work(hipStream_t s) {
+  for (size_t l = 0; l < lv.size(); ++l) {
+    MGLevel& L = lv[l];
+    const size_t n = (size_t)L.n * nv;
+    for (DevBuf<double>* b : {&L.xa, &L.xb, &L.r, &L.d, &L.dinv}) { b->alloc(n); b->zero(s); }
+    if (l > 0) {
+      L.x.alloc(n); L.x.zero(s);
+      L.b.alloc(n); L.b.zero(s);
+      L.own_mask.alloc(n); L.own_mask.zero(s);
+      L.mask = L.own_mask.p;
+    }
+  }
+  if (!parts.p) parts.alloc(kParts);
+}
+
+// masks (host, level 0) -> coarse levels by injection; dinv, lambda_max, coarse inverse
+void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular) {
+  std::vector<uint8_t> cur = mask0, nxt;
+  std::vector<double> hp(kParts);
+  for (size_t l = 0; l < lv.size(); ++l) {
+    MGLevel& L = lv[l];
+    const size_t n = (size_t)L.n * nv;
+    NSFEM_REQUIRE(cur.size() == n, "multigrid mask size mismatch");
+    if (l > 0) {
+      NSFEM_HIP(hipMemcpyAsync(L.own_mask.p, cur.data(), n, hipMemcpyHostToDevice, s));
+      NSFEM_HIP(hipStreamSynchronize(s));
+    }
+    launch_inv_diag(s, *L.A, nv, L.mask, L.dinv.p);
+    hipLaunchKernelGGL(k_gershgorin, dim3(kParts), dim3(256), 0, s, L.A->pat->n_rows, nv,
+                       L.A->pat->rowptr.p, L.A->vals.p, L.mask, L.dinv.p, parts.p);
+    NSFEM_HIP(hipGetLastError());
+    NSFEM_HIP(hipMemcpyAsync(hp.data(), parts.p, sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+    L.lmax = *std::max_element(hp.begin(), hp.end());
+    if (!(L.lmax > 0.0) || !std::isfinite(L.lmax)) L.lmax = 2.0;
+    if (l + 1 < lv.size()) {
+      const std::vector<int32_t>& inj = *L.h_inj;
+      nxt.assign((size_t)lv[l + 1].n * nv, 0);
+      for (int j = 0; j < lv[l + 1].n; ++j)
+        for (int v = 0; v < nv; ++v) nxt[(size_t)j * nv + v] = cur[(size_t)inj[j] * nv + v];
+      cur.swap(nxt);
+    }
+  }
+  // coarsest level: dense (pseudo-)inverse per component
+  MGLevel& C = lv.back();
+  dense_coarse = C.n <= coarse_dense_max;
+  if (dense_coarse) {
+    const Pattern& p = *C.A->pat;
+    const int n = C.n;
+    std::vector<double> v((size_t)p.nnz);
+    NSFEM_HIP(hipMemcpyAsync(v.data(), C.A->vals.p, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+    std::vector<double> all((size_t)nv * n * n);
+    for (int c = 0; c < nv; ++c) {
+      std::vector<double> a((size_t)n * n, 0.0);
+      bool any_mask = false;
+      for (int i = 0; i < n; ++i) {
+        const bool mi = cur[(size_t)i * nv + c] != 0;
+        any_mask |= mi;
+        for (int k = p.h_rowptr[i]; k < p.h_rowptr[i + 1]; ++k) {
+          const int j = p.h_col[k];
+          const bool mj = cur[(size_t)j * nv + c] != 0;
+          if (!mi && !mj) a[(size_t)i * n + j] = v[k];
+        }
+        if (mi) a[(size_t)i * n + i] = 1.0;
+      }
+      const bool sing = singular && !any_mask;
+      double gamma = 0.0;
+      if (sing) {
+        for (int i = 0; i < n; ++i) gamma += a[(size_t)i * n + i];
+        gamma /= n;
+        for (size_t t = 0; t < a.size(); ++t) a[t] += gamma / n;
+      }
+      invert_dense(a, n);
+      if (sing)
+        for (size_t t = 0; t < a.size(); ++t) a[t] -= 1.0 / (gamma * n);
+      // masked rows/cols of the inverse act as zero (corrections vanish there)
+      for (int i = 0; i < n; ++i)
+        if (cur[(size_t)i * nv + c])
+          for (int j = 0; j < n; ++j) a[(size_t)i * n + j] = a[(size_t)j * n + i] = 0.0;
+      std::copy(a.begin(), a.end(), all.begin() + (size_t)c * n * n);
+    }
+    coarse_inv.upload(all, s);
+  }
+  ready = true;
+}
+
+void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1, double& c2,
+                            double& rho) const {
+  const double b = 1.05 * L.lmax, a = b / eig_ratio;
+  const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
+  if (k == 0) {
+    c1 = 0.0;
+    c2 = 1.0 / theta;
+    rho = 1.0 / sigma;
+  } else {
+    rho = 1.0 / (2.0 * sigma - rho_prev);
+    c1 = rho * rho_prev;
+    c2 = 2.0 * rho / delta;
+  }
+}
+
+// `steps` Chebyshev steps on A x = b.  x_in == nullptr: zero initial guess.  The result
+// is written to x_out (which may alias x_in only when steps >= 2).
+void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
+                       double* x_out, int steps) {
+  const int64_t n = (int64_t)L.n * nv;
+  double rho = 0.0, c1, c2;
+  const double* cur = x_in;
+  for (int k = 0; k < steps; ++k) {
+    double rho_new;
+    cheb_coeffs(L, k, rho, c1, c2, rho_new);
+    rho = rho_new;
+    double* out;
+    if (k == steps - 1 && (x_out != cur)) out = x_out;
+    else out = (cur == L.xa.p) ? L.xb.p : L.xa.p;
+    if (cur == nullptr) {
+      int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+      hipLaunchKernelGGL(k_cheb_first, dim3(grid), dim3(256), 0, s, n, b, L.dinv.p, L.mask, c2,
+                         L.d.p, out);
+      NSFEM_HIP(hipGetLastError());
+    } else {
+      launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask);
+    }
+    cur = out;
+  }
+  if (cur != x_out)
+    NSFEM_HIP(hipMemcpyAsync(x_out, cur, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+}
+
+void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
+  MGLevel& L = lv[l];
+  const int64_t n = (int64_t)L.n * nv;
+  if (l + 1 == lv.size()) {
+    if (dense_coarse) {
+      const int tot = L.n * nv;
+      hipLaunchKernelGGL(k_dense_apply, dim3((tot + 255) / 256), dim3(256), 0, s, L.n, nv,
+                         coarse_inv.p, b, x);
+      NSFEM_HIP(hipGetLastError());
+    } else {
+      smooth(s, L, b, nullptr, x, coarse_steps);
+    }
+    return;
+  }
+  MGLevel& C = lv[l + 1];
+  smooth(s, L, b, nullptr, x, degree);
+  launch_residual(s, *L.A, nv, x, b, L.r.p, L.mask, MASK_ZERO);
+  launch_spmv(s, *L.R, nv, L.r.p, C.b.p, C.mask, MASK_ZERO);
+  vcycle(s, l + 1, C.b.p, C.x.p);
+  launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask);
+  smooth(s, L, b, x, x, degree);
+  (void)n;
+}
+
+void Multigrid::apply(hipStream_t s, const double* r, double* z) {
+  NSFEM_REQUIRE(ready, "multigrid hierarchy not refreshed");
+  vcycle(s, 0, r, z);
+}
+
+}  // namespace nsfem

@@ -43,6 +43,7 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
   ~DevBuf() { release(); }
   void release() {
     if (p) (void)hipFree(p);
@@ -117,6 +118,14 @@ void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, doub
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
                      const double* b, double* y, const uint8_t* rowmask, int maskmode);
 
+// y += A x (masked rows -> 0);  Chebyshev/Jacobi smoother step
+//   d = c1 d + c2 dinv (b - A x) ; xout = x + d   (masked rows -> 0)
+void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
+                            const uint8_t* rowmask);
+void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
+                      const double* dinv, double* d, double c1, double c2, double* xout,
+                      const uint8_t* rowmask);
+
 // element kernels
 struct MeshDev {
   int n_cells = 0, n_p2 = 0, n_p1 = 0, n_vertices = 0;
@@ -169,13 +178,64 @@ struct KrylovWork {
   ~KrylovWork();
 };
 
+// general preconditioner z = M^{-1} r (multigrid); nullptr in LinOp => Jacobi (dinv)
+struct Precond {
+  virtual ~Precond() {}
+  virtual void apply(hipStream_t s, const double* r, double* z) = 0;
+};
+
 struct LinOp {
   const BlockMat* A = nullptr;
   int nv = 1;
   const uint8_t* rowmask = nullptr;
   int maskmode = MASK_NONE;
   const double* dinv = nullptr;     // Jacobi
+  Precond* prec = nullptr;          // overrides dinv when set
 };
+
+// ---- multigrid ------------------------------------------------------------------
+// P (rows = finer level, cols = coarser level) and R = P^T as scalar CSR operators
+struct Transfer {
+  Pattern patP, patR;
+  BlockMat P, R;
+  std::vector<int32_t> h_inj;   // coarse node -> coinciding finer-level node
+  void build(hipStream_t s, int n_fine, int n_coarse, const int32_t* rowptr, const int32_t* col,
+             const double* val);
+};
+
+struct MGLevel {
+  const BlockMat* A = nullptr;   // scalar operator of this level
+  int n = 0;                     // scalar unknowns
+  const uint8_t* mask = nullptr; // [n * nv]; level 0 uses the context's mask
+  DevBuf<uint8_t> own_mask;
+  DevBuf<double> dinv, xa, xb, x, b, r, d;
+  double lmax = 2.0;
+  const BlockMat* P = nullptr;   // transfer to / from the next coarser level
+  const BlockMat* R = nullptr;
+  const std::vector<int32_t>* h_inj = nullptr;
+};
+
+struct Multigrid : Precond {
+  int nv = 1;
+  std::vector<MGLevel> lv;
+  int degree = 2;                // Chebyshev steps per pre/post smoothing
+  double eig_ratio = 4.0;        // smoothing interval [lmax / ratio, lmax]
+  int coarse_dense_max = 1200;
+  int coarse_steps = 30;
+  bool dense_coarse = true, ready = false;
+  DevBuf<double> coarse_inv, parts;
+  void setup_work(hipStream_t s);
+  void refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular);
+  void apply(hipStream_t s, const double* r, double* z) override;
+  void vcycle(hipStream_t s, size_t l, const double* b, double* x);
+  void smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
+              int steps);
+  void cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1, double& c2,
+                   double& rho) const;
+};
+
+// z[dofs] = r[dofs]
+void launch_copy_at(hipStream_t s, int n, const int32_t* dofs, const double* r, double* z);
 
 // Jacobi-preconditioned BiCGStab; x holds the initial guess on entry
 int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
@@ -216,4 +276,26 @@ struct nsfem_ctx {
   nsfem::KrylovWork kw;
   int assembled_system = -1;
   double area = 0.0;
+  // ---- multigrid hierarchy (optional; nsfem_mg_add_level / nsfem_mg_finalize)
+  struct P1Level {
+    int n = 0;
+    nsfem::MeshDev mesh;
+    nsfem::Pattern pat;
+    nsfem::BlockMat K, M, Lc;
+    nsfem::Transfer to_finer;
+  };
+  std::vector<int32_t> h_p2map, h_p1map;       // host copies of the fine dof maps
+  std::vector<P1Level*> coarse;                // owned
+  nsfem::Transfer t_p2p1;                      // P2 (fine mesh) <- P1 (fine mesh)
+  nsfem::BlockMat Lc0;                         // alpha0/k M_p + c_v A_p on the fine P1 space
+  nsfem::Multigrid mg_p, mg_v;
+  bool mg_built = false, mg_p_dirty = true, mg_v_dirty = true;
+  std::vector<int32_t> h_bc_v, h_bc_p;         // host copies of the Dirichlet dof sets
+  struct MomentumPrec : nsfem::Precond {
+    nsfem_ctx* c = nullptr;
+    void apply(hipStream_t s, const double* r, double* z) override;
+  } mom_prec;
+  ~nsfem_ctx() {
+    for (P1Level* p : coarse) delete p;
+  }
 };

@@ -214,4 +214,6 @@ def rectangle_mesh(p0, p1, nx, ny):
     cells = np.empty((2 * nx * ny, 3), dtype=np.int32)
     cells[0::2] = np.stack([v0, v1, v3], axis=1)
     cells[1::2] = np.stack([v0, v2, v3], axis=1)
-    return Mesh(coords, cells)
+    mesh = Mesh(coords, cells)
+    mesh.structured = (tuple(p0), tuple(p1), int(nx), int(ny))   # enables the multigrid hierarchy
+    return mesh

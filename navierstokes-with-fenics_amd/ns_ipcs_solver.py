@@ -80,6 +80,8 @@ class IPCSSolver(InstationarySolverBase):
         for k in (o.momentum, o.poisson, o.correction):
             k.rtol = self.krylov_rtol
             k.max_iter = self.krylov_max_iter
+        if self._mg_levels is not None:
+            o.momentum.precond = o.poisson.precond = 1
         return o
 
     def _solve_time_step(self):
@@ -91,12 +93,13 @@ class IPCSSolver(InstationarySolverBase):
             return
         # ---- explicit path: dolfin NewtonSolver control, driven through the seam
         ctx, kw = self._ctx, dict(rtol=self.krylov_rtol, max_iter=self.krylov_max_iter)
+        mg = dict(kw, precond=1 if self._mg_levels is not None else 0)
         self._assemble_system(nat.SYS_MOMENTUM, new_step=True)
         r0 = r = ctx.residual_norm(nat.SYS_MOMENTUM)
         residuals, it = [r], 0
         converged = r < self._tol
         while not converged and it < self._maxiter:
-            ctx.solve(nat.SYS_MOMENTUM, **kw)          # J dx = b ; u* -= dx
+            ctx.solve(nat.SYS_MOMENTUM, **mg)          # J dx = b ; u* -= dx
             it += 1
             self._assemble_system(nat.SYS_MOMENTUM)
             r = ctx.residual_norm(nat.SYS_MOMENTUM)
@@ -105,7 +108,7 @@ class IPCSSolver(InstationarySolverBase):
         if not converged:
             raise RuntimeError("Newton solver did not converge")
         self.last_newton_residuals = residuals
-        self._projection_solver.solve(**kw)
+        self._projection_solver.solve(**mg)
         self._velocity_correction_solver.solve(**kw)
 
     def set_initial_conditions(self, initial_conditions):

@@ -21,6 +21,7 @@ import fem_host
 from discrete_time import DiscreteTime
 from fem_function import MixedFunction
 from fem_mesh import FacetMarkers, Mesh, TaylorHoodDofMap
+from multigrid import attach_hierarchy
 
 
 class VelocityBCType(Enum):
@@ -215,6 +216,11 @@ class SolverBase:
         self._n_dofs = dm.n_dofs
         self._Wh = dm
         print("Number of cells {0}, number of DoFs: {1}".format(self._n_cells, self._n_dofs))
+        # geometric multigrid hierarchy for the Krylov preconditioners (structured meshes
+        # coarsen; any mesh gets at least the P2 -> P1 two-level hierarchy)
+        self._mg_levels = None
+        if getattr(self, "use_multigrid", True):
+            self._mg_levels = attach_hierarchy(self._ctx, self._mesh)
         self._push_coefficients()
 
     def _push_coefficients(self):
@@ -364,6 +370,8 @@ class InstationarySolverBase(SolverBase):
         # Krylov options of the device solves (the reference uses sparse LU instead)
         self.krylov_rtol = 1.0e-12
         self.krylov_max_iter = 20000
+        #: geometric multigrid preconditioning of the momentum and Poisson solves
+        self.use_multigrid = True
 
     # -- state ------------------------------------------------------------------
     def _setup_function_spaces(self):

@@ -8,6 +8,9 @@ from fem_mesh import rectangle_mesh, TaylorHoodDofMap, FacetMarkers
 
 n = int(sys.argv[1]); k = float(sys.argv[2]); nsteps = int(sys.argv[3])
 rtol = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-12
+mg = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # 0 none, 1 poisson, 2 poisson+momentum
+degree = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+ratio = float(sys.argv[7]) if len(sys.argv) > 7 else 4.0
 t0 = time.time()
 m = rectangle_mesh((0, 0), (1, 1), n, n)
 dm = TaylorHoodDofMap(m)
@@ -26,7 +29,12 @@ for mid, val in ((1, (0., 0.)), (2, (0., 0.)), (3, (0., 0.)), (4, (1., 0.))):
 ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
 ctx.set_dirichlet(nat.VELOCITY, np.concatenate(dofs), np.concatenate(vals))
 ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+if mg:
+    from multigrid import attach_hierarchy
+    t0 = time.time(); nl = attach_hierarchy(ctx, m, degree, ratio); print("mg levels %d setup %.2fs" % (nl, time.time() - t0))
 o = ctx.default_step_opts()
+if mg >= 1: o.poisson.precond = 1
+if mg >= 2: o.momentum.precond = 1
 for kk in (o.momentum, o.poisson, o.correction):
     kk.rtol = rtol
 for step in range(nsteps):

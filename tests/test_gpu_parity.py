@@ -132,6 +132,76 @@ def test_ipcs_cavity_steps_match_oracle():
     ctx.close()
 
 
+def test_ipcs_cavity_multigrid_preconditioning_same_answer():
+    """Multigrid-preconditioned Krylov (the production setting) vs the LU oracle."""
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(32, 32)
+    ctx = context(mesh, dm)
+    assert attach_hierarchy(ctx, mesh, coarsest=4) == 3
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    vbc = cavity_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-13
+    opts.momentum.precond = opts.poisson.precond = 1
+    for step in range(3):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, 0.01)
+        info = ctx.step_ipcs(opts)
+        orc.step(alpha, 0.01, vbc)
+        assert info.newton_iterations == orc.newton_its[step]
+        assert info.krylov_iterations_poisson <= 15          # mesh-independent convergence
+        assert info.krylov_iterations_momentum <= 10 * info.newton_iterations
+        ctx.advance(0)
+        orc.advance()
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    pg, po = ctx.get_state(nat.P_OLD), orc.p_old
+    assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
+    ctx.close()
+
+
+def test_multigrid_with_pressure_dirichlet_and_time_dependent_inlet():
+    """Channel with pressure outlet (masked coarse levels) on a mesh that coarsens once in
+    y; inlet values change every step (values refresh without rebuilding the hierarchy)."""
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(80, 8, p1=(10.0, 1.0))
+    ctx = context(mesh, dm)
+    assert attach_hierarchy(ctx, mesh, coarsest=4) == 1
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.1, body_force_term=None)
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    ctx.set_coeffs(1.0, 1.0, 0.1)
+    zero = lambda X: np.zeros((X.shape[0], 2))
+    pn = np.unique(dm.facet_p1_nodes(marks.facets_with_id(2)))
+    pbc = (pn, np.zeros(pn.size))
+    ctx.set_dirichlet(nat.PRESSURE, *pbc)
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-13
+    opts.momentum.precond = opts.poisson.precond = 1
+    for step in range(3):
+        t = 0.01 * (step + 1)
+        inlet = lambda X: np.stack([6.0 * X[:, 1] * (1.0 - X[:, 1]) * (1.0 + 0.5 * np.sin(np.pi * t)),
+                                    0.0 * X[:, 1]], axis=1)
+        vbc = velocity_bc(dm, marks, [(1, inlet), (3, zero), (4, zero)])
+        ctx.set_dirichlet(nat.VELOCITY, *vbc)
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, 0.01)
+        info = ctx.step_ipcs(opts)
+        orc.step(alpha, 0.01, vbc, pbc)
+        assert info.krylov_iterations_poisson <= 40
+        ctx.advance(0)
+        orc.advance()
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    assert rel(ctx.get_state(nat.P_OLD), orc.p_old) < 1e-9
+    ctx.close()
+
+
 def test_ipcs_stokes_channel_linear_steps_1e10():
     """Linear (convective term None) channel steps with a pressure Dirichlet outlet --
     the reference's tests/test_ipcs_solver.py case; north_star tolerance 1e-10."""

@@ -44,7 +44,7 @@ static int64_t slot_size(const nsfem_ctx* c, int slot) {
   }
 }
 
-static void upload_pattern(hipStream_t s, HostPattern& h, Pattern& d) {
+static void upload_pattern(hipStream_t s, HostPattern& h, Pattern& d, bool want_contrib = false) {
   d.n_rows = h.n_rows;
   d.n_cols = h.n_cols;
   d.nr = h.nr;
@@ -54,6 +54,15 @@ static void upload_pattern(hipStream_t s, HostPattern& h, Pattern& d) {
   d.col.upload(h.col, s);
   if (!h.diag.empty()) d.diag.upload(h.diag, s);
   d.slot.upload(h.slot, s);
+  if (want_contrib) {
+    const int64_t nc = (int64_t)h.slot.size() / (h.nr * h.nc), loc = h.nr * h.nc;
+    std::vector<int32_t> ptr, idx;
+    build_inverse_index(d.nnz, nc * loc,
+                        [&](int64_t src) { return h.slot[(size_t)(src % loc) * nc + src / loc]; },
+                        ptr, idx);
+    d.cptr.upload(ptr, s);
+    d.cidx.upload(idx, s);
+  }
   d.h_rowptr.swap(h.rowptr);
   d.h_col.swap(h.col);
   std::vector<int32_t>().swap(h.slot);
@@ -121,13 +130,22 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   {
     HostPattern h;
     build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, 6, m->p2_dofmap, 6, true, h);
-    upload_pattern(s, h, fresh->p22);
+    upload_pattern(s, h, fresh->p22, true);
+    {
+      std::vector<int32_t> ptr, idx;
+      build_inverse_index(m->n_p2, (int64_t)nc * 6,
+                          [&](int64_t src) { return m->p2_dofmap[src]; }, ptr, idx);
+      fresh->mesh.nptr.upload(ptr, s);
+      fresh->mesh.nidx.upload(idx, s);
+      fresh->mesh.ebuf.alloc((size_t)nc * 144);
+      fresh->mesh.rbuf.alloc((size_t)nc * 12);
+    }
     build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, 3, m->p1_dofmap, 3, true, h);
-    upload_pattern(s, h, fresh->p11);
+    upload_pattern(s, h, fresh->p11, true);
     build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, 3, m->p2_dofmap, 6, false, h);
-    upload_pattern(s, h, fresh->p12);
+    upload_pattern(s, h, fresh->p12, true);
     build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, 6, m->p1_dofmap, 3, false, h);
-    upload_pattern(s, h, fresh->p21);
+    upload_pattern(s, h, fresh->p21, true);
   }
   // ---- constant operators, integrated on the device
   QuadTables qt;
@@ -390,11 +408,13 @@ static double momentum_residual(nsfem_ctx* c) {
 
 static void momentum_jacobian(nsfem_ctx* c) {
   hipStream_t s = c->stream;
-  launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, c->traction_form ? c->E.vals.p : nullptr,
-                       c->coef[2], c->J.vals.p);
+  const double* E = c->traction_form ? c->E.vals.p : nullptr;
   const double cc = cc_of(c);
   if (cc != 0.0)
-    launch_convection_jacobian(s, c->mesh, c->p22, c->state[NSFEM_USTAR].p, cc, c->J.vals.p);
+    launch_convection_jacobian(s, c->mesh, c->p22, c->state[NSFEM_USTAR].p, cc, c->L.vals.p, E,
+                               c->coef[2], c->J.vals.p);
+  else
+    launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
   launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
 }
 
@@ -572,7 +592,7 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
   lv->mesh.p1.upload(p1, s);
   HostPattern h;
   build_pattern(d->n_vertices, d->n_vertices, nc, d->cells, 3, d->cells, 3, true, h);
-  upload_pattern(s, h, lv->pat);
+  upload_pattern(s, h, lv->pat, true);
   lv->K.init(&lv->pat, 1, 1, s);
   lv->M.init(&lv->pat, 1, 1, s);
   lv->Lc.init(&lv->pat, 1, 1, s);

@@ -12,8 +12,10 @@
 //     wave-uniform, so they arrive through the scalar cache (s_load) and occupy no
 //     VGPRs / LDS;
 //   * element tensors stay in registers (<= 24 fp64 accumulators per thread);
-//   * scatter into CSR values through the precomputed slot map with hardware
-//     fp64 atomics (global_atomic_add_f64, no CAS loop).
+//   * no atomics: every element tensor is written with plain stores to an element
+//     buffer indexed by (cell, i, j); a second kernel sums, for every CSR slot / dof,
+//     the entries listed in a precomputed inverted index in a fixed order.  Results
+//     are bitwise reproducible and each CSR value is written exactly once.
 //
 // All integrands are polynomials of degree <= 5 on affine cells, so the 7-point
 // degree-5 rule reproduces FEniCS' integrals to round-off.
@@ -55,7 +57,6 @@ __device__ __forceinline__ void phys(const CellGeo& g, double dr0, double dr1, d
   gy = g.ji01 * dr0 + g.ji11 * dr1;
 }
 
-__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // ------------------------------------------------------------------ scalar P2
 __global__ __launch_bounds__(256) void k_p2_scalar(int nc, const double* __restrict__ vx,
@@ -84,9 +85,9 @@ __global__ __launch_bounds__(256) void k_p2_scalar(int nc, const double* __restr
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const int s = slot[(size_t)(i * 6 + j) * nc + c];
-    atomic_add(mass + s, m[j]);
-    atomic_add(stiff + s, k[j]);
+    const size_t s = ((size_t)c * 6 + i) * 6 + j;     // element-buffer index (cell, i, j)
+    mass[s] = m[j];
+    stiff[s] = k[j];
   }
 }
 
@@ -108,9 +109,9 @@ __global__ __launch_bounds__(256) void k_p1_scalar(int nc, const double* __restr
     phys(g, dl[j][0], dl[j][1], gjx, gjy);
     double m = 0.0;
     for (int q = 0; q < 7; ++q) m += c_q.w[q] * c_q.phi1[q][i] * c_q.phi1[q][j];
-    const int s = slot[(size_t)(i * 3 + j) * nc + c];
-    atomic_add(stiff + s, 0.5 * g.adet * (gix * gjx + giy * gjy));
-    atomic_add(mass + s, m * g.adet);
+    const size_t s = ((size_t)c * 3 + i) * 3 + j;
+    stiff[s] = 0.5 * g.adet * (gix * gjx + giy * gjy);
+    mass[s] = m * g.adet;
   }
 }
 
@@ -137,9 +138,9 @@ __global__ __launch_bounds__(256) void k_div(int nc, const double* __restrict__ 
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const int s = slot12[(size_t)(i * 6 + j) * nc + c];
-    atomic_add(div + (size_t)2 * s, dx[j]);
-    atomic_add(div + (size_t)2 * s + 1, dy[j]);
+    const size_t s = ((size_t)c * 3 + i) * 6 + j;
+    div[2 * s] = dx[j];
+    div[2 * s + 1] = dy[j];
   }
 }
 
@@ -173,11 +174,11 @@ __global__ __launch_bounds__(256) void k_grad(int nc, const double* __restrict__
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int s = slot21[(size_t)(i * 3 + j) * nc + c];
-    atomic_add(grad + (size_t)2 * s, gr[j][0]);
-    atomic_add(grad + (size_t)2 * s + 1, gr[j][1]);
-    atomic_add(divT + (size_t)2 * s, dt[j][0]);
-    atomic_add(divT + (size_t)2 * s + 1, dt[j][1]);
+    const size_t s = ((size_t)c * 6 + i) * 3 + j;
+    grad[2 * s] = gr[j][0];
+    grad[2 * s + 1] = gr[j][1];
+    divT[2 * s] = dt[j][0];
+    divT[2 * s + 1] = dt[j][1];
   }
 }
 
@@ -208,9 +209,9 @@ __global__ __launch_bounds__(256) void k_visc_extra(int nc, const double* __rest
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const int s = slot[(size_t)(i * 6 + j) * nc + c];
+    const size_t s = ((size_t)c * 6 + i) * 6 + j;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomic_add(E + (size_t)4 * s + e, acc[j][e]);
+    for (int e = 0; e < 4; ++e) E[4 * s + e] = acc[j][e];
   }
 }
 
@@ -237,9 +238,8 @@ __global__ __launch_bounds__(256) void k_jac_init(int nnz, const double* __restr
 // (Gateaux derivative of dot(dot(grad(u), u), v), source/ns_solver_base.py:378)
 __global__ __launch_bounds__(256) void k_conv_jac(int nc, const double* __restrict__ vx,
                                                   const int32_t* __restrict__ p2,
-                                                  const int32_t* __restrict__ slot,
                                                   const double* __restrict__ u, double cc,
-                                                  double* __restrict__ J) {
+                                                  double* __restrict__ ebuf) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)nc * 6) return;
   const int i = (int)(t / nc), c = (int)(t % nc);
@@ -280,29 +280,56 @@ __global__ __launch_bounds__(256) void k_conv_jac(int nc, const double* __restri
       acc[j][3] += wpi * (udg + pj * g11);
     }
   }
+  // plain stores of the 6 blocks of row i: ebuf[cell][i][j][4]
+  double2* out = reinterpret_cast<double2*>(ebuf) + ((size_t)c * 36 + (size_t)i * 6) * 2;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const int s = slot[(size_t)(i * 6 + j) * nc + c];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomic_add(J + (size_t)4 * s + e, acc[j][e]);
+    out[2 * j] = make_double2(acc[j][0], acc[j][1]);
+    out[2 * j + 1] = make_double2(acc[j][2], acc[j][3]);
   }
+}
+
+// J[s] = L[s] (x) I_2 + cvE * E[s] + sum of the element blocks scattered to slot s, summed
+// in ascending (cell, i, j) order: deterministic, every value written exactly once
+__global__ __launch_bounds__(256) void k_jac_gather(int nnz, const int32_t* __restrict__ cptr,
+                                                    const int32_t* __restrict__ cidx,
+                                                    const double* __restrict__ ebuf,
+                                                    const double* __restrict__ L,
+                                                    const double* __restrict__ E, double cvE,
+                                                    double* __restrict__ J) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  const double l = L[s];
+  double2 r0 = make_double2(l, 0.0), r1 = make_double2(0.0, l);
+  if (E) {
+    const double2 e0 = reinterpret_cast<const double2*>(E)[2 * (size_t)s];
+    const double2 e1 = reinterpret_cast<const double2*>(E)[2 * (size_t)s + 1];
+    r0.x += cvE * e0.x; r0.y += cvE * e0.y;
+    r1.x += cvE * e1.x; r1.y += cvE * e1.y;
+  }
+  for (int k = cptr[s]; k < cptr[s + 1]; ++k) {
+    const double2* src = reinterpret_cast<const double2*>(ebuf) + 2 * (size_t)cidx[k];
+    const double2 a = src[0], b = src[1];
+    r0.x += a.x; r0.y += a.y;
+    r1.x += b.x; r1.y += b.y;
+  }
+  reinterpret_cast<double2*>(J)[2 * (size_t)s] = r0;
+  reinterpret_cast<double2*>(J)[2 * (size_t)s + 1] = r1;
 }
 
 // ---- convection residual:  b_(i,a) += cc * int ((grad u) u)_a phi_i
 __global__ __launch_bounds__(256) void k_conv_res(int nc, const double* __restrict__ vx,
                                                   const int32_t* __restrict__ p2,
                                                   const double* __restrict__ u, double cc,
-                                                  double* __restrict__ b) {
+                                                  double* __restrict__ rbuf) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)nc * 6) return;
   const int i = (int)(t / nc), c = (int)(t % nc);
   const CellGeo g = load_geo(vx, nc, c);
   double ux[6], uy[6];
-  int node_i = 0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int node = p2[(size_t)k * nc + c];
-    if (k == i) node_i = node;
     const double2 v = reinterpret_cast<const double2*>(u)[node];
     ux[k] = v.x;
     uy[k] = v.y;
@@ -326,38 +353,97 @@ __global__ __launch_bounds__(256) void k_conv_res(int nc, const double* __restri
     rx += wpi * (g00 * uqx + g01 * uqy);
     ry += wpi * (g10 * uqx + g11 * uqy);
   }
-  atomic_add(b + (size_t)2 * node_i, rx);
-  atomic_add(b + (size_t)2 * node_i + 1, ry);
+  reinterpret_cast<double2*>(rbuf)[(size_t)c * 6 + i] = make_double2(rx, ry);
+}
+
+// b[(node, a)] += sum of the element vectors of the cells around the node (fixed order)
+__global__ __launch_bounds__(256) void k_res_gather(int n_nodes, const int32_t* __restrict__ nptr,
+                                                    const int32_t* __restrict__ nidx,
+                                                    const double* __restrict__ rbuf,
+                                                    double* __restrict__ b) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_nodes) return;
+  double2 acc = reinterpret_cast<double2*>(b)[n];
+  for (int k = nptr[n]; k < nptr[n + 1]; ++k) {
+    const double2 v = reinterpret_cast<const double2*>(rbuf)[nidx[k]];
+    acc.x += v.x;
+    acc.y += v.y;
+  }
+  reinterpret_cast<double2*>(b)[n] = acc;
+}
+
+// vals[slot][bs] = sum over the slot's sources of ebuf[source][bs]  (fixed order)
+__global__ __launch_bounds__(256) void k_gather_vals(int nnz, int bs,
+                                                     const int32_t* __restrict__ cptr,
+                                                     const int32_t* __restrict__ cidx,
+                                                     const double* __restrict__ ebuf,
+                                                     double* __restrict__ vals) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nnz * bs) return;
+  const int s = (int)(t / bs), e = (int)(t % bs);
+  double acc = 0.0;
+  for (int k = cptr[s]; k < cptr[s + 1]; ++k) acc += ebuf[(size_t)cidx[k] * bs + e];
+  vals[t] = acc;
 }
 
 // ------------------------------------------------------------- launch wrappers
 static inline int grid_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
+static void gather_vals(hipStream_t s, const Pattern& p, int bs, const double* ebuf, double* vals) {
+  NSFEM_REQUIRE(p.cptr.p && p.cidx.p, "pattern has no inverted index");
+  hipLaunchKernelGGL(k_gather_vals, dim3(grid_for((int64_t)p.nnz * bs)), dim3(kBlock), 0, s,
+                     p.nnz, bs, p.cptr.p, p.cidx.p, ebuf, vals);
+  NSFEM_HIP(hipGetLastError());
+}
+
 void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p22, double* mass,
                                double* stiff) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 72);
+  double* t0 = tmp.p;
+  double* t1 = tmp.p + (size_t)m.n_cells * 36;
   hipLaunchKernelGGL(k_p2_scalar, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
-                     m.n_cells, m.vx.p, p22.slot.p, mass, stiff);
-  NSFEM_HIP(hipGetLastError());
+                     m.n_cells, m.vx.p, p22.slot.p, t0, t1);
+  gather_vals(s, p22, 1, t0, mass);
+  gather_vals(s, p22, 1, t1, stiff);
+  NSFEM_HIP(hipStreamSynchronize(s));
 }
 void launch_assemble_p1_scalar(hipStream_t s, const MeshDev& m, const Pattern& p11, double* stiff,
                                double* mass) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 18);
+  double* t0 = tmp.p;
+  double* t1 = tmp.p + (size_t)m.n_cells * 9;
   hipLaunchKernelGGL(k_p1_scalar, dim3(grid_for((int64_t)m.n_cells * 3)), dim3(kBlock), 0, s,
-                     m.n_cells, m.vx.p, p11.slot.p, stiff, mass);
-  NSFEM_HIP(hipGetLastError());
+                     m.n_cells, m.vx.p, p11.slot.p, t0, t1);
+  gather_vals(s, p11, 1, t0, stiff);
+  gather_vals(s, p11, 1, t1, mass);
+  NSFEM_HIP(hipStreamSynchronize(s));
 }
 void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p12,
                               const Pattern& p21, double* div, double* grad, double* divT) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 36 * 3);
+  double* t0 = tmp.p;
+  double* t1 = tmp.p + (size_t)m.n_cells * 36;
+  double* t2 = tmp.p + (size_t)m.n_cells * 72;
   hipLaunchKernelGGL(k_div, dim3(grid_for((int64_t)m.n_cells * 3)), dim3(kBlock), 0, s, m.n_cells,
-                     m.vx.p, p12.slot.p, div);
+                     m.vx.p, p12.slot.p, t0);
   hipLaunchKernelGGL(k_grad, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s, m.n_cells,
-                     m.vx.p, p21.slot.p, grad, divT);
-  NSFEM_HIP(hipGetLastError());
+                     m.vx.p, p21.slot.p, t1, t2);
+  gather_vals(s, p12, 2, t0, div);
+  gather_vals(s, p21, 2, t1, grad);
+  gather_vals(s, p21, 2, t2, divT);
+  NSFEM_HIP(hipStreamSynchronize(s));
 }
 void launch_assemble_viscous_extra(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                    double* extra) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 144);
   hipLaunchKernelGGL(k_visc_extra, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
-                     m.n_cells, m.vx.p, p22.slot.p, extra);
-  NSFEM_HIP(hipGetLastError());
+                     m.n_cells, m.vx.p, p22.slot.p, tmp.p);
+  gather_vals(s, p22, 4, tmp.p, extra);
+  NSFEM_HIP(hipStreamSynchronize(s));
 }
 void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double* E, double cvE,
                           double* J) {
@@ -367,15 +453,20 @@ void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double*
   NSFEM_HIP(hipGetLastError());
 }
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
-                                const double* u, double cc, double* J) {
+                                const double* u, double cc, const double* L, const double* E,
+                                double cvE, double* J) {
   hipLaunchKernelGGL(k_conv_jac, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
-                     m.n_cells, m.vx.p, m.p2.p, p22.slot.p, u, cc, J);
+                     m.n_cells, m.vx.p, m.p2.p, u, cc, m.ebuf.p);
+  hipLaunchKernelGGL(k_jac_gather, dim3(grid_for(p22.nnz)), dim3(kBlock), 0, s, p22.nnz,
+                     p22.cptr.p, p22.cidx.p, m.ebuf.p, L, E, cvE, J);
   NSFEM_HIP(hipGetLastError());
 }
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b) {
   hipLaunchKernelGGL(k_conv_res, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
-                     m.n_cells, m.vx.p, m.p2.p, u, cc, b);
+                     m.n_cells, m.vx.p, m.p2.p, u, cc, m.rbuf.p);
+  hipLaunchKernelGGL(k_res_gather, dim3(grid_for(m.n_p2)), dim3(kBlock), 0, s, m.n_p2, m.nptr.p,
+                     m.nidx.p, m.rbuf.p, b);
   NSFEM_HIP(hipGetLastError());
 }
 

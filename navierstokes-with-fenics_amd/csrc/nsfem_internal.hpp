@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <functional>
 #include "../../include/nsfem.h"
 
 namespace nsfem {
@@ -80,8 +81,12 @@ void build_pattern(int n_rows, int n_cols, int n_cells, const int32_t* rowmap, i
 struct Pattern {
   int n_rows = 0, n_cols = 0, nnz = 0, nr = 0, nc = 0;
   DevBuf<int32_t> rowptr, col, diag, slot;
+  DevBuf<int32_t> cptr, cidx;             // per slot: sources (cell * nr*nc + i * nc + j)
   std::vector<int32_t> h_rowptr, h_col;   // kept for export
 };
+void build_inverse_index(int n_targets, int64_t n_sources,
+                         const std::function<int32_t(int64_t)>& target_of,
+                         std::vector<int32_t>& ptr, std::vector<int32_t>& idx);
 
 // block matrix on a pattern; vals[nnz][BR][BC] row-major blocks
 struct BlockMat {
@@ -132,6 +137,9 @@ struct MeshDev {
   DevBuf<double> vx;        // SoA vertex coords per cell: [6][n_cells] (x0,y0,x1,y1,x2,y2)
   DevBuf<int32_t> p2;       // SoA [6][n_cells]
   DevBuf<int32_t> p1;       // SoA [3][n_cells]
+  DevBuf<int32_t> nptr, nidx;   // per P2 node: sources (cell * 6 + i) of vector assembly
+  DevBuf<double> ebuf;      // element Jacobian blocks [cell][6][6][4] (plain stores)
+  DevBuf<double> rbuf;      // element residual [cell][6][2]
 };
 void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                double* mass, double* stiff);
@@ -144,8 +152,10 @@ void launch_assemble_viscous_extra(hipStream_t s, const MeshDev& m, const Patter
 // J(2x2 blocks) = L (scalar) (x) I_2 [+ cv_extra * E]  then  += cc * conv'(u)
 void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double* E,
                           double cvE, double* J);
+// J = L (x) I_2 + cvE * E + cc * conv'(u): element blocks are stored, then gathered per slot
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
-                                const double* u, double cc, double* J);
+                                const double* u, double cc, const double* L, const double* E,
+                                double cvE, double* J);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b);
 // diag extraction: d[(i,a)] = 1 / A_ii[a][a]  (mask rows -> 1)

@@ -111,3 +111,22 @@ void fill_quad_tables(QuadTables& t) {
 }
 
 }  // namespace nsfem
+
+namespace nsfem {
+
+// Inverted index: for every target (CSR slot / dof) the ascending list of sources that
+// scatter into it.  Lets the assembly kernels store element tensors with plain stores and
+// sum per target in a fixed order (deterministic, no atomics).
+void build_inverse_index(int n_targets, int64_t n_sources,
+                         const std::function<int32_t(int64_t)>& target_of,
+                         std::vector<int32_t>& ptr, std::vector<int32_t>& idx) {
+  if (n_sources > INT32_MAX) throw Error(NSFEM_ERR_ARG, "inverse index exceeds int32");
+  ptr.assign((size_t)n_targets + 1, 0);
+  for (int64_t s = 0; s < n_sources; ++s) ptr[(size_t)target_of(s) + 1]++;
+  for (int t = 0; t < n_targets; ++t) ptr[t + 1] += ptr[t];
+  idx.resize((size_t)n_sources);
+  std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t s = 0; s < n_sources; ++s) idx[fill[target_of(s)]++] = (int32_t)s;
+}
+
+}  // namespace nsfem

@@ -68,7 +68,13 @@ enum nsfem_slot {
 };
 
 /* fields for Dirichlet sets */
-enum nsfem_field { NSFEM_VELOCITY = 0, NSFEM_PRESSURE = 1 };
+enum nsfem_field {
+  NSFEM_VELOCITY = 0,
+  NSFEM_PRESSURE = 1,
+  NSFEM_PRESSURE_PRECOND = 2   /* Dirichlet set of the pressure Laplacian used inside the
+                                  Schur-complement preconditioner of the monolithic scheme
+                                  (P1 nodes on open boundaries + true pressure conditions) */
+};
 
 /* operators that can be exported / applied (parity tests, _assemble_system) */
 enum nsfem_operator {

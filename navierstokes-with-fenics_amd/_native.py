@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libnsfem_hip.so")
 # ---- enums (mirror include/nsfem.h) ------------------------------------------
 OK, ERR_ARG, ERR_HIP, ERR_BREAKDOWN, ERR_NOT_CONVERGED, ERR_COMM = 0, -1, -2, -3, -4, -5
 U0, U1, U2, USTAR, P, P_OLD, BODY_FORCE, TRACTION, P2_OLD = range(9)
-VELOCITY, PRESSURE = 0, 1
+VELOCITY, PRESSURE, PRESSURE_PRECOND = 0, 1, 2
 (OP_MASS_P2, OP_STIFF_P2, OP_STIFF_P1, OP_MASS_P1, OP_DIV, OP_GRAD, OP_DIVT,
  OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA) = range(9)
 SYS_MOMENTUM, SYS_POISSON, SYS_CORRECTION, SYS_MONOLITHIC = range(4)

@@ -254,8 +254,29 @@ extern "C" int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const i
                                    const double* vals) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
-  NSFEM_REQUIRE(field == NSFEM_VELOCITY || field == NSFEM_PRESSURE, "bad field");
-  NSFEM_REQUIRE(n >= 0 && (n == 0 || (dofs && vals)), "bad Dirichlet arrays");
+  NSFEM_REQUIRE(field == NSFEM_VELOCITY || field == NSFEM_PRESSURE ||
+                    field == NSFEM_PRESSURE_PRECOND, "bad field");
+  NSFEM_REQUIRE(n >= 0 && (n == 0 || dofs), "bad Dirichlet arrays");
+  if (field == NSFEM_PRESSURE_PRECOND) {
+    // Dirichlet set of the pressure Laplacian inside the Schur-complement preconditioner of
+    // the monolithic scheme (open boundaries + true pressure conditions); values unused
+    std::vector<int32_t> d(dofs, dofs + n);
+    std::sort(d.begin(), d.end());
+    d.erase(std::unique(d.begin(), d.end()), d.end());
+    for (int32_t k : d) NSFEM_REQUIRE(k >= 0 && k < npre(ctx), "Dirichlet dof out of range");
+    if (d != ctx->h_bc_s || !ctx->mask_s.p) {
+      DevBuf<int32_t> dd;
+      dd.upload(d, ctx->stream);
+      if (!ctx->mask_s.p) ctx->mask_s.alloc((size_t)npre(ctx));
+      ctx->mask_s.zero(ctx->stream);
+      launch_fill_mask(ctx->stream, (int)d.size(), dd.p, ctx->mask_s.p);
+      NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+      ctx->h_bc_s.swap(d);
+      ctx->mg_s_dirty = true;
+    }
+    return NSFEM_OK;
+  }
+  NSFEM_REQUIRE(n == 0 || vals, "bad Dirichlet arrays");
   const int64_t size = field == NSFEM_VELOCITY ? nvel(ctx) : npre(ctx);
   // later entries win on duplicates (list order of dolfin bc.apply): dedupe on host
   std::vector<int32_t> d;
@@ -342,6 +363,19 @@ static void ensure_L(nsfem_ctx* c) {
 }
 
 // (re)build masks / smoother data / coarse inverse of a hierarchy when its inputs changed
+static void mg_refresh_schur(nsfem_ctx* c) {
+  if (c->mg_s_dirty) {
+    std::vector<uint8_t> m((size_t)npre(c), 0);
+    for (int32_t d : c->h_bc_s) m[d] = 1;
+    c->mg_s.refresh(c->stream, m, c->h_bc_s.empty());
+    c->mg_s_dirty = false;
+  }
+  if (!c->mg_m.ready) {
+    std::vector<uint8_t> m((size_t)npre(c), 0);
+    c->mg_m.refresh(c->stream, m, false);
+  }
+}
+
 static void mg_refresh(nsfem_ctx* c, bool momentum) {
   if (momentum) {
     ensure_L(c);
@@ -369,7 +403,7 @@ static double cc_of(const nsfem_ctx* c) { return std::isfinite(c->coef[0]) ? c->
 
 // time-step constant part of the momentum residual:
 //   g = M (a1 u1 + a2 u2) / k - c_p (p_old, div w) - c_b M f + traction
-static void momentum_begin_step(nsfem_ctx* c) {
+static void momentum_begin_step(nsfem_ctx* c, bool with_old_pressure = true) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c);
   ensure_L(c);
@@ -382,36 +416,39 @@ static void momentum_begin_step(nsfem_ctx* c) {
     launch_axpby(s, nv, a1, c->state[NSFEM_U1].p, a2, c->state[NSFEM_U2].p, c->tmp_v.p);
   }
   launch_spmv(s, c->M2, 2, c->tmp_v.p, c->gconst.p, nullptr, MASK_NONE);
-  launch_spmv(s, c->DT, 1, c->state[NSFEM_P_OLD].p, c->tmp_v.p, nullptr, MASK_NONE);
-  launch_axpby(s, nv, 1.0, c->gconst.p, -c->coef[1], c->tmp_v.p, c->gconst.p);
+  if (with_old_pressure)   // IPCS: - c_p (p_old, div w); the monolithic scheme keeps p unknown
+    launch_spmv_axpy(s, c->DT, 1, -c->coef[1], c->state[NSFEM_P_OLD].p, c->gconst.p, nullptr);
   if (c->have_traction)
     launch_axpby(s, nv, 1.0, c->gconst.p, 1.0, c->state[NSFEM_TRACTION].p, c->gconst.p);
 }
 
 // b = L u* [+ c_v E u*] + g + c_c conv(u*) ;  Dirichlet rows: u*_i - g_i ;  returns |b|
+static void momentum_residual_raw(nsfem_ctx* c, const double* u, double* out) {
+  hipStream_t s = c->stream;
+  const int64_t nv = nvel(c);
+  launch_spmv(s, c->L, 2, u, out, nullptr, MASK_NONE);
+  launch_axpby(s, nv, 1.0, out, 1.0, c->gconst.p, out);
+  if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], u, out, nullptr);
+  const double cc = cc_of(c);
+  if (cc != 0.0) launch_convection_residual(s, c->mesh, u, cc, out);
+}
+
 static double momentum_residual(nsfem_ctx* c) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c);
   double* u = c->state[NSFEM_USTAR].p;
-  launch_spmv(s, c->L, 2, u, c->rhs_v.p, nullptr, MASK_NONE);
-  launch_axpby(s, nv, 1.0, c->rhs_v.p, 1.0, c->gconst.p, c->rhs_v.p);
-  if (c->traction_form) {
-    launch_spmv(s, c->E, 1, u, c->tmp_v.p, nullptr, MASK_NONE);
-    launch_axpby(s, nv, 1.0, c->rhs_v.p, c->coef[2], c->tmp_v.p, c->rhs_v.p);
-  }
-  const double cc = cc_of(c);
-  if (cc != 0.0) launch_convection_residual(s, c->mesh, u, cc, c->rhs_v.p);
+  momentum_residual_raw(c, u, c->rhs_v.p);
   launch_set_bc_residual(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, c->rhs_v.p);
   launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, c->kw.parts.p + 5 * kParts);
   return std::sqrt(host_sum_parts(s, c->kw, 5));
 }
 
-static void momentum_jacobian(nsfem_ctx* c) {
+static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
   hipStream_t s = c->stream;
   const double* E = c->traction_form ? c->E.vals.p : nullptr;
   const double cc = cc_of(c);
   if (cc != 0.0)
-    launch_convection_jacobian(s, c->mesh, c->p22, c->state[NSFEM_USTAR].p, cc, c->L.vals.p, E,
+    launch_convection_jacobian(s, c->mesh, c->p22, c->state[vel_slot].p, cc, c->L.vals.p, E,
                                c->coef[2], c->J.vals.p);
   else
     launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
@@ -666,8 +703,29 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
     }
     mg.setup_work(s);
   }
+  // Schur-complement pressure Laplacian (own Dirichlet set) and pressure mass smoother
+  {
+    if (!ctx->mask_s.p) { ctx->mask_s.alloc((size_t)npre(ctx)); ctx->mask_s.zero(s); }
+    Multigrid& mg = ctx->mg_s;
+    mg.nv = 1; mg.degree = degree; mg.eig_ratio = ratio; mg.coarse_dense_max = dense_max;
+    mg.lv.clear();
+    mg.lv.resize(1 + ctx->coarse.size());
+    mg.lv[0].A = &ctx->Ap; mg.lv[0].n = ctx->mesh.n_p1; mg.lv[0].mask = ctx->mask_s.p;
+    for (size_t l = 0; l < ctx->coarse.size(); ++l) {
+      nsfem_ctx::P1Level* c = ctx->coarse[l];
+      mg.lv[l].P = &c->to_finer.P; mg.lv[l].R = &c->to_finer.R; mg.lv[l].h_inj = &c->to_finer.h_inj;
+      mg.lv[l + 1].A = &c->K; mg.lv[l + 1].n = c->n;
+    }
+    mg.setup_work(s);
+    Multigrid& mm = ctx->mg_m;          // 4 Chebyshev-Jacobi steps on the P1 mass matrix
+    mm.nv = 1; mm.coarse_dense_max = 0; mm.coarse_steps = 4; mm.eig_ratio = 8.0;
+    mm.lv.clear();
+    mm.lv.resize(1);
+    mm.lv[0].A = &ctx->Mp; mm.lv[0].n = ctx->mesh.n_p1; mm.lv[0].mask = nullptr;
+    mm.setup_work(s);
+  }
   ctx->mg_built = true;
-  ctx->mg_p_dirty = ctx->mg_v_dirty = true;
+  ctx->mg_p_dirty = ctx->mg_v_dirty = ctx->mg_s_dirty = true;
   ctx->L_dirty = true;       // (re)compute the coarse momentum operators
   NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
@@ -745,10 +803,104 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   API_END(ctx)
 }
 
-extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts*, nsfem_step_info*) {
+// ---------------------------------------------------------------- monolithic BDF
+// mixed operator  [[J, -c_p D^T], [-c_p D, 0]]  with identity rows on Dirichlet dofs
+void nsfem_ctx::MixedOp::apply(hipStream_t s, const double* x, double* y) {
+  const int64_t nv = nvel(c);
+  const double cp = c->coef[1];
+  launch_spmv(s, c->J, 1, x, y, c->mask_v.p, MASK_IDENTITY);
+  launch_spmv_axpy(s, c->DT, 1, -cp, x + nv, y, c->mask_v.p);
+  launch_spmv_scaled(s, c->Dv, 1, -cp, x, y + nv);
+  launch_copy_at(s, c->nbc_p, c->bc_p_dofs.p, x + nv, y + nv);
+}
+
+// upper block-triangular preconditioner with the Cahouet-Chabard Schur approximation
+//   z_p = -(1/c_p^2) (c_v M_p^{-1} + alpha0/k A_p^{+}) r_p ;  z_u = F^{-1} (r_u + c_p D^T z_p)
+// F^{-1}, A_p^{+}: one multigrid V-cycle each;  M_p^{-1}: 4 Chebyshev-Jacobi steps
+void nsfem_ctx::BlockPrec::apply(hipStream_t s, const double* r, double* z) {
+  const int64_t nv = nvel(c), np = npre(c);
+  const double cp = c->coef[1], cv = c->coef[2], a = c->alpha[0] / c->k;
+  const double* rp = r + nv;
+  double* zp = z + nv;
+  c->mg_s.apply(s, rp, c->tmp_p.p);
+  c->mg_m.apply(s, rp, c->rhs_p.p);
+  launch_axpby(s, np, -a / (cp * cp), c->tmp_p.p, -cv / (cp * cp), c->rhs_p.p, zp);
+  launch_copy_at(s, c->nbc_p, c->bc_p_dofs.p, rp, zp);
+  NSFEM_HIP(hipMemcpyAsync(c->tmp_v.p, r, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+  launch_spmv_axpy(s, c->DT, 1, cp, zp, c->tmp_v.p, c->mask_v.p);
+  c->mg_v.apply(s, c->tmp_v.p, z);
+  launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, c->tmp_v.p, z);
+}
+
+// F_u = L u + g + c_c conv(u) - c_p D^T p ; F_p = -c_p D u ; Dirichlet rows x_i - g_i
+static double bdf_residual(nsfem_ctx* c) {
+  hipStream_t s = c->stream;
+  const int64_t nv = nvel(c), np = npre(c);
+  double* u = c->state[NSFEM_U0].p;
+  double* p = c->state[NSFEM_P].p;
+  double* b = c->rhs_m.p;
+  momentum_residual_raw(c, u, b);
+  launch_spmv_axpy(s, c->DT, 1, -c->coef[1], p, b, nullptr);
+  launch_set_bc_residual(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, b);
+  launch_spmv_scaled(s, c->Dv, 1, -c->coef[1], u, b + nv);
+  launch_set_bc_residual(s, c->nbc_p, c->bc_p_dofs.p, c->bc_p_vals.p, p, b + nv);
+  launch_dot(s, nv + np, b, b, c->kw.parts.p + 5 * kParts);
+  return std::sqrt(host_sum_parts(s, c->kw, 5));
+}
+
+extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info) {
+  nsfem_step_info local;
   API_BEGIN
-  NSFEM_REQUIRE(ctx, "null context");
-  throw Error(NSFEM_ERR_ARG, "nsfem_step_bdf: monolithic step not built yet");
+  NSFEM_REQUIRE(ctx && opts, "null argument");
+  NSFEM_REQUIRE(opts->convective_form == 0, "only the standard convective form is implemented");
+  NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
+                "newton_max_iter out of range");
+  NSFEM_REQUIRE(ctx->mg_built, "the monolithic step needs the multigrid hierarchy "
+                               "(block preconditioner): call nsfem_mg_finalize");
+  nsfem_step_info& inf = info ? *info : local;
+  std::memset(&inf, 0, sizeof(inf));
+  hipStream_t s = ctx->stream;
+  const int64_t nv = nvel(ctx), np = npre(ctx);
+  if (!ctx->rhs_m.p) {
+    ctx->rhs_m.alloc((size_t)(nv + np));
+    ctx->dx_m.alloc((size_t)(nv + np));
+  }
+  ctx->mixed_op.c = ctx;
+  ctx->mixed_op.n = nv + np;
+  ctx->block_prec.c = ctx;
+  momentum_begin_step(ctx, false);
+  double r = bdf_residual(ctx);
+  const double r0 = r;
+  inf.newton_residuals[0] = r;
+  int it = 0;
+  bool converged = r < opts->newton_atol;
+  while (!converged && it < opts->newton_max_iter) {
+    momentum_jacobian(ctx, NSFEM_U0);
+    mg_refresh(ctx, true);
+    mg_refresh_schur(ctx);
+    ctx->dx_m.zero(s);
+    LinOp op;
+    op.custom = &ctx->mixed_op;
+    op.prec = &ctx->block_prec;
+    nsfem_solve_info si;
+    int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, opts->momentum, si);
+    inf.krylov_iterations_momentum += si.iterations;
+    if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the monolithic step");
+    if (rc == NSFEM_ERR_NOT_CONVERGED)
+      throw Error(rc, "BiCGStab did not converge in the monolithic step");
+    double* u = ctx->state[NSFEM_U0].p;
+    double* p = ctx->state[NSFEM_P].p;
+    launch_axpby(s, nv, 1.0, u, -1.0, ctx->dx_m.p, u);
+    launch_axpby(s, np, 1.0, p, -1.0, ctx->dx_m.p + nv, p);
+    ++it;
+    r = bdf_residual(ctx);
+    inf.newton_residuals[it] = r;
+    if (!std::isfinite(r)) throw Error(NSFEM_ERR_BREAKDOWN, "Newton residual is not finite");
+    converged = (r / r0 < opts->newton_rtol) || (r < opts->newton_atol);
+  }
+  inf.newton_iterations = it;
+  if (!converged) throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
+  ctx->assembled_system = -1;
   API_END(ctx)
 }
 

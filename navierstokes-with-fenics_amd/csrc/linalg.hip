@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
         val = a.b[idx] - val;
       a.y[idx] = val;
     } else if (EPI == EPI_ACCUM) {
-      a.y[idx] = m ? 0.0 : a.y[idx] + val;
+      // y += c2 * A x ; masked rows: zero (MASK_ZERO) or left untouched (MASK_IDENTITY)
+      if (!m) a.y[idx] += a.c2 * val;
+      else if (a.maskmode == MASK_ZERO) a.y[idx] = 0.0;
     } else if (EPI == EPI_CHEB) {
       double dn = 0.0, xn = 0.0;
       if (!m) {
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
       a.y[idx] = xn;
     } else {
       if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
+      else val *= a.c2;
       a.y[idx] = val;
     }
   }
@@ -136,7 +139,7 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
   SpmvArgs a;
   a.x = x; a.b = b; a.y = y; a.mask = mask;
   a.maskmode = mask ? maskmode : MASK_NONE;
-  a.dinv = nullptr; a.d = nullptr; a.c1 = 0.0; a.c2 = 0.0;
+  a.dinv = nullptr; a.d = nullptr; a.c1 = 0.0; a.c2 = 1.0;
   return a;
 }
 
@@ -151,6 +154,18 @@ void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x, 
 void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
                             const uint8_t* rowmask) {
   spmv_dispatch<EPI_ACCUM>(s, A, nv, make_args(x, nullptr, y, rowmask, MASK_ZERO));
+}
+void launch_spmv_scaled(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
+                        double* y) {
+  SpmvArgs a = make_args(x, nullptr, y, nullptr, MASK_NONE);
+  a.c2 = scale;
+  spmv_dispatch<EPI_STORE>(s, A, nv, a);
+}
+void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
+                      double* y, const uint8_t* skipmask) {
+  SpmvArgs a = make_args(x, nullptr, y, skipmask, MASK_IDENTITY);
+  a.c2 = scale;
+  spmv_dispatch<EPI_ACCUM>(s, A, nv, a);
 }
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
@@ -475,12 +490,21 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __rest
 
 int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
              const nsfem_krylov_opts& o, nsfem_solve_info& info) {
-  const Pattern& pat = *op.A->pat;
-  const int64_t n = (int64_t)pat.n_rows * op.A->br * op.nv;
+  const int64_t n = op.custom ? op.custom->n
+                              : (int64_t)op.A->pat->n_rows * op.A->br * op.nv;
   w.ensure(n);
   double* parts = w.parts.p;
   double* scal = w.scal.p;
-  launch_residual(s, *op.A, op.nv, x, b, w.r.p, op.rowmask, op.maskmode);
+  auto apply = [&](const double* in, double* out) {
+    if (op.custom) op.custom->apply(s, in, out);
+    else launch_spmv(s, *op.A, op.nv, in, out, op.rowmask, op.maskmode);
+  };
+  if (op.custom) {
+    op.custom->apply(s, x, w.r.p);
+    launch_axpby(s, n, 1.0, b, -1.0, w.r.p, w.r.p);
+  } else {
+    launch_residual(s, *op.A, op.nv, x, b, w.r.p, op.rowmask, op.maskmode);
+  }
   LAUNCH(k_bicg_start, kParts, s, n, w.r.p, w.rhat.p, parts, scal);
   double rr = host_sum_parts(s, w, P_RR);
   const double r0 = std::sqrt(rr);
@@ -498,12 +522,12 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     LAUNCH(k_bicg_p, kParts, s, n, it == 0 ? 1 : 0, w.r.p, w.v.p, op.prec ? nullptr : op.dinv,
            w.p.p, w.phat.p, parts, scal);
     if (op.prec) op.prec->apply(s, w.p.p, w.phat.p);
-    launch_spmv(s, *op.A, op.nv, w.phat.p, w.v.p, op.rowmask, op.maskmode);
+    apply(w.phat.p, w.v.p);
     launch_dot(s, n, w.rhat.p, w.v.p, parts + P_RTV * kParts);
     LAUNCH(k_bicg_s, kParts, s, n, w.r.p, w.v.p, op.prec ? nullptr : op.dinv, w.s.p, w.shat.p,
            parts, scal);
     if (op.prec) op.prec->apply(s, w.s.p, w.shat.p);
-    launch_spmv(s, *op.A, op.nv, w.shat.p, w.t.p, op.rowmask, op.maskmode);
+    apply(w.shat.p, w.t.p);
     LAUNCH(k_dot_ts_tt, kParts, s, n, w.t.p, w.s.p, parts);
     LAUNCH(k_bicg_xr, kParts, s, n, w.phat.p, w.shat.p, w.s.p, w.t.p, w.rhat.p, x, w.r.p, parts,
            scal);

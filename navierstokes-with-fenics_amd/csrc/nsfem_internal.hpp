@@ -127,6 +127,11 @@ void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
 //   d = c1 d + c2 dinv (b - A x) ; xout = x + d   (masked rows -> 0)
 void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
                             const uint8_t* rowmask);
+// y = scale * A x ;  y += scale * A x on rows not flagged in skipmask (flagged rows untouched)
+void launch_spmv_scaled(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
+                        double* y);
+void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
+                      double* y, const uint8_t* skipmask);
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
                       const uint8_t* rowmask);
@@ -194,7 +199,15 @@ struct Precond {
   virtual void apply(hipStream_t s, const double* r, double* z) = 0;
 };
 
+// abstract operator (block systems): y = A x on vectors of length n
+struct Operator {
+  int64_t n = 0;
+  virtual ~Operator() {}
+  virtual void apply(hipStream_t s, const double* x, double* y) = 0;
+};
+
 struct LinOp {
+  Operator* custom = nullptr;       // overrides A / nv / rowmask when set (BiCGStab only)
   const BlockMat* A = nullptr;
   int nv = 1;
   const uint8_t* rowmask = nullptr;
@@ -305,6 +318,20 @@ struct nsfem_ctx {
     nsfem_ctx* c = nullptr;
     void apply(hipStream_t s, const double* r, double* z) override;
   } mom_prec;
+  // monolithic BDF system: mixed operator, block preconditioner and their data
+  nsfem::Multigrid mg_s, mg_m;                 // Schur Laplacian V-cycle, pressure-mass smoother
+  bool mg_s_dirty = true;
+  std::vector<int32_t> h_bc_s;
+  nsfem::DevBuf<uint8_t> mask_s;
+  nsfem::DevBuf<double> rhs_m, dx_m;
+  struct MixedOp : nsfem::Operator {
+    nsfem_ctx* c = nullptr;
+    void apply(hipStream_t s, const double* x, double* y) override;
+  } mixed_op;
+  struct BlockPrec : nsfem::Precond {
+    nsfem_ctx* c = nullptr;
+    void apply(hipStream_t s, const double* r, double* z) override;
+  } block_prec;
   ~nsfem_ctx() {
     for (P1Level* p : coarse) delete p;
   }

@@ -34,7 +34,23 @@ class ImplicitBDFSolver(InstationarySolverBase):
         if not all(hasattr(self, attr) for attr in ("_next_step_size", "_alpha")):
             self._update_time_stepping_coefficients()
         self._setup_boundary_conditions()
+        self._push_schur_dirichlet_set()
         self._solver = nat.SYS_MONOLITHIC
+
+    def _push_schur_dirichlet_set(self):
+        """Dirichlet set of the pressure Laplacian inside the Schur-complement preconditioner:
+        P1 nodes on boundary parts without a full velocity condition (open / traction /
+        component-wise boundaries) plus the true pressure Dirichlet dofs.  Only the
+        preconditioner sees it; the discrete system is the reference's."""
+        import numpy as np
+        from ns_solver_base import VelocityBCType
+        full = {bc[1] for bc in getattr(self, "_velocity_bcs", [])
+                if bc[0] in (VelocityBCType.no_slip, VelocityBCType.constant, VelocityBCType.function)}
+        marks, mesh, dm = self._boundary_markers, self._mesh, self._dofmap
+        open_facets = np.nonzero(mesh.edge_on_boundary & ~np.isin(marks.values, list(full)))[0]
+        nodes = np.unique(dm.facet_p1_nodes(open_facets)) if open_facets.size else np.zeros(0, np.int64)
+        nodes = np.union1d(nodes, self._dirichlet_bcs["pressure"][0]).astype(np.int32)
+        self._ctx.set_dirichlet(nat.PRESSURE_PRECOND, nodes, np.zeros(nodes.size))
 
     def _step_options(self):
         o = self._ctx.default_step_opts()
@@ -43,6 +59,7 @@ class ImplicitBDFSolver(InstationarySolverBase):
         o.newton_max_iter = self._maxiter
         o.momentum.rtol = self.krylov_rtol
         o.momentum.max_iter = self.krylov_max_iter
+        o.momentum.precond = 1
         return o
 
     def _solve_time_step(self):

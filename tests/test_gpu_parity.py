@@ -332,3 +332,74 @@ def test_full_size_properties_n512():
         assert np.isfinite(u).all() and np.isfinite(ctx.get_state(nat.P)).all()
         ctx.advance(0)
     ctx.close()
+
+
+# --------------------------------------------------------------- monolithic BDF-2
+def _run_bdf(ctx, orc, nsteps, k, vbc, rtol=1e-12):
+    opts = ctx.default_step_opts()
+    opts.momentum.rtol = rtol
+    opts.momentum.precond = 1
+    opts.momentum.max_iter = 500
+    infos = []
+    for step in range(nsteps):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, k)
+        infos.append(ctx.step_bdf(opts))
+        orc.step(alpha, k, vbc)
+        ctx.advance(1)
+        orc.advance()
+    return infos
+
+
+def test_bdf_monolithic_cavity_matches_oracle():
+    """ImplicitBDFSolver path (source/ns_bdf_solver.py:36-106): mixed Newton system solved by
+    block-preconditioned BiCGStab vs sparse LU of the same saddle-point matrix."""
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(16, 16)
+    ctx = context(mesh, dm)
+    attach_hierarchy(ctx, mesh, coarsest=4)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
+    orc = fo.BDFOracle(s, coef, pin_pressure=True)
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    vbc = cavity_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+    infos = _run_bdf(ctx, orc, 3, 0.01, vbc)
+    nv = dm.n_velocity
+    for step, info in enumerate(infos):
+        assert info.newton_iterations == orc.newton_its[step]
+        hist = orc.newton_history[step]
+        for i, r in enumerate(hist[:-1]):
+            assert abs(info.newton_residuals[i] - r) <= 1e-6 * r + 1e-12 * hist[0]
+    assert rel(ctx.get_state(nat.U1), orc.sol[1][:nv]) < 1e-9
+    pg, po = ctx.get_state(nat.P_OLD), orc.sol[1][nv:]
+    assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
+    ctx.close()
+
+
+def test_bdf_monolithic_open_channel_and_stokes_limit():
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(32, 4, p1=(8.0, 1.0))
+    zero = lambda X: np.zeros((X.shape[0], 2))
+    inlet = lambda X: np.stack([6.0 * X[:, 1] * (1.0 - X[:, 1]), 0.0 * X[:, 1]], axis=1)
+    vbc = velocity_bc(dm, marks, [(1, inlet), (3, zero), (4, zero)])
+    schur = np.unique(dm.facet_p1_nodes(marks.facets_with_id(2))).astype(np.int32)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    for cc, tol in ((1.0, 1e-9), (None, 1e-10)):           # Navier-Stokes, then linear Stokes
+        ctx = context(mesh, dm)
+        attach_hierarchy(ctx, mesh, coarsest=2)
+        coef = dict(convective_term=cc, pressure_term=1.0, viscous_term=0.1, body_force_term=None)
+        orc = fo.BDFOracle(s, coef)
+        ctx.set_coeffs(cc, 1.0, 0.1)
+        ctx.set_dirichlet(nat.VELOCITY, *vbc)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        ctx.set_dirichlet(nat.PRESSURE_PRECOND, schur, np.zeros(schur.size))
+        infos = _run_bdf(ctx, orc, 3, 0.01, vbc, rtol=1e-13)
+        if cc is None:
+            assert all(i.newton_iterations == 1 for i in infos)
+        nv = dm.n_velocity
+        assert rel(ctx.get_state(nat.U1), orc.sol[1][:nv]) < tol
+        assert rel(ctx.get_state(nat.P_OLD), orc.sol[1][nv:]) < tol     # open outlet fixes the level
+        ctx.close()

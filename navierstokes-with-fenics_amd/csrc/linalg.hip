@@ -41,6 +41,7 @@ struct SpmvArgs {
   const double* dinv;
   double* d;
   double c1, c2;
+  int nt;          // stream matrix values / column ids with non-temporal loads
 };
 
 template <int BR, int BC, int NV, int G, int EPI>
@@ -62,10 +63,18 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
   for (int o = 0; o < NO; ++o) acc[o] = 0.0;
   const int s = rowptr[row], e = rowptr[row + 1];
   for (int k = s + lane; k < e; k += G) {
-    const int c = col[k];
     double av[BR * BC], xv[BC * NV];
+    int c;
+    if (a.nt) {
+      c = __builtin_nontemporal_load(col + k);
 #pragma unroll
-    for (int t = 0; t < BR * BC; ++t) av[t] = vals[(size_t)k * (BR * BC) + t];
+      for (int t = 0; t < BR * BC; ++t)
+        av[t] = __builtin_nontemporal_load(vals + (size_t)k * (BR * BC) + t);
+    } else {
+      c = col[k];
+#pragma unroll
+      for (int t = 0; t < BR * BC; ++t) av[t] = vals[(size_t)k * (BR * BC) + t];
+    }
 #pragma unroll
     for (int t = 0; t < BC * NV; ++t) xv[t] = x[(size_t)c * (BC * NV) + t];
 #pragma unroll
@@ -117,13 +126,33 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
 template <int EPI>
 static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvArgs& a) {
   const Pattern& p = *A.pat;
-  constexpr int G = 8;
+  // lanes per block row: 4 for short rows (P1 7-point, P2 x P1), 8 otherwise; the
+  // NSFEM_SPMV_G environment variable overrides it (tuning experiments only)
+  static const int forced = [] {
+    const char* e = std::getenv("NSFEM_SPMV_G");
+    return e ? std::atoi(e) : 0;
+  }();
+  // measured on MI355X (scripts/gpu_spmv_sweep.py, n = 512): rows with <= ~200 B of matrix data
+  // (scalar P2 / P1 operators, grad) run 15-30 % faster with 4 lanes per row, the 2x2
+  // Jacobian (414 B/row) and div (460 B/row) with 8
+  const double row_bytes = (double)p.nnz / (p.n_rows > 0 ? p.n_rows : 1) * (8.0 * A.br * A.bc + 4.0);
+  int G = forced ? forced : (row_bytes <= 200.0 ? 4 : (row_bytes <= 1600.0 ? 8 : 16));
+  if (G != 4 && G != 8 && G != 16) G = 8;
   const int rpb = 256 / G;
   int grid = (p.n_rows + rpb - 1) / rpb;
   grid = (grid + 7) & ~7;
-#define NSFEM_SPMV(BR, BC, NV)                                                           \
-  hipLaunchKernelGGL((k_spmv<BR, BC, NV, G, EPI>), dim3(grid), dim3(256), 0, s, p.n_rows, \
-                     p.rowptr.p, p.col.p, A.vals.p, a)
+#define NSFEM_SPMV(BR, BC, NV)                                                                \
+  do {                                                                                        \
+    if (G == 4)                                                                               \
+      hipLaunchKernelGGL((k_spmv<BR, BC, NV, 4, EPI>), dim3(grid), dim3(256), 0, s, p.n_rows,  \
+                         p.rowptr.p, p.col.p, A.vals.p, a);                                   \
+    else if (G == 8)                                                                          \
+      hipLaunchKernelGGL((k_spmv<BR, BC, NV, 8, EPI>), dim3(grid), dim3(256), 0, s, p.n_rows,  \
+                         p.rowptr.p, p.col.p, A.vals.p, a);                                   \
+    else                                                                                      \
+      hipLaunchKernelGGL((k_spmv<BR, BC, NV, 16, EPI>), dim3(grid), dim3(256), 0, s, p.n_rows, \
+                         p.rowptr.p, p.col.p, A.vals.p, a);                                   \
+  } while (0)
   if (A.br == 2 && A.bc == 2 && nv == 1) NSFEM_SPMV(2, 2, 1);
   else if (A.br == 1 && A.bc == 1 && nv == 2) NSFEM_SPMV(1, 1, 2);
   else if (A.br == 1 && A.bc == 1 && nv == 1) NSFEM_SPMV(1, 1, 1);
@@ -140,6 +169,11 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
   a.x = x; a.b = b; a.y = y; a.mask = mask;
   a.maskmode = mask ? maskmode : MASK_NONE;
   a.dinv = nullptr; a.d = nullptr; a.c1 = 0.0; a.c2 = 1.0;
+  static const int nt = [] {
+    const char* e = std::getenv("NSFEM_SPMV_NT");
+    return e ? std::atoi(e) : 0;
+  }();
+  a.nt = nt;
   return a;
 }
 

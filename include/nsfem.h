@@ -183,6 +183,11 @@ int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y);
  * library integrates the coarse operators on the device, adds the P2 <- P1 transfer of
  * the fine mesh itself and builds two V-cycle preconditioners: pressure Poisson and
  * alpha0/k M + c_v K.  Selected per solve with nsfem_krylov_opts.precond = 1. */
+/* contiguous halo ranges of a strip partition, in node units (offset, count) */
+typedef struct {
+  int64_t send_up_off, send_up_cnt, recv_above_off, recv_above_cnt;
+  int64_t send_down_off, send_down_cnt, recv_below_off, recv_below_cnt;
+} nsfem_halo;
 typedef struct {
   int32_t n_vertices, n_cells;
   const double* coords;      /* [n_vertices * 2] */
@@ -191,6 +196,8 @@ typedef struct {
   const int32_t* p_rowptr;   /* [n_fine + 1]     */
   const int32_t* p_col;
   const double* p_val;
+  const uint8_t* ghost;      /* [n_vertices] nonzero = ghost node; NULL on unpartitioned meshes */
+  nsfem_halo halo;           /* used when ghost != NULL */
 } nsfem_mg_level_desc;
 typedef struct {
   int32_t smoother_degree;   /* Chebyshev steps per pre/post smoothing (default 2) */
@@ -198,7 +205,30 @@ typedef struct {
   double eig_ratio;          /* smoothing interval [lmax/ratio, lmax] (default 4)   */
 } nsfem_mg_opts;
 int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* level);
+/* partitioned hierarchies: the GLOBAL coarsest mesh (solved redundantly on every rank);
+ * offset = global id of this rank's local coarsest node 0 */
+int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cells,
+                               const double* coords, const int32_t* cells, int64_t offset);
 int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* opts /* may be NULL */);
+
+/* ---- multi-GPU: one process per GPU, each owning a strip of the mesh (new; the reference
+ * is serial).  The context is created on the LOCAL mesh (own cell rows + one ghost row);
+ * nsfem_set_partition marks the ghost nodes and the contiguous halo ranges; a communicator is
+ * attached either over RCCL (production) or in-process (several contexts on one device, one
+ * host thread per rank: single-GPU testing of the partitioned algorithm). */
+typedef struct {
+  int32_t rank, size;
+  const uint8_t* p2_ghost;   /* [n_p2] nonzero = ghost (owned by a neighbour) */
+  const uint8_t* p1_ghost;   /* [n_p1] */
+  nsfem_halo p2_halo, p1_halo;
+  int64_t n_p2_global, n_p1_global;
+} nsfem_partition_desc;
+int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* part);
+int nsfem_comm_unique_id(char* id128 /* 128 bytes out */);
+int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int rank, int size);
+int nsfem_comm_local_create(int size, void** group);
+void nsfem_comm_local_destroy(void* group);
+int nsfem_comm_attach_local(nsfem_ctx* ctx, void* group, int rank);
 
 /* ---- fused per-step drivers: replace _solve_time_step
  * (ns_ipcs_solver.py:198-208, ns_bdf_solver.py:102-106) ------------------------ */

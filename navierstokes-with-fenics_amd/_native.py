@@ -30,7 +30,9 @@ EXPORTED_SYMBOLS = (
     "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply",
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
-    "nsfem_mg_add_level", "nsfem_mg_finalize",
+    "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
+    "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
+    "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
 
 
@@ -64,11 +66,34 @@ class StepInfo(C.Structure):
                 ("newton_residuals", C.c_double * MAX_NEWTON)]
 
 
+class Halo(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("send_up_off", "send_up_cnt", "recv_above_off",
+                                         "recv_above_cnt", "send_down_off", "send_down_cnt",
+                                         "recv_below_off", "recv_below_cnt")]
+
+    @classmethod
+    def from_dict(cls, d):
+        h = cls()
+        if d:
+            for key in ("send_up", "recv_above", "send_down", "recv_below"):
+                setattr(h, key + "_off", int(d[key][0]))
+                setattr(h, key + "_cnt", int(d[key][1]))
+        return h
+
+
 class MgLevelDesc(C.Structure):
     _fields_ = [("n_vertices", C.c_int32), ("n_cells", C.c_int32),
                 ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
                 ("n_fine", C.c_int32), ("p_rowptr", C.POINTER(C.c_int32)),
-                ("p_col", C.POINTER(C.c_int32)), ("p_val", C.POINTER(C.c_double))]
+                ("p_col", C.POINTER(C.c_int32)), ("p_val", C.POINTER(C.c_double)),
+                ("ghost", C.POINTER(C.c_uint8)), ("halo", Halo)]
+
+
+class PartitionDesc(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("size", C.c_int32),
+                ("p2_ghost", C.POINTER(C.c_uint8)), ("p1_ghost", C.POINTER(C.c_uint8)),
+                ("p2_halo", Halo), ("p1_halo", Halo),
+                ("n_p2_global", C.c_int64), ("n_p1_global", C.c_int64)]
 
 
 class MgOpts(C.Structure):
@@ -128,6 +153,13 @@ def load_library(path=None):
         "nsfem_synchronize": (C.c_int, [vp]),
         "nsfem_mg_add_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
         "nsfem_mg_finalize": (C.c_int, [vp, C.POINTER(MgOpts)]),
+        "nsfem_mg_set_global_coarse": (C.c_int, [vp, i32, i32, pd, pi, i64]),
+        "nsfem_set_partition": (C.c_int, [vp, C.POINTER(PartitionDesc)]),
+        "nsfem_comm_unique_id": (C.c_int, [C.c_char_p]),
+        "nsfem_comm_attach_rccl": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
+        "nsfem_comm_local_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "nsfem_comm_local_destroy": (None, [vp]),
+        "nsfem_comm_attach_local": (C.c_int, [vp, vp, C.c_int]),
         "nsfem_mass_solve": (C.c_int, [vp, C.c_int, pd, pd, C.POINTER(KrylovOpts),
                                        C.POINTER(SolveInfo)]),
     }
@@ -138,6 +170,28 @@ def load_library(path=None):
     if path == LIB_PATH:
         _lib = lib
     return lib
+
+
+def local_group_create(size):
+    """In-process communicator group (several contexts on one device; testing only)."""
+    lib = load_library()
+    g = C.c_void_p()
+    rc = lib.nsfem_comm_local_create(int(size), C.byref(g))
+    if rc != OK:
+        raise NativeError(rc, "nsfem_comm_local_create failed")
+    return g
+
+
+def local_group_destroy(group):
+    load_library().nsfem_comm_local_destroy(group)
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = load_library().nsfem_comm_unique_id(buf)
+    if rc != OK:
+        raise NativeError(rc, "ncclGetUniqueId failed")
+    return buf.raw
 
 
 def _dp(a):
@@ -276,15 +330,41 @@ class NsfemContext:
                                                C.byref(info)))
         return x
 
-    def mg_add_level(self, coords, cells, p_rowptr, p_col, p_val):
+    def mg_add_level(self, coords, cells, p_rowptr, p_col, p_val, ghost=None, halo=None):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         rp = np.ascontiguousarray(p_rowptr, dtype=np.int32)
         pc = np.ascontiguousarray(p_col, dtype=np.int32)
         pv = np.ascontiguousarray(p_val, dtype=np.float64)
+        g = None if ghost is None else np.ascontiguousarray(ghost, dtype=np.uint8)
+        gp = g.ctypes.data_as(C.POINTER(C.c_uint8)) if g is not None else None
         d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
-                        _ip(rp), _ip(pc), _dp(pv))
+                        _ip(rp), _ip(pc), _dp(pv), gp, Halo.from_dict(halo))
         self._check(self._lib.nsfem_mg_add_level(self._h, C.byref(d)))
+
+    def mg_set_global_coarse(self, coords, cells, offset):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self._check(self._lib.nsfem_mg_set_global_coarse(self._h, coords.shape[0], cells.shape[0],
+                                                         _dp(coords), _ip(cells), int(offset)))
+
+    # -- multi-GPU --------------------------------------------------------------------
+    def set_partition(self, rank, size, p2_ghost, p1_ghost, p2_halo, p1_halo, n_p2_global,
+                      n_p1_global):
+        g2 = np.ascontiguousarray(p2_ghost, dtype=np.uint8)
+        g1 = np.ascontiguousarray(p1_ghost, dtype=np.uint8)
+        assert g2.size == self.n_p2 and g1.size == self.n_p1
+        d = PartitionDesc(rank, size, g2.ctypes.data_as(C.POINTER(C.c_uint8)),
+                          g1.ctypes.data_as(C.POINTER(C.c_uint8)), Halo.from_dict(p2_halo),
+                          Halo.from_dict(p1_halo), int(n_p2_global), int(n_p1_global))
+        self._check(self._lib.nsfem_set_partition(self._h, C.byref(d)))
+
+    def attach_local_comm(self, group, rank):
+        self._check(self._lib.nsfem_comm_attach_local(self._h, group, rank))
+
+    def attach_rccl_comm(self, unique_id, rank, size):
+        assert len(unique_id) == 128
+        self._check(self._lib.nsfem_comm_attach_rccl(self._h, unique_id, rank, size))
 
     def mg_finalize(self, degree=2, eig_ratio=4.0, coarse_dense_max=1200):
         o = MgOpts(int(degree), int(coarse_dense_max), float(eig_ratio))

@@ -44,6 +44,15 @@ static int64_t slot_size(const nsfem_ctx* c, int slot) {
   }
 }
 
+static HaloRange to_halo(const nsfem_halo& h) {
+  HaloRange r;
+  r.send_up_off = h.send_up_off; r.send_up_cnt = h.send_up_cnt;
+  r.recv_above_off = h.recv_above_off; r.recv_above_cnt = h.recv_above_cnt;
+  r.send_down_off = h.send_down_off; r.send_down_cnt = h.send_down_cnt;
+  r.recv_below_off = h.recv_below_off; r.recv_below_cnt = h.recv_below_cnt;
+  return r;
+}
+
 static void upload_pattern(hipStream_t s, HostPattern& h, Pattern& d, bool want_contrib = false) {
   d.n_rows = h.n_rows;
   d.n_cols = h.n_cols;
@@ -301,6 +310,7 @@ extern "C" int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const i
   dv.upload(v, s);
   mask.zero(s);
   launch_fill_mask(s, (int)d.size(), dd.p, mask.p);
+  launch_overlay_ghost(s, size, field == NSFEM_VELOCITY ? ctx->ghost_v.p : ctx->ghost_p.p, mask.p);
   std::vector<int32_t>& prev = field == NSFEM_VELOCITY ? ctx->h_bc_v : ctx->h_bc_p;
   const bool changed = prev != d;
   if (field == NSFEM_VELOCITY) {
@@ -357,6 +367,10 @@ static void ensure_L(nsfem_ctx* c) {
     launch_scale_combine(c->stream, c->p11.nnz, a, c->Mp.vals.p, b, c->Ap.vals.p, c->Lc0.vals.p);
     for (nsfem_ctx::P1Level* lv : c->coarse)
       launch_scale_combine(c->stream, lv->pat.nnz, a, lv->M.vals.p, b, lv->K.vals.p, lv->Lc.vals.p);
+    if (c->global_coarse) {
+      nsfem_ctx::P1Level* g = c->global_coarse;
+      launch_scale_combine(c->stream, g->pat.nnz, a, g->M.vals.p, b, g->K.vals.p, g->Lc.vals.p);
+    }
     c->mg_v_dirty = true;
   }
   c->L_dirty = false;
@@ -382,13 +396,18 @@ static void mg_refresh(nsfem_ctx* c, bool momentum) {
     if (!c->mg_v_dirty) return;
     std::vector<uint8_t> m((size_t)nvel(c), 0);
     for (int32_t d : c->h_bc_v) m[d] = 1;
+    for (size_t i = 0; i < c->h_ghost_p2.size(); ++i)
+      if (c->h_ghost_p2[i]) m[2 * i] = m[2 * i + 1] = 2;
     c->mg_v.refresh(c->stream, m, false);
     c->mg_v_dirty = false;
   } else {
     if (!c->mg_p_dirty) return;
     std::vector<uint8_t> m((size_t)npre(c), 0);
     for (int32_t d : c->h_bc_p) m[d] = 1;
-    c->mg_p.refresh(c->stream, m, c->h_bc_p.empty());
+    for (size_t i = 0; i < c->h_ghost_p1.size(); ++i)
+      if (c->h_ghost_p1[i]) m[i] = 2;
+    // partitioned: whether the problem is singular is decided on the all-reduced mask
+    c->mg_p.refresh(c->stream, m, c->distributed() ? true : c->h_bc_p.empty());
     c->mg_p_dirty = false;
   }
 }
@@ -423,6 +442,25 @@ static void momentum_begin_step(nsfem_ctx* c, bool with_old_pressure = true) {
 }
 
 // b = L u* [+ c_v E u*] + g + c_c conv(u*) ;  Dirichlet rows: u*_i - g_i ;  returns |b|
+// |x|_2 over owned entries (ghost entries are zeroed first), all-reduced over the ranks
+static double global_norm(nsfem_ctx* c, int64_t n, double* x, const uint8_t* ghostmask) {
+  hipStream_t s = c->stream;
+  if (ghostmask) launch_zero_ghost(s, n, ghostmask, x);
+  double* parts = c->kw.parts.p + (size_t)10 * kParts;
+  launch_dot(s, n, x, x, parts);
+  if (c->distributed()) c->comm->allreduce_sum(s, parts, kParts);
+  return std::sqrt(host_sum_parts(s, c->kw, 10));
+}
+
+static void fill_linop(nsfem_ctx* c, LinOp& op, bool velocity) {
+  if (!c->distributed()) return;
+  op.comm = c->comm;
+  op.halo = velocity ? &c->halo_p2 : &c->halo_p1;
+  op.halo_width = velocity ? 2 : 1;
+  op.ghostmask = velocity ? c->mask_v.p : c->mask_p.p;
+  op.n_global = velocity ? 2 * c->n_p2_global : c->n_p1_global;
+}
+
 static void momentum_residual_raw(nsfem_ctx* c, const double* u, double* out) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c);
@@ -439,8 +477,7 @@ static double momentum_residual(nsfem_ctx* c) {
   double* u = c->state[NSFEM_USTAR].p;
   momentum_residual_raw(c, u, c->rhs_v.p);
   launch_set_bc_residual(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, c->rhs_v.p);
-  launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, c->kw.parts.p + 5 * kParts);
-  return std::sqrt(host_sum_parts(s, c->kw, 5));
+  return global_norm(c, nv, c->rhs_v.p, c->ghost_v.p ? c->mask_v.p : nullptr);
 }
 
 static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
@@ -465,6 +502,7 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
   op.rowmask = c->mask_v.p;
   op.maskmode = MASK_IDENTITY;
   op.dinv = c->dinv_v.p;
+  fill_linop(c, op, true);
   if (o.precond == 1) {
     NSFEM_REQUIRE(c->mg_built, "multigrid requested but no hierarchy was set (nsfem_mg_finalize)");
     mg_refresh(c, true);
@@ -484,6 +522,7 @@ static void poisson_assemble(nsfem_ctx* c) {
   launch_spmv(s, c->Ap, 1, c->state[NSFEM_P_OLD].p, c->rhs_p.p, nullptr, MASK_NONE);
   launch_spmv(s, c->Dv, 1, c->state[NSFEM_USTAR].p, c->tmp_p.p, nullptr, MASK_NONE);
   launch_axpby(s, np, 1.0, c->rhs_p.p, -c->alpha[0] / c->k, c->tmp_p.p, c->rhs_p.p);
+  if (c->ghost_p.p) launch_zero_ghost(s, np, c->mask_p.p, c->rhs_p.p);
   NSFEM_HIP(hipMemcpyAsync(c->state[NSFEM_P].p, c->state[NSFEM_P_OLD].p, sizeof(double) * np,
                            hipMemcpyDeviceToDevice, s));
   launch_set_values(s, c->nbc_p, c->bc_p_dofs.p, c->bc_p_vals.p, c->state[NSFEM_P].p);
@@ -500,6 +539,7 @@ static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_i
   op.rowmask = c->mask_p.p;
   op.maskmode = MASK_ZERO;
   op.dinv = c->dinv_p.p;
+  fill_linop(c, op, false);
   if (o.precond == 1) {
     NSFEM_REQUIRE(c->mg_built, "multigrid requested but no hierarchy was set (nsfem_mg_finalize)");
     mg_refresh(c, false);
@@ -516,6 +556,7 @@ static void correction_assemble(nsfem_ctx* c) {
   launch_axpby(s, np, 1.0, c->state[NSFEM_P].p, -1.0, c->state[NSFEM_P_OLD].p, c->tmp_p.p);
   launch_spmv(s, c->Gr, 1, c->tmp_p.p, c->tmp_v.p, nullptr, MASK_NONE);
   launch_axpby(s, nv, 1.0, c->rhs_v.p, -c->k / c->alpha[0], c->tmp_v.p, c->rhs_v.p);
+  if (c->ghost_v.p) launch_zero_ghost(s, nv, c->mask_v.p, c->rhs_v.p);
   NSFEM_HIP(hipMemcpyAsync(c->state[NSFEM_U0].p, c->state[NSFEM_USTAR].p, sizeof(double) * nv,
                            hipMemcpyDeviceToDevice, s));
   launch_set_values(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, c->state[NSFEM_U0].p);
@@ -532,6 +573,7 @@ static int correction_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solv
   op.rowmask = c->mask_v.p;
   op.maskmode = MASK_ZERO;
   op.dinv = c->dinv_m.p;
+  fill_linop(c, op, true);
   return pcg(c->stream, c->kw, op, c->rhs_v.p, c->state[NSFEM_U0].p, o, info, false);
 }
 
@@ -566,8 +608,7 @@ extern "C" int nsfem_residual_norm(nsfem_ctx* ctx, int system, double* out) {
   const bool vel = (system != NSFEM_SYS_POISSON);
   const double* b = vel ? ctx->rhs_v.p : ctx->rhs_p.p;
   const int64_t n = vel ? nvel(ctx) : npre(ctx);
-  launch_dot(ctx->stream, n, b, b, ctx->kw.parts.p + 5 * kParts);
-  *out = std::sqrt(host_sum_parts(ctx->stream, ctx->kw, 5));
+  *out = global_norm(ctx, n, const_cast<double*>(b), nullptr);
   API_END(ctx)
 }
 
@@ -635,8 +676,122 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
   lv->Lc.init(&lv->pat, 1, 1, s);
   launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
   lv->to_finer.build(s, n_fine, d->n_vertices, d->p_rowptr, d->p_col, d->p_val);
+  if (d->ghost) {
+    lv->h_ghost.assign(d->ghost, d->ghost + d->n_vertices);
+    lv->halo = to_halo(d->halo);
+    lv->has_halo = true;
+  }
   NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
+}
+
+// replicated global coarsest mesh of a partitioned hierarchy; `offset` = global id of this
+// rank's local coarsest node 0
+extern "C" int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cells,
+                                          const double* coords, const int32_t* cells,
+                                          int64_t offset) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && coords && cells && n_vertices > 0 && n_cells > 0, "bad argument");
+  NSFEM_REQUIRE(!ctx->mg_built, "hierarchy already finalized");
+  hipStream_t s = ctx->stream;
+  delete ctx->global_coarse;
+  nsfem_ctx::P1Level* lv = ctx->global_coarse = new nsfem_ctx::P1Level();
+  lv->n = n_vertices;
+  std::vector<double> vx((size_t)6 * n_cells);
+  std::vector<int32_t> p1((size_t)3 * n_cells);
+  for (int c = 0; c < n_cells; ++c)
+    for (int v = 0; v < 3; ++v) {
+      const int vid = cells[(size_t)c * 3 + v];
+      NSFEM_REQUIRE(vid >= 0 && vid < n_vertices, "coarse cell vertex id out of range");
+      p1[(size_t)v * n_cells + c] = vid;
+      for (int k = 0; k < 2; ++k) vx[(size_t)(2 * v + k) * n_cells + c] = coords[(size_t)vid * 2 + k];
+    }
+  lv->mesh.n_cells = n_cells;
+  lv->mesh.n_p1 = lv->mesh.n_vertices = n_vertices;
+  lv->mesh.vx.upload(vx, s);
+  lv->mesh.p1.upload(p1, s);
+  HostPattern h;
+  build_pattern(n_vertices, n_vertices, n_cells, cells, 3, cells, 3, true, h);
+  upload_pattern(s, h, lv->pat, true);
+  lv->K.init(&lv->pat, 1, 1, s);
+  lv->M.init(&lv->pat, 1, 1, s);
+  lv->Lc.init(&lv->pat, 1, 1, s);
+  launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+  ctx->glob_off = offset;
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && d && d->p2_ghost && d->p1_ghost, "null argument");
+  NSFEM_REQUIRE(!ctx->mg_built, "set the partition before building the multigrid hierarchy");
+  hipStream_t s = ctx->stream;
+  const int n2 = ctx->mesh.n_p2, n1 = ctx->mesh.n_p1;
+  ctx->h_ghost_p2.assign(d->p2_ghost, d->p2_ghost + n2);
+  ctx->h_ghost_p1.assign(d->p1_ghost, d->p1_ghost + n1);
+  std::vector<uint8_t> gv((size_t)2 * n2), gp((size_t)n1);
+  for (int i = 0; i < n2; ++i) gv[2 * i] = gv[2 * i + 1] = d->p2_ghost[i] ? 2 : 0;
+  for (int i = 0; i < n1; ++i) gp[i] = d->p1_ghost[i] ? 2 : 0;
+  ctx->ghost_v.upload(gv, s);
+  ctx->ghost_p.upload(gp, s);
+  ctx->halo_p2 = to_halo(d->p2_halo);
+  ctx->halo_p1 = to_halo(d->p1_halo);
+  ctx->n_p2_global = d->n_p2_global;
+  ctx->n_p1_global = d->n_p1_global;
+  // masks carry the ghost flag from now on
+  launch_overlay_ghost(s, 2 * (int64_t)n2, ctx->ghost_v.p, ctx->mask_v.p);
+  launch_overlay_ghost(s, n1, ctx->ghost_p.p, ctx->mask_p.p);
+  ctx->dinv_m_ready = ctx->dinv_p_ready = false;
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_comm_attach_local(nsfem_ctx* ctx, void* group, int rank) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && group, "null argument");
+  delete ctx->comm;
+  ctx->comm = nullptr;
+  ctx->comm = make_local_comm(group, rank);
+  API_END(ctx)
+}
+
+extern "C" int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int rank, int size) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && id128, "null argument");
+  NSFEM_HIP(hipSetDevice(ctx->device));
+  delete ctx->comm;
+  ctx->comm = nullptr;
+  ctx->comm = make_rccl_comm(id128, rank, size);
+  API_END(ctx)
+}
+
+// partitioned meshes: communicator, halo ranges and ghost flags of every level, and the
+// replicated global coarsest operator.  `first_p1` = index of the fine P1 level in mg.lv.
+static void wire_partition(nsfem_ctx* ctx, Multigrid& mg, size_t first_p1, bool momentum) {
+  if (!ctx->distributed()) return;
+  NSFEM_REQUIRE(ctx->global_coarse, "partitioned multigrid needs nsfem_mg_set_global_coarse");
+  mg.comm = ctx->comm;
+  if (first_p1 == 1) {
+    mg.lv[0].halo = ctx->halo_p2;
+    mg.lv[0].has_halo = true;
+    mg.lv[0].h_ghost = &ctx->h_ghost_p2;
+  }
+  mg.lv[first_p1].halo = ctx->halo_p1;
+  mg.lv[first_p1].has_halo = true;
+  mg.lv[first_p1].h_ghost = &ctx->h_ghost_p1;
+  for (size_t l = 0; l < ctx->coarse.size(); ++l) {
+    nsfem_ctx::P1Level* c = ctx->coarse[l];
+    NSFEM_REQUIRE(c->has_halo, "coarse level without partition data");
+    mg.lv[first_p1 + 1 + l].halo = c->halo;
+    mg.lv[first_p1 + 1 + l].has_halo = true;
+    mg.lv[first_p1 + 1 + l].h_ghost = &c->h_ghost;
+  }
+  mg.globA = momentum ? &ctx->global_coarse->Lc : &ctx->global_coarse->K;
+  mg.n_glob = ctx->global_coarse->n;
+  mg.glob_off = ctx->glob_off;
+  NSFEM_REQUIRE(mg.glob_off >= 0 && mg.glob_off + mg.lv.back().n <= mg.n_glob,
+                "local coarsest level does not fit into the global coarsest mesh");
 }
 
 extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
@@ -684,6 +839,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
       mg.lv[l].P = &c->to_finer.P; mg.lv[l].R = &c->to_finer.R; mg.lv[l].h_inj = &c->to_finer.h_inj;
       mg.lv[l + 1].A = &c->K; mg.lv[l + 1].n = c->n;
     }
+    wire_partition(ctx, mg, 0, false);
     mg.setup_work(s);
   }
   // momentum hierarchy: P2 fine -> P1 fine -> coarse P1 levels, operator a M + b K
@@ -701,6 +857,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
       mg.lv[l + 1].h_inj = &c->to_finer.h_inj;
       mg.lv[l + 2].A = &c->Lc; mg.lv[l + 2].n = c->n;
     }
+    wire_partition(ctx, mg, 1, true);
     mg.setup_work(s);
   }
   // Schur-complement pressure Laplacian (own Dirichlet set) and pressure mass smoother
@@ -716,6 +873,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
       mg.lv[l].P = &c->to_finer.P; mg.lv[l].R = &c->to_finer.R; mg.lv[l].h_inj = &c->to_finer.h_inj;
       mg.lv[l + 1].A = &c->K; mg.lv[l + 1].n = c->n;
     }
+    wire_partition(ctx, mg, 0, false);
     mg.setup_work(s);
     Multigrid& mm = ctx->mg_m;          // 4 Chebyshev-Jacobi steps on the P1 mass matrix
     mm.nv = 1; mm.coarse_dense_max = 0; mm.coarse_steps = 4; mm.eig_ratio = 8.0;
@@ -844,8 +1002,7 @@ static double bdf_residual(nsfem_ctx* c) {
   launch_set_bc_residual(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, b);
   launch_spmv_scaled(s, c->Dv, 1, -c->coef[1], u, b + nv);
   launch_set_bc_residual(s, c->nbc_p, c->bc_p_dofs.p, c->bc_p_vals.p, p, b + nv);
-  launch_dot(s, nv + np, b, b, c->kw.parts.p + 5 * kParts);
-  return std::sqrt(host_sum_parts(s, c->kw, 5));
+  return global_norm(c, nv + np, b, nullptr);
 }
 
 extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info) {
@@ -855,6 +1012,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   NSFEM_REQUIRE(opts->convective_form == 0, "only the standard convective form is implemented");
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
+  NSFEM_REQUIRE(!ctx->distributed(), "the monolithic step is not partitioned yet (use IPCS)");
   NSFEM_REQUIRE(ctx->mg_built, "the monolithic step needs the multigrid hierarchy "
                                "(block preconditioner): call nsfem_mg_finalize");
   nsfem_step_info& inf = info ? *info : local;

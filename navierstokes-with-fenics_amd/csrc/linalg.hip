@@ -94,8 +94,14 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
     for (int o = 1; o < NO; ++o)
       if (lane == o) val = acc[o];
     const size_t idx = (size_t)row * NO + lane;
-    const bool m = (a.maskmode != MASK_NONE) && a.mask[idx];
-    if (EPI == EPI_RESID) {
+    // mask values: 0 free, 1 Dirichlet (mode-dependent), 2 ghost of a partitioned mesh (the
+    // owner computes the row: output 0, which also keeps ghosts out of the dot products)
+    const int mv = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    const bool m = mv != 0;
+    if (mv == 2) {
+      if (EPI == EPI_CHEB) a.d[idx] = 0.0;
+      a.y[idx] = 0.0;
+    } else if (EPI == EPI_RESID) {
       // identity rows: b - x ; zero rows: 0
       if (m)
         val = (a.maskmode == MASK_IDENTITY) ? a.b[idx] - x[idx] : 0.0;
@@ -282,10 +288,11 @@ __global__ __launch_bounds__(256) void k_add_scalar(int64_t n, double a, double*
   GRID_STRIDE(i, n) x[i] += a;
 }
 // x -= mean(x) with the sum given as partials (sum over all n entries)
-__global__ __launch_bounds__(256) void k_sub_mean(int64_t n, const double* __restrict__ parts,
+__global__ __launch_bounds__(256) void k_sub_mean(int64_t n, int64_t n_global,
+                                                  const double* __restrict__ parts,
                                                   double* __restrict__ x) {
   __shared__ double sh[4];
-  const double mean = sum_parts(parts, sh) / (double)n;
+  const double mean = sum_parts(parts, sh) / (double)n_global;
   GRID_STRIDE(i, n) x[i] -= mean;
 }
 __global__ __launch_bounds__(256) void k_sum(int64_t n, const double* __restrict__ x,
@@ -359,6 +366,20 @@ __global__ __launch_bounds__(256) void k_copy_at(int n, const int32_t* __restric
 void launch_copy_at(hipStream_t s, int n, const int32_t* dofs, const double* r, double* z) {
   if (n) LAUNCH(k_copy_at, vgrid(n), s, n, dofs, r, z);
 }
+__global__ __launch_bounds__(256) void k_zero_ghost(int64_t n, const uint8_t* __restrict__ mask,
+                                                    double* __restrict__ x) {
+  GRID_STRIDE(i, n) if (mask[i] == 2) x[i] = 0.0;
+}
+__global__ __launch_bounds__(256) void k_overlay_ghost(int64_t n, const uint8_t* __restrict__ ghost,
+                                                       uint8_t* __restrict__ mask) {
+  GRID_STRIDE(i, n) if (ghost[i]) mask[i] = 2;
+}
+void launch_overlay_ghost(hipStream_t s, int64_t n, const uint8_t* ghost, uint8_t* mask) {
+  if (ghost) LAUNCH(k_overlay_ghost, vgrid(n), s, n, ghost, mask);
+}
+void launch_zero_ghost(hipStream_t s, int64_t n, const uint8_t* mask, double* x) {
+  if (mask) LAUNCH(k_zero_ghost, vgrid(n), s, n, mask, x);
+}
 void launch_mask_zero(hipStream_t s, int64_t n, const uint8_t* mask, double* x) {
   LAUNCH(k_mask_zero, vgrid(n), s, n, mask, x);
 }
@@ -379,9 +400,9 @@ void KrylovWork::ensure(int64_t n_) {
   n = n_;
   for (DevBuf<double>* b : {&r, &rhat, &p, &v, &s, &t, &phat, &shat, &z, &q}) b->alloc((size_t)n);
   if (!parts.p) {
-    parts.alloc((size_t)8 * kParts);
+    parts.alloc((size_t)kPartSlots * kParts);
     scal.alloc(16);
-    NSFEM_HIP(hipHostMalloc((void**)&h_parts, sizeof(double) * 8 * kParts));
+    NSFEM_HIP(hipHostMalloc((void**)&h_parts, sizeof(double) * kPartSlots * kParts));
   }
 }
 KrylovWork::~KrylovWork() {
@@ -400,7 +421,8 @@ double host_sum_parts(hipStream_t s, KrylovWork& w, int which) {
 
 // --------------------------------------------------------------- BiCGStab
 // partial-sum slots
-enum { P_RHO = 0, P_RTV = 1, P_TS = 2, P_TT = 3, P_RR = 4, P_PQ = 5, P_RZ0 = 6, P_RZ1 = 7 };
+// (RHO, RR), (TS, TT) and the CG pairs (RZ, RR') are adjacent: one all-reduce per kernel
+enum { P_RHO = 0, P_RR = 1, P_TS = 2, P_TT = 3, P_RTV = 4, P_PQ = 5, P_RZ0 = 6, P_RZ1 = 8 };
 // device scalars
 enum { S_RHO_OLD = 0, S_ALPHA = 1, S_OMEGA = 2, S_RHO = 3 };
 
@@ -522,6 +544,15 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __rest
   }
 }
 
+// all-reduce `nslots` adjacent partial-sum slots over the ranks of a partitioned mesh
+static inline void reduce_slots(const LinOp& op, hipStream_t s, double* parts, int slot, int nslots) {
+  if (op.comm) op.comm->allreduce_sum(s, parts + (size_t)slot * kParts, (int64_t)nslots * kParts);
+}
+// fill the ghost entries of an SpMV input from their owners
+static inline void fill_ghosts(const LinOp& op, hipStream_t s, const double* v) {
+  if (op.comm && op.halo) op.comm->exchange(s, *op.halo, const_cast<double*>(v), op.halo_width);
+}
+
 int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
              const nsfem_krylov_opts& o, nsfem_solve_info& info) {
   const int64_t n = op.custom ? op.custom->n
@@ -530,8 +561,12 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   double* parts = w.parts.p;
   double* scal = w.scal.p;
   auto apply = [&](const double* in, double* out) {
-    if (op.custom) op.custom->apply(s, in, out);
-    else launch_spmv(s, *op.A, op.nv, in, out, op.rowmask, op.maskmode);
+    if (op.custom) {
+      op.custom->apply(s, in, out);          // custom operators exchange their own inputs
+    } else {
+      fill_ghosts(op, s, in);
+      launch_spmv(s, *op.A, op.nv, in, out, op.rowmask, op.maskmode);
+    }
   };
   if (op.custom) {
     op.custom->apply(s, x, w.r.p);
@@ -540,10 +575,12 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     launch_residual(s, *op.A, op.nv, x, b, w.r.p, op.rowmask, op.maskmode);
   }
   LAUNCH(k_bicg_start, kParts, s, n, w.r.p, w.rhat.p, parts, scal);
+  reduce_slots(op, s, parts, P_RHO, 2);
   double rr = host_sum_parts(s, w, P_RR);
   const double r0 = std::sqrt(rr);
   // |b| for the relative criterion
   launch_dot(s, n, b, b, parts + P_PQ * kParts);
+  reduce_slots(op, s, parts, P_PQ, 1);
   const double bnorm = std::sqrt(host_sum_parts(s, w, P_PQ));
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
   info.residual0 = r0;
@@ -558,13 +595,16 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     if (op.prec) op.prec->apply(s, w.p.p, w.phat.p);
     apply(w.phat.p, w.v.p);
     launch_dot(s, n, w.rhat.p, w.v.p, parts + P_RTV * kParts);
+    reduce_slots(op, s, parts, P_RTV, 1);
     LAUNCH(k_bicg_s, kParts, s, n, w.r.p, w.v.p, op.prec ? nullptr : op.dinv, w.s.p, w.shat.p,
            parts, scal);
     if (op.prec) op.prec->apply(s, w.s.p, w.shat.p);
     apply(w.shat.p, w.t.p);
     LAUNCH(k_dot_ts_tt, kParts, s, n, w.t.p, w.s.p, parts);
+    reduce_slots(op, s, parts, P_TS, 2);
     LAUNCH(k_bicg_xr, kParts, s, n, w.phat.p, w.shat.p, w.s.p, w.t.p, w.rhat.p, x, w.r.p, parts,
            scal);
+    reduce_slots(op, s, parts, P_RHO, 2);
     ++it;
     if (it % check == 0 || it == o.max_iter) {
       rr = host_sum_parts(s, w, P_RR);
@@ -600,7 +640,7 @@ __global__ __launch_bounds__(256) void k_cg_start(int64_t n, const double* __res
   rr = block_sum(rr, sh);
   if (threadIdx.x == 0) {
     parts[rz_slot * kParts + blockIdx.x] = rz;
-    parts[P_RR * kParts + blockIdx.x] = rr;
+    parts[(rz_slot + 1) * kParts + blockIdx.x] = rr;
   }
 }
 
@@ -633,7 +673,7 @@ __global__ __launch_bounds__(256) void k_cg_update(int64_t n, const double* __re
   __syncthreads();
   if (threadIdx.x == 0) {
     if (dinv) parts[rz_next * kParts + blockIdx.x] = rz;
-    parts[P_RR * kParts + blockIdx.x] = rr;
+    parts[(rz_next + 1) * kParts + blockIdx.x] = rr;
   }
 }
 
@@ -660,16 +700,21 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
     // make the right-hand side compatible with the constant null space
     NSFEM_HIP(hipMemcpyAsync(w.t.p, b, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     LAUNCH(k_sum, kParts, s, n, w.t.p, parts + P_TS * kParts);
-    LAUNCH(k_sub_mean, vgrid(n), s, n, parts + P_TS * kParts, w.t.p);
+    reduce_slots(op, s, parts, P_TS, 1);
+    LAUNCH(k_sub_mean, vgrid(n), s, n, op.n_global > 0 ? op.n_global : n, parts + P_TS * kParts,
+           w.t.p);
+    if (op.ghostmask) launch_zero_ghost(s, n, op.ghostmask, w.t.p);
     rhs = w.t.p;
   }
   launch_residual(s, *op.A, op.nv, x, rhs, w.r.p, op.rowmask, op.maskmode);
   int cur = P_RZ0, nxt = P_RZ1;
   if (op.prec) op.prec->apply(s, w.r.p, w.p.p);
   LAUNCH(k_cg_start, kParts, s, n, w.r.p, op.prec ? nullptr : op.dinv, w.p.p, parts, cur);
-  double rr = host_sum_parts(s, w, P_RR);
+  reduce_slots(op, s, parts, cur, 2);
+  double rr = host_sum_parts(s, w, cur + 1);
   const double r0 = std::sqrt(rr);
   launch_dot(s, n, rhs, rhs, parts + P_TT * kParts);
+  reduce_slots(op, s, parts, P_TT, 1);
   const double bnorm = std::sqrt(host_sum_parts(s, w, P_TT));
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
   info.residual0 = r0;
@@ -679,19 +724,22 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   const int check = o.check_every > 0 ? o.check_every : 1;
   int it = 0;
   while (!info.converged && it < o.max_iter) {
+    fill_ghosts(op, s, w.p.p);
     launch_spmv(s, *op.A, op.nv, w.p.p, w.q.p, op.rowmask, op.maskmode);
     launch_dot(s, n, w.p.p, w.q.p, parts + P_PQ * kParts);
+    reduce_slots(op, s, parts, P_PQ, 1);
     LAUNCH(k_cg_update, kParts, s, n, w.p.p, w.q.p, op.prec ? nullptr : op.dinv, x, w.r.p, w.z.p,
            parts, cur, nxt);
     if (op.prec) {
       op.prec->apply(s, w.r.p, w.z.p);
       launch_dot(s, n, w.r.p, w.z.p, parts + nxt * kParts);
     }
+    reduce_slots(op, s, parts, nxt, 2);
     LAUNCH(k_cg_p, kParts, s, n, w.z.p, w.p.p, parts, cur, nxt);
     std::swap(cur, nxt);
     ++it;
     if (it % check == 0 || it == o.max_iter) {
-      rr = host_sum_parts(s, w, P_RR);
+      rr = host_sum_parts(s, w, cur + 1);
       if (!std::isfinite(rr)) {
         info.iterations = it;
         info.residual = rr;

@@ -102,8 +102,8 @@ void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* row
       fill[j]++;
       if (rowptr[i + 1] - rowptr[i] == 1 && std::fabs(val[k] - 1.0) < 1e-14) h_inj[j] = i;
     }
-  for (int j = 0; j < n_coarse; ++j)
-    NSFEM_REQUIRE(h_inj[j] >= 0, "coarse node without a coinciding fine node (spaces not nested)");
+  // (on partitioned meshes the coarse ghost line above the strip has no fine counterpart:
+  //  h_inj stays -1 there; such nodes are flagged as ghosts by the caller)
   patR.n_rows = n_coarse; patR.n_cols = n_fine; patR.nnz = nnz;
   patR.h_rowptr = rp; patR.h_col = rc;
   patR.rowptr.upload(rp, s);
@@ -178,14 +178,31 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
     NSFEM_HIP(hipMemcpyAsync(hp.data(), parts.p, sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
     NSFEM_HIP(hipStreamSynchronize(s));
     L.lmax = *std::max_element(hp.begin(), hp.end());
+    if (comm && comm->size > 1) {
+      // every rank must smooth with the same Chebyshev polynomial
+      NSFEM_HIP(hipMemcpyAsync(parts.p, &L.lmax, sizeof(double), hipMemcpyHostToDevice, s));
+      comm->allreduce_max(s, parts.p, 1);
+      NSFEM_HIP(hipMemcpyAsync(&L.lmax, parts.p, sizeof(double), hipMemcpyDeviceToHost, s));
+      NSFEM_HIP(hipStreamSynchronize(s));
+    }
     if (!(L.lmax > 0.0) || !std::isfinite(L.lmax)) L.lmax = 2.0;
     if (l + 1 < lv.size()) {
       const std::vector<int32_t>& inj = *L.h_inj;
-      nxt.assign((size_t)lv[l + 1].n * nv, 0);
-      for (int j = 0; j < lv[l + 1].n; ++j)
-        for (int v = 0; v < nv; ++v) nxt[(size_t)j * nv + v] = cur[(size_t)inj[j] * nv + v];
+      const MGLevel& C = lv[l + 1];
+      nxt.assign((size_t)C.n * nv, 0);
+      for (int j = 0; j < C.n; ++j)
+        for (int v = 0; v < nv; ++v) {
+          uint8_t m = inj[j] >= 0 ? cur[(size_t)inj[j] * nv + v] : 0;
+          if (C.h_ghost && (*C.h_ghost)[j]) m = 2;
+          nxt[(size_t)j * nv + v] = m;
+        }
       cur.swap(nxt);
     }
+  }
+  if (comm && comm->size > 1) {
+    refresh_global_coarse(s, cur, singular);
+    ready = true;
+    return;
   }
   // coarsest level: dense (pseudo-)inverse per component
   MGLevel& C = lv.back();
@@ -231,6 +248,60 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
   ready = true;
 }
 
+// partitioned meshes: the coarsest problem is solved redundantly on every rank on the GLOBAL
+// coarsest mesh; its Dirichlet mask is the all-reduced union of the ranks' owned masks
+void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>& cur,
+                                      bool singular) {
+  NSFEM_REQUIRE(globA && n_glob > 0, "partitioned multigrid needs the global coarsest mesh");
+  const MGLevel& C = lv.back();
+  const int n = n_glob;
+  std::vector<double> gm((size_t)n * nv, 0.0);
+  for (int i = 0; i < C.n; ++i)
+    for (int v = 0; v < nv; ++v)
+      if (cur[(size_t)i * nv + v] == 1) gm[((size_t)glob_off + i) * nv + v] = 1.0;
+  gb.alloc((size_t)n * nv);
+  gx.alloc((size_t)n * nv);
+  NSFEM_HIP(hipMemcpyAsync(gb.p, gm.data(), sizeof(double) * gm.size(), hipMemcpyHostToDevice, s));
+  comm->allreduce_sum(s, gb.p, (int64_t)gm.size());
+  NSFEM_HIP(hipMemcpyAsync(gm.data(), gb.p, sizeof(double) * gm.size(), hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  const Pattern& p = *globA->pat;
+  NSFEM_REQUIRE(p.n_rows == n, "global coarsest operator size mismatch");
+  std::vector<double> v((size_t)p.nnz);
+  NSFEM_HIP(hipMemcpyAsync(v.data(), globA->vals.p, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  std::vector<double> all((size_t)nv * n * n);
+  for (int c = 0; c < nv; ++c) {
+    std::vector<double> a((size_t)n * n, 0.0);
+    bool any_mask = false;
+    for (int i = 0; i < n; ++i) {
+      const bool mi = gm[(size_t)i * nv + c] > 0.5;
+      any_mask |= mi;
+      for (int k = p.h_rowptr[i]; k < p.h_rowptr[i + 1]; ++k) {
+        const int j = p.h_col[k];
+        if (!mi && !(gm[(size_t)j * nv + c] > 0.5)) a[(size_t)i * n + j] = v[k];
+      }
+      if (mi) a[(size_t)i * n + i] = 1.0;
+    }
+    const bool sing = singular && !any_mask;
+    double gamma = 0.0;
+    if (sing) {
+      for (int i = 0; i < n; ++i) gamma += a[(size_t)i * n + i];
+      gamma /= n;
+      for (size_t t = 0; t < a.size(); ++t) a[t] += gamma / n;
+    }
+    invert_dense(a, n);
+    if (sing)
+      for (size_t t = 0; t < a.size(); ++t) a[t] -= 1.0 / (gamma * n);
+    for (int i = 0; i < n; ++i)
+      if (gm[(size_t)i * nv + c] > 0.5)
+        for (int j = 0; j < n; ++j) a[(size_t)i * n + j] = a[(size_t)j * n + i] = 0.0;
+    std::copy(a.begin(), a.end(), all.begin() + (size_t)c * n * n);
+  }
+  coarse_inv.upload(all, s);
+  dense_coarse = true;
+}
+
 void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1, double& c2,
                             double& rho) const {
   const double b = 1.05 * L.lmax, a = b / eig_ratio;
@@ -266,6 +337,7 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
                          L.d.p, out);
       NSFEM_HIP(hipGetLastError());
     } else {
+      halo_fill(s, L, cur);
       launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask);
     }
     cur = out;
@@ -274,10 +346,29 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
     NSFEM_HIP(hipMemcpyAsync(x_out, cur, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
 }
 
+void Multigrid::halo_fill(hipStream_t s, const MGLevel& L, const double* v) {
+  if (comm && comm->size > 1 && L.has_halo) comm->exchange(s, L.halo, const_cast<double*>(v), nv);
+}
+
 void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
   if (l + 1 == lv.size()) {
+    if (comm && comm->size > 1) {
+      // gather the owned right-hand sides into the global coarse vector (ghost entries are
+      // zero, so overlapping lines add up correctly), solve redundantly, copy the local part
+      gb.zero(s);
+      NSFEM_HIP(hipMemcpyAsync(gb.p + (size_t)glob_off * nv, b, sizeof(double) * n,
+                               hipMemcpyDeviceToDevice, s));
+      comm->allreduce_sum(s, gb.p, (int64_t)n_glob * nv);
+      const int tot = n_glob * nv;
+      hipLaunchKernelGGL(k_dense_apply, dim3((tot + 255) / 256), dim3(256), 0, s, n_glob, nv,
+                         coarse_inv.p, gb.p, gx.p);
+      NSFEM_HIP(hipGetLastError());
+      NSFEM_HIP(hipMemcpyAsync(x, gx.p + (size_t)glob_off * nv, sizeof(double) * n,
+                               hipMemcpyDeviceToDevice, s));
+      return;
+    }
     if (dense_coarse) {
       const int tot = L.n * nv;
       hipLaunchKernelGGL(k_dense_apply, dim3((tot + 255) / 256), dim3(256), 0, s, L.n, nv,
@@ -290,9 +381,12 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   }
   MGLevel& C = lv[l + 1];
   smooth(s, L, b, nullptr, x, degree);
+  halo_fill(s, L, x);
   launch_residual(s, *L.A, nv, x, b, L.r.p, L.mask, MASK_ZERO);
+  halo_fill(s, L, L.r.p);
   launch_spmv(s, *L.R, nv, L.r.p, C.b.p, C.mask, MASK_ZERO);
   vcycle(s, l + 1, C.b.p, C.x.p);
+  halo_fill(s, C, C.x.p);
   launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask);
   smooth(s, L, b, x, x, degree);
   (void)n;

@@ -35,6 +35,7 @@ struct Error : std::runtime_error {
 // number of partial sums every reduction kernel emits (= its grid size); the
 // consumer kernels re-reduce them in a fixed order => bitwise reproducible dots.
 constexpr int kParts = 512;
+constexpr int kPartSlots = 12;   // partial-sum slots of the Krylov work space (slots 10, 11: drivers)
 constexpr int kBlock = 256;
 
 template <class T>
@@ -199,6 +200,22 @@ struct Precond {
   virtual void apply(hipStream_t s, const double* r, double* z) = 0;
 };
 
+// ---- partitioned meshes: halo ranges (node units) and the communicator interface ---------
+struct HaloRange {
+  int64_t send_up_off = 0, send_up_cnt = 0, recv_above_off = 0, recv_above_cnt = 0;
+  int64_t send_down_off = 0, send_down_cnt = 0, recv_below_off = 0, recv_below_cnt = 0;
+};
+struct Comm {
+  int rank = 0, size = 1;
+  virtual ~Comm() {}
+  // in-place sum over the ranks of `count` doubles in device memory, ordered on stream s
+  virtual void allreduce_sum(hipStream_t s, double* dev, int64_t count) = 0;
+  virtual void allreduce_max(hipStream_t s, double* dev, int64_t count) = 0;
+  // fill the ghost ranges of `vec` (width entries per node) from the neighbouring ranks
+  virtual void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) = 0;
+};
+void launch_zero_ghost(hipStream_t s, int64_t n, const uint8_t* mask, double* x);  // x[mask==2]=0
+
 // abstract operator (block systems): y = A x on vectors of length n
 struct Operator {
   int64_t n = 0;
@@ -214,6 +231,12 @@ struct LinOp {
   int maskmode = MASK_NONE;
   const double* dinv = nullptr;     // Jacobi
   Precond* prec = nullptr;          // overrides dinv when set
+  // partitioned meshes (all null / 0 in serial runs)
+  Comm* comm = nullptr;
+  const HaloRange* halo = nullptr;
+  int halo_width = 1;               // vector entries per node
+  const uint8_t* ghostmask = nullptr;
+  int64_t n_global = 0;             // global length (mean projection)
 };
 
 // ---- multigrid ------------------------------------------------------------------
@@ -236,6 +259,10 @@ struct MGLevel {
   const BlockMat* P = nullptr;   // transfer to / from the next coarser level
   const BlockMat* R = nullptr;
   const std::vector<int32_t>* h_inj = nullptr;
+  // partitioned meshes
+  const std::vector<uint8_t>* h_ghost = nullptr;   // per node: nonzero = ghost
+  HaloRange halo;
+  bool has_halo = false;
 };
 
 struct Multigrid : Precond {
@@ -247,6 +274,14 @@ struct Multigrid : Precond {
   int coarse_steps = 30;
   bool dense_coarse = true, ready = false;
   DevBuf<double> coarse_inv, parts;
+  // partitioned meshes: communicator + replicated global coarsest problem
+  Comm* comm = nullptr;
+  const BlockMat* globA = nullptr;
+  int n_glob = 0;
+  int64_t glob_off = 0;
+  DevBuf<double> gb, gx;
+  void refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>& cur, bool singular);
+  void halo_fill(hipStream_t s, const MGLevel& L, const double* v);
   void setup_work(hipStream_t s);
   void refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular);
   void apply(hipStream_t s, const double* r, double* z) override;
@@ -259,6 +294,11 @@ struct Multigrid : Precond {
 
 // z[dofs] = r[dofs]
 void launch_copy_at(hipStream_t s, int n, const int32_t* dofs, const double* r, double* z);
+// mask[i] = 2 where ghost[i] != 0
+void launch_overlay_ghost(hipStream_t s, int64_t n, const uint8_t* ghost, uint8_t* mask);
+// communicators (comm.hip)
+Comm* make_local_comm(void* group, int rank);
+Comm* make_rccl_comm(const char* id128, int rank, int size);
 
 // Jacobi-preconditioned BiCGStab; x holds the initial guess on entry
 int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
@@ -306,7 +346,19 @@ struct nsfem_ctx {
     nsfem::Pattern pat;
     nsfem::BlockMat K, M, Lc;
     nsfem::Transfer to_finer;
+    std::vector<uint8_t> h_ghost;              // per node (partitioned meshes)
+    nsfem::HaloRange halo;
+    bool has_halo = false;
   };
+  // ---- partitioned meshes (nsfem_set_partition + nsfem_comm_attach_*)
+  nsfem::Comm* comm = nullptr;                 // owned
+  nsfem::HaloRange halo_p2, halo_p1;
+  std::vector<uint8_t> h_ghost_p2, h_ghost_p1; // per node: nonzero = ghost
+  nsfem::DevBuf<uint8_t> ghost_v, ghost_p;     // per vector entry: 0 / 2
+  int64_t n_p2_global = 0, n_p1_global = 0;
+  P1Level* global_coarse = nullptr;            // replicated global coarsest mesh (owned)
+  int64_t glob_off = 0;
+  bool distributed() const { return comm && comm->size > 1; }
   std::vector<int32_t> h_p2map, h_p1map;       // host copies of the fine dof maps
   std::vector<P1Level*> coarse;                // owned
   nsfem::Transfer t_p2p1;                      // P2 (fine mesh) <- P1 (fine mesh)
@@ -334,5 +386,7 @@ struct nsfem_ctx {
   } block_prec;
   ~nsfem_ctx() {
     for (P1Level* p : coarse) delete p;
+    delete global_coarse;
+    delete comm;
   }
 };

@@ -1,0 +1,147 @@
+"""Element-partition domain decomposition of structured meshes over the GPUs of one node.
+
+New functionality (the reference runs serially): the mesh is cut into
+strips of cell rows, one per rank.  Rank r owns the dofs of its cell rows except its bottom
+lattice line (owned by rank r-1) and additionally assembles ONE ghost row of cells above its
+strip, so that every matrix row of an owned dof is complete without any assembly
+communication.  Because all node numberings are lexicographic, every halo is a contiguous
+range of the local vectors:
+
+    send up   : the top owned line            -> bottom ghost line of rank r+1
+    send down : the first owned line(s)       -> top ghost line(s) of rank r-1
+                (two P2 lattice lines, one P1 line)
+
+Dot products run over owned dofs only (ghost entries of the Krylov vectors are kept zero by
+the ghost row mask of the SpMV kernels); the per-block partial sums are all-reduced.
+The same partition is applied to every multigrid level (own rows / 2^l + one coarse ghost
+row); the coarsest level is solved redundantly on every rank from an all-reduced right-hand
+side.
+"""
+import numpy as np
+
+from fem_mesh import Mesh, TaylorHoodDofMap
+from multigrid import structured_prolongation
+
+GHOST = 2     # row-mask value of ghost dofs (1 = Dirichlet)
+
+
+class StripLevel:
+    """One P1 level of one rank: local mesh (own rows + ghost row), ghost flags, halo ranges."""
+
+    def __init__(self, p0, p1, nx, ny, row0, own_rows, ghost_rows):
+        hx = (p1[0] - p0[0])
+        x = np.linspace(p0[0], p1[0], nx + 1)
+        y_all = np.linspace(p0[1], p1[1], ny + 1)
+        rows = own_rows + ghost_rows
+        y = y_all[row0: row0 + rows + 1]
+        X, Y = np.meshgrid(x, y, indexing="xy")
+        coords = np.stack([X.ravel(), Y.ravel()], axis=1)
+        ix, iy = np.meshgrid(np.arange(nx), np.arange(rows), indexing="xy")
+        v0 = (iy * (nx + 1) + ix).ravel()
+        v1, v2 = v0 + 1, v0 + (nx + 1)
+        v3 = v2 + 1
+        cells = np.empty((2 * nx * rows, 3), dtype=np.int32)
+        cells[0::2] = np.stack([v0, v1, v3], axis=1)
+        cells[1::2] = np.stack([v0, v2, v3], axis=1)
+        self.mesh = Mesh(coords, cells)
+        self.nx, self.rows, self.own_rows, self.row0 = nx, rows, own_rows, row0
+        self.has_below, self.has_above = row0 > 0, ghost_rows > 0
+        w1 = nx + 1
+        self.w1 = w1
+        self.n_p1 = w1 * (rows + 1)
+        ghost = np.zeros(self.n_p1, dtype=np.uint8)
+        if self.has_below:
+            ghost[:w1] = GHOST
+        if self.has_above:
+            ghost[w1 * (own_rows + 1):] = GHOST
+        self.p1_ghost = ghost
+        # halo ranges in P1 node units: (offset, count)
+        self.p1_halo = dict(
+            send_up=(w1 * own_rows, w1) if self.has_above else (0, 0),
+            recv_above=(w1 * (own_rows + 1), w1) if self.has_above else (0, 0),
+            send_down=(w1, w1) if self.has_below else (0, 0),
+            recv_below=(0, w1) if self.has_below else (0, 0))
+        del hx
+
+    def global_p1_offset(self):
+        """global node id of local P1 node 0 on this level (lexicographic lines)."""
+        return self.row0 * self.w1
+
+
+class StripPartition:
+    """Everything rank ``rank`` of ``size`` needs: local fine mesh + dof map, ghost masks,
+    halo ranges, local multigrid levels with prolongations, and the replicated coarsest mesh."""
+
+    def __init__(self, p0, p1, nx, ny, rank, size, coarsest=8):
+        assert ny % size == 0, "cell rows must divide evenly over the ranks"
+        own = ny // size
+        self.rank, self.size = rank, size
+        self.p0, self.p1, self.nx, self.ny = tuple(p0), tuple(p1), nx, ny
+        g = 1 if rank < size - 1 else 0
+        self.fine = StripLevel(p0, p1, nx, ny, rank * own, own, g)
+        self.mesh = self.fine.mesh
+        self.dofmap = TaylorHoodDofMap(self.mesh)
+        dm = self.dofmap
+        # P2 lattice lines: 2*rows + 1 lines of w2 nodes, lexicographic (dof map reorders so)
+        w2 = 2 * nx + 1
+        self.w2 = w2
+        lines = 2 * self.fine.rows + 1
+        assert dm.n_p2 == w2 * lines
+        ghost2 = np.zeros(dm.n_p2, dtype=np.uint8)
+        if self.fine.has_below:
+            ghost2[:w2] = GHOST
+        if self.fine.has_above:
+            ghost2[w2 * (2 * own + 1):] = GHOST
+        self.p2_ghost = ghost2
+        self.p2_halo = dict(
+            send_up=(w2 * 2 * own, w2) if self.fine.has_above else (0, 0),
+            recv_above=(w2 * (2 * own + 1), 2 * w2) if self.fine.has_above else (0, 0),
+            send_down=(w2, 2 * w2) if self.fine.has_below else (0, 0),
+            recv_below=(0, w2) if self.fine.has_below else (0, 0))
+        self.p1_ghost = self.fine.p1_ghost
+        self.p1_halo = self.fine.p1_halo
+        # global numbering of the local nodes (for gathering results / tests)
+        self.p2_global = rank * own * 2 * w2 + np.arange(dm.n_p2)
+        self.p1_global = rank * own * (nx + 1) + np.arange(dm.n_p1)
+        self.p2_owned = ghost2 == 0
+        self.p1_owned = self.p1_ghost == 0
+        # multigrid levels: coarsen while every rank keeps >= 2 own rows and the global mesh
+        # keeps >= coarsest cells per direction
+        self.levels = []          # (StripLevel, prolongation csr to the finer level)
+        lx, ly, lown, fine_level = nx, ny, own, self.fine
+        while lx % 2 == 0 and lown % 2 == 0 and lown // 2 >= 1 and min(lx, ly) // 2 >= coarsest:
+            cx, cy, cown = lx // 2, ly // 2, lown // 2
+            lev = StripLevel(p0, p1, cx, cy, rank * cown, cown, g)
+            # prolongation for the (cx, lev.rows) -> (lx, 2 * lev.rows) refinement, truncated
+            # to the vertex rows the finer local mesh actually has
+            rowptr, col, val = structured_prolongation(lx, 2 * lev.rows)
+            n_fine = (lx + 1) * (fine_level.rows + 1)
+            rowptr = rowptr[: n_fine + 1].copy()
+            nnz = rowptr[-1]
+            self.levels.append((lev, (rowptr, col[:nnz].copy(), val[:nnz].copy())))
+            lx, ly, lown, fine_level = cx, cy, cown, lev
+        # replicated coarsest problem: the global mesh of the last level
+        last = self.levels[-1][0] if self.levels else self.fine
+        self.coarse_global_shape = (last.nx, ly)
+        self.coarse_global_offset = last.global_p1_offset()
+
+    def attach(self, ctx, degree=2, eig_ratio=4.0):
+        """Ship the partition, the local multigrid levels and the replicated global coarsest
+        mesh to a device context created on ``self.mesh`` (a communicator must already be
+        attached when size > 1)."""
+        n2g, n1g = global_dof_counts(self.nx, self.ny)
+        ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, self.p2_halo,
+                          self.p1_halo, n2g, n1g)
+        for lev, (rowptr, col, val) in self.levels:
+            ctx.mg_add_level(lev.mesh.coords, lev.mesh.cells, rowptr, col, val,
+                             ghost=lev.p1_ghost, halo=lev.p1_halo)
+        cx, cy = self.coarse_global_shape
+        from fem_mesh import rectangle_mesh
+        cg = rectangle_mesh(self.p0, self.p1, cx, cy)
+        ctx.mg_set_global_coarse(cg.coords, cg.cells, self.coarse_global_offset)
+        ctx.mg_finalize(degree, eig_ratio)
+        return len(self.levels)
+
+
+def global_dof_counts(nx, ny):
+    return (2 * nx + 1) * (2 * ny + 1), (nx + 1) * (ny + 1)

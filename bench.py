@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- headline metric of BASELINE.json: time-steps/sec (and DoF-updates/sec) of the
+"""bench.py -- headline metric of BASELINE.json: DoF-updates/sec and time-steps/sec of the
 2D lid-driven cavity, Re = 100, IPCS pressure-projection, Taylor-Hood P2/P1, on MI355X.
 
 N = 1 workload = BASELINE.json configs[1]: 512 x 512 right-diagonal triangles
 (2,364,419 dofs), k = 1e-3.  One "step" = one full IPCS time step (Newton diffusion step,
 pressure Poisson, velocity correction, time-level shift) on device-resident state.
 
-Prints ONE JSON line (see the driver contract) that also carries
+N > 1 (launched by torch.distributed.run, one process per GPU): WEAK scaling -- every rank
+owns a 512 x 512-cell strip of a 512 x (512 N) cavity [0,1] x [0,N] (lid on top), i.e. the
+per-GPU work is fixed; the strips are coupled through RCCL (halo exchange of 1-2 lattice
+lines per SpMV, all-reduce of the partial dot products; csrc/comm.hip).  The aggregate
+`value` is DoF-updates/s = (global dofs) x (time steps/s).
+
+Prints ONE JSON line (driver contract) that also carries
   "roofline":     dominant kernel (block-CSR SpMV of the momentum Jacobian), algorithmic
                   bytes per launch / HIP-event time on the kernel's stream vs 8 TB/s HBM;
   "cpu_baseline": the CPU oracle configured as the reference works (full re-assembly +
                   sparse LU every Newton iteration, Poisson/mass re-factorised every step)
-                  timed on a bounded sample on this host.
+                  timed on a bounded sample on this host (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -25,30 +31,28 @@ sys.path[:0] = [PKG]
 
 import numpy as np  # noqa: E402
 
+# load the HIP library (and with it ROCm's libamdhip64 / librccl) BEFORE torch is imported
+import _native as nat  # noqa: E402
+nat.load_library()
+
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cavity_setup(n, device):
-    import _native as nat
-    from fem_mesh import TaylorHoodDofMap
-    from grid_generator import hyper_cube
-    mesh, marks = hyper_cube(2, n)
-    dm = TaylorHoodDofMap(mesh)
-    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1,
-                           device)
-    dofs, vals = [], []
-    for mid, val in ((1, (0.0, 0.0)), (2, (0.0, 0.0)), (3, (0.0, 0.0)), (4, (1.0, 0.0))):
-        nodes = np.unique(dm.facet_p2_nodes(marks.facets_with_id(mid)))
-        for a in range(2):
-            dofs.append(2 * nodes + a)
-            vals.append(np.full(nodes.size, val[a]))
-    ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
-    ctx.set_dirichlet(nat.VELOCITY, np.concatenate(dofs), np.concatenate(vals))   # lid wins at corners
-    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
-    return mesh, dm, ctx, nat
+def cavity_dirichlet(dm, height):
+    """no-slip on left/right/bottom, lid (1, 0) on top (wins at the corners) for the boundary
+    nodes this (local) dof map holds; reference: demo/cavity_flow.py:21-29."""
+    X = dm.p2_coords
+    tol = 1e-12
+    on = (np.abs(X[:, 0]) < tol) | (np.abs(X[:, 0] - 1.0) < tol) | (np.abs(X[:, 1]) < tol) | \
+        (np.abs(X[:, 1] - height) < tol)
+    nodes = np.nonzero(on)[0]
+    lid = np.abs(X[nodes, 1] - height) < tol
+    dofs = np.concatenate([2 * nodes, 2 * nodes + 1]).astype(np.int32)
+    vals = np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(nodes.size)])
+    return dofs, vals
 
 
-def cpu_baseline(n_sample, k, steps, full_dofs):
+def cpu_baseline(n_sample, k, steps):
     """Reference algorithm on the host CPU (1 process, as the reference runs): per Newton
     iteration full re-assembly + SuperLU; Poisson and mass matrices re-assembled and
     re-factorised each step (dolfin LinearVariationalSolver behaviour)."""
@@ -56,17 +60,12 @@ def cpu_baseline(n_sample, k, steps, full_dofs):
     import fem_oracle as fo
     from fem_mesh import TaylorHoodDofMap
     from grid_generator import hyper_cube
-    mesh, marks = hyper_cube(2, n_sample)
+    mesh, _ = hyper_cube(2, n_sample)
     dm = TaylorHoodDofMap(mesh)
     s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
-    last = {}
-    for mid, val in ((1, (0.0, 0.0)), (2, (0.0, 0.0)), (3, (0.0, 0.0)), (4, (1.0, 0.0))):
-        nodes = np.unique(dm.facet_p2_nodes(marks.facets_with_id(mid)))
-        for a in range(2):
-            for d in 2 * nodes + a:
-                last[int(d)] = val[a]
-    bd = np.array(sorted(last))
-    bv = np.array([last[d] for d in bd])
+    bd, bv = cavity_dirichlet(dm, 1.0)
+    order = np.argsort(bd, kind="stable")
+    bd, bv = bd[order].astype(np.int64), bv[order]
     coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
     orc = fo.IPCSOracle(s, coef, refactor_every_step=True)
     orc.step(fo.bdf_alpha(0, 1.0), k, (bd, bv))     # warm-up (BDF-1 start step)
@@ -77,13 +76,12 @@ def cpu_baseline(n_sample, k, steps, full_dofs):
         orc.advance()
     dt = time.perf_counter() - t0
     sps = steps / dt
-    return {"value": sps * dm.n_dofs / full_dofs, "unit": "time-steps/s", "cores": 1, "kind": "port",
+    return {"value": sps * dm.n_dofs, "unit": "DoF-updates/s", "cores": 1, "kind": "port",
             "sample": "oracle IPCS (re-assembly + SuperLU per Newton iteration, Poisson/mass "
                       "re-factorised per step) on the n=%d cavity (%d dofs), %d steps after 1 warm-up: "
-                      "%.3f steps/s there; value = that rate x %d/%d dofs (linear-in-dofs scaling, "
-                      "optimistic for sparse LU)" % (n_sample, dm.n_dofs, steps, sps, dm.n_dofs, full_dofs),
-            "sample_steps_per_s": sps, "sample_dofs": dm.n_dofs,
-            "host_cpus": os.cpu_count()}
+                      "%.3f steps/s x %d dofs (sparse LU scales super-linearly, so the rate at "
+                      "2.36 M dofs would be lower)" % (n_sample, dm.n_dofs, steps, sps, dm.n_dofs),
+            "sample_steps_per_s": sps, "sample_dofs": dm.n_dofs, "host_cpus": os.cpu_count()}
 
 
 def main():
@@ -91,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="cells per side (512 = BASELINE config 2)")
+    ap.add_argument("--n", type=int, default=512, help="cells per side and per rank (512 = BASELINE config 2)")
     ap.add_argument("--dt", type=float, default=1.0e-3)
     ap.add_argument("--krylov-rtol", type=float, default=1.0e-10)
     ap.add_argument("--cpu-sample-n", type=int, default=64)
@@ -102,17 +100,44 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if world > 1 and args.gpus != world:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    force_comm = os.environ.get("NSFEM_FORCE_COMM") is not None
     dist = None
-    if world > 1:
+    if world > 1 or force_comm:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    mesh, dm, ctx, nat = cavity_setup(args.n, local_rank)
-    from multigrid import attach_hierarchy
-    mg_levels = attach_hierarchy(ctx, mesh) if not args.no_multigrid else None
+    # ---- local problem: strip `rank` of the 512 x (512 * world) mesh (own rows + ghost row)
+    from partition import StripPartition, global_dof_counts
+    n = args.n
+    part = StripPartition((0.0, 0.0), (1.0, float(world)), n, n * world, rank, world)
+    dm = part.dofmap
+    device = local_rank
+    if os.environ.get("NSFEM_SHARE_GPU"):        # rehearsal of several ranks on a one-GPU box
+        device = 0
+    ctx = nat.NsfemContext(part.mesh.coords, part.mesh.cells, dm.p2_dofmap, dm.p1_dofmap,
+                           dm.n_p2, dm.n_p1, device)
+    if dist is not None:
+        ids = [nat.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.attach_rccl_comm(ids[0], rank, world)
+    mg_levels = None
+    if not args.no_multigrid:
+        mg_levels = part.attach(ctx)
+    else:
+        n2g, n1g = global_dof_counts(n, n * world)
+        ctx.set_partition(rank, world, part.p2_ghost, part.p1_ghost, part.p2_halo, part.p1_halo,
+                          n2g, n1g)
+    ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
+    ctx.set_dirichlet(nat.VELOCITY, *cavity_dirichlet(dm, float(world)))
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    n2g, n1g = global_dof_counts(n, n * world)
+    n_dofs = 2 * n2g + n1g
+
     opts = ctx.default_step_opts()
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = args.krylov_rtol
@@ -131,11 +156,12 @@ def main():
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    newton = kry = 0
+    newton = kry = poi = 0
     for i in range(args.warmup, args.warmup + args.steps):
         info = one_step(i)
         newton += info.newton_iterations
         kry += info.krylov_iterations_momentum
+        poi += info.krylov_iterations_poisson
     ctx.synchronize()
     if dist is not None:
         dist.barrier()
@@ -146,31 +172,41 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
-    # every rank advanced an independent replica of the workload (no mesh partitioning yet)
-    steps_per_s = world * args.steps / elapsed
+    steps_per_s = args.steps / elapsed
     ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write_size.json")
+    if world == 1 and n == 512 and os.path.exists(pmc):
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload:
+        # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
+        c = json.load(open(pmc))
+        key = "void nsfem::k_spmv<2, 2, 1, 8, 0>"
+        if key in c["fetch"] and key in c["write"]:
+            traffic = (2.0 * c["fetch"][key]["median_KB"] + c["write"][key]["median_KB"]) * 1024.0
     out = {
-        "metric": "time_steps_per_sec", "value": steps_per_s, "unit": "time-steps/s",
+        "metric": "dof_updates_per_sec", "value": steps_per_s * n_dofs, "unit": "DoF-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "dof_updates_per_sec": steps_per_s * dm.n_dofs,
+        "time_steps_per_sec": steps_per_s,
         "config": {"workload": "2D lid-driven cavity Re=100, %dx%d right-diagonal Taylor-Hood P2/P1 "
                                "(%d dofs), IPCS, BDF-2, dt=%g, zero initial state" % (
-                                   args.n, args.n, dm.n_dofs, args.dt),
-                   "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
-                   "preconditioner": "jacobi" if mg_levels is None else "geometric multigrid V(2,2) Chebyshev, %d coarse P1 levels" % mg_levels,
-                   "parallelism": "1 GPU" if world == 1 else "%d independent replicas" % world,
+                                   n, n * world, n_dofs, args.dt),
+                   "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "preconditioner": "jacobi" if mg_levels is None else
+                   "geometric multigrid V(2,2) Chebyshev, %d coarse P1 levels" % mg_levels,
+                   "parallelism": "1 GPU" if world == 1 else
+                   "%d strips of 512 cell rows, RCCL halo exchange + all-reduce" % world,
                    "newton_its_per_step": newton / args.steps,
-                   "bicgstab_its_per_step": kry / args.steps},
+                   "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps},
         "roofline": {"bound": "hbm", "kernel": "k_spmv<2,2,1,8> (momentum Jacobian, 2x2 block CSR)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.dt, 2, dm.n_dofs)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.dt, 2)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

@@ -178,7 +178,7 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
     NSFEM_HIP(hipMemcpyAsync(hp.data(), parts.p, sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
     NSFEM_HIP(hipStreamSynchronize(s));
     L.lmax = *std::max_element(hp.begin(), hp.end());
-    if (comm && comm->size > 1) {
+    if (comm_active()) {
       // every rank must smooth with the same Chebyshev polynomial
       NSFEM_HIP(hipMemcpyAsync(parts.p, &L.lmax, sizeof(double), hipMemcpyHostToDevice, s));
       comm->allreduce_max(s, parts.p, 1);
@@ -199,7 +199,7 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
       cur.swap(nxt);
     }
   }
-  if (comm && comm->size > 1) {
+  if (comm_active()) {
     refresh_global_coarse(s, cur, singular);
     ready = true;
     return;
@@ -347,14 +347,14 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
 }
 
 void Multigrid::halo_fill(hipStream_t s, const MGLevel& L, const double* v) {
-  if (comm && comm->size > 1 && L.has_halo) comm->exchange(s, L.halo, const_cast<double*>(v), nv);
+  if (comm_active() && L.has_halo) comm->exchange(s, L.halo, const_cast<double*>(v), nv);
 }
 
 void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
   if (l + 1 == lv.size()) {
-    if (comm && comm->size > 1) {
+    if (comm_active()) {
       // gather the owned right-hand sides into the global coarse vector (ghost entries are
       // zero, so overlapping lines add up correctly), solve redundantly, copy the local part
       gb.zero(s);

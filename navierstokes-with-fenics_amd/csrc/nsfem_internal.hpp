@@ -275,7 +275,8 @@ struct Multigrid : Precond {
   bool dense_coarse = true, ready = false;
   DevBuf<double> coarse_inv, parts;
   // partitioned meshes: communicator + replicated global coarsest problem
-  Comm* comm = nullptr;
+  Comm* comm = nullptr;          // set only when the context is partitioned (or forced)
+  bool comm_active() const { return comm != nullptr; }
   const BlockMat* globA = nullptr;
   int n_glob = 0;
   int64_t glob_off = 0;
@@ -358,7 +359,12 @@ struct nsfem_ctx {
   int64_t n_p2_global = 0, n_p1_global = 0;
   P1Level* global_coarse = nullptr;            // replicated global coarsest mesh (owned)
   int64_t glob_off = 0;
-  bool distributed() const { return comm && comm->size > 1; }
+  // NSFEM_FORCE_COMM=1 routes a single-rank run through the communicator as well (lets a
+  // one-GPU box exercise the RCCL all-reduce calls)
+  bool distributed() const {
+    static const bool force = std::getenv("NSFEM_FORCE_COMM") != nullptr;
+    return comm && (comm->size > 1 || force);
+  }
   std::vector<int32_t> h_p2map, h_p1map;       // host copies of the fine dof maps
   std::vector<P1Level*> coarse;                // owned
   nsfem::Transfer t_p2p1;                      // P2 (fine mesh) <- P1 (fine mesh)

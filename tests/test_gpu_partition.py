@@ -1,0 +1,133 @@
+"""Partitioned (multi-GPU) path on ONE GPU: several contexts in one process, one host thread per
+rank, coupled by the in-process communicator that implements the same interface as the RCCL
+one (csrc/comm.hip).  The strip-partitioned IPCS step -- halo exchange before every SpMV,
+all-reduced partial dot products, partitioned multigrid with a replicated global coarse solve
+-- must reproduce the single-context run: same Newton/Krylov iteration counts, fields equal to
+round-off, ghost copies consistent with their owners.  A second test drives bench.py through
+RCCL itself with one rank (NSFEM_FORCE_COMM routes the single-rank run through ncclAllReduce)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import _native as nat
+from gpu_common import box, context, rel
+from multigrid import attach_hierarchy
+from partition import StripPartition
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cavity_bc(dm, height=1.0):
+    X = dm.p2_coords
+    on = (np.abs(X[:, 0]) < 1e-12) | (np.abs(X[:, 0] - 1) < 1e-12) | (np.abs(X[:, 1]) < 1e-12) | \
+        (np.abs(X[:, 1] - height) < 1e-12)
+    nodes = np.nonzero(on)[0]
+    lid = np.abs(X[nodes, 1] - height) < 1e-12
+    return (np.concatenate([2 * nodes, 2 * nodes + 1]).astype(np.int32),
+            np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(nodes.size)]))
+
+
+def _run(ctx, dm, nsteps, k, use_mg, out, key):
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    ctx.set_dirichlet(nat.VELOCITY, *_cavity_bc(dm))
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-12
+    if use_mg:
+        opts.momentum.precond = opts.poisson.precond = 1
+    infos = []
+    for step in range(nsteps):
+        ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
+        infos.append(ctx.step_ipcs(opts))
+        ctx.advance(0)
+    out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
+
+
+@pytest.mark.parametrize("n,size,use_mg", [(16, 2, False), (32, 4, True), (64, 2, True)])
+def test_partitioned_ipcs_equals_single_context(n, size, use_mg):
+    nsteps, k, coarsest = 3, 0.01, 2
+    mesh, dm, _ = box(n, n)
+    ref = {}
+    ctx0 = context(mesh, dm)
+    if use_mg:
+        attach_hierarchy(ctx0, mesh, coarsest=coarsest)
+    _run(ctx0, dm, nsteps, k, use_mg, ref, 0)
+    u_ref, p_ref, inf_ref = ref[0]
+    ctx0.close()
+
+    group = nat.local_group_create(size)
+    parts = [StripPartition((0.0, 0.0), (1.0, 1.0), n, n, r, size, coarsest=coarsest)
+             for r in range(size)]
+    ctxs = []
+    for r, part in enumerate(parts):
+        pdm = part.dofmap
+        c = nat.NsfemContext(part.mesh.coords, part.mesh.cells, pdm.p2_dofmap, pdm.p1_dofmap,
+                             pdm.n_p2, pdm.n_p1)
+        c.attach_local_comm(group, r)
+        ctxs.append(c)
+    out, errors = {}, []
+
+    def worker(r):
+        try:
+            part = parts[r]
+            if use_mg:
+                part.attach(ctxs[r])
+            else:
+                ctxs[r].set_partition(r, size, part.p2_ghost, part.p1_ghost, part.p2_halo,
+                                      part.p1_halo, (2 * n + 1) ** 2, (n + 1) ** 2)
+            _run(ctxs[r], part.dofmap, nsteps, k, use_mg, out, r)
+        except BaseException as exc:                     # a dead rank would deadlock the others
+            errors.append((r, repr(exc)))
+            os._exit(17)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    u = np.zeros_like(u_ref)
+    p = np.zeros_like(p_ref)
+    for r, part in enumerate(parts):
+        ul, pl, infos = out[r]
+        u.reshape(-1, 2)[part.p2_global[part.p2_owned]] = ul.reshape(-1, 2)[part.p2_owned]
+        p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
+        for a, b in zip(infos, inf_ref):                 # the partitioned algorithm IS the serial one
+            assert a.newton_iterations == b.newton_iterations
+            assert a.krylov_iterations_momentum == b.krylov_iterations_momentum
+            assert a.krylov_iterations_poisson == b.krylov_iterations_poisson
+    assert rel(u, u_ref) < 1e-11
+    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-10
+    for r, part in enumerate(parts):                     # ghosts are copies of the owners' values
+        ul, _, _ = out[r]
+        assert np.abs(ul.reshape(-1, 2) - u.reshape(-1, 2)[part.p2_global]).max() < 1e-13
+    for c in ctxs:
+        c.close()
+    nat.local_group_destroy(group)
+
+
+def test_bench_through_rccl_single_rank():
+    """bench.py with the RCCL communicator attached (1 rank): ncclCommInitRank, the all-reduces
+    of every dot product and the torch.distributed(gloo) bootstrap all run for real."""
+    env = dict(os.environ, NSFEM_FORCE_COMM="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "64", "--steps", "2", "--warmup",
+           "1", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["metric"] == "dof_updates_per_sec" and line["value"] > 0
+    # the same run without a communicator gives the same iteration counts
+    env2 = {k: v for k, v in os.environ.items() if k != "NSFEM_FORCE_COMM"}
+    res2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=600)
+    assert res2.returncode == 0, res2.stderr[-2000:]
+    line2 = json.loads(res2.stdout.strip().splitlines()[-1])
+    for key in ("newton_its_per_step", "bicgstab_its_per_step", "poisson_cg_its_per_step"):
+        assert line["config"][key] == line2["config"][key]

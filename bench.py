@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="cells per side and per rank (512 = BASELINE config 2)")
+    ap.add_argument("--cells", dest="n", type=int, default=512, help="cells per side and per rank (512 = BASELINE config 2)")
     ap.add_argument("--dt", type=float, default=1.0e-3)
     ap.add_argument("--krylov-rtol", type=float, default=1.0e-10)
     ap.add_argument("--cpu-sample-n", type=int, default=64)

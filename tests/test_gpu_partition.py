@@ -118,7 +118,7 @@ def test_bench_through_rccl_single_rank():
     of every dot product and the torch.distributed(gloo) bootstrap all run for real."""
     env = dict(os.environ, NSFEM_FORCE_COMM="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "64", "--steps", "2", "--warmup",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "64", "--steps", "2", "--warmup",
            "1", "--no-cpu-baseline"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]

@@ -114,7 +114,10 @@ def main():
     # ---- local problem: strip `rank` of the 512 x (512 * world) mesh (own rows + ghost row)
     from partition import StripPartition, global_dof_counts
     n = args.n
-    part = StripPartition((0.0, 0.0), (1.0, float(world)), n, n * world, rank, world)
+    # coarsest global mesh: 16 cells across on one GPU (289-node dense solve), 8 across when
+    # partitioned (the replicated coarse problem grows with the number of strips)
+    part = StripPartition((0.0, 0.0), (1.0, float(world)), n, n * world, rank, world,
+                          coarsest=16 if world == 1 else 8)
     dm = part.dofmap
     device = local_rank
     if os.environ.get("NSFEM_SHARE_GPU"):        # rehearsal of several ranks on a one-GPU box

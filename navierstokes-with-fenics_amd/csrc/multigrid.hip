@@ -36,13 +36,18 @@ __global__ __launch_bounds__(256) void k_dense_apply(int n, int nv,
                                                      const double* __restrict__ Ainv,
                                                      const double* __restrict__ b,
                                                      double* __restrict__ x) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wavefront per output (row, component): lanes stride the columns (A is symmetric, so
+  // row `row` of A is read contiguously), shuffle reduction
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (idx >= n * nv) return;
   const int v = idx / n, row = idx % n;
-  const double* A = Ainv + (size_t)v * n * n;
+  const double* A = Ainv + (size_t)v * n * n + (size_t)row * n;
   double acc = 0.0;
-  for (int c = 0; c < n; ++c) acc += A[(size_t)c * n + row] * b[(size_t)c * nv + v];
-  x[(size_t)row * nv + v] = acc;
+  for (int c = lane; c < n; c += 64) acc += A[c] * b[(size_t)c * nv + v];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) x[(size_t)row * nv + v] = acc;
 }
 
 // Gershgorin bound of D^{-1} A over unmasked rows: max_i dinv_i sum_j |a_ij|
@@ -362,7 +367,7 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
                                hipMemcpyDeviceToDevice, s));
       comm->allreduce_sum(s, gb.p, (int64_t)n_glob * nv);
       const int tot = n_glob * nv;
-      hipLaunchKernelGGL(k_dense_apply, dim3((tot + 255) / 256), dim3(256), 0, s, n_glob, nv,
+      hipLaunchKernelGGL(k_dense_apply, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, n_glob, nv,
                          coarse_inv.p, gb.p, gx.p);
       NSFEM_HIP(hipGetLastError());
       NSFEM_HIP(hipMemcpyAsync(x, gx.p + (size_t)glob_off * nv, sizeof(double) * n,
@@ -371,7 +376,7 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
     }
     if (dense_coarse) {
       const int tot = L.n * nv;
-      hipLaunchKernelGGL(k_dense_apply, dim3((tot + 255) / 256), dim3(256), 0, s, L.n, nv,
+      hipLaunchKernelGGL(k_dense_apply, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, L.n, nv,
                          coarse_inv.p, b, x);
       NSFEM_HIP(hipGetLastError());
     } else {

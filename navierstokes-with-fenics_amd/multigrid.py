@@ -44,7 +44,7 @@ def structured_prolongation(nx, ny):
     return rowptr, col, val
 
 
-def structured_hierarchy(p0, p1, nx, ny, coarsest=8):
+def structured_hierarchy(p0, p1, nx, ny, coarsest=16):
     """[(coarse mesh, prolongation CSR to the next finer mesh), ...] finest-first, stopping
     when a direction becomes odd or smaller than ``coarsest`` cells."""
     levels = []
@@ -55,7 +55,7 @@ def structured_hierarchy(p0, p1, nx, ny, coarsest=8):
     return levels
 
 
-def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=8):
+def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=16):
     """Build the hierarchy of a structured mesh (``mesh.structured`` = (p0, p1, nx, ny)) on the
     device context.  Returns the number of coarse P1 levels (0: mesh cannot be coarsened; the
     two-level P2 -> P1 hierarchy is still built)."""

@@ -403,3 +403,70 @@ def test_bdf_monolithic_open_channel_and_stokes_limit():
         assert rel(ctx.get_state(nat.U1), orc.sol[1][:nv]) < tol
         assert rel(ctx.get_state(nat.P_OLD), orc.sol[1][nv:]) < tol     # open outlet fixes the level
         ctx.close()
+
+
+def test_unstructured_mesh_ipcs_and_bdf_match_oracle():
+    """General triangle meshes: vertices of a structured mesh are jittered, and cells and
+    vertices randomly renumbered (no lattice, no hierarchy: the multigrid degenerates to the
+    two-level P2 -> P1 cycle with a dense P1 solve).  Channel-type BCs, both schemes."""
+    from fem_mesh import FacetMarkers, Mesh, TaylorHoodDofMap
+    from multigrid import attach_hierarchy
+    rng = np.random.default_rng(42)
+    base, _, _ = box(14, 10, p1=(1.4, 1.0))
+    coords = base.coords.copy()
+    interior = (coords[:, 0] > 1e-9) & (coords[:, 0] < 1.4 - 1e-9) & (coords[:, 1] > 1e-9) & \
+        (coords[:, 1] < 1.0 - 1e-9)
+    coords[interior] += 0.03 * (rng.random((interior.sum(), 2)) - 0.5)
+    vperm = rng.permutation(coords.shape[0])                # new id of old vertex
+    new_coords = np.empty_like(coords)
+    new_coords[vperm] = coords
+    cells = vperm[base.cells][rng.permutation(base.cells.shape[0])].astype(np.int32)
+    mesh = Mesh(new_coords, cells)
+    assert not hasattr(mesh, "structured")
+    dm = TaylorHoodDofMap(mesh)
+    marks = FacetMarkers(mesh)
+    marks.mark(lambda X: np.abs(X[:, 0]) < 1e-12, 1)
+    marks.mark(lambda X: np.abs(X[:, 0] - 1.4) < 1e-12, 2)
+    marks.mark(lambda X: np.abs(X[:, 1]) < 1e-12, 3)
+    marks.mark(lambda X: np.abs(X[:, 1] - 1.0) < 1e-12, 4)
+    zero = lambda X: np.zeros((X.shape[0], 2))
+    inlet = lambda X: np.stack([4.0 * X[:, 1] * (1.0 - X[:, 1]), 0.0 * X[:, 1]], axis=1)
+    vbc = velocity_bc(dm, marks, [(1, inlet), (3, zero), (4, zero)])
+    pn = np.unique(dm.facet_p1_nodes(marks.facets_with_id(2)))
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.05, body_force_term=None)
+    # ---- IPCS with pressure outlet
+    ctx = context(mesh, dm)
+    assert attach_hierarchy(ctx, mesh) == 0
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    ctx.set_coeffs(1.0, 1.0, 0.05)
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, pn, np.zeros(pn.size))
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-13
+    opts.momentum.precond = opts.poisson.precond = 1
+    for step in range(3):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, 0.02)
+        info = ctx.step_ipcs(opts)
+        orc.step(alpha, 0.02, vbc, (pn, np.zeros(pn.size)))
+        assert info.newton_iterations == orc.newton_its[step]
+        ctx.advance(0)
+        orc.advance()
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    assert rel(ctx.get_state(nat.P_OLD), orc.p_old) < 1e-9
+    ctx.close()
+    # ---- monolithic BDF with natural outflow
+    ctx = context(mesh, dm)
+    attach_hierarchy(ctx, mesh)
+    orc = fo.BDFOracle(s, coef)
+    ctx.set_coeffs(1.0, 1.0, 0.05)
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, pn.astype(np.int32), np.zeros(pn.size))
+    _run_bdf(ctx, orc, 3, 0.02, vbc, rtol=1e-13)
+    nv = dm.n_velocity
+    assert rel(ctx.get_state(nat.U1), orc.sol[1][:nv]) < 1e-9
+    assert rel(ctx.get_state(nat.P_OLD), orc.sol[1][nv:]) < 1e-9
+    ctx.close()

@@ -116,7 +116,7 @@ typedef struct {
   double newton_atol;   /* reference: tol (1e-10)   ns_ipcs_solver.py:144       */
   double newton_rtol;   /* reference: 10 * tol                                  */
   int32_t newton_max_iter; /* reference: 50                                     */
-  int32_t convective_form; /* 0 standard (others: NSFEM_ERR_ARG for now)        */
+  int32_t convective_form; /* 0 standard, 1 rotational, 2 divergence, 3 skew-symmetric */
   nsfem_krylov_opts momentum;   /* BiCGStab */
   nsfem_krylov_opts poisson;    /* CG       */
   nsfem_krylov_opts correction; /* CG       */
@@ -148,6 +148,10 @@ int nsfem_set_bdf(nsfem_ctx* ctx, const double alpha[3], double k);
  * velocity (interleaved) or pressure vector; later entries win on duplicates. */
 int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const int32_t* dofs,
                         const double* vals);
+/* convective term form (ns_solver_base.py:370-390): 0 standard, 1 rotational, 2 divergence,
+ * 3 skew-symmetric; picard != 0 selects the Picard linearisation (:478-499) for the matrices
+ * assembled through nsfem_assemble (the fused step drivers take the form from their options) */
+int nsfem_set_convective_form(nsfem_ctx* ctx, int form, int picard);
 /* viscous term form: 0 reduced, 1 traction (ns_solver_base.py:662-673) */
 int nsfem_set_viscous_form(nsfem_ctx* ctx, int traction_form);
 

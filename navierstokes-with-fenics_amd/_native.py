@@ -25,6 +25,7 @@ MAX_NEWTON = 64
 EXPORTED_SYMBOLS = (
     "nsfem_create", "nsfem_destroy", "nsfem_last_error", "nsfem_version",
     "nsfem_set_coeffs", "nsfem_set_bdf", "nsfem_set_dirichlet", "nsfem_set_viscous_form",
+    "nsfem_set_convective_form",
     "nsfem_set_state", "nsfem_get_state", "nsfem_state_size", "nsfem_state_devptr",
     "nsfem_assemble", "nsfem_residual_norm", "nsfem_get_rhs", "nsfem_solve",
     "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply",
@@ -132,6 +133,7 @@ def load_library(path=None):
         "nsfem_set_bdf": (C.c_int, [vp, pd, dbl]),
         "nsfem_set_dirichlet": (C.c_int, [vp, C.c_int, i32, pi, pd]),
         "nsfem_set_viscous_form": (C.c_int, [vp, C.c_int]),
+        "nsfem_set_convective_form": (C.c_int, [vp, C.c_int, C.c_int]),
         "nsfem_set_state": (C.c_int, [vp, C.c_int, pd, i64]),
         "nsfem_get_state": (C.c_int, [vp, C.c_int, pd, i64]),
         "nsfem_state_size": (i64, [vp, C.c_int]),
@@ -255,6 +257,9 @@ class NsfemContext:
         v = np.ascontiguousarray(vals, dtype=np.float64)
         assert d.shape == v.shape and d.ndim == 1
         self._check(self._lib.nsfem_set_dirichlet(self._h, field, d.size, _ip(d), _dp(v)))
+
+    def set_convective_form(self, form, picard=False):
+        self._check(self._lib.nsfem_set_convective_form(self._h, int(form), int(bool(picard))))
 
     def set_viscous_form(self, traction_form):
         self._check(self._lib.nsfem_set_viscous_form(self._h, int(bool(traction_form))))

@@ -247,6 +247,15 @@ extern "C" int nsfem_set_bdf(nsfem_ctx* ctx, const double alpha[3], double k) {
   API_END(ctx)
 }
 
+extern "C" int nsfem_set_convective_form(nsfem_ctx* ctx, int form, int picard) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(form >= 0 && form <= 3, "unknown convective form");
+  ctx->conv_form = form;
+  ctx->picard = picard != 0;
+  API_END(ctx)
+}
+
 extern "C" int nsfem_set_viscous_form(nsfem_ctx* ctx, int traction_form) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
@@ -468,7 +477,7 @@ static void momentum_residual_raw(nsfem_ctx* c, const double* u, double* out) {
   launch_axpby(s, nv, 1.0, out, 1.0, c->gconst.p, out);
   if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], u, out, nullptr);
   const double cc = cc_of(c);
-  if (cc != 0.0) launch_convection_residual(s, c->mesh, u, cc, out);
+  if (cc != 0.0) launch_convection_residual(s, c->mesh, u, cc, out, c->conv_form);
 }
 
 static double momentum_residual(nsfem_ctx* c) {
@@ -486,7 +495,7 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
   const double cc = cc_of(c);
   if (cc != 0.0)
     launch_convection_jacobian(s, c->mesh, c->p22, c->state[vel_slot].p, cc, c->L.vals.p, E,
-                               c->coef[2], c->J.vals.p);
+                               c->coef[2], c->J.vals.p, c->conv_form, c->picard);
   else
     launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
   launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
@@ -913,9 +922,10 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   nsfem_step_info local;
   API_BEGIN
   NSFEM_REQUIRE(ctx && opts, "null argument");
-  NSFEM_REQUIRE(opts->convective_form == 0, "only the standard convective form is implemented");
+  NSFEM_REQUIRE(opts->convective_form >= 0 && opts->convective_form <= 3, "unknown convective form");
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
+  ctx->conv_form = opts->convective_form;
   nsfem_step_info& inf = info ? *info : local;
   std::memset(&inf, 0, sizeof(inf));
   // ---- diffusion step: Newton (dolfin NewtonSolver, residual criterion)
@@ -1009,9 +1019,10 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   nsfem_step_info local;
   API_BEGIN
   NSFEM_REQUIRE(ctx && opts, "null argument");
-  NSFEM_REQUIRE(opts->convective_form == 0, "only the standard convective form is implemented");
+  NSFEM_REQUIRE(opts->convective_form >= 0 && opts->convective_form <= 3, "unknown convective form");
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
+  ctx->conv_form = opts->convective_form;
   NSFEM_REQUIRE(!ctx->distributed(), "the monolithic step is not partitioned yet (use IPCS)");
   NSFEM_REQUIRE(ctx->mg_built, "the monolithic step needs the multigrid hierarchy "
                                "(block preconditioner): call nsfem_mg_finalize");

@@ -234,8 +234,15 @@ __global__ __launch_bounds__(256) void k_jac_init(int nnz, const double* __restr
   }
 }
 
-// ---- Newton convection block:  cc * [ phi_i (u.grad phi_j) delta_ab + phi_i phi_j d_b u_a ]
-// (Gateaux derivative of dot(dot(grad(u), u), v), source/ns_solver_base.py:378)
+// ---- convection blocks of the Newton (or Picard) matrix for the four weak forms of
+// source/ns_solver_base.py:370-390 (Gateaux derivatives) / :478-499 (Picard linearisations).
+// FORM: 0 standard, 1 rotational, 2 divergence, 3 skew-symmetric.  With u, G = grad u,
+// div, curl at the quadrature point, test (phi_i, a), trial (phi_j, b):
+//   standard    phi_i [ (u.g_j) d_ab + phi_j G_ab ]                 (Picard: first term)
+//   divergence  standard + 1/2 phi_i [ g_j,b u_a + div phi_j d_ab ] (Picard: 1st + 4th term)
+//   skew        1/2 standard - 1/2 [ g_i,b phi_j u_a + (u.g_i) phi_j d_ab ]
+//   rotational  phi_i e_a [ dcurl_j,b u_(1-a) + curl phi_j d_(b,1-a) ],  e = (-1, +1)
+template <int FORM, bool PICARD>
 __global__ __launch_bounds__(256) void k_conv_jac(int nc, const double* __restrict__ vx,
                                                   const int32_t* __restrict__ p2,
                                                   const double* __restrict__ u, double cc,
@@ -258,6 +265,7 @@ __global__ __launch_bounds__(256) void k_conv_jac(int nc, const double* __restri
   for (int q = 0; q < 7; ++q) {
     double gx[6], gy[6];
     double uqx = 0.0, uqy = 0.0, g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
+    double gix = 0.0, giy = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       phys(g, c_q.dphi2[q][k][0], c_q.dphi2[q][k][1], gx[k], gy[k]);
@@ -268,16 +276,54 @@ __global__ __launch_bounds__(256) void k_conv_jac(int nc, const double* __restri
       g01 += gy[k] * ux[k];   // d_y u_x
       g10 += gx[k] * uy[k];   // d_x u_y
       g11 += gy[k] * uy[k];   // d_y u_y
+      if (k == i) { gix = gx[k]; giy = gy[k]; }
     }
-    const double wpi = c_q.w[q] * g.adet * c_q.phi2[q][i] * cc;
+    const double w = c_q.w[q] * g.adet * cc;
+    const double wpi = w * c_q.phi2[q][i];
+    const double div = g00 + g11, curl = g10 - g01;
+    const double udgi = uqx * gix + uqy * giy;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const double udg = uqx * gx[j] + uqy * gy[j];
       const double pj = c_q.phi2[q][j];
-      acc[j][0] += wpi * (udg + pj * g00);
-      acc[j][1] += wpi * (pj * g01);
-      acc[j][2] += wpi * (pj * g10);
-      acc[j][3] += wpi * (udg + pj * g11);
+      if (FORM == 0) {
+        acc[j][0] += wpi * (udg + (PICARD ? 0.0 : pj * g00));
+        acc[j][3] += wpi * (udg + (PICARD ? 0.0 : pj * g11));
+        if (!PICARD) {
+          acc[j][1] += wpi * (pj * g01);
+          acc[j][2] += wpi * (pj * g10);
+        }
+      } else if (FORM == 2) {
+        const double hd = 0.5 * div * pj;
+        acc[j][0] += wpi * (udg + hd + (PICARD ? 0.0 : pj * g00 + 0.5 * gx[j] * uqx));
+        acc[j][3] += wpi * (udg + hd + (PICARD ? 0.0 : pj * g11 + 0.5 * gy[j] * uqy));
+        if (!PICARD) {
+          acc[j][1] += wpi * (pj * g01 + 0.5 * gy[j] * uqx);
+          acc[j][2] += wpi * (pj * g10 + 0.5 * gx[j] * uqy);
+        }
+      } else if (FORM == 3) {
+        const double sk = 0.5 * (wpi * udg - w * udgi * pj);
+        acc[j][0] += sk;
+        acc[j][3] += sk;
+        if (!PICARD) {
+          const double hw = 0.5 * w * pj;
+          acc[j][0] += 0.5 * wpi * pj * g00 - hw * gix * uqx;
+          acc[j][1] += 0.5 * wpi * pj * g01 - hw * giy * uqx;
+          acc[j][2] += 0.5 * wpi * pj * g10 - hw * gix * uqy;
+          acc[j][3] += 0.5 * wpi * pj * g11 - hw * giy * uqy;
+        }
+      } else {   // rotational: rows a = 0 (e = -1, u_1) and a = 1 (e = +1, u_0)
+        const double cj = curl * pj;
+        acc[j][1] += wpi * (-cj);          // a = 0, b = 1 = 1 - a
+        acc[j][2] += wpi * (cj);           // a = 1, b = 0
+        if (!PICARD) {
+          // dcurl_j,0 = -d_y phi_j ; dcurl_j,1 = d_x phi_j
+          acc[j][0] += wpi * (gy[j] * uqy);
+          acc[j][1] += wpi * (-gx[j] * uqy);
+          acc[j][2] += wpi * (-gy[j] * uqx);
+          acc[j][3] += wpi * (gx[j] * uqx);
+        }
+      }
     }
   }
   // plain stores of the 6 blocks of row i: ebuf[cell][i][j][4]
@@ -317,7 +363,8 @@ __global__ __launch_bounds__(256) void k_jac_gather(int nnz, const int32_t* __re
   reinterpret_cast<double2*>(J)[2 * (size_t)s + 1] = r1;
 }
 
-// ---- convection residual:  b_(i,a) += cc * int ((grad u) u)_a phi_i
+// ---- convection residual  b_(i,a) += cc * int c(u)_a phi_i  for the four weak forms
+template <int FORM>
 __global__ __launch_bounds__(256) void k_conv_res(int nc, const double* __restrict__ vx,
                                                   const int32_t* __restrict__ p2,
                                                   const double* __restrict__ u, double cc,
@@ -336,7 +383,7 @@ __global__ __launch_bounds__(256) void k_conv_res(int nc, const double* __restri
   }
   double rx = 0.0, ry = 0.0;
   for (int q = 0; q < 7; ++q) {
-    double uqx = 0.0, uqy = 0.0, g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
+    double uqx = 0.0, uqy = 0.0, g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0, gix = 0.0, giy = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       double gx, gy;
@@ -348,10 +395,27 @@ __global__ __launch_bounds__(256) void k_conv_res(int nc, const double* __restri
       g01 += gy * ux[k];
       g10 += gx * uy[k];
       g11 += gy * uy[k];
+      if (k == i) { gix = gx; giy = gy; }
     }
-    const double wpi = c_q.w[q] * g.adet * c_q.phi2[q][i] * cc;
-    rx += wpi * (g00 * uqx + g01 * uqy);
-    ry += wpi * (g10 * uqx + g11 * uqy);
+    const double w = c_q.w[q] * g.adet * cc;
+    const double wpi = w * c_q.phi2[q][i];
+    const double ax = g00 * uqx + g01 * uqy, ay = g10 * uqx + g11 * uqy;   // (grad u) u
+    if (FORM == 0) {
+      rx += wpi * ax;
+      ry += wpi * ay;
+    } else if (FORM == 1) {
+      const double curl = g10 - g01;
+      rx += wpi * (-curl * uqy);
+      ry += wpi * (curl * uqx);
+    } else if (FORM == 2) {
+      const double hd = 0.5 * (g00 + g11);
+      rx += wpi * (ax + hd * uqx);
+      ry += wpi * (ay + hd * uqy);
+    } else {
+      const double udgi = uqx * gix + uqy * giy;
+      rx += 0.5 * (wpi * ax - w * udgi * uqx);
+      ry += 0.5 * (wpi * ay - w * udgi * uqy);
+    }
   }
   reinterpret_cast<double2*>(rbuf)[(size_t)c * 6 + i] = make_double2(rx, ry);
 }
@@ -454,17 +518,39 @@ void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double*
 }
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                 const double* u, double cc, const double* L, const double* E,
-                                double cvE, double* J) {
-  hipLaunchKernelGGL(k_conv_jac, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
-                     m.n_cells, m.vx.p, m.p2.p, u, cc, m.ebuf.p);
+                                double cvE, double* J, int form, bool picard) {
+  const dim3 grid(grid_for((int64_t)m.n_cells * 6)), block(kBlock);
+#define NSFEM_CJ(F, P) \
+  hipLaunchKernelGGL((k_conv_jac<F, P>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.ebuf.p)
+  switch (form * 2 + (picard ? 1 : 0)) {
+    case 0: NSFEM_CJ(0, false); break;
+    case 1: NSFEM_CJ(0, true); break;
+    case 2: NSFEM_CJ(1, false); break;
+    case 3: NSFEM_CJ(1, true); break;
+    case 4: NSFEM_CJ(2, false); break;
+    case 5: NSFEM_CJ(2, true); break;
+    case 6: NSFEM_CJ(3, false); break;
+    case 7: NSFEM_CJ(3, true); break;
+    default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
+  }
+#undef NSFEM_CJ
   hipLaunchKernelGGL(k_jac_gather, dim3(grid_for(p22.nnz)), dim3(kBlock), 0, s, p22.nnz,
                      p22.cptr.p, p22.cidx.p, m.ebuf.p, L, E, cvE, J);
   NSFEM_HIP(hipGetLastError());
 }
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
-                                double* b) {
-  hipLaunchKernelGGL(k_conv_res, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
-                     m.n_cells, m.vx.p, m.p2.p, u, cc, m.rbuf.p);
+                                double* b, int form) {
+  const dim3 grid(grid_for((int64_t)m.n_cells * 6)), block(kBlock);
+#define NSFEM_CR(F) \
+  hipLaunchKernelGGL((k_conv_res<F>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.rbuf.p)
+  switch (form) {
+    case 0: NSFEM_CR(0); break;
+    case 1: NSFEM_CR(1); break;
+    case 2: NSFEM_CR(2); break;
+    case 3: NSFEM_CR(3); break;
+    default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
+  }
+#undef NSFEM_CR
   hipLaunchKernelGGL(k_res_gather, dim3(grid_for(m.n_p2)), dim3(kBlock), 0, s, m.n_p2, m.nptr.p,
                      m.nidx.p, m.rbuf.p, b);
   NSFEM_HIP(hipGetLastError());

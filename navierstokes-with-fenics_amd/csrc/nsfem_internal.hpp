@@ -161,9 +161,9 @@ void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double*
 // J = L (x) I_2 + cvE * E + cc * conv'(u): element blocks are stored, then gathered per slot
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                 const double* u, double cc, const double* L, const double* E,
-                                double cvE, double* J);
+                                double cvE, double* J, int form, bool picard);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
-                                double* b);
+                                double* b, int form);
 // diag extraction: d[(i,a)] = 1 / A_ii[a][a]  (mask rows -> 1)
 void launch_inv_diag(hipStream_t s, const BlockMat& A, int nv, const uint8_t* rowmask,
                      double* dinv);
@@ -340,6 +340,8 @@ struct nsfem_ctx {
   nsfem::KrylovWork kw;
   int assembled_system = -1;
   double area = 0.0;
+  int conv_form = 0;        // 0 standard, 1 rotational, 2 divergence, 3 skew-symmetric
+  bool picard = false;      // Picard instead of Newton linearisation of the convection
   // ---- multigrid hierarchy (optional; nsfem_mg_add_level / nsfem_mg_finalize)
   struct P1Level {
     int n = 0;

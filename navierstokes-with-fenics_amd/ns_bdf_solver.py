@@ -12,6 +12,9 @@ import _native as nat
 from bdf_time_stepping import BDFTimeStepping
 from ns_solver_base import InstationarySolverBase, WeakFormConvectiveTerm
 
+_FORM_ID = {WeakFormConvectiveTerm.standard_form: 0, WeakFormConvectiveTerm.rotational_form: 1,
+            WeakFormConvectiveTerm.divergence_form: 2, WeakFormConvectiveTerm.skew_symmetric_form: 3}
+
 
 class ImplicitBDFSolver(InstationarySolverBase):
     # NB: the reference writes ("_solver") -- a string, so its _setup_problem re-runs
@@ -29,8 +32,7 @@ class ImplicitBDFSolver(InstationarySolverBase):
     def _setup_problem(self):
         if not all(hasattr(self, attr) for attr in ("_Wh", "_solutions")):  # pragma: no cover
             self._setup_function_spaces()
-        if self._form_convective_term is not WeakFormConvectiveTerm.standard_form:
-            raise NotImplementedError("only the standard convective form has device kernels")
+        self._ctx.set_convective_form(_FORM_ID[self._form_convective_term])
         if not all(hasattr(self, attr) for attr in ("_next_step_size", "_alpha")):
             self._update_time_stepping_coefficients()
         self._setup_boundary_conditions()
@@ -57,6 +59,7 @@ class ImplicitBDFSolver(InstationarySolverBase):
         o.newton_atol = self._tol
         o.newton_rtol = 10.0 * self._tol
         o.newton_max_iter = self._maxiter
+        o.convective_form = _FORM_ID[self._form_convective_term]
         o.momentum.rtol = self.krylov_rtol
         o.momentum.max_iter = self.krylov_max_iter
         o.momentum.precond = 1

@@ -19,6 +19,9 @@ from bdf_time_stepping import BDFTimeStepping
 from fem_function import DeviceFunction, MixedFunction
 from ns_solver_base import InstationarySolverBase, WeakFormConvectiveTerm
 
+_FORM_ID = {WeakFormConvectiveTerm.standard_form: 0, WeakFormConvectiveTerm.rotational_form: 1,
+            WeakFormConvectiveTerm.divergence_form: 2, WeakFormConvectiveTerm.skew_symmetric_form: 3}
+
 
 class _DeviceSystem:
     """Handle of one linear/non-linear system living in the device context (takes the
@@ -63,8 +66,7 @@ class IPCSSolver(InstationarySolverBase):
         if not all(hasattr(self, a) for a in ("_Wh", "_solutions", "_intermediate_velocity",
                                               "_velocities", "_pressure", "_old_pressure")):  # pragma: no cover
             self._setup_function_spaces()
-        if self._form_convective_term is not WeakFormConvectiveTerm.standard_form:
-            raise NotImplementedError("only the standard convective form has device kernels")
+        self._ctx.set_convective_form(_FORM_ID[self._form_convective_term])
         if not all(hasattr(self, a) for a in ("_next_step_size", "_alpha")):
             self._update_time_stepping_coefficients()
         self._setup_boundary_conditions()
@@ -77,6 +79,7 @@ class IPCSSolver(InstationarySolverBase):
         o.newton_atol = self._tol
         o.newton_rtol = 10.0 * self._tol
         o.newton_max_iter = self._maxiter
+        o.convective_form = _FORM_ID[self._form_convective_term]
         for k in (o.momentum, o.poisson, o.correction):
             k.rtol = self.krylov_rtol
             k.max_iter = self.krylov_max_iter

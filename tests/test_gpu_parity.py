@@ -470,3 +470,60 @@ def test_unstructured_mesh_ipcs_and_bdf_match_oracle():
     assert rel(ctx.get_state(nat.U1), orc.sol[1][:nv]) < 1e-9
     assert rel(ctx.get_state(nat.P_OLD), orc.sol[1][nv:]) < 1e-9
     ctx.close()
+
+
+@pytest.mark.parametrize("form_id,form", [(0, "standard"), (1, "rotational"), (2, "divergence"),
+                                          (3, "skew_symmetric")])
+def test_convective_forms_residual_jacobian_and_step(setup16, form_id, form):
+    """All four weak forms of source/ns_solver_base.py:370-390: device residual and Newton
+    matrix vs the oracle's exact Gateaux derivative, Picard matrix (:478-499) for the standard
+    form, and IPCS steps with that form."""
+    mesh, dm, marks, ctx, s = setup16
+    rng = np.random.default_rng(17 + form_id)
+    u = rng.standard_normal(dm.n_velocity)
+    zeros_v, zeros_p = np.zeros(dm.n_velocity), np.zeros(dm.n_p1)
+    ctx.set_coeffs(0.8, 1.0, 0.02, 1.0)      # (the shared context carries a body force slot)
+    ctx.set_bdf((1.5, -2.0, 0.5), 0.05)
+    ctx.set_dirichlet(nat.VELOCITY, np.zeros(0, np.int32), np.zeros(0))
+    for slot, v in ((nat.U1, zeros_v), (nat.U2, zeros_v), (nat.USTAR, u), (nat.P_OLD, zeros_p),
+                    (nat.BODY_FORCE, zeros_v)):
+        ctx.set_state(slot, v)
+    ctx.set_convective_form(form_id)
+    ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+    L = 1.5 / 0.05 * s.vector_mass() + 0.02 * s.vector_stiffness()
+    b = L @ u + 0.8 * s.convection_residual(u, form)
+    assert rel(ctx.get_rhs(nat.SYS_MOMENTUM), b) < 1e-13
+    Jref = L + 0.8 * s.convection_jacobian(u, form)
+    J = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
+    assert abs(J - Jref).max() <= 1e-13 * abs(Jref).max()
+    if form == "standard":
+        ctx.set_convective_form(0, picard=True)
+        ctx.assemble(nat.SYS_MOMENTUM)
+        Jp = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
+        Jpref = L + 0.8 * s.picard_convection(u)
+        assert abs(Jp - Jpref).max() <= 1e-13 * abs(Jpref).max()
+    ctx.set_convective_form(0)
+    # two IPCS steps of the cavity with this form
+    m2, dm2, marks2 = box(12, 12)
+    c2 = context(m2, dm2)
+    s2 = fo.Space(m2.coords, m2.cells, dm2.p2_dofmap, dm2.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
+    orc = fo.IPCSOracle(s2, coef, form=form, refactor_every_step=False)
+    c2.set_coeffs(1.0, 1.0, 0.01)
+    vbc = cavity_bc(dm2, marks2)
+    c2.set_dirichlet(nat.VELOCITY, *vbc)
+    c2.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    opts = c2.default_step_opts()
+    opts.convective_form = form_id
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-13
+    for step in range(2):
+        alpha = fo.bdf_alpha(step, 1.0)
+        c2.set_bdf(alpha, 0.02)
+        info = c2.step_ipcs(opts)
+        orc.step(alpha, 0.02, vbc)
+        assert info.newton_iterations == orc.newton_its[step]
+        c2.advance(0)
+        orc.advance()
+    assert rel(c2.get_state(nat.U1), orc.vel[1]) < 1e-9
+    c2.close()

@@ -217,3 +217,47 @@ def rectangle_mesh(p0, p1, nx, ny):
     mesh = Mesh(coords, cells)
     mesh.structured = (tuple(p0), tuple(p1), int(nx), int(ny))   # enables the multigrid hierarchy
     return mesh
+
+
+def periodic_entity_map(mesh, domain):
+    """Master entity of every vertex and edge under a dolfin-style periodic ``SubDomain``
+    (``inside(x, on_boundary)`` marks the master part of the boundary, ``map(x_slave, x_master)``
+    sends a slave point to its master; reference usage: tests/test_transient_solvers.py:20-46,
+    source/ns_solver_base.py:516-518).  Returns (entity_master [nv + ne], vertex_master [nv]):
+    indices into the entity list (vertices, then edges)."""
+    nv, ne = mesh.num_vertices(), mesh.num_edges()
+    pts = np.concatenate([mesh.coords, mesh.edge_midpoints()], axis=0)
+    on_bnd = np.zeros(nv + ne, dtype=bool)
+    bedges = np.nonzero(mesh.edge_on_boundary)[0]
+    on_bnd[nv + bedges] = True
+    on_bnd[mesh.edges[bedges].ravel()] = True
+    scale = 1.0 / max(mesh.hmin(), 1e-300)
+
+    def key(p):
+        return (int(round(p[0] * 8.0 * scale)), int(round(p[1] * 8.0 * scale)))
+
+    is_master = np.zeros(nv + ne, dtype=bool)
+    for i in np.nonzero(on_bnd)[0]:
+        is_master[i] = bool(domain.inside(pts[i], True))
+    lookup_v = {key(pts[i]): i for i in range(nv) if is_master[i]}
+    lookup_e = {key(pts[i]): i for i in range(nv, nv + ne) if is_master[i]}
+    master = np.arange(nv + ne, dtype=np.int64)
+    # every boundary entity (masters included: a corner such as (0, 1) lies on the master edge
+    # x = 0 but is itself the image of (0, 0) under the y-shift) is sent through ``map``; chains
+    # are followed to their root so that all periodic images of a point share one dof.  [The
+    # reference's PeriodicDomain does not treat the corner explicitly; how dolfin resolves that
+    # chain cannot be checked here -- the mathematically periodic space is built.]
+    for i in np.nonzero(on_bnd)[0]:
+        target = np.array([np.nan, np.nan])
+        domain.map(pts[i].copy(), target)
+        if not np.all(np.isfinite(target)):
+            continue
+        j = (lookup_v if i < nv else lookup_e).get(key(target))
+        if j is not None and j != i:
+            master[i] = j
+    for i in np.nonzero(on_bnd)[0]:
+        root, hops = master[i], 0
+        while master[root] != root and hops < 8:
+            root, hops = master[root], hops + 1
+        master[i] = root
+    return master, master[:nv].copy()

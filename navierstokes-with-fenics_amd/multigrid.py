@@ -59,7 +59,7 @@ def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=16):
     """Build the hierarchy of a structured mesh (``mesh.structured`` = (p0, p1, nx, ny)) on the
     device context.  Returns the number of coarse P1 levels (0: mesh cannot be coarsened; the
     two-level P2 -> P1 hierarchy is still built)."""
-    info = getattr(mesh, "structured", None)
+    info = getattr(mesh, "structured", None) if mesh is not None else None
     levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
     for coarse_mesh, (rowptr, col, val) in levels:
         ctx.mg_add_level(coarse_mesh.coords, coarse_mesh.cells, rowptr, col, val)

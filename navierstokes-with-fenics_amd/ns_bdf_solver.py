@@ -49,7 +49,8 @@ class ImplicitBDFSolver(InstationarySolverBase):
         full = {bc[1] for bc in getattr(self, "_velocity_bcs", [])
                 if bc[0] in (VelocityBCType.no_slip, VelocityBCType.constant, VelocityBCType.function)}
         marks, mesh, dm = self._boundary_markers, self._mesh, self._dofmap
-        open_facets = np.nonzero(mesh.edge_on_boundary & ~np.isin(marks.values, list(full)))[0]
+        closed = list(full) + list(getattr(self, "_constrained_boundary_ids", ()))   # periodic parts
+        open_facets = np.nonzero(mesh.edge_on_boundary & ~np.isin(marks.values, closed))[0]
         nodes = np.unique(dm.facet_p1_nodes(open_facets)) if open_facets.size else np.zeros(0, np.int64)
         nodes = np.union1d(nodes, self._dirichlet_bcs["pressure"][0]).astype(np.int32)
         self._ctx.set_dirichlet(nat.PRESSURE_PRECOND, nodes, np.zeros(nodes.size))

@@ -20,7 +20,7 @@ import dlfn_compat as dlfn
 import fem_host
 from discrete_time import DiscreteTime
 from fem_function import MixedFunction
-from fem_mesh import FacetMarkers, Mesh, TaylorHoodDofMap
+from fem_mesh import FacetMarkers, Mesh, TaylorHoodDofMap, periodic_entity_map
 from multigrid import attach_hierarchy
 
 
@@ -206,10 +206,12 @@ class SolverBase:
     # ------------------------------------------------------------- device setup
     def _setup_function_spaces(self):
         """Taylor-Hood dof maps + device context (reference: :501-524)."""
+        periodic = None
         if hasattr(self, "_constrained_domain"):
-            raise NotImplementedError("periodic constraints are not built yet "
-                                      "(SURVEY.md section 8f N3)")
-        self._dofmap = TaylorHoodDofMap(self._mesh)
+            # periodic constraint: slave entities share the dofs of their masters (dolfin
+            # FunctionSpace(..., constrained_domain=...), reference :516-518)
+            periodic = periodic_entity_map(self._mesh, self._constrained_domain)
+        self._dofmap = TaylorHoodDofMap(self._mesh, periodic_map=periodic)
         dm = self._dofmap
         self._ctx = nat.NsfemContext(self._mesh.coords, self._mesh.cells, dm.p2_dofmap,
                                      dm.p1_dofmap, dm.n_p2, dm.n_p1, device=self._device)
@@ -220,7 +222,9 @@ class SolverBase:
         # coarsen; any mesh gets at least the P2 -> P1 two-level hierarchy)
         self._mg_levels = None
         if getattr(self, "use_multigrid", True):
-            self._mg_levels = attach_hierarchy(self._ctx, self._mesh)
+            # (periodic spaces: P1 nodes are not vertex ids, so only the two-level
+            # P2 -> P1 hierarchy is built)
+            self._mg_levels = attach_hierarchy(self._ctx, None if periodic else self._mesh)
         self._push_coefficients()
 
     def _push_coefficients(self):

@@ -242,3 +242,113 @@ def test_bdf_transient_gravity_driven_flow():
     assert solver.last_step_info.newton_iterations >= 1
     u = solver.solution.split()[0].vector()
     assert np.isfinite(u).all() and np.abs(u).max() > 0.0
+
+
+# ---- the reference's periodic Taylor-Green test (tests/test_transient_solvers.py:20-46,133-171)
+class PeriodicDomain(dlfn.SubDomain):
+    def inside(self, x, on_boundary):
+        """Return True if `x` is located on the master edge and False else."""
+        inside = False
+        if (dlfn.near(x[0], 0.0) and on_boundary):
+            inside = True
+        elif (dlfn.near(x[1], 0.0) and on_boundary):
+            inside = True
+        return inside
+
+    def map(self, x_slave, x_master):
+        if dlfn.near(x_slave[0], 1.0):
+            x_master[0] = x_slave[0] - 1.0
+            x_master[1] = x_slave[1]
+        elif dlfn.near(x_slave[1], 1.0):
+            x_master[0] = x_slave[0]
+            x_master[1] = x_slave[1] - 1.0
+        else:
+            x_master[0] = -10.0
+            x_master[1] = -10.0
+
+
+class TaylorGreenVortex(InstationaryProblem):
+    _gamma = gamma = 2.0 * dlfn.pi
+
+    def __init__(self, main_dir=None):
+        super().__init__(main_dir, start_time=0.0, end_time=1.0,
+                         desired_start_time_step=0.1, n_max_steps=10)
+        self._problem_name = "TaylorGreenVortex"
+        self._n_points = 16
+        self._output_frequency = 0
+        self._postprocessing_frequency = 0
+        self.set_solver_class(ImplicitBDFSolver)
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_cube(2, self._n_points)
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=100.0)
+
+    def set_initial_conditions(self):
+        self._initial_conditions = dict()
+        self._initial_conditions["velocity"] = \
+            dlfn.Expression(("cos(gamma * x[0]) * sin(gamma * x[1])",
+                             "-sin(gamma * x[0]) * cos(gamma * x[1])"),
+                            gamma=self._gamma, degree=3)
+        self._initial_conditions["pressure"] = \
+            dlfn.Expression("-1.0/4.0 * (cos(2.0 * gamma * x[0]) + cos(2.0 * gamma * x[1]))",
+                            gamma=self._gamma, degree=3)
+
+    def set_boundary_conditions(self):
+        self._bcs = ((PressureBCType.mean_value, None, 0.0), )
+
+    def set_periodic_boundary_conditions(self):
+        self._periodic_bcs = PeriodicDomain()
+        self._periodic_boundary_ids = (HyperCubeBoundaryMarkers.left.value,
+                                       HyperCubeBoundaryMarkers.right.value,
+                                       HyperCubeBoundaryMarkers.top.value,
+                                       HyperCubeBoundaryMarkers.bottom.value)
+
+
+def test_taylor_green_vortex_periodic():
+    taylor_green = TaylorGreenVortex()
+    taylor_green.solve_problem()
+    solver = taylor_green._get_solver()
+    dm = solver._dofmap
+    assert dm.n_p2 == 32 * 32 and dm.n_p1 == 16 * 16               # slaves share master dofs
+    velocity, pressure = solver.solution.split()
+    # mean-value constraint: int p = 0 (ns_solver_base.py:1190-1203)
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    assert abs((s.mass_p1() @ pressure.vector()).sum()) < 1e-12
+    # analytic solution at t = 1 (convergence_test/taylor_green_vortex.py:111-117): BDF-2 with
+    # dt = 0.1 and h = 1/16 is within a few per cent
+    g, Re, t = 2.0 * np.pi, 100.0, 1.0
+    X = dm.p2_coords
+    ue = np.exp(-2.0 * g * g * t / Re) * np.stack([np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]),
+                                                   -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1])], axis=1)
+    u = velocity.nodal_values()
+    assert np.abs(u - ue).max() < 0.05 * np.abs(ue).max()
+    # oracle replay on the same periodic dof maps (LU; pressure level pinned -> compare mod const)
+    orc = fo.BDFOracle(s, solver._equation_coefficients, pin_pressure=True)
+    u0 = fem_host_project(solver, taylor_green._initial_conditions["velocity"], 2)
+    orc.set_initial(u0, None)
+    p0 = fem_host_project(solver, taylor_green._initial_conditions["pressure"], 1)
+    for i in (0, 1):
+        orc.sol[i][dm.n_velocity:] = p0
+    for step in range(10):
+        orc.step(fo.bdf_alpha(step, 1.0), 0.1)
+        orc.advance()
+    nv = dm.n_velocity
+    assert np.linalg.norm(velocity.vector() - orc.sol[1][:nv]) < 1e-6 * np.linalg.norm(orc.sol[1][:nv])
+    pg, po = pressure.vector(), orc.sol[1][nv:]
+    assert np.linalg.norm((pg - pg.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())
+
+
+def fem_host_project(solver, expression, degree):
+    """L2 projection with the oracle's mass matrix (same load vector as the solver's)."""
+    import fem_host
+    dm = solver._dofmap
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    if degree == 2:
+        b = fem_host.load_vector(dm.mesh, dm.p2_dofmap, dm.n_p2, lambda X: dlfn.evaluate(expression, X),
+                                 degree=2, n_comp=2)
+        return fo.spla.spsolve(s.vector_mass().tocsc(), b)
+    b = fem_host.load_vector(dm.mesh, dm.p1_dofmap, dm.n_p1, lambda X: dlfn.evaluate(expression, X),
+                             degree=1, n_comp=1)
+    return fo.spla.spsolve(s.mass_p1().tocsc(), b)

@@ -120,6 +120,10 @@ typedef struct {
   nsfem_krylov_opts momentum;   /* BiCGStab */
   nsfem_krylov_opts poisson;    /* CG       */
   nsfem_krylov_opts correction; /* CG       */
+  int32_t picard;               /* monolithic step: Picard instead of Newton matrix
+                                   (StationarySolverBase, ns_solver_base.py:930-934)        */
+  int32_t allow_nonconvergence; /* monolithic step: return instead of failing when the
+                                   iteration limit is hit (error_on_nonconvergence=False)   */
 } nsfem_step_opts;
 
 #define NSFEM_MAX_NEWTON 64
@@ -129,6 +133,8 @@ typedef struct {
   int32_t krylov_iterations_poisson;
   int32_t krylov_iterations_correction;
   double newton_residuals[NSFEM_MAX_NEWTON]; /* |b| after 0,1,.. updates        */
+  int32_t converged;
+  int32_t reserved;
 } nsfem_step_info;
 
 /* ---- life cycle: replaces FunctionSpace/Function construction

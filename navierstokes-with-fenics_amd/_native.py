@@ -57,14 +57,16 @@ class SolveInfo(C.Structure):
 class StepOpts(C.Structure):
     _fields_ = [("newton_atol", C.c_double), ("newton_rtol", C.c_double),
                 ("newton_max_iter", C.c_int32), ("convective_form", C.c_int32),
-                ("momentum", KrylovOpts), ("poisson", KrylovOpts), ("correction", KrylovOpts)]
+                ("momentum", KrylovOpts), ("poisson", KrylovOpts), ("correction", KrylovOpts),
+                ("picard", C.c_int32), ("allow_nonconvergence", C.c_int32)]
 
 
 class StepInfo(C.Structure):
     _fields_ = [("newton_iterations", C.c_int32), ("krylov_iterations_momentum", C.c_int32),
                 ("krylov_iterations_poisson", C.c_int32),
                 ("krylov_iterations_correction", C.c_int32),
-                ("newton_residuals", C.c_double * MAX_NEWTON)]
+                ("newton_residuals", C.c_double * MAX_NEWTON),
+                ("converged", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Halo(C.Structure):

@@ -240,7 +240,8 @@ extern "C" int nsfem_set_coeffs(nsfem_ctx* ctx, const double c[6]) {
 extern "C" int nsfem_set_bdf(nsfem_ctx* ctx, const double alpha[3], double k) {
   API_BEGIN
   NSFEM_REQUIRE(ctx && alpha, "null argument");
-  NSFEM_REQUIRE(k > 0.0 && std::isfinite(k) && alpha[0] != 0.0, "bad BDF coefficients");
+  // alpha = (0, 0, 0) selects the stationary equations (monolithic step only)
+  NSFEM_REQUIRE(k > 0.0 && std::isfinite(k) && std::isfinite(alpha[0]), "bad BDF coefficients");
   if (alpha[0] != ctx->alpha[0] || k != ctx->k) ctx->L_dirty = true;
   for (int i = 0; i < 3; ++i) ctx->alpha[i] = alpha[i];
   ctx->k = k;
@@ -925,7 +926,9 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   NSFEM_REQUIRE(opts->convective_form >= 0 && opts->convective_form <= 3, "unknown convective form");
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
+  NSFEM_REQUIRE(ctx->alpha[0] != 0.0, "the pressure-correction scheme needs alpha0 != 0");
   ctx->conv_form = opts->convective_form;
+  ctx->picard = false;
   nsfem_step_info& inf = info ? *info : local;
   std::memset(&inf, 0, sizeof(inf));
   // ---- diffusion step: Newton (dolfin NewtonSolver, residual criterion)
@@ -950,6 +953,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     converged = (r / r0 < opts->newton_rtol) || (r < opts->newton_atol);
   }
   inf.newton_iterations = it;
+  inf.converged = converged ? 1 : 0;
   if (!converged) throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
   // ---- projection step
   {
@@ -1037,6 +1041,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   ctx->mixed_op.c = ctx;
   ctx->mixed_op.n = nv + np;
   ctx->block_prec.c = ctx;
+  ctx->picard = opts->picard != 0;
   momentum_begin_step(ctx, false);
   double r = bdf_residual(ctx);
   const double r0 = r;
@@ -1068,7 +1073,10 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     converged = (r / r0 < opts->newton_rtol) || (r < opts->newton_atol);
   }
   inf.newton_iterations = it;
-  if (!converged) throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
+  inf.converged = converged ? 1 : 0;
+  ctx->picard = false;
+  if (!converged && !opts->allow_nonconvergence)
+    throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
   ctx->assembled_system = -1;
   API_END(ctx)
 }

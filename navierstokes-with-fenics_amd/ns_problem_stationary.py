@@ -1,0 +1,77 @@
+"""Stationary problem driver with Reynolds-number continuation (reference:
+``StationaryProblem`` source/ns_problem.py:363-501).  Hook protocol as ``ProblemBase``; on a
+failed nonlinear solve the Reynolds number is ramped up logarithmically from a solvable value
+(:462-501)."""
+import math
+
+import numpy as np
+
+import dlfn_compat as dlfn
+from auxiliary_classes import EquationCoefficientHandler
+from ns_problem import ProblemBase
+from ns_solver_base import StationarySolverBase as StationarySolver
+
+
+class StationaryProblem(ProblemBase):
+    def __init__(self, main_dir=None, form_convective_term="standard", tol=1e-10, maxiter=50,
+                 tol_picard=1e-2, maxiter_picard=10):
+        super().__init__(main_dir)
+        assert isinstance(form_convective_term, str)
+        assert all(isinstance(i, int) and i > 0 for i in (maxiter, maxiter_picard))
+        assert all(isinstance(i, float) and i > 0.0 for i in (tol_picard, tol))
+        self._form_convective_term = form_convective_term
+        self._tol_picard, self._maxiter_picard = tol_picard, maxiter_picard
+        self._tol, self._maxiter = tol, maxiter
+
+    def _get_solver(self):
+        return self._navier_stokes_solver
+
+    def solve_problem(self):
+        self.setup_mesh()
+        assert self._mesh is not None
+        self._space_dim = self._mesh.geometry().dim()
+        self._n_cells = self._mesh.num_cells()
+        self.set_periodic_boundary_conditions()
+        self.set_internal_constraints()
+        self.set_boundary_conditions()
+        self.set_body_force()
+        self.set_equation_coefficients()
+        assert isinstance(getattr(self, "_coefficient_handler", None), EquationCoefficientHandler)
+        self._coefficient_handler.close()
+        if not hasattr(self, "_bcs"):
+            assert hasattr(self, "_periodic_bcs")
+        if not hasattr(self, "_navier_stokes_solver"):
+            self._navier_stokes_solver = StationarySolver(
+                self._mesh, self._boundary_markers, self._form_convective_term, self._tol,
+                self._maxiter, self._tol_picard, self._maxiter_picard)
+        solver = self._navier_stokes_solver
+        solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
+        if hasattr(self, "_body_force"):
+            solver.set_body_force(self._body_force)
+        if hasattr(self, "_periodic_bcs"):
+            solver.set_periodic_boundary_conditions(self._periodic_bcs, self._periodic_boundary_ids)
+        if hasattr(self, "_bcs"):
+            if hasattr(self, "_internal_constraints"):
+                solver.set_boundary_conditions(self._bcs, self._internal_constraints)
+            else:
+                solver.set_boundary_conditions(self._bcs)
+        try:
+            Re = self._coefficient_handler.Re
+            dlfn.info("Solving problem with Re = {0:.2f}".format(Re if Re is not None else float("nan")))
+            solver.solve()
+            self.postprocess_solution()
+            self._write_xdmf_file()
+            return
+        except (RuntimeError, AssertionError):
+            pass
+        # Reynolds continuation: logarithmic ramp from Re = 10 to the target
+        Re_final = self._coefficient_handler.Re
+        assert Re_final is not None and Re_final > 10.0, "nonlinear solve failed"
+        n_steps = int(math.ceil(math.log10(Re_final / 10.0) * 4.0)) + 1
+        for Re in np.logspace(1.0, math.log10(Re_final), num=n_steps):
+            self._coefficient_handler.modify_dimensionless_number("Re", float(Re))
+            solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
+            dlfn.info("Solving problem with Re = {0:.2f}".format(Re))
+            solver.solve()
+        self.postprocess_solution()
+        self._write_xdmf_file()

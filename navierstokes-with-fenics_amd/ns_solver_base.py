@@ -496,3 +496,73 @@ class InstationarySolverBase(SolverBase):
     @property
     def solution(self):
         return self._solutions[0]
+
+
+class StationarySolverBase(SolverBase):
+    """Stationary Navier-Stokes: hybrid Picard -> Newton iteration on the mixed P2-P1 system
+    (reference: source/ns_solver_base.py:873-988).  The residual is the monolithic one without the
+    acceleration term; the Picard matrix linearises the convection as ((grad v) u_k, w)
+    (:930-934), the Newton matrix is the exact Jacobian (:936).  Both are integrated and solved
+    on the device (nsfem_step_bdf with alpha = 0; block-preconditioned BiCGStab instead of
+    PETSc LU)."""
+
+    def __init__(self, mesh, boundary_markers, form_convective_term, tol=1e-10, maxiter=50,
+                 tol_picard=1e-2, maxiter_picard=10, device=0):
+        super().__init__(mesh, boundary_markers, form_convective_term, device=device)
+        assert all(isinstance(i, int) and i > 0 for i in (maxiter, maxiter_picard))
+        assert all(isinstance(i, float) and i > 0.0 for i in (tol, tol_picard))
+        self._tol_picard = tol_picard
+        self._maxiter_picard = maxiter_picard
+        self._tol = tol
+        self._maxiter = maxiter
+        self.krylov_rtol = 1.0e-12
+        self.krylov_max_iter = 5000
+        self.use_multigrid = True
+
+    def _setup_problem(self):
+        assert hasattr(self, "_equation_coefficients")
+        self._setup_function_spaces()
+        if self._mg_levels is None:
+            raise RuntimeError("the stationary solver needs the multigrid block preconditioner")
+        self._setup_boundary_conditions()
+        from ns_bdf_solver import ImplicitBDFSolver, _FORM_ID
+        ImplicitBDFSolver._push_schur_dirichlet_set(self)
+        self._form_id = _FORM_ID[self._form_convective_term]
+        self._ctx.set_convective_form(self._form_id)
+        self._ctx.set_bdf((0.0, 0.0, 0.0), 1.0)              # no acceleration term
+        self._solution = MixedFunction(self, nat.U0, nat.P, name="solution")
+        self._nonlinear_solver = self._picard_problem = self._newton_problem = self._ctx
+
+    def _nonlinear_solve(self, picard, atol, maxiter, allow_nonconvergence):
+        o = self._ctx.default_step_opts()
+        o.newton_atol = atol
+        o.newton_rtol = 1.0e-9                                # dolfin NewtonSolver default
+        o.newton_max_iter = maxiter
+        o.convective_form = self._form_id
+        o.picard = 1 if picard else 0
+        o.allow_nonconvergence = 1 if allow_nonconvergence else 0
+        o.momentum.rtol = self.krylov_rtol
+        o.momentum.max_iter = self.krylov_max_iter
+        o.momentum.precond = 1
+        try:
+            return self._ctx.step_bdf(o)
+        except nat.NativeError as err:
+            raise RuntimeError(str(err))
+
+    def solve(self):
+        if not all(hasattr(self, attr) for attr in ("_nonlinear_solver", "_picard_problem",
+                                                    "_newton_problem", "_solution")):
+            self._setup_problem()
+        # initial residual (zero iterations of the nonlinear loop)
+        info = self._nonlinear_solve(True, 1.0e300, 1, True)
+        residual = info.newton_residuals[0]
+        if residual < self._tol_picard and residual > 0.0:
+            order = math.floor(math.log10(residual))
+            self._tol_picard = (residual / 10.0 ** order - 1.0) * 10.0 ** order
+        dlfn.info("Starting Picard iteration...")
+        self.picard_info = self._nonlinear_solve(True, self._tol_picard, self._maxiter_picard, False)
+        dlfn.info("Starting Newton iteration...")
+        self.newton_info = self._nonlinear_solve(False, self._tol, self._maxiter, True)
+        n = self.newton_info.newton_iterations
+        residual = self.newton_info.newton_residuals[n]
+        assert residual <= self._tol, "Newton iteration did not converge."

@@ -352,3 +352,106 @@ def fem_host_project(solver, expression, degree):
     b = fem_host.load_vector(dm.mesh, dm.p1_dofmap, dm.n_p1, lambda X: dlfn.evaluate(expression, X),
                              degree=1, n_comp=1)
     return fo.spla.spsolve(s.mass_p1().tocsc(), b)
+
+
+# ---- stationary solver (reference: demo/cavity_flow.py, tests/test_stationary_solvers.py) ----
+from ns_problem_stationary import StationaryProblem  # noqa: E402
+
+
+class StationaryCavityProblem(StationaryProblem):
+    """demo/cavity_flow.py:11-33 as shipped (stationary, Re = 10)."""
+
+    def __init__(self, n_points, main_dir=None):
+        super().__init__(main_dir)
+        self._n_points = n_points
+        self._problem_name = "Cavity"
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_cube(2, self._n_points)
+
+    def set_boundary_conditions(self):
+        no_slip = VelocityBCType.no_slip
+        constant = VelocityBCType.constant
+        BoundaryMarkers = HyperCubeBoundaryMarkers
+        self._bcs = ((no_slip, BoundaryMarkers.left.value, None),
+                     (no_slip, BoundaryMarkers.right.value, None),
+                     (no_slip, BoundaryMarkers.bottom.value, None),
+                     (constant, BoundaryMarkers.top.value, (1.0, 0.0)))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=10.0)
+
+
+class StationaryChannelFlowProblem(StationaryProblem):
+    """tests/test_stationary_solvers.py:145-215 ("inlet" variant: inlet profile, no-slip walls,
+    natural outlet, Re = 1)."""
+
+    def __init__(self, n_points, form_convective_term="standard"):
+        super().__init__(None, form_convective_term=form_convective_term)
+        self._n_points = n_points
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_rectangle((0.0, 0.0), (10.0, 1.0),
+                                                             (10 * self._n_points, self._n_points))
+
+    def set_boundary_conditions(self):
+        inlet_velocity = dlfn.Expression(("6.0*x[1]*(1.0-x[1])", "0.0"), degree=2)
+        self._bcs = ((VelocityBCType.function, HyperRectangleBoundaryMarkers.left.value, inlet_velocity),
+                     (VelocityBCType.no_slip, HyperRectangleBoundaryMarkers.bottom.value, None),
+                     (VelocityBCType.no_slip, HyperRectangleBoundaryMarkers.top.value, None))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=1.0)
+
+
+def _stationary_oracle(solver):
+    dm = solver._dofmap
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    vd, vv = solver._dirichlet_bcs["velocity"]
+    _, first = np.unique(vd[::-1], return_index=True)
+    keep = len(vd) - 1 - first
+    return s, (vd[keep].astype(np.int64), vv[keep])
+
+
+def test_stationary_cavity_as_shipped():
+    cavity_flow = StationaryCavityProblem(25)
+    cavity_flow.solve_problem()
+    solver = cavity_flow._get_solver()
+    assert solver._n_dofs == 5878                                   # SURVEY.md D2
+    assert solver.picard_info.newton_iterations >= 1
+    n = solver.newton_info.newton_iterations
+    assert solver.newton_info.newton_residuals[n] <= 1e-10
+    s, vbc = _stationary_oracle(solver)
+    orc = fo.BDFOracle(s, solver._equation_coefficients, pin_pressure=True)
+    orc.step((0.0, 0.0, 0.0), 1.0, vbc)                             # Newton + LU on the same system
+    dm = solver._dofmap
+    u, p = solver.solution.split()
+    uo, po = orc.sol[0][: dm.n_velocity], orc.sol[0][dm.n_velocity:]
+    assert np.linalg.norm(u.vector() - uo) < 1e-6 * np.linalg.norm(uo)
+    pg = p.vector()
+    assert np.linalg.norm((pg - pg.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())
+
+
+@pytest.mark.parametrize("form", ["standard", "rotational", "divergence", "skew_symmetric"])
+def test_stationary_channel_flow_reproduces_poiseuille(form):
+    """K1: the steady state u = (6y(1-y), 0), p = 12 c_v (10 - x) is in the
+    discrete space, so every convective form must return it to round-off on the GPU."""
+    problem = StationaryChannelFlowProblem(3, form)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    u, p = solver.solution.split()
+    X2, X1 = dm.p2_coords, dm.p1_coords
+    ue = np.stack([6.0 * X2[:, 1] * (1.0 - X2[:, 1]), np.zeros(dm.n_p2)], axis=1)
+    if form in ("standard", "divergence"):
+        # the convective term vanishes identically on the Poiseuille profile (div u = 0)
+        assert np.abs(u.nodal_values() - ue).max() < 1e-9
+        assert np.abs(p.vector() - 12.0 * (10.0 - X1[:, 0])).max() < 1e-7
+    # every form (the rotational and skew-symmetric ones change the meaning of the natural
+    # outflow condition, so they do not return Poiseuille): Newton + LU oracle on the same system
+    s, vbc = _stationary_oracle(solver)
+    orc = fo.BDFOracle(s, solver._equation_coefficients, form=form)
+    orc.step((0.0, 0.0, 0.0), 1.0, vbc)
+    uo, po = orc.sol[0][: dm.n_velocity], orc.sol[0][dm.n_velocity:]
+    assert np.linalg.norm(u.vector() - uo) < 1e-6 * np.linalg.norm(uo)
+    assert np.linalg.norm(p.vector() - po) < 1e-6 * np.linalg.norm(po)

@@ -74,6 +74,7 @@ static void upload_pattern(hipStream_t s, HostPattern& h, Pattern& d, bool want_
   }
   d.h_rowptr.swap(h.rowptr);
   d.h_col.swap(h.col);
+  build_rowblocks(d, s);
   std::vector<int32_t>().swap(h.slot);
 }
 

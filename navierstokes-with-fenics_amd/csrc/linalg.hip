@@ -129,9 +129,135 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
   }
 }
 
+// --- CSR-stream variant (Greathouse & Daga): a workgroup owns a contiguous block of rows with
+// <= kStreamNnz nonzeros; phase 1 streams the nonzeros with ALL lanes (perfectly coalesced
+// value / column loads, one nonzero per lane and pass), multiplies with the gathered x and parks
+// the products in LDS; phase 2 sums each row's contiguous LDS segment (ascending order) and runs
+// the same epilogue.  No idle lanes on the 9/19-entry rows of the P2 operators.
+#ifndef NSFEM_STREAM_NNZ
+#define NSFEM_STREAM_NNZ 1024
+#endif
+constexpr int kStreamNnz = NSFEM_STREAM_NNZ;
+// which shapes use the stream kernel unless NSFEM_SPMV_STREAM overrides it (set from the
+// measured sweep, see profiles/)
+static inline bool kStreamDefault(bool shape22) { (void)shape22; return true; }
+
+template <int BR, int BC, int NV, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* __restrict__ rblk,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const double* __restrict__ vals, SpmvArgs a) {
+  constexpr int NO = BR * NV;
+  __shared__ double prod[kStreamNnz * NO];
+  const int per = gridDim.x >> 3;
+  const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (lb >= n_rblk) return;
+  const int r0 = rblk[lb], r1 = rblk[lb + 1];
+  const int s0 = rowptr[r0], s1 = rowptr[r1];
+  const double* __restrict__ x = a.x;
+  for (int k = s0 + (int)threadIdx.x; k < s1; k += 256) {
+    const int c = col[k];
+    double av[BR * BC], xv[BC * NV];
+#pragma unroll
+    for (int t = 0; t < BR * BC; ++t) av[t] = vals[(size_t)k * (BR * BC) + t];
+#pragma unroll
+    for (int t = 0; t < BC * NV; ++t) xv[t] = x[(size_t)c * (BC * NV) + t];
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        double acc = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < BC; ++cc) acc += av[r * BC + cc] * xv[cc * NV + v];
+        prod[(k - s0) * NO + r * NV + v] = acc;
+      }
+  }
+  __syncthreads();
+  // one thread per output entry (row, o)
+  const int nout = (r1 - r0) * NO;
+  for (int t = threadIdx.x; t < nout; t += 256) {
+    const int row = r0 + t / NO, o = t % NO;
+    double val = 0.0;
+    for (int k = rowptr[row] - s0, e = rowptr[row + 1] - s0; k < e; ++k) val += prod[k * NO + o];
+    const size_t idx = (size_t)row * NO + o;
+    const int mv = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    const bool m = mv != 0;
+    if (mv == 2) {
+      if (EPI == EPI_CHEB) a.d[idx] = 0.0;
+      a.y[idx] = 0.0;
+    } else if (EPI == EPI_RESID) {
+      if (m)
+        val = (a.maskmode == MASK_IDENTITY) ? a.b[idx] - x[idx] : 0.0;
+      else
+        val = a.b[idx] - val;
+      a.y[idx] = val;
+    } else if (EPI == EPI_ACCUM) {
+      if (!m) a.y[idx] += a.c2 * val;
+      else if (a.maskmode == MASK_ZERO) a.y[idx] = 0.0;
+    } else if (EPI == EPI_CHEB) {
+      double dn = 0.0, xn = 0.0;
+      if (!m) {
+        dn = a.c2 * a.dinv[idx] * (a.b[idx] - val);
+        if (a.c1 != 0.0) dn += a.c1 * a.d[idx];
+        xn = x[idx] + dn;
+      }
+      a.d[idx] = dn;
+      a.y[idx] = xn;
+    } else {
+      if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
+      else val *= a.c2;
+      a.y[idx] = val;
+    }
+  }
+}
+
+// greedy row blocks with <= kStreamNnz nonzeros (host, once per pattern); patterns with a
+// longer row keep n_rblk = 0 and use the lane-group kernel
+void build_rowblocks(Pattern& p, hipStream_t s) {
+  std::vector<int32_t> blk;
+  blk.push_back(0);
+  int start = 0;
+  for (int r = 0; r < p.n_rows; ++r) {
+    const int len = p.h_rowptr[r + 1] - p.h_rowptr[r];
+    if (len > kStreamNnz) { p.n_rblk = 0; return; }
+    if (p.h_rowptr[r + 1] - p.h_rowptr[start] > kStreamNnz) {
+      blk.push_back(r);
+      start = r;
+    }
+  }
+  blk.push_back(p.n_rows);
+  p.n_rblk = (int)blk.size() - 1;
+  p.rblk.upload(blk, s);
+}
+
 template <int EPI>
 static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvArgs& a) {
   const Pattern& p = *A.pat;
+  static const int use_stream = [] {
+    const char* e = std::getenv("NSFEM_SPMV_STREAM");
+    return e ? std::atoi(e) : -1;          // -1: per-shape default
+  }();
+  const bool shape22 = A.br == 2 && A.bc == 2;
+  // measured (n = 512): the stream kernel wins on every operator except the short-row P2 x P1
+  // gradient (4.6 entries per row), which keeps the lane-group kernel
+  const bool long_rows = (double)p.nnz >= 6.0 * p.n_rows;
+  const bool stream = p.n_rblk > 0 &&
+                      (use_stream == 1 || (use_stream == -1 && kStreamDefault(shape22) && long_rows));
+  if (stream) {
+    const int grid = (p.n_rblk + 7) & ~7;
+#define NSFEM_STREAM(BR, BC, NV)                                                              \
+  hipLaunchKernelGGL((k_spmv_stream<BR, BC, NV, EPI>), dim3(grid), dim3(256), 0, s, p.n_rblk, \
+                     p.rblk.p, p.rowptr.p, p.col.p, A.vals.p, a)
+    if (A.br == 2 && A.bc == 2 && nv == 1) NSFEM_STREAM(2, 2, 1);
+    else if (A.br == 1 && A.bc == 1 && nv == 2) NSFEM_STREAM(1, 1, 2);
+    else if (A.br == 1 && A.bc == 1 && nv == 1) NSFEM_STREAM(1, 1, 1);
+    else if (A.br == 1 && A.bc == 2 && nv == 1) NSFEM_STREAM(1, 2, 1);
+    else if (A.br == 2 && A.bc == 1 && nv == 1) NSFEM_STREAM(2, 1, 1);
+    else throw Error(NSFEM_ERR_ARG, "unsupported block shape in spmv");
+#undef NSFEM_STREAM
+    NSFEM_HIP(hipGetLastError());
+    return;
+  }
   // lanes per block row: 4 for short rows (P1 7-point, P2 x P1), 8 otherwise; the
   // NSFEM_SPMV_G environment variable overrides it (tuning experiments only)
   static const int forced = [] {

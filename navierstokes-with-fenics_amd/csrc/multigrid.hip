@@ -115,6 +115,8 @@ void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* row
   patR.col.upload(rc, s);
   R.pat = &patR; R.br = R.bc = 1;
   R.vals.upload(rv, s);
+  build_rowblocks(patP, s);
+  build_rowblocks(patR, s);
 }
 
 static void invert_dense(std::vector<double>& a, int n) {

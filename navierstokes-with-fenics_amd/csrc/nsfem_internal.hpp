@@ -83,8 +83,11 @@ struct Pattern {
   int n_rows = 0, n_cols = 0, nnz = 0, nr = 0, nc = 0;
   DevBuf<int32_t> rowptr, col, diag, slot;
   DevBuf<int32_t> cptr, cidx;             // per slot: sources (cell * nr*nc + i * nc + j)
+  DevBuf<int32_t> rblk;                   // row blocks of the CSR-stream SpMV (n_rblk + 1)
+  int n_rblk = 0;
   std::vector<int32_t> h_rowptr, h_col;   // kept for export
 };
+void build_rowblocks(Pattern& p, hipStream_t s);
 void build_inverse_index(int n_targets, int64_t n_sources,
                          const std::function<int32_t(int64_t)>& target_of,
                          std::vector<int32_t>& ptr, std::vector<int32_t>& idx);

@@ -324,6 +324,8 @@ extern "C" int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const i
   launch_overlay_ghost(s, size, field == NSFEM_VELOCITY ? ctx->ghost_v.p : ctx->ghost_p.p, mask.p);
   std::vector<int32_t>& prev = field == NSFEM_VELOCITY ? ctx->h_bc_v : ctx->h_bc_p;
   const bool changed = prev != d;
+  if (changed) ctx->graph_epoch++;  // the device dof arrays were re-allocated (values-only
+                                    // updates keep the pointers: captured graphs stay valid)
   if (field == NSFEM_VELOCITY) {
     ctx->nbc_v = (int)d.size();
     if (changed) { ctx->dinv_m_ready = false; ctx->mg_v_dirty = true; }
@@ -390,6 +392,7 @@ static void ensure_L(nsfem_ctx* c) {
 // (re)build masks / smoother data / coarse inverse of a hierarchy when its inputs changed
 static void mg_refresh_schur(nsfem_ctx* c) {
   if (c->mg_s_dirty) {
+    c->graph_epoch++;
     std::vector<uint8_t> m((size_t)npre(c), 0);
     for (int32_t d : c->h_bc_s) m[d] = 1;
     c->mg_s.refresh(c->stream, m, c->h_bc_s.empty());
@@ -405,6 +408,7 @@ static void mg_refresh(nsfem_ctx* c, bool momentum) {
   if (momentum) {
     ensure_L(c);
     if (!c->mg_v_dirty) return;
+    c->graph_epoch++;
     std::vector<uint8_t> m((size_t)nvel(c), 0);
     for (int32_t d : c->h_bc_v) m[d] = 1;
     for (size_t i = 0; i < c->h_ghost_p2.size(); ++i)
@@ -413,6 +417,7 @@ static void mg_refresh(nsfem_ctx* c, bool momentum) {
     c->mg_v_dirty = false;
   } else {
     if (!c->mg_p_dirty) return;
+    c->graph_epoch++;
     std::vector<uint8_t> m((size_t)npre(c), 0);
     for (int32_t d : c->h_bc_p) m[d] = 1;
     for (size_t i = 0; i < c->h_ghost_p1.size(); ++i)
@@ -464,6 +469,7 @@ static double global_norm(nsfem_ctx* c, int64_t n, double* x, const uint8_t* gho
 }
 
 static void fill_linop(nsfem_ctx* c, LinOp& op, bool velocity) {
+  op.graph_epoch = c->graph_epoch;
   if (!c->distributed()) return;
   op.comm = c->comm;
   op.halo = velocity ? &c->halo_p2 : &c->halo_p1;
@@ -519,6 +525,7 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
     mg_refresh(c, true);
     op.prec = &c->mom_prec;
   }
+  op.graph_epoch = c->graph_epoch;
   int rc = bicgstab(s, c->kw, op, c->rhs_v.p, c->dx_v.p, o, info);
   if (rc != NSFEM_OK) return rc;
   double* u = c->state[NSFEM_USTAR].p;
@@ -556,6 +563,7 @@ static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_i
     mg_refresh(c, false);
     op.prec = &c->mg_p;
   }
+  op.graph_epoch = c->graph_epoch;
   return pcg(c->stream, c->kw, op, c->rhs_p.p, c->state[NSFEM_P].p, o, info, c->nbc_p == 0);
 }
 
@@ -1057,6 +1065,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     LinOp op;
     op.custom = &ctx->mixed_op;
     op.prec = &ctx->block_prec;
+    op.graph_epoch = ctx->graph_epoch;
     nsfem_solve_info si;
     int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, opts->momentum, si);
     inf.krylov_iterations_momentum += si.iterations;

@@ -187,12 +187,30 @@ void launch_mask_zero(hipStream_t s, int64_t n, const uint8_t* mask, double* x);
 void launch_add_scalar(hipStream_t s, int64_t n, double a, double* x);
 
 // Krylov scratch + drivers
+struct LinOp;
+// identity of one captured Krylov iteration body (all baked kernel arguments)
+struct GraphKey {
+  const void *op, *prec, *x, *dinv;
+  int64_t n;
+  int parity;
+  uint64_t epoch;
+  bool operator==(const GraphKey& o) const {
+    return op == o.op && prec == o.prec && x == o.x && dinv == o.dinv && n == o.n &&
+           parity == o.parity && epoch == o.epoch;
+  }
+};
 struct KrylovWork {
   int64_t n = 0;
   DevBuf<double> r, rhat, p, v, s, t, phat, shat, z, q;
-  DevBuf<double> parts;     // [8][kParts]
+  DevBuf<double> parts;     // [kPartSlots][kParts]
   DevBuf<double> scal;      // device scalars
-  double* h_parts = nullptr;   // pinned host [8][kParts]
+  double* h_parts = nullptr;   // pinned host [kPartSlots][kParts]
+  // captured HIP graphs of the iteration bodies
+  std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+  uint64_t epoch = 0;
+  bool graphs_enabled(const LinOp& op) const;
+  void replay(hipStream_t s, const GraphKey& key, const std::function<void()>& body);
+  void clear_graphs();
   void ensure(int64_t n_);
   ~KrylovWork();
 };
@@ -240,6 +258,7 @@ struct LinOp {
   int halo_width = 1;               // vector entries per node
   const uint8_t* ghostmask = nullptr;
   int64_t n_global = 0;             // global length (mean projection)
+  uint64_t graph_epoch = 0;         // bumped whenever baked kernel arguments may have changed
 };
 
 // ---- multigrid ------------------------------------------------------------------
@@ -343,6 +362,7 @@ struct nsfem_ctx {
   nsfem::KrylovWork kw;
   int assembled_system = -1;
   double area = 0.0;
+  uint64_t graph_epoch = 1; // captured iteration graphs are valid within one epoch
   int conv_form = 0;        // 0 standard, 1 rotational, 2 divergence, 3 skew-symmetric
   bool picard = false;      // Picard instead of Newton linearisation of the convection
   // ---- multigrid hierarchy (optional; nsfem_mg_add_level / nsfem_mg_finalize)

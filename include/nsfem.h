@@ -215,6 +215,12 @@ typedef struct {
   double eig_ratio;          /* smoothing interval [lmax/ratio, lmax] (default 4)   */
 } nsfem_mg_opts;
 int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* level);
+/* monolithic scheme: algebraic pressure Laplacian  D_f diag(M_v)^{-1} D_f^T  (and its Galerkin
+ * coarsenings) for level `level` of the Schur-complement hierarchy; scalar CSR with a stored
+ * diagonal, n = number of P1 nodes of that level (level 0 = fine mesh); singular != 0 when no
+ * boundary is open (constants in the kernel: the coarse solve uses the pseudo-inverse) */
+int nsfem_mg_set_schur_operator(nsfem_ctx* ctx, int level, int32_t n, const int32_t* rowptr,
+                                const int32_t* col, const double* val, int singular);
 /* partitioned hierarchies: the GLOBAL coarsest mesh (solved redundantly on every rank);
  * offset = global id of this rank's local coarsest node 0 */
 int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cells,

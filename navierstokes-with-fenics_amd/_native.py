@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
+    "nsfem_mg_set_schur_operator",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -157,6 +158,9 @@ def load_library(path=None):
         "nsfem_synchronize": (C.c_int, [vp]),
         "nsfem_mg_add_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
         "nsfem_mg_finalize": (C.c_int, [vp, C.POINTER(MgOpts)]),
+        "nsfem_mg_set_schur_operator": (C.c_int, [vp, C.c_int, C.c_int32, C.POINTER(C.c_int32),
+                                                  C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                                  C.c_int]),
         "nsfem_mg_set_global_coarse": (C.c_int, [vp, i32, i32, pd, pi, i64]),
         "nsfem_set_partition": (C.c_int, [vp, C.POINTER(PartitionDesc)]),
         "nsfem_comm_unique_id": (C.c_int, [C.c_char_p]),
@@ -348,6 +352,17 @@ class NsfemContext:
         d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
                         _ip(rp), _ip(pc), _dp(pv), gp, Halo.from_dict(halo))
         self._check(self._lib.nsfem_mg_add_level(self._h, C.byref(d)))
+
+    def mg_set_schur_operator(self, level, csr, singular):
+        """Level ``level`` of the algebraic Schur-complement Laplacian (scipy CSR, sorted)."""
+        csr = csr.tocsr()
+        csr.sort_indices()
+        rp = np.ascontiguousarray(csr.indptr, dtype=np.int32)
+        ci = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        cv = np.ascontiguousarray(csr.data, dtype=np.float64)
+        self._check(self._lib.nsfem_mg_set_schur_operator(self._h, int(level), csr.shape[0],
+                                                          _ip(rp), _ip(ci), _dp(cv),
+                                                          1 if singular else 0))
 
     def mg_set_global_coarse(self, coords, cells, offset):
         coords = np.ascontiguousarray(coords, dtype=np.float64)

@@ -395,7 +395,7 @@ static void mg_refresh_schur(nsfem_ctx* c) {
     c->graph_epoch++;
     std::vector<uint8_t> m((size_t)npre(c), 0);
     for (int32_t d : c->h_bc_s) m[d] = 1;
-    c->mg_s.refresh(c->stream, m, c->h_bc_s.empty());
+    c->mg_s.refresh(c->stream, m, c->schur_singular >= 0 ? c->schur_singular != 0 : c->h_bc_s.empty());
     c->mg_s_dirty = false;
   }
   if (!c->mg_m.ready) {
@@ -701,6 +701,50 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
     lv->has_halo = true;
   }
   NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+// Algebraic pressure Laplacian of the Schur-complement preconditioner, level by level (level 0 =
+// fine P1 space): A_L = D_f diag(M_v)^{-1} D_f^T and its Galerkin coarsenings, computed by the
+// host at set-up.  Replaces the geometric stiffness matrices in the mg_s hierarchy: the algebraic
+// form carries the correct behaviour on open (natural-outflow) boundaries, where a strongly
+// imposed Dirichlet condition leaves one badly preconditioned mode per outflow node.
+extern "C" int nsfem_mg_set_schur_operator(nsfem_ctx* ctx, int level, int32_t n,
+                                           const int32_t* rowptr, const int32_t* col,
+                                           const double* val, int singular) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && rowptr && col && val, "null argument");
+  ctx->schur_singular = singular ? 1 : 0;
+  NSFEM_REQUIRE(ctx->mg_built, "build the hierarchy first (nsfem_mg_finalize)");
+  NSFEM_REQUIRE(level >= 0 && level < (int)ctx->mg_s.lv.size(), "no such level");
+  NSFEM_REQUIRE(n == ctx->mg_s.lv[level].n, "operator size does not match the level");
+  hipStream_t s = ctx->stream;
+  if (ctx->schur_ops.size() < ctx->mg_s.lv.size()) ctx->schur_ops.resize(ctx->mg_s.lv.size());
+  nsfem_ctx::CsrOp*& op = ctx->schur_ops[level];
+  delete op;
+  op = new nsfem_ctx::CsrOp();
+  Pattern& p = op->pat;
+  p.n_rows = p.n_cols = n;
+  p.nnz = rowptr[n];
+  p.h_rowptr.assign(rowptr, rowptr + n + 1);
+  p.h_col.assign(col, col + p.nnz);
+  std::vector<int32_t> diag((size_t)n, -1);
+  for (int r = 0; r < n; ++r)
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      NSFEM_REQUIRE(col[k] >= 0 && col[k] < n, "column out of range");
+      if (col[k] == r) diag[r] = k;
+    }
+  for (int r = 0; r < n; ++r) NSFEM_REQUIRE(diag[r] >= 0, "operator without a stored diagonal");
+  p.rowptr.upload(p.h_rowptr, s);
+  p.col.upload(p.h_col, s);
+  p.diag.upload(diag, s);
+  build_rowblocks(p, s);
+  op->mat.pat = &p;
+  op->mat.br = op->mat.bc = 1;
+  op->mat.vals.upload(val, (size_t)p.nnz, s);
+  NSFEM_HIP(hipStreamSynchronize(s));
+  ctx->mg_s.lv[level].A = &op->mat;
+  ctx->mg_s_dirty = true;
   API_END(ctx)
 }
 

@@ -595,7 +595,7 @@ double host_sum_parts(hipStream_t s, KrylovWork& w, int which) {
 // (RHO, RR), (TS, TT) and the CG pairs (RZ, RR') are adjacent: one all-reduce per kernel
 enum { P_RHO = 0, P_RR = 1, P_TS = 2, P_TT = 3, P_RTV = 4, P_PQ = 5, P_RZ0 = 6, P_RZ1 = 8 };
 // device scalars
-enum { S_RHO_OLD = 0, S_ALPHA = 1, S_OMEGA = 2, S_RHO = 3 };
+enum { S_RHO_OLD = 0, S_ALPHA = 1, S_OMEGA = 2, S_RHO = 3, S_RHAT2 = 4, S_RHAT2_NEXT = 5 };
 
 // rhat = r ; parts[RHO] = parts[RR] = r.r
 __global__ __launch_bounds__(256) void k_bicg_start(int64_t n, const double* __restrict__ r,
@@ -621,24 +621,42 @@ __global__ __launch_bounds__(256) void k_bicg_start(int64_t n, const double* __r
   }
 }
 
-// p = r + beta (p - omega v) ; phat = dinv * p
+// p = r + beta (p - omega v) ; phat = dinv * p.  When the shadow residual has become
+// (numerically) orthogonal to r -- rho = rhat.r ~ 0, e.g. a start residual supported on the
+// Dirichlet rows only, which every later residual vanishes on -- the recurrence breaks down:
+// restart it from the current residual (rhat = r, p = r).  Every block takes the same decision
+// from the same partial sums.
 __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, int first, const double* __restrict__ r,
                                                 const double* __restrict__ v,
                                                 const double* __restrict__ dinv,
                                                 double* __restrict__ p, double* __restrict__ phat,
+                                                double* __restrict__ rhat,
                                                 const double* __restrict__ parts,
                                                 double* __restrict__ scal) {
   __shared__ double sh[4];
-  const double rho = sum_parts(parts + P_RHO * kParts, sh);
+  double rho = sum_parts(parts + P_RHO * kParts, sh);
+  const double rr = sum_parts(parts + P_RR * kParts, sh);
   const double rho_old = scal[S_RHO_OLD], alpha = scal[S_ALPHA], omega = scal[S_OMEGA];
+  double rhat2 = first ? rho : scal[S_RHAT2];
+  const bool restart = !first && (rho * rho <= 1e-16 * rr * rhat2 || rho_old == 0.0 || omega == 0.0);
   double beta = 0.0;
-  if (!first && rho_old != 0.0 && omega != 0.0) beta = (rho / rho_old) * (alpha / omega);
+  if (restart) {
+    rho = rr;
+    rhat2 = rr;
+  } else if (!first) {
+    beta = (rho / rho_old) * (alpha / omega);
+  }
   GRID_STRIDE(i, n) {
-    const double pi = first ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
+    const double ri = r[i];
+    const double pi = (first || restart) ? ri : ri + beta * (p[i] - omega * v[i]);
     p[i] = pi;
+    if (restart) rhat[i] = ri;
     if (dinv) phat[i] = dinv[i] * pi;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_RHO] = rho;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[S_RHO] = rho;
+    scal[S_RHAT2_NEXT] = rhat2;
+  }
 }
 
 // alpha = rho / (rhat.v) ; s = r - alpha v ; shat = dinv * s
@@ -657,7 +675,10 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restr
     sv[i] = si;
     if (dinv) shat[i] = dinv[i] * si;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_ALPHA] = alpha;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[S_ALPHA] = alpha;
+    scal[S_RHAT2] = scal[S_RHAT2_NEXT];
+  }
 }
 
 // parts[TS] = t.s ; parts[TT] = t.t
@@ -762,7 +783,7 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   int it = 0;
   auto body = [&](int first) {
     LAUNCH(k_bicg_p, kParts, s, n, first, w.r.p, w.v.p, op.prec ? nullptr : op.dinv,
-           w.p.p, w.phat.p, parts, scal);
+           w.p.p, w.phat.p, w.rhat.p, parts, scal);
     if (op.prec) op.prec->apply(s, w.p.p, w.phat.p);
     apply(w.phat.p, w.v.p);
     launch_dot(s, n, w.rhat.p, w.v.p, parts + P_RTV * kParts);
@@ -787,13 +808,15 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     ++it;
     if (it % check == 0 || it == o.max_iter) {
       rr = host_sum_parts(s, w, P_RR);
-      if (!std::isfinite(rr)) {
+      if (!std::isfinite(rr) || rr > 1e20 * std::max(r0 * r0, bnorm * bnorm)) {   // NaN / diverging
         info.iterations = it;
         info.residual = rr;
         return NSFEM_ERR_BREAKDOWN;
       }
       info.residual = std::sqrt(rr);
       info.converged = info.residual <= target;
+      static const bool dbg = std::getenv("NSFEM_DEBUG_KRYLOV") != nullptr;
+      if (dbg) std::fprintf(stderr, "  bicgstab it %d |r| %.3e (target %.3e)\n", it, info.residual, target);
     }
   }
   info.iterations = it;

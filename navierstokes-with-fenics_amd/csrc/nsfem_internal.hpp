@@ -401,6 +401,13 @@ struct nsfem_ctx {
     nsfem_ctx* c = nullptr;
     void apply(hipStream_t s, const double* r, double* z) override;
   } mom_prec;
+  // host-supplied CSR operators (algebraic Schur Laplacian per multigrid level)
+  struct CsrOp {
+    nsfem::Pattern pat;
+    nsfem::BlockMat mat;
+  };
+  std::vector<CsrOp*> schur_ops;               // owned
+  int schur_singular = -1;                     // -1: geometric hierarchy (singular iff no Dirichlet set)
   // monolithic BDF system: mixed operator, block preconditioner and their data
   nsfem::Multigrid mg_s, mg_m;                 // Schur Laplacian V-cycle, pressure-mass smoother
   bool mg_s_dirty = true;
@@ -417,6 +424,7 @@ struct nsfem_ctx {
   } block_prec;
   ~nsfem_ctx() {
     for (P1Level* p : coarse) delete p;
+    for (CsrOp* p : schur_ops) delete p;
     delete global_coarse;
     delete comm;
   }

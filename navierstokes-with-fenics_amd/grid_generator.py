@@ -91,3 +91,103 @@ def open_hyper_cube(dim, n_points=10, openings=None):
             return (np.abs(X[:, a] - v) < _NEAR) & (np.abs(X[:, o] - c) <= half)
         markers.mark(window, ids.opening.value)
     return mesh, markers
+
+
+# ---------------------------------------------------------------------------------------------
+# DFG 2D-2 channel with a cylinder (BASELINE config 3).  The reference reads this mesh from the
+# un-vendored gmsh-collection submodule through gmsh + meshio (source/grid_generator.py:406-455,
+# demo/dfg_benchmark.py); neither tool nor the .geo file is available, so an unstructured
+# triangle mesh of the same non-dimensional geometry is generated here: channel 22 x 4.1,
+# unit-diameter cylinder centred at (2, 2).
+# ---------------------------------------------------------------------------------------------
+class DFGBoundaryMarkers(Enum):
+    inlet = 1
+    outlet = 2
+    bottom = 3
+    top = 4
+    cylinder = 5
+
+
+_DFG = dict(length=22.0, height=4.1, center=(2.0, 2.0), radius=0.5)
+
+
+def _dfg_project(mesh, markers, mid):
+    """move the midpoints of cylinder edges onto the circle"""
+    c, r = np.array(_DFG["center"]), _DFG["radius"]
+    on = markers.values == DFGBoundaryMarkers.cylinder.value
+    d = mid[on] - c
+    mid[on] = c + r * d / np.linalg.norm(d, axis=1)[:, None]
+    return mid
+
+
+def dfg_channel(m=4, n_refine=0, grading=1.3):
+    """Coarse block mesh (an O-grid of ``4 m`` sectors inside the box [1,3]^2 around the
+    cylinder, structured right-diagonal triangles elsewhere), refined ``n_refine`` times with
+    projection of new cylinder vertices onto the circle.  The returned mesh carries the multigrid
+    hierarchy (``mesh.mg_levels``).  m must be even."""
+    from fem_mesh import Mesh
+    from multigrid import refinement_hierarchy
+    assert m % 2 == 0 and m >= 2
+    L, H, (cx, cy), R = _DFG["length"], _DFG["height"], _DFG["center"], _DFG["radius"]
+    s = 2.0 / m
+    n_right = int(np.ceil(19.0 / (1.5 * s)))
+    n_top = max(1, int(round(1.1 / s)))
+    xs = np.concatenate([np.linspace(0.0, 1.0, m // 2 + 1)[:-1], np.linspace(1.0, 3.0, m + 1)[:-1],
+                         np.linspace(3.0, L, n_right + 1)])
+    ys = np.concatenate([np.linspace(0.0, 1.0, m // 2 + 1)[:-1], np.linspace(1.0, 3.0, m + 1)[:-1],
+                         np.linspace(3.0, H, n_top + 1)])
+    nxg, nyg = xs.size - 1, ys.size - 1
+    b0 = m // 2                                    # first box cell index (both directions)
+    node_id = -np.ones((nyg + 1, nxg + 1), dtype=np.int64)
+    coords = []
+    for iy in range(nyg + 1):
+        for ix in range(nxg + 1):
+            if b0 < ix < b0 + m and b0 < iy < b0 + m:
+                continue                           # strictly inside the box: replaced by the O-grid
+            node_id[iy, ix] = len(coords)
+            coords.append((xs[ix], ys[iy]))
+    cells = []
+    for iy in range(nyg):
+        for ix in range(nxg):
+            if b0 <= ix < b0 + m and b0 <= iy < b0 + m:
+                continue
+            v0, v1 = node_id[iy, ix], node_id[iy, ix + 1]
+            v2, v3 = node_id[iy + 1, ix], node_id[iy + 1, ix + 1]
+            cells += [(v0, v1, v3), (v0, v2, v3)]
+    # box perimeter, counter-clockwise from the lower-left corner
+    per = [(b0 + i, b0) for i in range(m)] + [(b0 + m, b0 + j) for j in range(m)] + \
+          [(b0 + m - i, b0 + m) for i in range(m)] + [(b0, b0 + m - j) for j in range(m)]
+    per_ids = [node_id[iy, ix] for ix, iy in per]
+    n_rad = m // 2 + 1
+    rings = [None] * (n_rad + 1)
+    rings[n_rad] = per_ids
+    q = np.array([coords[i] for i in per_ids])
+    ang = np.arctan2(q[:, 1] - cy, q[:, 0] - cx)
+    circle = np.stack([cx + R * np.cos(ang), cy + R * np.sin(ang)], axis=1)
+    for j in range(n_rad):
+        t = (j / n_rad) ** grading
+        pts = circle + t * (q - circle)
+        rings[j] = list(range(len(coords), len(coords) + len(per_ids)))
+        coords += [tuple(p) for p in pts]
+    K = len(per_ids)
+    for j in range(n_rad):
+        for k in range(K):
+            a, b = rings[j][k], rings[j][(k + 1) % K]
+            c, d = rings[j + 1][k], rings[j + 1][(k + 1) % K]
+            cells += [(a, b, d), (a, c, d)]
+    coarse = Mesh(np.array(coords), np.array(cells, dtype=np.int32))
+    marks = FacetMarkers(coarse, 0)
+    ids = DFGBoundaryMarkers
+    marks.mark(lambda X: np.abs(X[:, 0]) < 1e-12, ids.inlet.value)
+    marks.mark(lambda X: np.abs(X[:, 0] - L) < 1e-12, ids.outlet.value)
+    marks.mark(lambda X: np.abs(X[:, 1]) < 1e-12, ids.bottom.value)
+    marks.mark(lambda X: np.abs(X[:, 1] - H) < 1e-12, ids.top.value)
+    e = coarse.edges
+    rad = np.hypot(coarse.coords[:, 0] - cx, coarse.coords[:, 1] - cy)
+    on_circle = np.abs(rad - R) < 1e-9
+    cyl = coarse.edge_on_boundary & on_circle[e[:, 0]] & on_circle[e[:, 1]]
+    marks.values[cyl] = ids.cylinder.value
+    if n_refine == 0:
+        coarse.mg_levels = []
+        return coarse, marks
+    return refinement_hierarchy(coarse, marks, n_refine, project=_dfg_project)

@@ -60,8 +60,96 @@ def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=16):
     device context.  Returns the number of coarse P1 levels (0: mesh cannot be coarsened; the
     two-level P2 -> P1 hierarchy is still built)."""
     info = getattr(mesh, "structured", None) if mesh is not None else None
-    levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
+    if mesh is not None and hasattr(mesh, "mg_levels"):
+        levels = mesh.mg_levels                        # refinement hierarchy of a general mesh
+    else:
+        levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
+    ctx.mg_prolongations = []                          # kept for attach_schur_laplacian
     for coarse_mesh, (rowptr, col, val) in levels:
         ctx.mg_add_level(coarse_mesh.coords, coarse_mesh.cells, rowptr, col, val)
+        ctx.mg_prolongations.append((coarse_mesh.coords.shape[0], (rowptr, col, val)))
     ctx.mg_finalize(degree, eig_ratio)
     return len(levels)
+
+
+def attach_schur_laplacian(ctx, velocity_bc_dofs):
+    """Algebraic pressure Laplacian of the monolithic scheme's Schur-complement preconditioner:
+    A_L = D_f diag(M_v)^{-1} D_f^T on the fine P1 space (D_f = divergence block without the
+    Dirichlet velocity columns, M_v = P2 mass matrix) and its Galerkin coarsenings P^T A P along
+    the hierarchy ``attach_hierarchy`` installed.  Set-up-time host work (scipy sparse products of
+    operators exported from the device); the per-step path only sees the resulting CSR levels.
+    A_L is singular (constants) exactly when every velocity boundary dof is constrained."""
+    import scipy.sparse as sp
+    import _native as nat
+    D = ctx.operator_csr(nat.OP_DIV).tocsc()                        # n_p1 x 2 n_p2
+    m = ctx.operator_csr(nat.OP_MASS_P2).diagonal()
+    w = np.repeat(1.0 / m, 2)
+    free = np.ones(D.shape[1], dtype=bool)
+    free[np.asarray(velocity_bc_dofs, dtype=np.int64)] = False
+    w[~free] = 0.0
+    A = (D @ sp.diags(w) @ D.T).tocsr()
+    ones = np.ones(A.shape[0])
+    singular = bool(np.abs(A @ ones).max() <= 1e-10 * np.abs(A.diagonal()).max())
+    ctx.mg_set_schur_operator(0, A, singular)
+    for l, (n_coarse, (rowptr, col, val)) in enumerate(ctx.mg_prolongations):
+        P = sp.csr_matrix((val, col, rowptr), shape=(A.shape[0], n_coarse))
+        A = (P.T @ A @ P).tocsr()
+        ctx.mg_set_schur_operator(l + 1, A, singular)
+    return singular
+
+
+# ---------------------------------------------------------------------------------------------
+# hierarchies of general (unstructured) triangle meshes by uniform refinement
+# ---------------------------------------------------------------------------------------------
+def refine_uniform(mesh, markers=None, project=None):
+    """Red refinement: one new vertex per edge (its midpoint, optionally moved by
+    ``project(mesh, markers, midpoints) -> midpoints`` to follow a curved boundary), four children
+    per cell.
+    Old vertices keep their ids, the midpoint of edge e gets id nv + e, so the P1 prolongation is
+    identity on old vertices and (1/2, 1/2) on new ones.  Facet markers are inherited by the two
+    children of every marked edge.  Returns (fine mesh, fine markers | None, prolongation CSR)."""
+    from fem_mesh import FacetMarkers, Mesh
+    nv, ne = mesh.num_vertices(), mesh.num_edges()
+    mid = mesh.edge_midpoints()
+    if project is not None:
+        mid = np.asarray(project(mesh, markers, mid.copy()), dtype=np.float64)
+    coords = np.concatenate([mesh.coords, mid], axis=0)
+    c = mesh.cells.astype(np.int64)
+    m = nv + mesh.cell_edges.astype(np.int64)          # m[:, k] = midpoint of the edge opposite v_k
+    v0, v1, v2 = c[:, 0], c[:, 1], c[:, 2]
+    m0, m1, m2 = m[:, 0], m[:, 1], m[:, 2]
+    cells = np.stack([np.stack([v0, m2, m1], 1), np.stack([m2, v1, m0], 1),
+                      np.stack([m1, m0, v2], 1), np.stack([m0, m1, m2], 1)], axis=1).reshape(-1, 3)
+    fine = Mesh(coords, cells.astype(np.int32))
+    rowptr = np.concatenate([np.arange(nv + 1), nv + 2 * np.arange(1, ne + 1)]).astype(np.int32)
+    col = np.concatenate([np.arange(nv), mesh.edges.astype(np.int64).ravel()]).astype(np.int32)
+    val = np.concatenate([np.ones(nv), np.full(2 * ne, 0.5)])
+    fine_markers = None
+    if markers is not None:
+        fine_markers = FacetMarkers(fine, 0)
+        nvf = fine.num_vertices()
+        fkey = fine.edges[:, 0].astype(np.int64) * nvf + fine.edges[:, 1]       # sorted (np.unique)
+        e = mesh.edges.astype(np.int64)
+        for end in (0, 1):
+            a, b = e[:, end], nv + np.arange(ne)
+            key = np.minimum(a, b) * nvf + np.maximum(a, b)
+            pos = np.searchsorted(fkey, key)
+            assert np.array_equal(fkey[pos], key)
+            fine_markers.values[pos] = markers.values
+    return fine, fine_markers, (rowptr, col, val)
+
+
+def refinement_hierarchy(coarse_mesh, coarse_markers, n_refine, project=None):
+    """Refine ``n_refine`` times; the finest mesh carries ``mg_levels`` (finest-first list of
+    (coarse mesh, prolongation)) which ``attach_hierarchy`` ships to the device.  With a boundary
+    projection the spaces are only approximately nested: the coarse operators (integrated on the
+    coarse meshes) are then not exactly Galerkin, which is fine for a preconditioner."""
+    meshes, marks, prolongs = [coarse_mesh], [coarse_markers], []
+    for _ in range(n_refine):
+        f, fm, P = refine_uniform(meshes[-1], marks[-1], project)
+        meshes.append(f)
+        marks.append(fm)
+        prolongs.append(P)
+    fine = meshes[-1]
+    fine.mg_levels = [(meshes[l], prolongs[l]) for l in range(n_refine - 1, -1, -1)]
+    return fine, marks[-1]

@@ -52,6 +52,15 @@ class ImplicitBDFSolver(InstationarySolverBase):
         closed = list(full) + list(getattr(self, "_constrained_boundary_ids", ()))   # periodic parts
         open_facets = np.nonzero(mesh.edge_on_boundary & ~np.isin(marks.values, closed))[0]
         nodes = np.unique(dm.facet_p1_nodes(open_facets)) if open_facets.size else np.zeros(0, np.int64)
+        if open_facets.size and getattr(self, "_mg_levels", None) is not None:
+            # open boundaries: the geometric Laplacian with a strong Dirichlet condition leaves one
+            # badly preconditioned mode per outflow node (iteration counts grow with the mesh);
+            # the algebraic Laplacian D_f diag(M)^-1 D_f^T carries the right boundary behaviour
+            from multigrid import attach_schur_laplacian
+            nodes = np.asarray(self._dirichlet_bcs["pressure"][0], dtype=np.int32)
+            self._ctx.set_dirichlet(nat.PRESSURE_PRECOND, nodes, np.zeros(nodes.size))
+            attach_schur_laplacian(self._ctx, self._dirichlet_bcs["velocity"][0])
+            return
         nodes = np.union1d(nodes, self._dirichlet_bcs["pressure"][0]).astype(np.int32)
         self._ctx.set_dirichlet(nat.PRESSURE_PRECOND, nodes, np.zeros(nodes.size))
 

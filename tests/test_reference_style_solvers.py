@@ -455,3 +455,131 @@ def test_stationary_channel_flow_reproduces_poiseuille(form):
     uo, po = orc.sol[0][: dm.n_velocity], orc.sol[0][dm.n_velocity:]
     assert np.linalg.norm(u.vector() - uo) < 1e-6 * np.linalg.norm(uo)
     assert np.linalg.norm(p.vector() - po) < 1e-6 * np.linalg.norm(po)
+
+
+# ---- DFG 2D-2 cylinder benchmark geometry (BASELINE config 3; reference demo/dfg_benchmark.py) --
+from grid_generator import DFGBoundaryMarkers, dfg_channel  # noqa: E402
+
+
+class DFGBenchmark(InstationaryProblem):
+    """demo/dfg_benchmark.py:14-43: channel 22 x 4.1 with a unit cylinder, Re = 100, parabolic
+    inlet 6 y/h (1 - y/h), no-slip walls and cylinder, natural outlet, BDF-2 with dt = 0.005.
+    The mesh is generated in-repo (gmsh-collection is not vendored)."""
+
+    def __init__(self, m, n_refine, n_steps, solver_class=ImplicitBDFSolver):
+        super().__init__(None, start_time=0.0, end_time=1.0, desired_start_time_step=0.005,
+                         n_max_steps=n_steps)
+        self._m, self._n_refine = m, n_refine
+        self._output_frequency = 0
+        self._postprocessing_frequency = 0
+        self.set_solver_class(solver_class)
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = dfg_channel(self._m, self._n_refine)
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=100.0)
+
+    def set_initial_conditions(self):
+        self._initial_conditions = {"velocity": (0.0, 0.0)}
+
+    def set_boundary_conditions(self):
+        inlet = dlfn.Expression(("6.0 * x[1] / h * (1.0 - x[1] / h)", "0.0"), h=4.1, degree=2)
+        ids = DFGBoundaryMarkers
+        self._bcs = ((VelocityBCType.function, ids.inlet.value, inlet),
+                     (VelocityBCType.no_slip, ids.bottom.value, None),
+                     (VelocityBCType.no_slip, ids.top.value, None),
+                     (VelocityBCType.no_slip, ids.cylinder.value, None))
+
+
+def test_dfg_cylinder_small_mesh_matches_oracle():
+    problem = DFGBenchmark(2, 1, 3)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    assert solver._mg_levels == 1
+    dm = solver._dofmap
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.BDFOracle(s, solver._equation_coefficients)
+    vd, vv = solver._dirichlet_bcs["velocity"]
+    _, first = np.unique(vd[::-1], return_index=True)
+    keep = len(vd) - 1 - first
+    for step in range(3):
+        orc.step(fo.bdf_alpha(step, 1.0), 0.005, (vd[keep].astype(np.int64), vv[keep]))
+        orc.advance()
+    nv = dm.n_velocity
+    u, p = solver.solution.split()
+    assert np.linalg.norm(u.vector() - orc.sol[1][:nv]) < 1e-6 * np.linalg.norm(orc.sol[1][:nv])
+    assert np.linalg.norm(p.vector() - orc.sol[1][nv:]) < 1e-6 * np.linalg.norm(orc.sol[1][nv:])
+
+
+def test_dfg_cylinder_refined_mesh_multigrid_iterations_stay_bounded():
+    """curved-boundary refinement hierarchy (3 refinements, 0.17 M dofs): Newton converges and the
+    block-preconditioned Krylov iteration counts stay mesh-independent."""
+    problem = DFGBenchmark(4, 3, 3)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    assert solver._mg_levels == 3 and solver._n_dofs > 160000
+    info = solver.last_step_info
+    assert 1 <= info.newton_iterations <= 5
+    assert info.krylov_iterations_momentum <= 30 * info.newton_iterations
+    u = solver.solution.split()[0].nodal_values()
+    assert np.isfinite(u).all() and 1.0 < np.abs(u).max() < 3.0
+
+
+class DFGBenchmarkIPCS(DFGBenchmark):
+    """The splitting scheme needs a pressure condition on the open outlet (its Poisson problem
+    is otherwise pure Neumann with an incompatible right-hand side)."""
+
+    def set_boundary_conditions(self):
+        super().set_boundary_conditions()
+        self._bcs += ((PressureBCType.constant, DFGBoundaryMarkers.outlet.value, 0.0), )
+
+
+def test_dfg_cylinder_refined_mesh_ipcs():
+    problem = DFGBenchmarkIPCS(4, 3, 3, solver_class=IPCSSolver)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    info = solver.last_step_info
+    assert 1 <= info.newton_iterations <= 5
+    assert info.krylov_iterations_poisson <= 30
+    u = solver.solution.split()[0].nodal_values()
+    assert np.isfinite(u).all() and 1.0 < np.abs(u).max() < 3.0
+
+
+def test_open_outlet_schur_laplacian_algebraic_vs_geometric():
+    """Open channel (8 x 1, Re = 100, impulsive start): with the geometric pressure Laplacian and
+    a strong Dirichlet condition at the outlet the block-preconditioned BiCGStab count grows
+    with the number of outlet nodes; the algebraic Laplacian D_f diag(M)^-1 D_f^T (host set-up,
+    nsfem_mg_set_schur_operator) keeps it bounded.  Both variants solve the same discrete
+    system: the states agree to the Newton tolerance."""
+    import _native as nat
+    from gpu_common import box, context, velocity_bc
+    from multigrid import attach_hierarchy, attach_schur_laplacian
+    mesh, dm, marks = box(128, 16, p1=(8.0, 1.0))
+    zero = lambda X: np.zeros((X.shape[0], 2))
+    inlet = lambda X: np.stack([6.0 * X[:, 1] * (1.0 - X[:, 1]), 0.0 * X[:, 1]], axis=1)
+    vbc = velocity_bc(dm, marks, [(1, inlet), (3, zero), (4, zero)])
+    outlet = np.unique(dm.facet_p1_nodes(marks.facets_with_id(2))).astype(np.int32)
+    res = {}
+    for kind in ("geometric", "algebraic"):
+        ctx = context(mesh, dm)
+        assert attach_hierarchy(ctx, mesh, coarsest=2) == 3
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, *vbc)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        if kind == "geometric":
+            ctx.set_dirichlet(nat.PRESSURE_PRECOND, outlet, np.zeros(outlet.size))
+        else:
+            ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+            assert attach_schur_laplacian(ctx, vbc[0]) is False      # open boundary: nonsingular
+        o = ctx.default_step_opts()
+        o.momentum.rtol, o.momentum.precond, o.momentum.max_iter = 1e-10, 1, 400
+        ctx.set_bdf((1.0, -1.0, 0.0), 0.005)
+        info = ctx.step_bdf(o)
+        res[kind] = (info.krylov_iterations_momentum / info.newton_iterations,
+                     ctx.get_state(nat.U0), ctx.get_state(nat.P))
+        ctx.close()
+    assert res["algebraic"][0] <= 20
+    assert res["algebraic"][0] < res["geometric"][0]
+    for a, b in zip(res["algebraic"][1:], res["geometric"][1:]):
+        assert np.linalg.norm(a - b) < 1e-7 * np.linalg.norm(b)

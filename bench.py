@@ -179,12 +179,12 @@ def main():
     ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write_size.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_fetch_write_size.json")
     if world == 1 and n == 512 and os.path.exists(pmc):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload:
         # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
         c = json.load(open(pmc))
-        key = "void nsfem::k_spmv<2, 2, 1, 8, 0>"
+        key = "void nsfem::k_spmv_stream<2, 2, 1, 0>"
         if key in c["fetch"] and key in c["write"]:
             traffic = (2.0 * c["fetch"][key]["median_KB"] + c["write"][key]["median_KB"]) * 1024.0
     out = {
@@ -203,7 +203,7 @@ def main():
                    "%d strips of 512 cell rows, RCCL halo exchange + all-reduce" % world,
                    "newton_its_per_step": newton / args.steps,
                    "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv<2,2,1,8> (momentum Jacobian, 2x2 block CSR)",
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<2,2,1,0> (momentum Jacobian, 2x2 block CSR, 25.2 M scalar nnz)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv},

@@ -84,6 +84,77 @@ def cpu_baseline(n_sample, k, steps):
             "sample_steps_per_s": sps, "sample_dofs": dm.n_dofs, "host_cpus": os.cpu_count()}
 
 
+def dfg_bdf_bench(args):
+    """BASELINE.json configs[2]: DFG 2D-2 cylinder channel (reference demo/dfg_benchmark.py),
+    Re = 100, BDF-2 monolithic scheme, dt = 0.005, curved-boundary refinement hierarchy of the
+    in-repo block mesh (m = 4, 5 refinements: 589,824 cells, ~2.65 M dofs).  1 GPU only."""
+    import grid_generator as gg
+    from fem_mesh import TaylorHoodDofMap
+    from multigrid import attach_hierarchy, attach_schur_laplacian
+    t_setup = time.perf_counter()
+    mesh, marks = gg.dfg_channel(4, args.dfg_refine)
+    dm = TaylorHoodDofMap(mesh)
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+    levels = attach_hierarchy(ctx, mesh)
+    ids = gg.DFGBoundaryMarkers
+    last = {}
+    for mid in (ids.inlet.value, ids.bottom.value, ids.top.value, ids.cylinder.value):
+        nodes = np.unique(dm.facet_p2_nodes(marks.facets_with_id(mid)))
+        y = dm.p2_coords[nodes, 1]
+        ux = 6.0 * y / 4.1 * (1 - y / 4.1) if mid == ids.inlet.value else np.zeros_like(y)
+        last.update(zip((2 * nodes).tolist(), ux.tolist()))
+        last.update(zip((2 * nodes + 1).tolist(), [0.0] * nodes.size))
+    bd = np.array(sorted(last), dtype=np.int32)
+    bv = np.array([last[d] for d in bd.tolist()])
+    ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+    attach_schur_laplacian(ctx, bd)
+    t_setup = time.perf_counter() - t_setup
+    opts = ctx.default_step_opts()
+    opts.momentum.rtol, opts.momentum.precond, opts.momentum.max_iter = args.krylov_rtol, 1, 500
+    dt = 0.005
+
+    def one_step(i):
+        ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), dt)
+        info = ctx.step_bdf(opts)
+        ctx.advance(1)
+        return info
+
+    for i in range(args.warmup):
+        one_step(i)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    newton = kry = 0
+    for i in range(args.warmup, args.warmup + args.steps):
+        info = one_step(i)
+        newton += info.newton_iterations
+        kry += info.krylov_iterations_momentum
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    sps = args.steps / elapsed
+    ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
+    achieved = nbytes / (ms_spmv * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "dof_updates_per_sec", "value": sps * dm.n_dofs, "unit": "DoF-updates/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "time_steps_per_sec": sps,
+        "config": {"workload": "DFG 2D-2 cylinder channel Re=100, %d unstructured triangles (%d dofs), "
+                               "BDF-2 monolithic, dt=%g, impulsive start" % (mesh.num_cells(), dm.n_dofs, dt),
+                   "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "preconditioner": "block-triangular (V-cycle velocity block, Cahouet-Chabard Schur "
+                                     "with algebraic pressure Laplacian), %d coarse P1 levels" % levels,
+                   "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
+                   "bicgstab_its_per_step": kry / args.steps, "host_setup_s": t_setup},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<2,2,1,0> (velocity Jacobian block)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv}}))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +166,16 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-multigrid", action="store_true")
+    ap.add_argument("--mg-degree", type=int, default=2, help="Chebyshev smoother degree")
+    ap.add_argument("--mg-eig-ratio", type=float, default=4.0)
+    ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf"), default="cavity-ipcs",
+                    help="cavity-ipcs = BASELINE configs[1] (headline); dfg-bdf = configs[2], 1 GPU")
+    ap.add_argument("--dfg-refine", type=int, default=5)
     args = ap.parse_args()
+    if args.workload == "dfg-bdf":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("the dfg-bdf workload is a single-GPU configuration")
+        return dfg_bdf_bench(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,7 +210,7 @@ def main():
         ctx.attach_rccl_comm(ids[0], rank, world)
     mg_levels = None
     if not args.no_multigrid:
-        mg_levels = part.attach(ctx)
+        mg_levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
     else:
         n2g, n1g = global_dof_counts(n, n * world)
         ctx.set_partition(rank, world, part.p2_ghost, part.p1_ghost, part.p2_halo, part.p1_halo,

@@ -261,6 +261,13 @@ int nsfem_mass_solve(nsfem_ctx* ctx, int field, const double* b, double* x,
                      const nsfem_krylov_opts* opts, nsfem_solve_info* info);
 /* mean-pressure shift (ns_solver_base.py:1190-1203): p -= (int p / |Omega| - target) */
 int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* mean_before);
+/* rotating frame of reference (2D): adds  2 c_coriolis omega (e_z x u, w)  to the momentum
+ * residual/Jacobian and  c_euler omega_dot (e_z x x, w)  to its right-hand side
+ * (reference source/ns_solver_base.py:173-211); call again when omega changes in time */
+int nsfem_set_angular_velocity(nsfem_ctx* ctx, double omega, double omega_dot);
+/* CFL diagnostic of velocity slot `slot` for the step size k: max-norm of the cell-local P2
+ * projection of  2 |u| k / h_circumdiameter  (reference source/ns_problem.py:554-587) */
+int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, double* cfl);
 
 /* ---- measurement hooks (bench.py): time `reps` launches of the dominant SpMV
  * with HIP events on the context's stream; ms per launch returned ------------- */

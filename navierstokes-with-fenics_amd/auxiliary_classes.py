@@ -94,3 +94,78 @@ def _number_property(key):
 
 for _key in ("Re", "Fr", "Ek", "Ro"):
     setattr(EquationCoefficientHandler, _key, _number_property(_key))
+
+
+class FunctionTime:
+    """Time-dependent value with an optional derivative (reference: source/auxiliary_classes.py:89-117)."""
+
+    def __init__(self, value_size, current_time=0.0):
+        assert isinstance(value_size, int) and value_size > 0
+        assert isinstance(current_time, float)
+        self._value_size = value_size
+        self._current_time = 0.0
+
+    def derivative(self):  # pragma: no cover
+        raise NotImplementedError("You are calling a purely virtual method.")
+
+    def set_time(self, current_time):
+        assert isinstance(current_time, float)
+        assert current_time >= self._current_time
+        self._current_time = current_time
+
+    def value(self):  # pragma: no cover
+        raise NotImplementedError("You are calling a purely virtual method.")
+
+    @property
+    def value_size(self):
+        return self._value_size
+
+
+class AngularVelocityVector:
+    """Angular velocity of the rotating frame of reference (reference:
+    source/auxiliary_classes.py:12-86).  ``value`` / ``derivative`` are plain floats here (the
+    reference wraps them in dolfin Constants that enter the forms); the solver pushes them to the
+    device before every solve (C ABI nsfem_set_angular_velocity).  2D only."""
+
+    def __init__(self, space_dim=2, function=None):
+        assert isinstance(space_dim, int) and space_dim in (2, 3)
+        assert space_dim == 2, "3D rotating frames are not built (SURVEY.md D4)"
+        self._space_dim = space_dim
+        self._current_time = 0.0
+        self._value_size = 1
+        if function is not None:
+            self.set_angular_velocity_function(function)
+
+    def _modify_time(self):
+        self._omega = float(self._angular_velocity.value())
+        if self._alpha is not None:
+            self._alpha = float(self._angular_velocity.derivative())
+
+    def set_angular_velocity_function(self, function):
+        assert isinstance(function, FunctionTime)
+        assert function.value_size == self._value_size
+        self._angular_velocity = function
+        self._omega = float(function.value())
+        try:                                   # the derivative is optional (:37-50)
+            self._alpha = float(function.derivative())
+        except (RuntimeError, NotImplementedError):
+            self._alpha = None
+
+    def set_time(self, current_time):
+        assert isinstance(current_time, float)
+        assert current_time >= self._current_time
+        self._current_time = current_time
+        self._angular_velocity.set_time(self._current_time)
+        self._modify_time()
+
+    @property
+    def derivative(self):
+        return self._alpha
+
+    @property
+    def space_dim(self):
+        return self._space_dim
+
+    @property
+    def value(self):
+        return self._omega

@@ -435,6 +435,12 @@ void nsfem_ctx::MomentumPrec::apply(hipStream_t s, const double* r, double* z) {
 }
 
 static double cc_of(const nsfem_ctx* c) { return std::isfinite(c->coef[0]) ? c->coef[0] : 0.0; }
+// Coriolis factor 2 c_cor omega (source/ns_solver_base.py:173-191, 2D branch)
+static double coriolis_gamma(const nsfem_ctx* c) {
+  if (c->omega == 0.0) return 0.0;
+  if (!std::isfinite(c->coef[4])) throw Error(NSFEM_ERR_ARG, "angular velocity set but coriolis_term coefficient is None");
+  return 2.0 * c->coef[4] * c->omega;
+}
 
 // time-step constant part of the momentum residual:
 //   g = M (a1 u1 + a2 u2) / k - c_p (p_old, div w) - c_b M f + traction
@@ -449,6 +455,14 @@ static void momentum_begin_step(nsfem_ctx* c, bool with_old_pressure = true) {
                     c->state[NSFEM_BODY_FORCE].p, c->tmp_v.p);
   } else {
     launch_axpby(s, nv, a1, c->state[NSFEM_U1].p, a2, c->state[NSFEM_U2].p, c->tmp_v.p);
+  }
+  if (c->omega_dot != 0.0) {      // Euler acceleration  c_e (d omega/dt) e_z x x  (ns_solver_base.py:193-211)
+    NSFEM_REQUIRE(std::isfinite(c->coef[5]), "angular acceleration set but euler_term coefficient is None");
+    if (!c->rot_field.p) {
+      c->rot_field.alloc((size_t)nv);
+      launch_rot_field(s, c->mesh, c->rot_field.p);
+    }
+    launch_axpby(s, nv, 1.0, c->tmp_v.p, c->coef[5] * c->omega_dot, c->rot_field.p, c->tmp_v.p);
   }
   launch_spmv(s, c->M2, 2, c->tmp_v.p, c->gconst.p, nullptr, MASK_NONE);
   if (with_old_pressure)   // IPCS: - c_p (p_old, div w); the monolithic scheme keeps p unknown
@@ -486,6 +500,12 @@ static void momentum_residual_raw(nsfem_ctx* c, const double* u, double* out) {
   if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], u, out, nullptr);
   const double cc = cc_of(c);
   if (cc != 0.0) launch_convection_residual(s, c->mesh, u, cc, out, c->conv_form);
+  const double g = coriolis_gamma(c);
+  if (g != 0.0) {                 // 2 c_cor omega (e_z x u, w) = M applied to the rotated field
+    if (!c->rot_tmp.p) c->rot_tmp.alloc((size_t)nv);
+    launch_rot90(s, c->mesh.n_p2, g, u, c->rot_tmp.p);
+    launch_spmv_axpy(s, c->M2, 2, 1.0, c->rot_tmp.p, out, nullptr);
+  }
 }
 
 static double momentum_residual(nsfem_ctx* c) {
@@ -506,6 +526,8 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
                                c->coef[2], c->J.vals.p, c->conv_form, c->picard);
   else
     launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
+  const double g = coriolis_gamma(c);
+  if (g != 0.0) launch_jac_add_skew(s, c->p22.nnz, g, c->M2.vals.p, c->J.vals.p);
   launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
 }
 
@@ -1197,6 +1219,38 @@ extern "C" int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* 
   if (mean_before) *mean_before = mean;
   launch_add_scalar(s, np, -(mean - target), ctx->state[NSFEM_P].p);
   NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+// rotating frame (2D): angular velocity omega and its time derivative at the new time level
+extern "C" int nsfem_set_angular_velocity(nsfem_ctx* ctx, double omega, double omega_dot) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(std::isfinite(omega) && std::isfinite(omega_dot), "non-finite angular velocity");
+  ctx->omega = omega;
+  ctx->omega_dot = omega_dot;
+  API_END(ctx)
+}
+
+// max over cells of the DG2-projected local CFL number  2 |u| k / h  (reference
+// source/ns_problem.py:554-587) of velocity slot `slot`; one kernel + a 256-value read-back
+extern "C" int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, double* cfl) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && cfl, "null argument");
+  NSFEM_REQUIRE(slot >= 0 && slot < NSFEM_N_SLOTS && slot_size(ctx, slot) == nvel(ctx),
+                "not a velocity slot");
+  hipStream_t s = ctx->stream;
+  const int n_parts = 256;
+  ctx->kw.ensure(nvel(ctx));
+  double* parts = ctx->kw.parts.p + 5 * kParts;
+  launch_cfl(s, ctx->mesh, ctx->state[slot].p, 2.0 * step_size, parts, n_parts);
+  if (ctx->distributed()) ctx->comm->allreduce_max(s, parts, n_parts);
+  double h[256];
+  NSFEM_HIP(hipMemcpyAsync(h, parts, sizeof(h), hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  double m = 0.0;
+  for (double v : h) m = std::max(m, v);
+  *cfl = m;
   API_END(ctx)
 }
 

@@ -363,6 +363,90 @@ __global__ __launch_bounds__(256) void k_jac_gather(int nnz, const int32_t* __re
   reinterpret_cast<double2*>(J)[2 * (size_t)s + 1] = r1;
 }
 
+// ---- CFL diagnostic (reference source/ns_problem.py:554-587): cell-local L2 projection onto
+// DG2 of  degree |u| k / h  (degree = 2, h = dolfin CellDiameter = circumdiameter) with the
+// degree-4 rule, then the max-norm of the coefficients.  One thread per cell, one partial max
+// per block.
+__global__ __launch_bounds__(256) void k_cfl(int nc, const double* __restrict__ vx,
+                                             const int32_t* __restrict__ p2,
+                                             const double* __restrict__ u, double scale,
+                                             double* __restrict__ parts) {
+  __shared__ double sh[4];
+  double best = 0.0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    const double x0 = vx[c], y0 = vx[(size_t)nc + c];
+    const double x1 = vx[(size_t)2 * nc + c], y1 = vx[(size_t)3 * nc + c];
+    const double x2 = vx[(size_t)4 * nc + c], y2 = vx[(size_t)5 * nc + c];
+    const double la = sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+    const double lb = sqrt((x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2));
+    const double lc = sqrt((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1));
+    const double area2 = fabs((x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0));
+    const double h = la * lb * lc / area2;                  // 2 R = abc / (2 A)
+    double ux[6], uy[6], f[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double2 v = reinterpret_cast<const double2*>(u)[p2[(size_t)k * nc + c]];
+      ux[k] = v.x;
+      uy[k] = v.y;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        a += c_q.cfl_phi[q][k] * ux[k];
+        b += c_q.cfl_phi[q][k] * uy[k];
+      }
+      f[q] = scale * sqrt(a * a + b * b) / h;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double ci = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) ci += c_q.cfl_inv[i][q] * f[q];
+      best = fmax(best, fabs(ci));
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// nodal values of e_z x x = (-y, x) at the P2 nodes (vertices and edge midpoints of the affine
+// cells; every cell sharing a node writes the same value)
+__global__ __launch_bounds__(256) void k_rot_field(int nc, const double* __restrict__ vx,
+                                                   const int32_t* __restrict__ p2,
+                                                   double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  double x[3], y[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    x[k] = vx[(size_t)(2 * k) * nc + c];
+    y[k] = vx[(size_t)(2 * k + 1) * nc + c];
+  }
+  const int pr[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double xn = k < 3 ? x[k] : 0.5 * (x[pr[k - 3][0]] + x[pr[k - 3][1]]);
+    const double yn = k < 3 ? y[k] : 0.5 * (y[pr[k - 3][0]] + y[pr[k - 3][1]]);
+    reinterpret_cast<double2*>(out)[p2[(size_t)k * nc + c]] = make_double2(-yn, xn);
+  }
+}
+void launch_rot_field(hipStream_t s, const MeshDev& m, double* out) {
+  hipLaunchKernelGGL(k_rot_field, dim3((m.n_cells + 255) / 256), dim3(256), 0, s, m.n_cells, m.vx.p,
+                     m.p2.p, out);
+  NSFEM_HIP(hipGetLastError());
+}
+
+void launch_cfl(hipStream_t s, const MeshDev& m, const double* u, double scale, double* parts,
+                int n_parts) {
+  hipLaunchKernelGGL(k_cfl, dim3(n_parts), dim3(256), 0, s, m.n_cells, m.vx.p, m.p2.p, u, scale,
+                     parts);
+  NSFEM_HIP(hipGetLastError());
+}
+
 // ---- convection residual  b_(i,a) += cc * int c(u)_a phi_i  for the four weak forms
 template <int FORM>
 __global__ __launch_bounds__(256) void k_conv_res(int nc, const double* __restrict__ vx,

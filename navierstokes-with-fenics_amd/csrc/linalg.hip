@@ -456,6 +456,30 @@ static inline int vgrid(int64_t n) {
     NSFEM_HIP(hipGetLastError());                                         \
   } while (0)
 
+// rotating frame: out = g * (-u_y, u_x) per node (2D cross product e_z x u)
+__global__ __launch_bounds__(256) void k_rot90(int64_t n_nodes, double g, const double* __restrict__ u,
+                                               double* __restrict__ out) {
+  GRID_STRIDE(i, n_nodes) {
+    const double2 v = reinterpret_cast<const double2*>(u)[i];
+    reinterpret_cast<double2*>(out)[i] = make_double2(-g * v.y, g * v.x);
+  }
+}
+// J[s] += g * M[s] * [[0,-1],[1,0]]  (Coriolis block of the velocity Jacobian)
+__global__ __launch_bounds__(256) void k_jac_add_skew(int64_t nnz, double g, const double* __restrict__ M,
+                                                      double* __restrict__ J) {
+  GRID_STRIDE(s, nnz) {
+    const double m = g * M[s];
+    J[4 * s + 1] -= m;
+    J[4 * s + 2] += m;
+  }
+}
+void launch_rot90(hipStream_t s, int64_t n_nodes, double g, const double* u, double* out) {
+  LAUNCH(k_rot90, vgrid(n_nodes), s, n_nodes, g, u, out);
+}
+void launch_jac_add_skew(hipStream_t s, int64_t nnz, double g, const double* M, double* J) {
+  LAUNCH(k_jac_add_skew, vgrid(nnz), s, nnz, g, M, J);
+}
+
 void launch_axpby(hipStream_t s, int64_t n, double a, const double* x, double b, const double* y,
                   double* z) {
   LAUNCH(k_axpby, vgrid(n), s, n, a, x, b, y ? y : x, z);

@@ -111,9 +111,16 @@ struct QuadTables {
   double dphi2[7][6][2];
   double phi1[7][3];
   // dphi1 is constant: (-1,-1), (1,0), (0,1)
+  // CFL diagnostic: P2 basis at the 6 points of the degree-4 Strang-Fix rule and its inverse
+  // (the local L2 projection onto P2 with that rule is interpolation at its points)
+  double cfl_phi[6][6];
+  double cfl_inv[6][6];
 };
 void fill_quad_tables(QuadTables& t);
 void upload_quad_tables(const QuadTables& t);
+struct MeshDev;
+void launch_cfl(hipStream_t s, const MeshDev& m, const double* u, double scale, double* parts,
+                int n_parts);
 
 // SpMV row-mask modes
 enum MaskMode { MASK_NONE = 0, MASK_IDENTITY = 1, MASK_ZERO = 2 };
@@ -172,6 +179,9 @@ void launch_inv_diag(hipStream_t s, const BlockMat& A, int nv, const uint8_t* ro
                      double* dinv);
 
 // vector kernels (n = number of doubles)
+void launch_rot90(hipStream_t s, int64_t n_nodes, double g, const double* u, double* out);
+void launch_jac_add_skew(hipStream_t s, int64_t nnz, double g, const double* M, double* J);
+void launch_rot_field(hipStream_t s, const MeshDev& m, double* out);
 void launch_axpby(hipStream_t s, int64_t n, double a, const double* x, double b, const double* y,
                   double* z);                                     // z = a x + b y
 void launch_lincomb3(hipStream_t s, int64_t n, double a, const double* x, double b,
@@ -347,6 +357,9 @@ struct nsfem_ctx {
   int traction_form = 0;
   double coef[6] = {1.0, 1.0, 1.0, NAN, NAN, NAN};
   double alpha[3] = {1.0, -1.0, 0.0};
+  // rotating frame (2D): angular velocity and its time derivative; rot_field = nodal (-y, x)
+  double omega = 0.0, omega_dot = 0.0;
+  nsfem::DevBuf<double> rot_field, rot_tmp;
   double k = 1.0;
   bool L_dirty = true;
   nsfem::DevBuf<double> state[NSFEM_N_SLOTS];

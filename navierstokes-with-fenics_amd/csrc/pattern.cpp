@@ -108,6 +108,32 @@ void fill_quad_tables(QuadTables& t) {
       for (int d = 0; d < 2; ++d) t.dphi2[q][3 + e][d] = 4.0 * (l[a] * dl[b][d] + l[b] * dl[a][d]);
     }
   }
+  // degree-4, 6-point Strang-Fix rule (FFC's "default" scheme for quadrature degree 4, which the
+  // reference's CFL projection requests: source/ns_problem.py:570): Phi[q][i] and its inverse
+  const double a = 0.445948490915965, b = 0.091576213509771;
+  const double p6[6][2] = {{a, a}, {1.0 - 2.0 * a, a}, {a, 1.0 - 2.0 * a},
+                           {b, b}, {1.0 - 2.0 * b, b}, {b, 1.0 - 2.0 * b}};
+  double m[6][12];
+  for (int q = 0; q < 6; ++q) {
+    double l[3] = {1.0 - p6[q][0] - p6[q][1], p6[q][0], p6[q][1]};
+    for (int i = 0; i < 3; ++i) t.cfl_phi[q][i] = l[i] * (2.0 * l[i] - 1.0);
+    for (int e = 0; e < 3; ++e) t.cfl_phi[q][3 + e] = 4.0 * l[pr[e][0]] * l[pr[e][1]];
+    for (int i = 0; i < 6; ++i) { m[q][i] = t.cfl_phi[q][i]; m[q][6 + i] = (i == q) ? 1.0 : 0.0; }
+  }
+  for (int c = 0; c < 6; ++c) {                       // Gauss-Jordan with partial pivoting
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r) if (std::fabs(m[r][c]) > std::fabs(m[piv][c])) piv = r;
+    for (int k = 0; k < 12; ++k) std::swap(m[c][k], m[piv][k]);
+    const double d = 1.0 / m[c][c];
+    for (int k = 0; k < 12; ++k) m[c][k] *= d;
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = m[r][c];
+      for (int k = 0; k < 12; ++k) m[r][k] -= f * m[c][k];
+    }
+  }
+  for (int i = 0; i < 6; ++i)
+    for (int q = 0; q < 6; ++q) t.cfl_inv[i][q] = m[i][6 + q];
 }
 
 }  // namespace nsfem

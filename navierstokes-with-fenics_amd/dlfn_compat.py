@@ -62,11 +62,68 @@ class Constant:
         return np.tile(self._v, (X.shape[0], 1))
 
 
-_NAMESPACE = dict(sin=np.sin, cos=np.cos, tan=np.tan, exp=np.exp, log=np.log, sqrt=np.sqrt,
+_NAMESPACE = dict(where=np.where, sin=np.sin, cos=np.cos, tan=np.tan, exp=np.exp, log=np.log, sqrt=np.sqrt,
                   pow=np.power, fabs=np.abs, abs=np.abs, tanh=np.tanh, sinh=np.sinh, cosh=np.cosh,
                   atan2=np.arctan2, atan=np.arctan, asin=np.arcsin, acos=np.arccos,
                   fmin=np.minimum, fmax=np.maximum, M_PI=math.pi, pi=math.pi, DOLFIN_PI=math.pi,
                   DOLFIN_EPS=DOLFIN_EPS)
+
+
+def _cpp_to_python(code):
+    """C++ expression -> numpy-evaluable Python: ``std::`` dropped, ``&&``/``||``/``!`` mapped to
+    elementwise logic, and the conditional operator ``c ? a : b`` (right-associative, lowest
+    precedence) rewritten as ``where(c, a, b)`` inside every parenthesis level."""
+    code = code.replace("std::", "").replace("&&", " & ").replace("||", " | ")
+
+    def ternary(expr):
+        depth, q = 0, -1
+        for i, ch in enumerate(expr):
+            depth += ch in "([" 
+            depth -= ch in ")]"
+            if ch == "?" and depth == 0:
+                q = i
+                break
+        if q < 0:
+            return expr
+        depth, nested = 0, 0
+        for j in range(q + 1, len(expr)):
+            ch = expr[j]
+            depth += ch in "(["
+            depth -= ch in ")]"
+            if depth == 0 and ch == "?":
+                nested += 1
+            elif depth == 0 and ch == ":":
+                if nested == 0:
+                    return "where(%s, %s, %s)" % (expr[:q], ternary(expr[q + 1:j]), ternary(expr[j + 1:]))
+                nested -= 1
+        raise SyntaxError("unbalanced conditional operator in expression: " + expr)
+
+    def walk(expr):                      # rewrite innermost parentheses first
+        out, i = "", 0
+        while i < len(expr):
+            if expr[i] == "(":
+                depth, j = 1, i + 1
+                while depth:
+                    depth += expr[j] == "("
+                    depth -= expr[j] == ")"
+                    j += 1
+                inner = expr[i + 1:j - 1]
+                parts, d, start = [], 0, 0          # split arguments at top-level commas
+                for k, ch in enumerate(inner):
+                    d += ch in "(["
+                    d -= ch in ")]"
+                    if ch == "," and d == 0:
+                        parts.append(inner[start:k])
+                        start = k + 1
+                parts.append(inner[start:])
+                out += "(" + ",".join(ternary(walk(a)) for a in parts) + ")"
+                i = j
+            else:
+                out += expr[i]
+                i += 1
+        return out
+
+    return ternary(walk(code)).strip()
 
 
 class Expression:
@@ -81,7 +138,7 @@ class Expression:
         self._code = (cpp_code,) if isinstance(cpp_code, str) else tuple(cpp_code)
         self._scalar = isinstance(cpp_code, str)
         self._degree = degree
-        self._compiled = [compile(c.replace("std::", ""), "<expression>", "eval") for c in self._code]
+        self._compiled = [compile(_cpp_to_python(c), "<expression>", "eval") for c in self._code]
         self._name = None
 
     def __getattr__(self, key):

@@ -4,8 +4,8 @@ Same entry points, argument meaning and marker enumeration as the reference's
 ``source/grid_generator.py`` (hyper_cube :111-151, hyper_rectangle :154-208,
 open_hyper_cube :211-353, HyperCubeBoundaryMarkers :36-46), producing the
 dolfin-free ``fem_mesh.Mesh`` / ``FacetMarkers`` pair.  2D only: every 3D branch
-of the reference solvers is "pragma: no cover" (SURVEY.md D4).  The mshr / gmsh
-factories (spherical_shell, *.geo readers) need external tools that are absent.
+of the reference solvers is "pragma: no cover" (SURVEY.md D4).  mshr / gmsh are
+absent: spherical_shell (2D annulus) and the DFG channel are triangulated in-repo instead.
 """
 from enum import Enum, auto
 
@@ -27,6 +27,11 @@ class HyperCubeBoundaryMarkers(Enum):
 
 
 HyperRectangleBoundaryMarkers = HyperCubeBoundaryMarkers
+
+
+class SphericalAnnulusBoundaryMarkers(Enum):
+    interior_boundary = auto()
+    exterior_boundary = auto()
 
 
 def _mark_box(mesh, lo, hi):
@@ -191,3 +196,57 @@ def dfg_channel(m=4, n_refine=0, grading=1.3):
         coarse.mg_levels = []
         return coarse, marks
     return refinement_hierarchy(coarse, marks, n_refine, project=_dfg_project)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2D annulus (reference: spherical_shell, source/grid_generator.py:67-108, built with mshr,
+# which is absent).  Same arguments and marker ids; the triangulation is a polar grid refined
+# with projection of new boundary vertices onto the two circles, so it carries a multigrid
+# hierarchy.  ``n_points`` keeps mshr's meaning: about n_points cells across the diameter.
+# ---------------------------------------------------------------------------------------------
+def spherical_shell(dim, radii, n_points=10):
+    from fem_mesh import Mesh
+    from multigrid import refinement_hierarchy
+    assert isinstance(dim, int) and dim == 2, "only the 2D annulus is built (SURVEY.md D4)"
+    assert isinstance(radii, (list, tuple)) and len(radii) == 2
+    ri, ro = radii
+    assert isinstance(ri, float) and ri > 0.0 and isinstance(ro, float) and ro > ri
+    assert isinstance(n_points, int) and n_points >= 0
+    h = 2.0 * ro / max(n_points, 1)
+    n_r = max(1, int(round((ro - ri) / h)))
+    n_refine = 0
+    while n_r % 2 == 0 and n_r > 2:
+        n_r //= 2
+        n_refine += 1
+    n_t = max(8, int(np.ceil(np.pi * (ri + ro) / h / 2 ** n_refine)))
+    n_t += (-n_t) % 4
+    r = np.linspace(ri, ro, n_r + 1)
+    t = 2.0 * np.pi * np.arange(n_t) / n_t
+    coords = np.stack([np.outer(r, np.cos(t)).ravel(), np.outer(r, np.sin(t)).ravel()], axis=1)
+    vid = lambda i, j: i * n_t + (j % n_t)
+    cells = []
+    for i in range(n_r):
+        for j in range(n_t):
+            a, b, c, d = vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)
+            cells += [(a, b, c), (a, c, d)]
+    coarse = Mesh(coords, np.array(cells, dtype=np.int32))
+    ids = SphericalAnnulusBoundaryMarkers
+    marks = FacetMarkers(coarse, 0)
+    rad = lambda X: np.hypot(X[:, 0], X[:, 1])
+    # chords of the boundary polygons: both end points on the circle (midpoints lie inside)
+    e = coarse.edges[coarse.edge_on_boundary]
+    rv = rad(coarse.coords)
+    on_bd = np.nonzero(coarse.edge_on_boundary)[0]
+    inner = np.abs(rv[e[:, 0]] - ri) < 1e-12 * ro
+    marks.values[on_bd[inner]] = ids.interior_boundary.value
+    marks.values[on_bd[~inner]] = ids.exterior_boundary.value
+
+    def project(mesh, markers, mid):
+        for value, radius in ((ids.interior_boundary.value, ri), (ids.exterior_boundary.value, ro)):
+            on = markers.values == value
+            mid[on] *= (radius / rad(mid[on]))[:, None]
+        return mid
+
+    if n_refine == 0:
+        return coarse, marks
+    return refinement_hierarchy(coarse, marks, n_refine, project=project)

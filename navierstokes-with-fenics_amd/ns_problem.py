@@ -117,20 +117,24 @@ class InstationaryProblem(ProblemBase):
         return self._navier_stokes_solver
 
     def _compute_cfl_number(self, step_size):
-        """max over P2 nodes of  p |u| k / h_min  (diagnostic; the reference's value is
-        likewise never used to change the step, :589-603)."""
-        u = self._get_velocity().nodal_values()
-        speed = float(np.sqrt((u * u).sum(axis=1)).max()) if u.size else 0.0
-        cfl = 2.0 * speed * step_size / self._mesh.hmin()
+        """Maximum local CFL number, evaluated on the device exactly as the reference defines it
+        (source/ns_problem.py:554-587): cell-local L2 projection onto DG2 of  p |u| k / h
+        (p = 2, h = CellDiameter) with the degree-4 rule, max-norm of the coefficients.  One
+        kernel + a 2 KB read-back (C ABI nsfem_cfl_number)."""
+        import _native as nat
+        cfl = self._get_solver()._ctx.cfl_number(nat.U0, step_size)
         assert math.isfinite(cfl) and cfl >= 0.0
         dlfn.info("Current CFL number = {0:6.2e}".format(cfl))
         return cfl
 
     def _set_next_step_size(self):
+        """source/ns_problem.py:589-603: the CFL number is computed every step; the step size is
+        only ever changed through the (uncovered) adaptive branch, which the reference leaves
+        switched off."""
         next_step_size = self._time_stepping.get_next_step_size()
         assert next_step_size > 0.0 and math.isfinite(next_step_size)
-        if getattr(self, "compute_cfl", False):
-            self._compute_cfl_number(next_step_size)
+        if getattr(self, "compute_cfl", True):
+            self._last_cfl = self._compute_cfl_number(next_step_size)
 
     def solve_problem(self):
         assert hasattr(self, "_InstationarySolverClass")
@@ -190,6 +194,10 @@ class InstationaryProblem(ProblemBase):
                 self.postprocess_solution()
             ts.advance_time()
             solver.advance_time()
+            if hasattr(self, "_angular_velocity"):
+                # the frame's angular velocity is moved to the NEW current time only after the
+                # step, i.e. step n -> n+1 uses omega(t_n) (reference :728-731)
+                solver._angular_velocity.set_time(ts.current_time)
             if self._output_frequency > 0 and ts.step_number % self._output_frequency == 0:
                 self._write_xdmf_file(current_time=ts.current_time)
         print(ts)

@@ -35,6 +35,7 @@ class StationaryProblem(ProblemBase):
         self.set_internal_constraints()
         self.set_boundary_conditions()
         self.set_body_force()
+        self.set_angular_velocity()
         self.set_equation_coefficients()
         assert isinstance(getattr(self, "_coefficient_handler", None), EquationCoefficientHandler)
         self._coefficient_handler.close()
@@ -48,6 +49,8 @@ class StationaryProblem(ProblemBase):
         solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
         if hasattr(self, "_body_force"):
             solver.set_body_force(self._body_force)
+        if hasattr(self, "_angular_velocity"):
+            solver.set_angular_velocity(self._angular_velocity)
         if hasattr(self, "_periodic_bcs"):
             solver.set_periodic_boundary_conditions(self._periodic_bcs, self._periodic_boundary_ids)
         if hasattr(self, "_bcs"):

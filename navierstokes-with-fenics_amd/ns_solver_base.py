@@ -124,8 +124,18 @@ class SolverBase:
         self._body_force.rename("body_force", "")
 
     def set_angular_velocity(self, angular_velocity):
-        raise NotImplementedError("rotating frames (Coriolis / Euler terms) are outside the "
-                                  "hot-path scope of this build (SURVEY.md section 8f N3)")
+        """Rotating frame of reference (reference :680-691): Coriolis term
+        2 c_cor omega (e_z x u, w) and Euler term c_e omega' (e_z x x, w), both integrated on the
+        device (csrc/api.hip: coriolis_gamma, momentum_begin_step)."""
+        from auxiliary_classes import AngularVelocityVector
+        assert isinstance(angular_velocity, AngularVelocityVector)
+        assert angular_velocity.space_dim == self._space_dim
+        self._angular_velocity = angular_velocity
+
+    def _push_angular_velocity(self):
+        if hasattr(self, "_angular_velocity") and hasattr(self, "_ctx"):
+            av = self._angular_velocity
+            self._ctx.set_angular_velocity(av.value, 0.0 if av.derivative is None else av.derivative)
 
     def set_periodic_boundary_conditions(self, constrained_domain, constrained_boundary_ids):
         assert isinstance(constrained_domain, dlfn.SubDomain)
@@ -486,6 +496,7 @@ class InstationarySolverBase(SolverBase):
         if not all(hasattr(self, attr) for attr in self._required_objects):
             self._setup_problem()
         self._set_time()
+        self._push_angular_velocity()
         # the reference tests a bound method here (always true): refresh every step
         self._update_time_stepping_coefficients()
         self._solve_time_step()
@@ -553,6 +564,7 @@ class StationarySolverBase(SolverBase):
         if not all(hasattr(self, attr) for attr in ("_nonlinear_solver", "_picard_problem",
                                                     "_newton_problem", "_solution")):
             self._setup_problem()
+        self._push_angular_velocity()
         # initial residual (zero iterations of the nonlinear loop)
         info = self._nonlinear_solve(True, 1.0e300, 1, True)
         residual = info.newton_residuals[0]

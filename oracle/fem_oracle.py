@@ -304,6 +304,34 @@ class Space:
 # --------------------------------------------------------------------------
 # Dirichlet handling (dolfin DirichletBC.apply semantics, third party)
 # --------------------------------------------------------------------------
+def strang_fix_6():
+    """6-point degree-4 rule (FFC/FIAT 'default' scheme for quadrature degree 4 on triangles,
+    which the reference's CFL projection requests: source/ns_problem.py:570)."""
+    a, b = 0.445948490915965, 0.091576213509771
+    wa, wb = 0.223381589678011, 0.109951743655322
+    pts = np.array([[a, a], [1 - 2 * a, a], [a, 1 - 2 * a], [b, b], [1 - 2 * b, b], [b, 1 - 2 * b]])
+    return pts, 0.5 * np.array([wa, wa, wa, wb, wb, wb])
+
+
+def cfl_number(space, u, step_size):
+    """source/ns_problem.py:554-587 restated: per cell, solve the local DG2 mass system
+    M c = int phi_i f  with  f = 2 |u| k / h  (h = dolfin CellDiameter = circumdiameter), both
+    sides integrated with the degree-4 rule; return max |c_i| over all cells."""
+    pts, wts = strang_fix_6()
+    phi, _ = p2_basis(pts)                                     # [q, 6]
+    x = space.geo.x                                            # [c, 3, 2]
+    la = np.linalg.norm(x[:, 1] - x[:, 2], axis=1)
+    lb = np.linalg.norm(x[:, 0] - x[:, 2], axis=1)
+    lc = np.linalg.norm(x[:, 0] - x[:, 1], axis=1)
+    h = la * lb * lc / space.geo.absdet                        # abc / (2 A), absdet = 2 A
+    uq = np.einsum("qk,cka->cqa", phi, u[space.vdof])
+    f = 2.0 * np.linalg.norm(uq, axis=2) * step_size / h[:, None]          # [c, q]
+    M = np.einsum("q,qi,qj->ij", wts, phi, phi)                # reference mass (area factor cancels)
+    rhs = np.einsum("q,qi,cq->ci", wts, phi, f)
+    c = np.linalg.solve(M, rhs.T).T
+    return float(np.abs(c).max())
+
+
 def apply_dirichlet_rows(A, dofs):
     """Zero the rows, put 1 on the diagonal, keep the columns (non-symmetric),
     as dolfin::DirichletBC::apply(A) does."""
@@ -493,6 +521,10 @@ class BDFOracle:
         self.pin_pressure = pin_pressure
         self.newton_history = []
         self.newton_its = []
+        # rotating frame (2D): angular velocity / acceleration at the new time level
+        # (source/ns_solver_base.py:173-211): + 2 c_cor omega (e_z x u, w) + c_e omega' (e_z x x, w)
+        self.omega = 0.0
+        self.omega_dot = 0.0
 
     def set_initial(self, u0, p0=None):
         for i in (0, 1):
@@ -515,6 +547,13 @@ class BDFOracle:
         if self.traction is not None:
             const += self.traction
         L = (a0 / k) * self.M + cv * self.K
+        if self.omega_dot:
+            X = s.p2_nodes()
+            rot = np.stack([-X[:, 1], X[:, 0]], axis=1).ravel()          # e_z x x, exact in P2
+            const += c["euler_term"] * self.omega_dot * (self.M @ rot)
+        if self.omega:
+            skew = sp.kron(s.mass_p2(), np.array([[0.0, -1.0], [1.0, 0.0]]), format="csr")
+            L = L + 2.0 * c["coriolis_term"] * self.omega * skew
         Bt = -cp * self.D.T
         B = -cp * self.D
         bd, bv = bc

@@ -269,6 +269,33 @@ def test_mass_projection_and_mean_pressure():
     ctx.close()
 
 
+def test_cfl_number_matches_oracle():
+    """nsfem_cfl_number vs the oracle's local-projection restatement of
+    source/ns_problem.py:554-587 on a distorted mesh with a random velocity; a constant field on
+    the uniform mesh gives the closed form 2 |u| k / h."""
+    mesh, dm, marks = box(12, 8, p1=(2.0, 1.0))
+    rng = np.random.default_rng(5)
+    coords = mesh.coords.copy()
+    interior = ~np.isin(np.arange(coords.shape[0]), np.unique(mesh.edges[mesh.edge_on_boundary]))
+    coords[interior] += 0.02 * rng.standard_normal((int(interior.sum()), 2))
+    from fem_mesh import Mesh, TaylorHoodDofMap
+    mesh2 = Mesh(coords, mesh.cells)
+    dm2 = TaylorHoodDofMap(mesh2)
+    ctx = context(mesh2, dm2)
+    s = fo.Space(mesh2.coords, mesh2.cells, dm2.p2_dofmap, dm2.p1_dofmap)
+    u = rng.standard_normal(dm2.n_velocity)
+    ctx.set_state(nat.U0, u)
+    assert abs(ctx.cfl_number(nat.U0, 0.01) - fo.cfl_number(s, u, 0.01)) < 1e-12 * fo.cfl_number(s, u, 0.01)
+    ctx.close()
+    ctx = context(mesh, dm)
+    u = np.tile([3.0, 4.0], dm.n_p2)
+    ctx.set_state(nat.U0, u)
+    hx, hy = 2.0 / 12, 1.0 / 8
+    h = np.hypot(hx, hy)                                     # circumdiameter of a right triangle
+    assert abs(ctx.cfl_number(nat.U0, 0.01) - 2.0 * 5.0 * 0.01 / h) < 1e-13
+    ctx.close()
+
+
 def test_error_paths_are_loud():
     mesh, dm, marks = box(4, 4)
     ctx = context(mesh, dm)
@@ -527,3 +554,39 @@ def test_convective_forms_residual_jacobian_and_step(setup16, form_id, form):
         orc.advance()
     assert rel(c2.get_state(nat.U1), orc.vel[1]) < 1e-9
     c2.close()
+
+
+def test_bdf_rotating_frame_coriolis_and_euler_terms_match_oracle():
+    """source/ns_solver_base.py:173-211: 2 c_cor omega (e_z x u, w) in residual and Jacobian,
+    c_e omega' (e_z x x, w) on the right-hand side -- two BDF steps of a lid-driven cavity in a
+    rotating frame against the LU oracle."""
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(8, 8)
+    ctx = context(mesh, dm)
+    attach_hierarchy(ctx, mesh, coarsest=2)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.05, body_force_term=None,
+                coriolis_term=1.5, euler_term=0.7)
+    ctx.set_coeffs(1.0, 1.0, 0.05, None, 1.5, 0.7)
+    bd, bv = cavity_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.BDFOracle(s, coef, pin_pressure=True)
+    o = ctx.default_step_opts()
+    o.momentum.rtol, o.momentum.precond = 1e-13, 1
+    for step, (omega, omega_dot) in enumerate([(0.8, 0.3), (1.1, -0.4)]):
+        ctx.set_angular_velocity(omega, omega_dot)
+        orc.omega, orc.omega_dot = omega, omega_dot
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, 0.05)
+        info = ctx.step_bdf(o)
+        ctx.advance(1)
+        orc.step(alpha, 0.05, (bd, bv))
+        orc.advance()
+        assert info.newton_iterations == orc.newton_its[-1]
+    nv = dm.n_velocity
+    assert rel(ctx.get_state(nat.U1), orc.sol[1][:nv]) < 1e-9
+    p, po = ctx.get_state(nat.P_OLD), orc.sol[1][nv:]
+    assert rel(p - p.mean(), po - po.mean()) < 1e-8
+    ctx.close()

@@ -162,3 +162,27 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             text = open(os.path.join(pkg, fn)).read()
             assert "fem_oracle" not in text and "import oracle" not in text, fn
+
+
+def test_expression_conditional_operator_and_annulus_mesh():
+    """C++ conditional operator in Expression strings (used by the reference's rotating-flow test)
+    and the in-repo annulus replacing mshr's spherical_shell."""
+    import dlfn_compat as dlfn
+    from grid_generator import SphericalAnnulusBoundaryMarkers, spherical_shell
+    e = dlfn.Expression(("x[1]*w*((t >= ta) ? 1.0: t / ta)", "x[0] < 0.5 ? (x[1] > 0.2 ? 1.0 : 2.0) : pow(x[0], 2)"),
+                        degree=2, w=2.0, ta=1.0, t=0.25)
+    X = np.array([[0.1, 0.1], [0.1, 0.5], [2.0, 3.0]])
+    assert np.allclose(e.eval_at(X), [[0.05, 2.0], [0.25, 1.0], [1.5, 4.0]])
+    e.t = 3.0
+    assert np.allclose(e.eval_at(X)[:, 0], 2.0 * X[:, 1])
+    mesh, marks = spherical_shell(2, (0.25, 1.0), 60)
+    ids = SphericalAnnulusBoundaryMarkers
+    assert len(mesh.mg_levels) == 1
+    r = np.hypot(*mesh.coords.T)
+    assert abs(r.min() - 0.25) < 1e-14 and abs(r.max() - 1.0) < 1e-14
+    for value, radius in ((ids.interior_boundary.value, 0.25), (ids.exterior_boundary.value, 1.0)):
+        ends = mesh.edges[marks.facets_with_id(value)]
+        assert ends.size and np.allclose(r[ends], radius)          # refined boundary vertices projected
+    area = 0.5 * np.abs(np.cross(mesh.coords[mesh.cells[:, 1]] - mesh.coords[mesh.cells[:, 0]],
+                                 mesh.coords[mesh.cells[:, 2]] - mesh.coords[mesh.cells[:, 0]])).sum()
+    assert abs(area - np.pi * (1.0 - 0.25 ** 2)) < 5e-3

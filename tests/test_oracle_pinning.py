@@ -216,3 +216,14 @@ def test_k4_hydrostatic_balance():
     # p = c_b f . x + const  (linear, exactly representable in P1)
     y = s.p1_nodes()[:, 1]
     assert np.abs((p - p[0]) - 4.0 * (-1.0) * (y - y[0])).max() < 1e-10
+
+
+def test_cfl_number_closed_form():
+    """constant velocity on a uniform right-diagonal mesh: the projected CFL field is the constant
+    2 |u| k / h with h the hypotenuse (circumdiameter of a right triangle)."""
+    from fem_mesh import TaylorHoodDofMap, rectangle_mesh
+    mesh = rectangle_mesh((0.0, 0.0), (1.0, 1.0), 4, 4)
+    dm = TaylorHoodDofMap(mesh)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    u = np.tile([0.6, 0.8], dm.n_p2)
+    assert abs(fo.cfl_number(s, u, 0.1) - 2.0 * 0.1 / (np.sqrt(2.0) / 4)) < 1e-13

@@ -583,3 +583,148 @@ def test_open_outlet_schur_laplacian_algebraic_vs_geometric():
     assert res["algebraic"][0] < res["geometric"][0]
     for a, b in zip(res["algebraic"][1:], res["geometric"][1:]):
         assert np.linalg.norm(a - b) < 1e-7 * np.linalg.norm(b)
+
+
+# ---- rotating frames: reference tests/test_stationary_rotating_flow.py, ------------------------
+# ---- tests/test_instationary_rotating_flow.py (Coriolis + Euler terms, annulus mesh) -----------
+from auxiliary_classes import AngularVelocityVector, FunctionTime  # noqa: E402
+from grid_generator import SphericalAnnulusBoundaryMarkers, spherical_shell  # noqa: E402
+
+
+class ConstantAngularVelocity(FunctionTime):
+    def __init__(self):
+        super().__init__(1)
+
+    def value(self):
+        return 1.0
+
+
+class RotatingCouetteFlow(StationaryProblem):
+    """tests/test_stationary_rotating_flow.py:19-47 (Re lowered from 1000 to 50: the V-cycle
+    velocity preconditioner is built for diffusion-dominated blocks)."""
+
+    def __init__(self, n_points, radii, Re=50.0):
+        super().__init__(None)
+        self._radii, self._n_points, self._Re = radii, n_points, Re
+        self._problem_name = "RotationalCouette"
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = spherical_shell(2, self._radii, self._n_points)
+
+    def set_angular_velocity(self):
+        self._angular_velocity = AngularVelocityVector(2, function=ConstantAngularVelocity())
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=self._Re, Ro=1.0)
+
+    def set_boundary_conditions(self):
+        velocity = dlfn.Expression(("x[1]", "-x[0]"), degree=2)
+        ids = SphericalAnnulusBoundaryMarkers
+        self._bcs = ((VelocityBCType.no_slip, ids.exterior_boundary.value, None),
+                     (VelocityBCType.function, ids.interior_boundary.value, velocity))
+
+
+def test_stationary_rotating_couette_flow_analytic_and_oracle():
+    ri, ro = 0.25, 1.0
+    problem = RotatingCouetteFlow(24, (ri, ro))
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    u = solver.solution.split()[0].nodal_values()
+    X = dm.p2_coords
+    r = np.hypot(X[:, 0], X[:, 1])
+    A = ri ** 2 / (ro ** 2 - ri ** 2)
+    B = -A * ro ** 2
+    ut = A * r + B / r                                   # circular Couette in the rotating frame
+    exact = np.stack([-ut * X[:, 1] / r, ut * X[:, 0] / r], axis=1)
+    assert np.abs(u - exact).max() < 2e-3                # discretisation error (polygonal circles)
+    # same discrete problem solved by the oracle (Newton + LU) from the device's solution
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.BDFOracle(s, solver._equation_coefficients, pin_pressure=True)
+    orc.omega = 1.0
+    vd, vv = solver._dirichlet_bcs["velocity"]
+    _, first = np.unique(vd[::-1], return_index=True)
+    keep = len(vd) - 1 - first
+    orc.step((0.0, 0.0, 0.0), 1.0, (vd[keep].astype(np.int64), vv[keep]))
+    nv = dm.n_velocity
+    assert np.linalg.norm(u.ravel() - orc.sol[0][:nv]) < 1e-7 * np.linalg.norm(orc.sol[0][:nv])
+    p = solver.solution.split()[1].vector()
+    po = orc.sol[0][nv:]
+    assert np.linalg.norm((p - p.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())
+
+
+class RampedAngularVelocity(FunctionTime):
+    """tests/test_instationary_rotating_flow.py:12-30"""
+
+    def __init__(self):
+        super().__init__(1)
+        self._ramp_time, self._alpha_acc = 1.0, 1.0
+
+    def value(self):
+        return self._alpha_acc * min(self._current_time, self._ramp_time)
+
+    def derivative(self):
+        return self._alpha_acc if self._current_time < self._ramp_time else 0.0
+
+
+class InstationaryRotatingCouetteFlow(InstationaryProblem):
+    """tests/test_instationary_rotating_flow.py:33-92"""
+
+    def __init__(self, n_points, radii):
+        super().__init__(None, start_time=0.0, end_time=2.0, desired_start_time_step=0.1,
+                         n_max_steps=10)
+        self._radii, self._n_points = radii, n_points
+        self._problem_name = "InstationaryRotatingCouette"
+        self._output_frequency = 20
+        self._postprocessing_frequency = 20
+        self.set_solver_class(ImplicitBDFSolver)
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = spherical_shell(2, self._radii, self._n_points)
+
+    def set_angular_velocity(self):
+        self._angular_velocity = AngularVelocityVector(2, function=RampedAngularVelocity())
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=200.0, Ro=1.0)
+
+    def set_initial_conditions(self):
+        self._initial_conditions = {"velocity": (0.0, 0.0)}
+
+    def set_boundary_conditions(self):
+        velocity = dlfn.Expression(
+            ("x[1]*omega* ( (t >= t_acceleration) ? 1.0: t / t_acceleration)",
+             "-x[0]*omega* ( (t >= t_acceleration) ? 1.0: t / t_acceleration)"),
+            degree=2, omega=1.0, t_acceleration=1.0, t=0.0)
+        ids = SphericalAnnulusBoundaryMarkers
+        self._bcs = ((VelocityBCType.no_slip, ids.exterior_boundary.value, None),
+                     (VelocityBCType.function, ids.interior_boundary.value, velocity))
+
+
+def test_instationary_rotating_couette_flow_matches_oracle():
+    problem = InstationaryRotatingCouetteFlow(10, (0.25, 0.5))
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.BDFOracle(s, solver._equation_coefficients, pin_pressure=True)
+    ids = SphericalAnnulusBoundaryMarkers
+    inner = np.unique(dm.facet_p2_nodes(solver._boundary_markers.facets_with_id(ids.interior_boundary.value)))
+    outer = np.unique(dm.facet_p2_nodes(solver._boundary_markers.facets_with_id(ids.exterior_boundary.value)))
+    X = dm.p2_coords
+    av = RampedAngularVelocity()
+    for step in range(10):
+        t_now, t_next = 0.1 * step, 0.1 * (step + 1)
+        av.set_time(float(t_now))                      # the frame lags one step (reference quirk)
+        orc.omega, orc.omega_dot = av.value(), av.derivative()
+        ramp = min(t_next, 1.0)
+        dofs = np.concatenate([2 * outer, 2 * outer + 1, 2 * inner, 2 * inner + 1])
+        vals = np.concatenate([np.zeros(2 * outer.size), ramp * X[inner, 1], -ramp * X[inner, 0]])
+        orc.step(fo.bdf_alpha(step, 1.0), 0.1, (dofs, vals))
+        orc.advance()
+    nv = dm.n_velocity
+    u, p = solver.solution.split()
+    uo, po = orc.sol[1][:nv], orc.sol[1][nv:]
+    assert np.linalg.norm(u.vector() - uo) < 1e-6 * np.linalg.norm(uo)
+    pv = p.vector()
+    assert np.linalg.norm((pv - pv.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())

@@ -88,3 +88,37 @@ class MixedFunction:
     def assign(self, other):
         for mine, theirs in zip(self._parts, other.split()):
             mine.assign(theirs)
+
+
+class HostField:
+    """Post-processing field living on the host: ``center`` "Node" (one value per mesh vertex) or
+    "Cell" (one value per cell); the reference returns dolfin DG Functions here
+    (source/ns_problem.py:55-103)."""
+
+    def __init__(self, mesh, name, center, values):
+        assert center in ("Node", "Cell")
+        self.mesh, self._name, self.center = mesh, name, center
+        self.values = np.asarray(values, dtype=np.float64)
+
+    def name(self):
+        return self._name
+
+    def rename(self, name, label=""):
+        self._name = name
+
+
+def vertex_or_cell_values(function):
+    """(mesh, "Node"|"Cell", values) of a DeviceFunction / HostField for file output: like
+    dolfin's XDMFFile.write, Lagrange fields are reduced to their values at the mesh vertices."""
+    if isinstance(function, HostField):
+        return function.mesh, function.center, function.values
+    dm = function._solver._dofmap
+    mesh = dm.mesh
+    cells = mesh.cells.astype(np.int64)
+    nv = mesh.coords.shape[0]
+    node_of_vertex = np.empty(nv, dtype=np.int64)
+    if function.field == "velocity":
+        node_of_vertex[cells.ravel()] = np.asarray(dm.p2_dofmap)[:, :3].ravel()
+    else:
+        node_of_vertex[cells.ravel()] = np.asarray(dm.p1_dofmap).ravel()
+    return mesh, "Node", function.nodal_values()[node_of_vertex]

@@ -7,11 +7,10 @@ Keeps the hook protocol and the transient time loop of the reference's
 ``set_initial_conditions``, ``set_body_force``, ``postprocess_solution`` ...) drive
 the device solvers unchanged.
 
-Out of scope here: XDMF/HDF5 output and the DG projections
-behind ``_compute_vorticity`` / ``_compute_pressure_gradient`` -- the writers are
-no-ops that keep the call protocol; the CFL number, which the reference computes
-every step through a DG LocalSolver and then discards (:554-603), is evaluated as a
-nodal estimate on the host copy of the velocity for diagnostics only.
+Field output goes through ``xdmf_io.XDMFFile`` (XDMF 3 with raw binary or inline heavy data;
+HDF5 is not available here); vorticity and pressure gradient are evaluated exactly on the
+host copy of the fields at post-processing steps; the CFL number, which the reference
+computes every step through a DG LocalSolver (:554-603), is one device kernel.
 """
 import math
 import os
@@ -72,22 +71,90 @@ class ProblemBase:
     def space_dim(self):
         return self._space_dim
 
-    # -- output protocol (I/O formats are out of scope: recorded, not written) -----------
+    # -- output protocol (reference source/ns_problem.py:31-53, 55-103, 217-264) -------------
     def _add_to_field_output(self, field):
         if not hasattr(self, "_additional_field_output"):
             self._additional_field_output = []
         self._additional_field_output.append(field)
 
+    def _get_filename(self):
+        assert hasattr(self, "_coefficient_handler")
+        name = getattr(self, "_problem_name", type(self).__name__)
+        fname = name + self._coefficient_handler.get_file_suffix() + self._suffix
+        return os.path.join(self._results_dir, fname)
+
+    def _create_xdmf_file(self):
+        from xdmf_io import XDMFFile
+        fname = self._get_filename()
+        assert fname.endswith(".xdmf")
+        os.makedirs(self._results_dir, exist_ok=True)
+        self._xdmf_file = XDMFFile(fname)
+        self._xdmf_file.parameters["flush_output"] = True
+        self._xdmf_file.parameters["functions_share_mesh"] = True
+        self._xdmf_file.parameters["rewrite_function_mesh"] = False
+
+    def _cell_gradients(self, nodal, dofmap, p2):
+        """physical gradients of a P1 / P2 field at the three vertices of every cell:
+        [nc, 3 vertices, components, 2]"""
+        mesh = self._mesh
+        x = mesh.coords[mesh.cells.astype(np.int64)]
+        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
+        JinvT = np.transpose(np.linalg.inv(J), (0, 2, 1))
+        dl = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+        lam_at = np.eye(3)
+        vals = nodal[np.asarray(dofmap, dtype=np.int64)]
+        if vals.ndim == 2:
+            vals = vals[:, :, None]
+        if not p2:
+            dphi = np.broadcast_to(dl, (3, 3, 2))
+        else:
+            dphi = np.zeros((3, 6, 2))
+            pairs = ((1, 2), (0, 2), (0, 1))
+            for v in range(3):
+                l = lam_at[v]
+                for i in range(3):
+                    dphi[v, i] = (4.0 * l[i] - 1.0) * dl[i]
+                for e, (a, b) in enumerate(pairs):
+                    dphi[v, 3 + e] = 4.0 * (l[a] * dl[b] + l[b] * dl[a])
+        ref = np.einsum("vkd,cka->cvad", dphi, vals)               # reference gradients
+        return np.einsum("cxd,cvad->cvax", JinvT, ref)
+
     def _compute_vorticity(self):
-        return None
+        """curl of the P2 velocity; it lies in DG1, so the reference's L2 projection onto DG1
+        (:55-83) reproduces it exactly.  Stored per cell as the mean of its three vertex values."""
+        from fem_function import HostField
+        dm = self._get_solver()._dofmap
+        g = self._cell_gradients(self._get_velocity().nodal_values(), dm.p2_dofmap, True)
+        curl = g[:, :, 1, 0] - g[:, :, 0, 1]
+        field = HostField(self._mesh, "vorticity", "Cell", curl.mean(axis=1))
+        field.vertex_values = curl
+        return field
 
     def _compute_pressure_gradient(self):
-        return None
+        """grad of the P1 pressure: piecewise constant = its DG0 projection (:85-103)."""
+        from fem_function import HostField
+        dm = self._get_solver()._dofmap
+        g = self._cell_gradients(self._get_pressure().nodal_values(), dm.p1_dofmap, False)
+        return HostField(self._mesh, "pressure gradient", "Cell", g[:, 0, 0, :])
 
     def _write_xdmf_file(self, current_time=0.0):
-        self._last_output_time = current_time
+        """velocity, pressure and the additional fields at ``current_time`` (:244-264)."""
+        assert isinstance(current_time, float)
+        if os.environ.get("NSFEM_NO_OUTPUT"):
+            return
+        if not hasattr(self, "_xdmf_file"):
+            self._create_xdmf_file()
+        solver = self._get_solver()
+        components = solver.solution.split()
+        for index, name in solver.sub_space_association.items():
+            components[index].rename(name, "")
+            self._xdmf_file.write(components[index], current_time)
         if hasattr(self, "_additional_field_output"):
+            for field in self._additional_field_output:
+                if field is not None:
+                    self._xdmf_file.write(field, current_time)
             self._additional_field_output.clear()
+        self._last_output_time = current_time
 
 
 class InstationaryProblem(ProblemBase):

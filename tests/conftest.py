@@ -15,3 +15,12 @@ for p in (ROOT, PKG, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _run_in_tmp_dir(tmp_path, monkeypatch):
+    """problem drivers write results/ under the current directory (as the reference does)"""
+    monkeypatch.chdir(tmp_path)

@@ -183,6 +183,7 @@ def test_expression_conditional_operator_and_annulus_mesh():
     for value, radius in ((ids.interior_boundary.value, 0.25), (ids.exterior_boundary.value, 1.0)):
         ends = mesh.edges[marks.facets_with_id(value)]
         assert ends.size and np.allclose(r[ends], radius)          # refined boundary vertices projected
-    area = 0.5 * np.abs(np.cross(mesh.coords[mesh.cells[:, 1]] - mesh.coords[mesh.cells[:, 0]],
-                                 mesh.coords[mesh.cells[:, 2]] - mesh.coords[mesh.cells[:, 0]])).sum()
+    d1 = mesh.coords[mesh.cells[:, 1]] - mesh.coords[mesh.cells[:, 0]]
+    d2 = mesh.coords[mesh.cells[:, 2]] - mesh.coords[mesh.cells[:, 0]]
+    area = 0.5 * np.abs(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]).sum()
     assert abs(area - np.pi * (1.0 - 0.25 ** 2)) < 5e-3

@@ -1,0 +1,141 @@
+"""I/O formats either side of the hot path: gmsh .msh ingest and XDMF
+field output.  CPU tests: format round trips and a hand-written MSH 4.1 fixture; the GPU test
+drives a problem with output switched on and reads the file back."""
+import os
+
+import numpy as np
+import pytest
+
+from fem_function import HostField
+from fem_mesh import FacetMarkers, TaylorHoodDofMap, rectangle_mesh
+from mesh_io import read_msh, write_msh
+from xdmf_io import XDMFFile, read_xdmf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_msh_v41_fixture():
+    mesh, marks, names, cell_phys = read_msh(os.path.join(HERE, "golden", "square_v41.msh"))
+    assert mesh.num_vertices() == 5 and mesh.num_cells() == 4
+    assert names == {"inlet": (1, 1), "wall": (1, 2), "fluid": (2, 3)}
+    assert (cell_phys == 3).all()
+    mid = mesh.edge_midpoints()
+    left = np.nonzero(marks.values == 1)[0]
+    assert left.size == 1 and np.allclose(mid[left[0]], [0.0, 0.5])
+    walls = mid[marks.values == 2]
+    assert walls.shape[0] == 3 and np.allclose(sorted(walls[:, 0]), [0.5, 0.5, 1.0])
+    x = mesh.coords[mesh.cells]
+    d1, d2 = x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]
+    det = d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]
+    assert (det > 0).all() and abs(0.5 * det.sum() - 1.0) < 1e-14
+
+
+def test_msh_v22_round_trip_of_the_dfg_mesh(tmp_path):
+    from grid_generator import DFGBoundaryMarkers, dfg_channel
+    mesh, marks = dfg_channel(2, 1)
+    names = {m.name: (1, m.value) for m in DFGBoundaryMarkers}
+    names["fluid"] = (2, 1)
+    path = str(tmp_path / "dfg.msh")
+    write_msh(path, mesh, marks, names)
+    mesh2, marks2, names2, _ = read_msh(path)
+    assert names2 == names
+    assert np.array_equal(mesh2.coords, mesh.coords)
+    assert np.array_equal(np.sort(mesh2.cells, axis=1), np.sort(mesh.cells, axis=1))
+    assert np.array_equal(mesh2.edges, mesh.edges) and np.array_equal(marks2.values, marks.values)
+    dm = TaylorHoodDofMap(mesh2)                      # the ingested mesh feeds the solver's dof map
+    assert dm.n_p1 == mesh.num_vertices() and dm.n_p2 == mesh.num_vertices() + mesh.num_edges()
+
+
+def test_msh_reader_rejects_what_it_cannot_represent(tmp_path):
+    p = tmp_path / "quad.msh"
+    p.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n4\n1 0 0 0\n2 1 0 0\n3 1 1 0\n4 0 1 0\n"
+                 "$EndNodes\n$Elements\n1\n1 3 2 1 1 1 2 3 4\n$EndElements\n")
+    with pytest.raises(ValueError):
+        read_msh(str(p))
+
+
+@pytest.mark.parametrize("encoding", ["binary", "xml"])
+def test_xdmf_writer_round_trip(tmp_path, encoding):
+    mesh = rectangle_mesh((0.0, 0.0), (2.0, 1.0), 4, 3)
+    f = XDMFFile(str(tmp_path / "out.xdmf"), encoding=encoding)
+    rng = np.random.default_rng(0)
+    written = []
+    for step, t in enumerate((0.0, 0.5, 1.25)):
+        u = rng.standard_normal((mesh.num_vertices(), 2))
+        p = rng.standard_normal(mesh.num_vertices())
+        w = rng.standard_normal(mesh.num_cells())
+        f.write(HostField(mesh, "velocity", "Node", u), t)
+        f.write(HostField(mesh, "pressure", "Node", p), t)
+        f.write(HostField(mesh, "vorticity", "Cell", w), t)
+        written.append((u, p, w))
+        back = read_xdmf(str(tmp_path / "out.xdmf"))      # flush_output: valid after every write
+        assert len(back["times"]) == step + 1
+    back = read_xdmf(str(tmp_path / "out.xdmf"))
+    assert back["times"] == [0.0, 0.5, 1.25]
+    assert np.array_equal(back["cells"], mesh.cells) and np.array_equal(back["coords"], mesh.coords)
+    assert back["centers"] == {"velocity": "Node", "pressure": "Node", "vorticity": "Cell"}
+    for i, (u, p, w) in enumerate(written):
+        assert np.array_equal(back["fields"]["velocity"][i][:, :2], u)
+        assert np.array_equal(back["fields"]["pressure"][i], p)
+        assert np.array_equal(back["fields"]["vorticity"][i], w)
+
+
+@pytest.mark.gpu
+def test_problem_writes_xdmf_with_vorticity_and_pressure_gradient(tmp_path):
+    """Poiseuille start-up channel written every 2 steps: vertex values in the file equal the
+    solver's fields; vorticity / pressure gradient of the exact parabolic profile are exact."""
+    import dlfn_compat as dlfn
+    from auxiliary_classes import EquationCoefficientHandler
+    from grid_generator import HyperRectangleBoundaryMarkers as M, hyper_rectangle
+    from ns_ipcs_solver import IPCSSolver
+    from ns_problem import InstationaryProblem, PressureBCType, VelocityBCType
+
+    class Channel(InstationaryProblem):
+        def __init__(self, main_dir):
+            super().__init__(main_dir, start_time=0.0, end_time=1.0, desired_start_time_step=0.05,
+                             n_max_steps=4)
+            self._problem_name = "Channel"
+            self._output_frequency = 2
+            self._postprocessing_frequency = 2
+            self.set_solver_class(IPCSSolver)
+
+        def setup_mesh(self):
+            self._mesh, self._boundary_markers = hyper_rectangle((0.0, 0.0), (2.0, 1.0), (8, 4))
+
+        def set_equation_coefficients(self):
+            self._coefficient_handler = EquationCoefficientHandler(Re=1.0)
+
+        def set_initial_conditions(self):
+            self._initial_conditions = {"velocity": dlfn.Expression(("6.0*x[1]*(1.0-x[1])", "0.0"), degree=2),
+                                        "pressure": dlfn.Expression("12.0*(2.0-x[0])", degree=1)}
+
+        def set_boundary_conditions(self):
+            inlet = dlfn.Expression(("6.0*x[1]*(1.0-x[1])", "0.0"), degree=2)
+            self._bcs = ((VelocityBCType.function, M.left.value, inlet),
+                         (VelocityBCType.no_slip, M.bottom.value, None),
+                         (VelocityBCType.no_slip, M.top.value, None),
+                         (PressureBCType.constant, M.right.value, 0.0))
+
+        def postprocess_solution(self):
+            self._add_to_field_output(self._compute_pressure_gradient())
+            self._add_to_field_output(self._compute_vorticity())
+
+    problem = Channel(str(tmp_path))
+    problem.solve_problem()
+    files = [f for f in os.listdir(tmp_path / "results") if f.endswith(".xdmf")]
+    assert files == ["Channel_Re1.000e+00.xdmf"]
+    back = read_xdmf(str(tmp_path / "results" / files[0]))
+    assert back["times"] == pytest.approx([0.0, 0.1, 0.2])
+    solver = problem._get_solver()
+    mesh = solver._mesh
+    u = solver.solution.split()[0]
+    vertex_u = np.array([u(x) for x in mesh.coords])
+    assert np.abs(back["fields"]["velocity"][-1][:, :2] - vertex_u).max() < 1e-12
+    X = mesh.coords
+    assert np.abs(back["fields"]["velocity"][-1][:, 0] - 6 * X[:, 1] * (1 - X[:, 1])).max() < 1e-8
+    assert np.abs(back["fields"]["pressure"][-1] - 12.0 * (2.0 - X[:, 0])).max() < 1e-6
+    gp = back["fields"]["pressure gradient"][-1]
+    assert back["centers"]["pressure gradient"] == "Cell" and np.abs(gp[:, 0] + 12.0).max() < 1e-6
+    xc = X[mesh.cells].mean(axis=1)
+    w = back["fields"]["vorticity"][-1]                  # -du_x/dy = -6 (1 - 2 y), linear: mean = centroid value
+    assert np.abs(w + 6.0 * (1.0 - 2.0 * xc[:, 1])).max() < 1e-7

@@ -250,3 +250,48 @@ def spherical_shell(dim, radii, n_points=10):
     if n_refine == 0:
         return coarse, marks
     return refinement_hierarchy(coarse, marks, n_refine, project=project)
+
+
+# ---------------------------------------------------------------------------------------------
+# externally generated meshes (reference: _read_external_mesh and its three users,
+# source/grid_generator.py:357-455).  The reference runs gmsh on a .geo file of the un-vendored
+# gmsh-collection and converts through meshio; here the gmsh OUTPUT (<name>.msh, ASCII 2.2 or
+# 4.1) is read directly when the user supplies it anywhere below the working directory.
+# ---------------------------------------------------------------------------------------------
+def _locate_file(basename):
+    import os
+    for root, _, files in os.walk(os.getcwd()):
+        if basename in files:
+            return os.path.join(root, basename)
+    return None
+
+
+def _read_external_mesh(basename):
+    """-> (mesh, facet markers, {physical name: id}) from ``<basename>.msh``."""
+    from mesh_io import read_msh
+    assert isinstance(basename, str) and basename.endswith(".geo")
+    msh_file = _locate_file(basename.replace(".geo", ".msh"))
+    if msh_file is None:
+        raise FileNotFoundError(
+            "%s not found below the working directory: generate it with `gmsh -2 -format msh41 %s` "
+            "(gmsh itself is not available in this environment)" % (basename.replace(".geo", ".msh"), basename))
+    mesh, markers, names, _ = read_msh(msh_file)
+    return mesh, markers, {name: tag for name, (dim, tag) in names.items() if dim == 1}
+
+
+def backward_facing_step():
+    return _read_external_mesh("BackwardFacingStep.geo")
+
+
+def blasius_plate():
+    return _read_external_mesh("BlasiusFlowProblem.geo")
+
+
+def channel_with_cylinder(m=4, n_refine=2):
+    """DFGBenchmark.msh when supplied, else the in-repo triangulation of the same geometry
+    (``dfg_channel``) with the marker map the .geo file would define."""
+    try:
+        return _read_external_mesh("DFGBenchmark.geo")
+    except FileNotFoundError:
+        mesh, markers = dfg_channel(m, n_refine)
+        return mesh, markers, {marker.name: marker.value for marker in DFGBoundaryMarkers}

@@ -139,3 +139,20 @@ def test_problem_writes_xdmf_with_vorticity_and_pressure_gradient(tmp_path):
     xc = X[mesh.cells].mean(axis=1)
     w = back["fields"]["vorticity"][-1]                  # -du_x/dy = -6 (1 - 2 y), linear: mean = centroid value
     assert np.abs(w + 6.0 * (1.0 - 2.0 * xc[:, 1])).max() < 1e-7
+
+
+def test_external_mesh_entry_points(tmp_path):
+    """grid_generator.channel_with_cylinder & co. (reference source/grid_generator.py:406-455):
+    a supplied .msh is picked up from below the working directory; without it the DFG channel
+    falls back to the in-repo triangulation and the other two say what is missing."""
+    import grid_generator as gg
+    mesh, marks, names = gg.channel_with_cylinder(2, 0)
+    assert names["cylinder"] == gg.DFGBoundaryMarkers.cylinder.value and mesh.num_cells() > 100
+    with pytest.raises(FileNotFoundError):
+        gg.blasius_plate()
+    os.makedirs("meshes")
+    write_msh(os.path.join("meshes", "DFGBenchmark.msh"), mesh, marks,
+              {"inlet": (1, 1), "cylinder": (1, 5), "fluid": (2, 1)})
+    mesh2, marks2, names2 = gg.channel_with_cylinder()
+    assert names2 == {"inlet": 1, "cylinder": 5}
+    assert mesh2.num_cells() == mesh.num_cells() and np.array_equal(marks2.values, marks.values)

@@ -12,6 +12,13 @@ per-GPU work is fixed; the strips are coupled through RCCL (halo exchange of 1-2
 lines per SpMV, all-reduce of the partial dot products; csrc/comm.hip).  The aggregate
 `value` is DoF-updates/s = (global dofs) x (time steps/s).
 
+Solver settings of the timed steps (SURVEY.md section 8d "throughput runs"): Newton stops on the
+reference's criterion (|F| < 1e-10 or |F|/|F0| < 1e-9, checked on the true nonlinear residual
+every iteration), the linear solves inside it are inexact (residual reduced by
+--newton-forcing = 1e-4, never below a tenth of the nonlinear target), Poisson / mass solves to
+--krylov-rtol = 1e-8.  The same steps with direct-solver accuracy (rtol 1e-12, exact Newton) are
+timed right after and reported as config.ms_per_step_with_krylov_rtol_1e-12_exact_newton.
+
 Prints ONE JSON line (driver contract) that also carries
   "roofline":     dominant kernel (block-CSR SpMV of the momentum Jacobian), algorithmic
                   bytes per launch / HIP-event time on the kernel's stream vs 8 TB/s HBM;
@@ -114,6 +121,7 @@ def dfg_bdf_bench(args):
     t_setup = time.perf_counter() - t_setup
     opts = ctx.default_step_opts()
     opts.momentum.rtol, opts.momentum.precond, opts.momentum.max_iter = args.krylov_rtol, 1, 500
+    opts.newton_forcing = args.newton_forcing
     dt = 0.005
 
     def one_step(i):
@@ -144,6 +152,7 @@ def dfg_bdf_bench(args):
         "config": {"workload": "DFG 2D-2 cylinder channel Re=100, %d unstructured triangles (%d dofs), "
                                "BDF-2 monolithic, dt=%g, impulsive start" % (mesh.num_cells(), dm.n_dofs, dt),
                    "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "newton_forcing": args.newton_forcing,
                    "preconditioner": "block-triangular (V-cycle velocity block, Cahouet-Chabard Schur "
                                      "with algebraic pressure Laplacian), %d coarse P1 levels" % levels,
                    "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
@@ -162,12 +171,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", dest="n", type=int, default=512, help="cells per side and per rank (512 = BASELINE config 2)")
     ap.add_argument("--dt", type=float, default=1.0e-3)
-    ap.add_argument("--krylov-rtol", type=float, default=1.0e-10)
+    ap.add_argument("--krylov-rtol", type=float, default=1.0e-8,
+                    help="relative residual of the linear solves (Poisson, mass; Newton solves when exact)")
+    ap.add_argument("--newton-forcing", type=float, default=1.0e-4,
+                    help="inexact Newton: reduce each Newton linear residual only by this factor "
+                         "(0 = exact Newton with --krylov-rtol)")
     ap.add_argument("--cpu-sample-n", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-multigrid", action="store_true")
     ap.add_argument("--mg-degree", type=int, default=2, help="Chebyshev smoother degree")
     ap.add_argument("--mg-eig-ratio", type=float, default=4.0)
+    ap.add_argument("--coarsest", type=int, default=0, help="cells across the coarsest multigrid mesh (0: default)")
     ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf"), default="cavity-ipcs",
                     help="cavity-ipcs = BASELINE configs[1] (headline); dfg-bdf = configs[2], 1 GPU")
     ap.add_argument("--dfg-refine", type=int, default=5)
@@ -197,7 +211,7 @@ def main():
     # coarsest global mesh: 16 cells across on one GPU (289-node dense solve), 8 across when
     # partitioned (the replicated coarse problem grows with the number of strips)
     part = StripPartition((0.0, 0.0), (1.0, float(world)), n, n * world, rank, world,
-                          coarsest=16 if world == 1 else 8)
+                          coarsest=args.coarsest if args.coarsest else (16 if world == 1 else 8))
     dm = part.dofmap
     device = local_rank
     if os.environ.get("NSFEM_SHARE_GPU"):        # rehearsal of several ranks on a one-GPU box
@@ -226,6 +240,7 @@ def main():
         o.rtol = args.krylov_rtol
     if mg_levels is not None:
         opts.momentum.precond = opts.poisson.precond = 1
+    opts.newton_forcing = args.newton_forcing
 
     def one_step(i):
         ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), args.dt)
@@ -256,6 +271,18 @@ def main():
         elapsed = float(t[0])
 
     steps_per_s = args.steps / elapsed
+    # the same steps with direct-solver accuracy in every linear solve (rtol 1e-12 of SURVEY 8d's
+    # parity runs, exact Newton): reported beside the headline, never as `value`
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1.0e-12
+    opts.newton_forcing = 0.0
+    n_par = max(2, min(5, args.steps))
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup + args.steps, args.warmup + args.steps + n_par):
+        one_step(i)
+    ctx.synchronize()
+    ms_parity = 1e3 * (time.perf_counter() - t0) / n_par
     ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9
     traffic = None
@@ -277,6 +304,8 @@ def main():
                                "(%d dofs), IPCS, BDF-2, dt=%g, zero initial state" % (
                                    n, n * world, n_dofs, args.dt),
                    "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "newton_forcing": args.newton_forcing,
+                   "ms_per_step_with_krylov_rtol_1e-12_exact_newton": ms_parity,
                    "preconditioner": "jacobi" if mg_levels is None else
                    "geometric multigrid V(2,2) Chebyshev, %d coarse P1 levels" % mg_levels,
                    "parallelism": "1 GPU" if world == 1 else

@@ -124,6 +124,11 @@ typedef struct {
                                    (StationarySolverBase, ns_solver_base.py:930-934)        */
   int32_t allow_nonconvergence; /* monolithic step: return instead of failing when the
                                    iteration limit is hit (error_on_nonconvergence=False)   */
+  double newton_forcing;        /* 0: every Newton linear solve to the Krylov tolerances given
+                                   (direct-solver accuracy, parity runs).  eta > 0: inexact
+                                   Newton -- linear residual reduced by eta, at most down to a
+                                   tenth of the nonlinear target; the Newton loop still stops on
+                                   the reference's criterion (throughput runs)              */
 } nsfem_step_opts;
 
 #define NSFEM_MAX_NEWTON 64

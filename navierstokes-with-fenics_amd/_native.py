@@ -59,7 +59,8 @@ class StepOpts(C.Structure):
     _fields_ = [("newton_atol", C.c_double), ("newton_rtol", C.c_double),
                 ("newton_max_iter", C.c_int32), ("convective_form", C.c_int32),
                 ("momentum", KrylovOpts), ("poisson", KrylovOpts), ("correction", KrylovOpts),
-                ("picard", C.c_int32), ("allow_nonconvergence", C.c_int32)]
+                ("picard", C.c_int32), ("allow_nonconvergence", C.c_int32),
+                ("newton_forcing", C.c_double)]
 
 
 class StepInfo(C.Structure):

@@ -994,6 +994,8 @@ extern "C" int nsfem_default_step_opts(nsfem_step_opts* o) {
   return NSFEM_OK;
 }
 
+static nsfem_krylov_opts forced_opts(const nsfem_step_opts* o, const nsfem_krylov_opts& base, double r0);
+
 extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info) {
   nsfem_step_info local;
   API_BEGIN
@@ -1016,7 +1018,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   while (!converged && it < opts->newton_max_iter) {
     momentum_jacobian(ctx);
     nsfem_solve_info si;
-    int rc = momentum_solve_update(ctx, opts->momentum, si);
+    int rc = momentum_solve_update(ctx, forced_opts(opts, opts->momentum, r0), si);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the diffusion step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)
@@ -1048,6 +1050,20 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   }
   ctx->assembled_system = -1;
   API_END(ctx)
+}
+
+// Krylov tolerances of one Newton linear solve.  newton_forcing = 0: the caller's tolerances
+// (a direct solver's accuracy, as the reference's LU).  newton_forcing = eta > 0 (inexact
+// Newton): reduce the linear residual by eta, but never below a tenth of what the nonlinear
+// criterion itself asks for -- the Newton loop still terminates on the reference's criterion,
+// evaluated on the true nonlinear residual.
+static nsfem_krylov_opts forced_opts(const nsfem_step_opts* o, const nsfem_krylov_opts& base, double r0) {
+  nsfem_krylov_opts k = base;
+  if (o->newton_forcing > 0.0) {
+    k.rtol = std::max(k.rtol, o->newton_forcing);
+    k.atol = std::max(k.atol, 0.1 * std::max(o->newton_atol, o->newton_rtol * r0));
+  }
+  return k;
 }
 
 // ---------------------------------------------------------------- monolithic BDF
@@ -1133,7 +1149,8 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     op.prec = &ctx->block_prec;
     op.graph_epoch = ctx->graph_epoch;
     nsfem_solve_info si;
-    int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, opts->momentum, si);
+    int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p,
+                      forced_opts(opts, opts->momentum, r0), si);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the monolithic step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)

@@ -230,6 +230,10 @@ int nsfem_mg_set_schur_operator(nsfem_ctx* ctx, int level, int32_t n, const int3
  * offset = global id of this rank's local coarsest node 0 */
 int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cells,
                                const double* coords, const int32_t* cells, int64_t offset);
+/* coarser levels of a REPLICATED hierarchy below the global coarsest mesh (finest first): when
+ * that mesh is too large for a dense solve every rank runs the remaining V-cycle redundantly on
+ * the all-reduced right-hand side, so the small levels cost no halo exchange */
+int nsfem_mg_add_global_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* level);
 int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* opts /* may be NULL */);
 
 /* ---- multi-GPU: one process per GPU, each owning a strip of the mesh (new; the reference

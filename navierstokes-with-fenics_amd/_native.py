@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
-    "nsfem_mg_set_schur_operator", "nsfem_cfl_number", "nsfem_set_angular_velocity",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -161,6 +161,7 @@ def load_library(path=None):
         "nsfem_synchronize": (C.c_int, [vp]),
         "nsfem_mg_add_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
         "nsfem_mg_finalize": (C.c_int, [vp, C.POINTER(MgOpts)]),
+        "nsfem_mg_add_global_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
         "nsfem_mg_set_schur_operator": (C.c_int, [vp, C.c_int, C.c_int32, C.POINTER(C.c_int32),
                                                   C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                                   C.c_int]),
@@ -366,6 +367,17 @@ class NsfemContext:
         self._check(self._lib.nsfem_mg_set_schur_operator(self._h, int(level), csr.shape[0],
                                                           _ip(rp), _ip(ci), _dp(cv),
                                                           1 if singular else 0))
+
+    def mg_add_global_level(self, coords, cells, p_rowptr, p_col, p_val):
+        """coarser level of the replicated hierarchy below the global coarsest mesh"""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        rp = np.ascontiguousarray(p_rowptr, dtype=np.int32)
+        pc = np.ascontiguousarray(p_col, dtype=np.int32)
+        pv = np.ascontiguousarray(p_val, dtype=np.float64)
+        d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
+                        _ip(rp), _ip(pc), _dp(pv), None, Halo.from_dict(None))
+        self._check(self._lib.nsfem_mg_add_global_level(self._h, C.byref(d)))
 
     def mg_set_global_coarse(self, coords, cells, offset):
         coords = np.ascontiguousarray(coords, dtype=np.float64)

@@ -159,6 +159,8 @@ void Multigrid::setup_work(hipStream_t s) {
     if (l > 0) {
       L.x.alloc(n); L.x.zero(s);
       L.b.alloc(n); L.b.zero(s);
+    }
+    if (l > 0 || own_mask0) {
       L.own_mask.alloc(n); L.own_mask.zero(s);
       L.mask = L.own_mask.p;
     }
@@ -174,7 +176,7 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
     MGLevel& L = lv[l];
     const size_t n = (size_t)L.n * nv;
     NSFEM_REQUIRE(cur.size() == n, "multigrid mask size mismatch");
-    if (l > 0) {
+    if (l > 0 || own_mask0) {
       NSFEM_HIP(hipMemcpyAsync(L.own_mask.p, cur.data(), n, hipMemcpyHostToDevice, s));
       NSFEM_HIP(hipStreamSynchronize(s));
     }
@@ -272,6 +274,13 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
   comm->allreduce_sum(s, gb.p, (int64_t)gm.size());
   NSFEM_HIP(hipMemcpyAsync(gm.data(), gb.p, sizeof(double) * gm.size(), hipMemcpyDeviceToHost, s));
   NSFEM_HIP(hipStreamSynchronize(s));
+  if (tail) {                      // replicated hierarchy instead of one dense solve
+    std::vector<uint8_t> gmask(gm.size());
+    for (size_t i = 0; i < gm.size(); ++i) gmask[i] = gm[i] > 0.5 ? 1 : 0;
+    tail->refresh(s, gmask, singular);
+    dense_coarse = false;
+    return;
+  }
   const Pattern& p = *globA->pat;
   NSFEM_REQUIRE(p.n_rows == n, "global coarsest operator size mismatch");
   std::vector<double> v((size_t)p.nnz);
@@ -368,10 +377,14 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
       NSFEM_HIP(hipMemcpyAsync(gb.p + (size_t)glob_off * nv, b, sizeof(double) * n,
                                hipMemcpyDeviceToDevice, s));
       comm->allreduce_sum(s, gb.p, (int64_t)n_glob * nv);
-      const int tot = n_glob * nv;
-      hipLaunchKernelGGL(k_dense_apply, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, n_glob, nv,
-                         coarse_inv.p, gb.p, gx.p);
-      NSFEM_HIP(hipGetLastError());
+      if (tail) {
+        tail->vcycle(s, 0, gb.p, gx.p);
+      } else {
+        const int tot = n_glob * nv;
+        hipLaunchKernelGGL(k_dense_apply, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, n_glob, nv,
+                           coarse_inv.p, gb.p, gx.p);
+        NSFEM_HIP(hipGetLastError());
+      }
       NSFEM_HIP(hipMemcpyAsync(x, gx.p + (size_t)glob_off * nv, sizeof(double) * n,
                                hipMemcpyDeviceToDevice, s));
       return;
@@ -387,11 +400,18 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
     return;
   }
   MGLevel& C = lv[l + 1];
-  smooth(s, L, b, nullptr, x, degree);
-  halo_fill(s, L, x);
-  launch_residual(s, *L.A, nv, x, b, L.r.p, L.mask, MASK_ZERO);
-  halo_fill(s, L, L.r.p);
-  launch_spmv(s, *L.R, nv, L.r.p, C.b.p, C.mask, MASK_ZERO);
+  const int pre = pre_degree >= 0 ? pre_degree : degree;
+  if (pre > 0) {
+    smooth(s, L, b, nullptr, x, pre);
+    halo_fill(s, L, x);
+    launch_residual(s, *L.A, nv, x, b, L.r.p, L.mask, MASK_ZERO);
+    halo_fill(s, L, L.r.p);
+    launch_spmv(s, *L.R, nv, L.r.p, C.b.p, C.mask, MASK_ZERO);
+  } else {            // no pre-smoothing: x = 0, the residual is b itself
+    NSFEM_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, s));
+    halo_fill(s, L, b);
+    launch_spmv(s, *L.R, nv, b, C.b.p, C.mask, MASK_ZERO);
+  }
   vcycle(s, l + 1, C.b.p, C.x.p);
   halo_fill(s, C, C.x.p);
   launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask);

@@ -301,6 +301,7 @@ struct Multigrid : Precond {
   int nv = 1;
   std::vector<MGLevel> lv;
   int degree = 2;                // Chebyshev steps per pre/post smoothing
+  int pre_degree = -1;           // >= 0: pre-smoothing steps differ from `degree` (non-symmetric cycle)
   double eig_ratio = 4.0;        // smoothing interval [lmax / ratio, lmax]
   int coarse_dense_max = 1200;
   int coarse_steps = 30;
@@ -313,6 +314,11 @@ struct Multigrid : Precond {
   int n_glob = 0;
   int64_t glob_off = 0;
   DevBuf<double> gb, gx;
+  // when the global coarsest mesh is too large for a dense solve it carries its own REPLICATED
+  // hierarchy: a serial multigrid (no communicator) every rank runs redundantly on the
+  // all-reduced right-hand side -- the small levels cost no halo exchanges at all
+  Multigrid* tail = nullptr;     // not owned
+  bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
   void refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>& cur, bool singular);
   void halo_fill(hipStream_t s, const MGLevel& L, const double* v);
   void setup_work(hipStream_t s);
@@ -396,6 +402,8 @@ struct nsfem_ctx {
   nsfem::DevBuf<uint8_t> ghost_v, ghost_p;     // per vector entry: 0 / 2
   int64_t n_p2_global = 0, n_p1_global = 0;
   P1Level* global_coarse = nullptr;            // replicated global coarsest mesh (owned)
+  std::vector<P1Level*> global_tail;           // its coarser levels, finest first (owned)
+  nsfem::Multigrid mg_p_tail, mg_v_tail;       // replicated hierarchies below global_coarse
   int64_t glob_off = 0;
   // NSFEM_FORCE_COMM=1 routes a single-rank run through the communicator as well (lets a
   // one-GPU box exercise the RCCL all-reduce calls)
@@ -438,6 +446,7 @@ struct nsfem_ctx {
   ~nsfem_ctx() {
     for (P1Level* p : coarse) delete p;
     for (CsrOp* p : schur_ops) delete p;
+    for (P1Level* p : global_tail) delete p;
     delete global_coarse;
     delete comm;
   }

@@ -72,7 +72,7 @@ class StripPartition:
     """Everything rank ``rank`` of ``size`` needs: local fine mesh + dof map, ghost masks,
     halo ranges, local multigrid levels with prolongations, and the replicated coarsest mesh."""
 
-    def __init__(self, p0, p1, nx, ny, rank, size, coarsest=8):
+    def __init__(self, p0, p1, nx, ny, rank, size, coarsest=8, global_coarsest=None):
         assert ny % size == 0, "cell rows must divide evenly over the ranks"
         own = ny // size
         self.rank, self.size = rank, size
@@ -124,6 +124,13 @@ class StripPartition:
         last = self.levels[-1][0] if self.levels else self.fine
         self.coarse_global_shape = (last.nx, ly)
         self.coarse_global_offset = last.global_p1_offset()
+        # replicated hierarchy below the global coarse mesh (no halo exchanges on its levels):
+        # lets the partitioned levels stop early (``coarsest`` large) without a huge dense solve
+        self.global_tail = []
+        if global_coarsest is not None:
+            from multigrid import structured_hierarchy
+            self.global_tail = structured_hierarchy(self.p0, self.p1, last.nx, ly,
+                                                    coarsest=global_coarsest)
 
     def attach(self, ctx, degree=2, eig_ratio=4.0):
         """Ship the partition, the local multigrid levels and the replicated global coarsest
@@ -139,6 +146,8 @@ class StripPartition:
         from fem_mesh import rectangle_mesh
         cg = rectangle_mesh(self.p0, self.p1, cx, cy)
         ctx.mg_set_global_coarse(cg.coords, cg.cells, self.coarse_global_offset)
+        for mesh, (rowptr, col, val) in self.global_tail:
+            ctx.mg_add_global_level(mesh.coords, mesh.cells, rowptr, col, val)
         ctx.mg_finalize(degree, eig_ratio)
         return len(self.levels)
 

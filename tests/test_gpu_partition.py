@@ -50,8 +50,11 @@ def _run(ctx, dm, nsteps, k, use_mg, out, key):
     out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
 
 
-@pytest.mark.parametrize("n,size,use_mg", [(16, 2, False), (32, 4, True), (64, 2, True)])
-def test_partitioned_ipcs_equals_single_context(n, size, use_mg):
+@pytest.mark.parametrize("n,size,use_mg,tail", [(16, 2, False, False), (32, 4, True, False),
+                                                (64, 2, True, False), (64, 2, True, True)])
+def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail):
+    """tail: the partitioned levels stop at 16 cells across and the rest of the hierarchy
+    (16 -> 8 -> 4 -> 2) is the replicated global one -- still the serial algorithm."""
     nsteps, k, coarsest = 3, 0.01, 2
     mesh, dm, _ = box(n, n)
     ref = {}
@@ -63,8 +66,10 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg):
     ctx0.close()
 
     group = nat.local_group_create(size)
-    parts = [StripPartition((0.0, 0.0), (1.0, 1.0), n, n, r, size, coarsest=coarsest)
+    parts = [StripPartition((0.0, 0.0), (1.0, 1.0), n, n, r, size, coarsest=16 if tail else coarsest,
+                            global_coarsest=coarsest if tail else None)
              for r in range(size)]
+    assert bool(parts[0].global_tail) == tail
     ctxs = []
     for r, part in enumerate(parts):
         pdm = part.dofmap

@@ -289,7 +289,7 @@ def main():
     ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_fetch_write_size.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_e_pmc_fetch_write_size.json")
     if world == 1 and n == 512 and os.path.exists(pmc):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload:
         # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
@@ -310,7 +310,7 @@ def main():
                    "newton_forcing": args.newton_forcing,
                    "ms_per_step_with_krylov_rtol_1e-12_exact_newton": ms_parity,
                    "preconditioner": "jacobi" if mg_levels is None else
-                   "geometric multigrid V(2,2) Chebyshev, %d coarse P1 levels" % mg_levels,
+                   "geometric multigrid, Chebyshev-Jacobi smoothing: V(0,3) momentum, V(2,2) Poisson; %d coarse P1 levels" % mg_levels,
                    "parallelism": "1 GPU" if world == 1 else
                    "%d strips of 512 cell rows, RCCL halo exchange + all-reduce" % world,
                    "newton_its_per_step": newton / args.steps,

@@ -408,13 +408,13 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
     halo_fill(s, L, L.r.p);
     launch_spmv(s, *L.R, nv, L.r.p, C.b.p, C.mask, MASK_ZERO);
   } else {            // no pre-smoothing: x = 0, the residual is b itself
-    NSFEM_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, s));
     halo_fill(s, L, b);
     launch_spmv(s, *L.R, nv, b, C.b.p, C.mask, MASK_ZERO);
   }
   vcycle(s, l + 1, C.b.p, C.x.p);
   halo_fill(s, C, C.x.p);
-  launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask);
+  if (pre > 0) launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask);
+  else launch_spmv(s, *L.P, nv, C.x.p, x, L.mask, MASK_ZERO);      // x = P x_c (every row stored)
   smooth(s, L, b, x, x, degree);
   (void)n;
 }

@@ -71,9 +71,9 @@ def traction_vector(dofmap, facet_ids, values_at_nodes):
 def boundary_normal(mesh, markers, boundary_id):
     """Common outward unit normal of a flat boundary part (tuple); asserts flatness."""
     facets = markers.facets_with_id(boundary_id)
-    facets = facets[mesh.edge_on_boundary[facets]]
+    facets = facets[mesh.facet_on_boundary[facets]]
     assert facets.size > 0, "Boundary id {0} was not found".format(boundary_id)
-    normals = mesh.edge_normals(facets)
+    normals = mesh.facet_normals(facets)
     assert np.abs(normals - normals[0]).max() < 5.0e-14, "boundary is not flat"
     return tuple(float(v) for v in normals[0])
 

@@ -7,8 +7,8 @@ vertex coordinates, cell->vertex connectivity, the edge (facet) entities with
 their markers, and the P2 / P1 cell dof maps handed to the C-ABI
 (include/nsfem.h: nsfem_mesh_desc).
 
-Vertex order, "right" diagonal and marker ids follow dolfin's RectangleMesh as
-used by source/grid_generator.py:111-208.
+Vertex order, "right" diagonal / Kuhn split and marker ids follow dolfin's RectangleMesh and
+BoxMesh as used by source/grid_generator.py:111-208.
 """
 import numpy as np
 
@@ -26,28 +26,56 @@ class _Topology(_Geometry):
 
 
 class Mesh:
-    """Triangular mesh: ``coords`` [nv, 2] float64, ``cells`` [nc, 3] int32."""
+    """Simplex mesh: triangles (``coords`` [nv, 2], ``cells`` [nc, 3]) or tetrahedra
+    (``coords`` [nv, 3], ``cells`` [nc, 4]).  Entities in UFC local order:
+    triangle edges e0 = (v1, v2), e1 = (v0, v2), e2 = (v0, v1);
+    tetrahedron edges e0 = (v2, v3), e1 = (v1, v3), e2 = (v1, v2), e3 = (v0, v3), e4 = (v0, v2),
+    e5 = (v0, v1) and faces f_i opposite v_i.  ``facets`` are the codimension-1 entities (edges
+    in 2D, faces in 3D) that carry the boundary markers."""
+
+    _TRI_EDGES = ((1, 2), (0, 2), (0, 1))
+    _TET_EDGES = ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+    _TET_FACES = ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))
 
     def __init__(self, coords, cells):
         self.coords = np.ascontiguousarray(coords, dtype=np.float64)
         self.cells = np.ascontiguousarray(cells, dtype=np.int32)
-        assert self.coords.ndim == 2 and self.coords.shape[1] == 2, "2D simplex meshes only"
-        assert self.cells.ndim == 2 and self.cells.shape[1] == 3
+        assert self.coords.ndim == 2 and self.coords.shape[1] in (2, 3), "2D / 3D simplex meshes only"
+        self._dim = dim = int(self.coords.shape[1])
+        assert self.cells.ndim == 2 and self.cells.shape[1] == dim + 1
         nv = self.coords.shape[0]
         c = self.cells.astype(np.int64)
-        # local edges in UFC order: e0 = (v1, v2), e1 = (v0, v2), e2 = (v0, v1)
-        pairs = np.stack([c[:, [1, 2]], c[:, [0, 2]], c[:, [0, 1]]], axis=1)   # [nc, 3, 2]
-        lo = pairs.min(axis=2)
-        hi = pairs.max(axis=2)
-        key = lo * nv + hi
+        nc = c.shape[0]
+        local_edges = self._TRI_EDGES if dim == 2 else self._TET_EDGES
+        pairs = np.stack([c[:, list(e)] for e in local_edges], axis=1)          # [nc, n_le, 2]
+        key = pairs.min(axis=2) * nv + pairs.max(axis=2)
         ukey, inv, counts = np.unique(key.ravel(), return_inverse=True, return_counts=True)
-        self.cell_edges = inv.reshape(-1, 3).astype(np.int32)
+        self.cell_edges = inv.reshape(nc, len(local_edges)).astype(np.int32)
         self.edges = np.stack([ukey // nv, ukey % nv], axis=1).astype(np.int32)     # [ne, 2]
-        self.edge_on_boundary = counts == 1
-        # one adjacent cell per edge (the only one for boundary edges)
-        self.edge_cell = np.empty(self.edges.shape[0], dtype=np.int32)
-        self.edge_cell[self.cell_edges.ravel()] = np.repeat(np.arange(c.shape[0], dtype=np.int32), 3)
-        self._dim = 2
+        if dim == 2:
+            self.edge_on_boundary = counts == 1
+            # one adjacent cell per edge (the only one for boundary edges)
+            self.edge_cell = np.empty(self.edges.shape[0], dtype=np.int32)
+            self.edge_cell[self.cell_edges.ravel()] = np.repeat(np.arange(nc, dtype=np.int32), 3)
+            self.facets = self.edges
+            self.cell_facets = self.cell_edges
+            self.facet_on_boundary = self.edge_on_boundary
+            self.facet_cell = self.edge_cell
+            return
+        tri = np.sort(np.stack([c[:, list(f)] for f in self._TET_FACES], axis=1), axis=2)   # [nc, 4, 3]
+        fkey = (tri[:, :, 0] * nv + tri[:, :, 1]) * nv + tri[:, :, 2]
+        ufk, finv, fcounts = np.unique(fkey.ravel(), return_inverse=True, return_counts=True)
+        self.cell_facets = finv.reshape(nc, 4).astype(np.int32)
+        self.facets = np.stack([ufk // (nv * nv), (ufk // nv) % nv, ufk % nv], axis=1).astype(np.int32)
+        self.facet_on_boundary = fcounts == 1
+        self.facet_cell = np.empty(self.facets.shape[0], dtype=np.int32)
+        self.facet_cell[self.cell_facets.ravel()] = np.repeat(np.arange(nc, dtype=np.int32), 4)
+        # the three edges of every face: (b, c), (a, c), (a, b) for the sorted face (a, b, c)
+        f = self.facets.astype(np.int64)
+        ekey = self.edges[:, 0].astype(np.int64) * nv + self.edges[:, 1]
+        self.facet_edges = np.stack(
+            [np.searchsorted(ekey, f[:, i] * nv + f[:, j]) for i, j in ((1, 2), (0, 2), (0, 1))],
+            axis=1).astype(np.int32)
 
     # -- the slice of the dolfin.Mesh API the reference touches -----------------
     def geometry(self):
@@ -71,6 +99,26 @@ class Mesh:
     def edge_midpoints(self):
         return 0.5 * (self.coords[self.edges[:, 0]] + self.coords[self.edges[:, 1]])
 
+    def num_facets(self):
+        return int(self.facets.shape[0])
+
+    def facet_midpoints(self):
+        return self.coords[self.facets.astype(np.int64)].mean(axis=1)
+
+    def facet_normals(self, facet_ids):
+        """Unit normals of the given facets pointing away from their adjacent cell (outward for
+        boundary facets)."""
+        if self._dim == 2:
+            return self.edge_normals(facet_ids)
+        f = self.facets[facet_ids].astype(np.int64)
+        a, b, c = self.coords[f[:, 0]], self.coords[f[:, 1]], self.coords[f[:, 2]]
+        n = np.cross(b - a, c - a)
+        n /= np.linalg.norm(n, axis=1)[:, None]
+        centroid = self.coords[self.cells[self.facet_cell[facet_ids]].astype(np.int64)].mean(axis=1)
+        flip = ((centroid - (a + b + c) / 3.0) * n).sum(axis=1) > 0.0
+        n[flip] *= -1.0
+        return n
+
     def edge_normals(self, edge_ids):
         """Unit normals of the given edges pointing away from their adjacent cell
         (outward for boundary edges)."""
@@ -90,14 +138,14 @@ class Mesh:
 
 
 class FacetMarkers:
-    """``MeshFunction("size_t", mesh, dim - 1)`` stand-in: one id per edge."""
+    """``MeshFunction("size_t", mesh, dim - 1)`` stand-in: one id per facet (edge / face)."""
 
     def __init__(self, mesh, value=0):
         self.mesh = mesh
-        self.values = np.full(mesh.num_edges(), value, dtype=np.int64)
+        self.values = np.full(mesh.num_facets(), value, dtype=np.int64)
 
     def dim(self):
-        return 1
+        return self.mesh._dim - 1
 
     def set_all(self, value):
         self.values[:] = value
@@ -106,18 +154,19 @@ class FacetMarkers:
         return self.values
 
     def mark(self, predicate, value, boundary_only=True):
-        """Mark every facet whose two vertices and midpoint satisfy
+        """Mark every facet whose vertices and midpoint satisfy
         ``predicate(x) -> bool array`` (dolfin SubDomain.mark semantics with
         check_midpoint=True); ``on_boundary`` is honoured via ``boundary_only``."""
         m = self.mesh
-        ok = predicate(m.coords[m.edges[:, 0]]) & predicate(m.coords[m.edges[:, 1]]) \
-            & predicate(m.edge_midpoints())
+        ok = predicate(m.facet_midpoints())
+        for k in range(m.facets.shape[1]):
+            ok &= predicate(m.coords[m.facets[:, k]])
         if boundary_only:
-            ok &= m.edge_on_boundary
+            ok &= m.facet_on_boundary
         self.values[ok] = value
 
     def ids(self, boundary_only=True):
-        v = self.values[self.mesh.edge_on_boundary] if boundary_only else self.values
+        v = self.values[self.mesh.facet_on_boundary] if boundary_only else self.values
         return set(int(i) for i in np.unique(v))
 
     def facets_with_id(self, marker_id):
@@ -143,10 +192,11 @@ class TaylorHoodDofMap:
         nv, ne = mesh.num_vertices(), mesh.num_edges()
         xy = np.concatenate([mesh.coords, mesh.edge_midpoints()], axis=0)      # entity order
         n_ent = nv + ne
+        dim = self.dim = mesh._dim
         if reorder:
             scale = 1.0 / max(mesh.hmin(), 1e-300)
             q = np.round(xy * (4.0 * scale)).astype(np.int64)      # robust lexicographic key
-            order = np.lexsort((q[:, 0], q[:, 1]))
+            order = np.lexsort(tuple(q[:, k] for k in range(dim)))   # x fastest, last axis slowest
             ent_to_node = np.empty(n_ent, dtype=np.int64)
             ent_to_node[order] = np.arange(n_ent)
         else:
@@ -169,29 +219,33 @@ class TaylorHoodDofMap:
         self.p1_vertex_node = p1_node
         self.p1_dofmap = np.ascontiguousarray(p1_node[c], dtype=np.int32)
         # node coordinates
-        self.p2_coords = np.zeros((self.n_p2, 2))
+        self.p2_coords = np.zeros((self.n_p2, dim))
         self.p2_coords[ent_to_node] = xy          # slaves written first or last: same set per node
         if periodic_map is not None:
             masters = np.nonzero(periodic_map[0] == np.arange(n_ent))[0]
             self.p2_coords[ent_to_node[masters]] = xy[masters]
-        self.p1_coords = np.zeros((self.n_p1, 2))
+        self.p1_coords = np.zeros((self.n_p1, dim))
         self.p1_coords[p1_node] = mesh.coords
         if periodic_map is not None:
             mv = np.nonzero(periodic_map[1] == np.arange(nv))[0]
             self.p1_coords[p1_node[mv]] = mesh.coords[mv]
-        self.n_velocity = 2 * self.n_p2
+        self.n_velocity = dim * self.n_p2
         self.n_dofs = self.n_velocity + self.n_p1
 
     # -- Dirichlet dof selection (topological, as dolfin's default) -------------
     def facet_p2_nodes(self, facet_ids):
-        """[nf, 3] scalar P2 node ids (end, end, midpoint) of the given edges."""
-        e = self.mesh.edges[facet_ids].astype(np.int64)
-        return np.stack([self.vertex_node[e[:, 0]], self.vertex_node[e[:, 1]],
-                         self.edge_node[facet_ids]], axis=1)
+        """scalar P2 node ids of the given facets: 2D [nf, 3] (end, end, midpoint); 3D [nf, 6]
+        (three vertices, then the midpoints of the edges opposite to them within the face)."""
+        f = self.mesh.facets[facet_ids].astype(np.int64)
+        if self.dim == 2:
+            return np.stack([self.vertex_node[f[:, 0]], self.vertex_node[f[:, 1]],
+                             self.edge_node[facet_ids]], axis=1)
+        return np.concatenate([self.vertex_node[f], self.edge_node[self.mesh.facet_edges[facet_ids]]],
+                              axis=1)
 
     def facet_p1_nodes(self, facet_ids):
-        e = self.mesh.edges[facet_ids].astype(np.int64)
-        return self.p1_vertex_node[e]
+        f = self.mesh.facets[facet_ids].astype(np.int64)
+        return self.p1_vertex_node[f]
 
 
 def _compact(ids):
@@ -216,6 +270,34 @@ def rectangle_mesh(p0, p1, nx, ny):
     cells[1::2] = np.stack([v0, v2, v3], axis=1)
     mesh = Mesh(coords, cells)
     mesh.structured = (tuple(p0), tuple(p1), int(nx), int(ny))   # enables the multigrid hierarchy
+    return mesh
+
+
+def box_mesh(p0, p1, nx, ny, nz):
+    """dolfin.BoxMesh(p0, p1, nx, ny, nz): vertex id = (iz (ny+1) + iy)(nx+1) + ix, six
+    tetrahedra per cube sharing the diagonal (0,0,0)-(1,1,1) (Kuhn / Freudenthal split), so the
+    mesh of a uniformly refined grid is the refinement of the coarse mesh (nested P1 spaces)."""
+    x = np.linspace(p0[0], p1[0], nx + 1)
+    y = np.linspace(p0[1], p1[1], ny + 1)
+    z = np.linspace(p0[2], p1[2], nz + 1)
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    sx, sy, sz = 1, nx + 1, (nx + 1) * (ny + 1)
+    v0 = (iz * sz + iy * sy + ix).ravel()
+    v = [v0 + bx * sx + by * sy + bz * sz for bz in (0, 1) for by in (0, 1) for bx in (0, 1)]
+    # v[k]: bit 0 = x, bit 1 = y, bit 2 = z
+    tets = ((0, 1, 3, 7), (0, 1, 7, 5), (0, 5, 7, 4), (0, 3, 2, 7), (0, 6, 4, 7), (0, 2, 6, 7))
+    cells = np.empty((6 * nx * ny * nz, 4), dtype=np.int64)
+    for k, t in enumerate(tets):
+        cells[k::6] = np.stack([v[i] for i in t], axis=1)
+    # positive orientation
+    a = coords[cells]
+    det = np.einsum("ci,ci->c", a[:, 1] - a[:, 0], np.cross(a[:, 2] - a[:, 0], a[:, 3] - a[:, 0]))
+    neg = det < 0
+    cells[neg] = cells[neg][:, [0, 2, 1, 3]]
+    mesh = Mesh(coords, cells.astype(np.int32))
+    mesh.structured = (tuple(p0), tuple(p1), int(nx), int(ny), int(nz))
     return mesh
 
 

@@ -50,7 +50,7 @@ class ImplicitBDFSolver(InstationarySolverBase):
                 if bc[0] in (VelocityBCType.no_slip, VelocityBCType.constant, VelocityBCType.function)}
         marks, mesh, dm = self._boundary_markers, self._mesh, self._dofmap
         closed = list(full) + list(getattr(self, "_constrained_boundary_ids", ()))   # periodic parts
-        open_facets = np.nonzero(mesh.edge_on_boundary & ~np.isin(marks.values, closed))[0]
+        open_facets = np.nonzero(mesh.facet_on_boundary & ~np.isin(marks.values, closed))[0]
         nodes = np.unique(dm.facet_p1_nodes(open_facets)) if open_facets.size else np.zeros(0, np.int64)
         if open_facets.size and getattr(self, "_mg_levels", None) is not None:
             # open boundaries: the geometric Laplacian with a strong Dirichlet condition leaves one

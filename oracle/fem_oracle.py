@@ -42,42 +42,57 @@ import scipy.sparse.linalg as spla
 # --------------------------------------------------------------------------
 # reference element
 # --------------------------------------------------------------------------
-def collapsed_gauss_rule(n):
-    """n x n Gauss-Legendre rule collapsed onto the reference triangle
-    (0,0),(1,0),(0,1); exact for total degree <= 2n-2."""
+def collapsed_gauss_rule(n, dim=2):
+    """n^dim Gauss-Legendre rule collapsed (Duffy) onto the reference simplex; exact for total
+    degree <= 2n-1-(dim-1) at least (the Jacobian factors cost one degree per collapse)."""
     x, w = np.polynomial.legendre.leggauss(n)
     x = 0.5 * (x + 1.0)
     w = 0.5 * w
-    a, b = np.meshgrid(x, x, indexing="ij")
-    wa, wb = np.meshgrid(w, w, indexing="ij")
-    xi = a.ravel()
-    eta = (b * (1.0 - a)).ravel()
-    wt = (wa * wb * (1.0 - a)).ravel()
-    return np.stack([xi, eta], axis=1), wt
+    if dim == 2:
+        a, b = np.meshgrid(x, x, indexing="ij")
+        wa, wb = np.meshgrid(w, w, indexing="ij")
+        xi = a.ravel()
+        eta = (b * (1.0 - a)).ravel()
+        wt = (wa * wb * (1.0 - a)).ravel()
+        return np.stack([xi, eta], axis=1), wt
+    a, b, c = np.meshgrid(x, x, x, indexing="ij")
+    wa, wb, wc = np.meshgrid(w, w, w, indexing="ij")
+    xi = a
+    eta = b * (1.0 - a)
+    zeta = c * (1.0 - a) * (1.0 - b)
+    wt = wa * wb * wc * (1.0 - a) ** 2 * (1.0 - b)
+    return np.stack([xi.ravel(), eta.ravel(), zeta.ravel()], axis=1), wt.ravel()
+
+
+# local edges (pairs of local vertices) carrying the P2 edge nodes, UFC order
+_EDGE_PAIRS = {2: ((1, 2), (0, 2), (0, 1)),
+               3: ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))}
 
 
 def p1_basis(pts):
-    xi, eta = pts[:, 0], pts[:, 1]
-    phi = np.stack([1.0 - xi - eta, xi, eta], axis=1)            # [q, 3]
-    dphi = np.zeros((pts.shape[0], 3, 2))
-    dphi[:, 0, :] = (-1.0, -1.0)
-    dphi[:, 1, :] = (1.0, 0.0)
-    dphi[:, 2, :] = (0.0, 1.0)
+    dim = pts.shape[1]
+    lam0 = 1.0 - pts.sum(axis=1)
+    phi = np.concatenate([lam0[:, None], pts], axis=1)            # [q, dim+1]
+    dphi = np.zeros((pts.shape[0], dim + 1, dim))
+    dphi[:, 0, :] = -1.0
+    for a in range(dim):
+        dphi[:, a + 1, a] = 1.0
     return phi, dphi
 
 
 def p2_basis(pts):
+    dim = pts.shape[1]
     lam, dlam = p1_basis(pts)
     q = pts.shape[0]
-    phi = np.zeros((q, 6))
-    dphi = np.zeros((q, 6, 2))
-    for i in range(3):
+    pairs = _EDGE_PAIRS[dim]
+    phi = np.zeros((q, dim + 1 + len(pairs)))
+    dphi = np.zeros((q, dim + 1 + len(pairs), dim))
+    for i in range(dim + 1):
         phi[:, i] = lam[:, i] * (2.0 * lam[:, i] - 1.0)
         dphi[:, i, :] = (4.0 * lam[:, i] - 1.0)[:, None] * dlam[:, i, :]
-    pairs = ((1, 2), (0, 2), (0, 1))
     for e, (a, b) in enumerate(pairs):
-        phi[:, 3 + e] = 4.0 * lam[:, a] * lam[:, b]
-        dphi[:, 3 + e, :] = 4.0 * (lam[:, a, None] * dlam[:, b, :] + lam[:, b, None] * dlam[:, a, :])
+        phi[:, dim + 1 + e] = 4.0 * lam[:, a] * lam[:, b]
+        dphi[:, dim + 1 + e, :] = 4.0 * (lam[:, a, None] * dlam[:, b, :] + lam[:, b, None] * dlam[:, a, :])
     return phi, dphi
 
 
@@ -85,21 +100,15 @@ class Geometry:
     """Affine maps of all cells: detJ (absolute), J^{-T}."""
 
     def __init__(self, coords, cells):
-        x = np.asarray(coords, dtype=np.float64)[np.asarray(cells)]   # [c, 3, 2]
-        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)   # columns
-        det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
-        Jinv = np.empty_like(J)
-        Jinv[:, 0, 0] = J[:, 1, 1] / det
-        Jinv[:, 0, 1] = -J[:, 0, 1] / det
-        Jinv[:, 1, 0] = -J[:, 1, 0] / det
-        Jinv[:, 1, 1] = J[:, 0, 0] / det
+        x = np.asarray(coords, dtype=np.float64)[np.asarray(cells)]   # [c, dim+1, dim]
+        J = np.stack([x[:, k + 1] - x[:, 0] for k in range(x.shape[2])], axis=2)   # columns
         self.x = x
-        self.absdet = np.abs(det)
-        self.JinvT = np.transpose(Jinv, (0, 2, 1))
+        self.absdet = np.abs(np.linalg.det(J))
+        self.JinvT = np.transpose(np.linalg.inv(J), (0, 2, 1))
         self.n_cells = x.shape[0]
 
     def phys_grad(self, dphi):
-        """dphi [q, n, 2] (reference) -> [c, q, n, 2] (physical)."""
+        """dphi [q, n, dim] (reference) -> [c, q, n, dim] (physical)."""
         return np.einsum("cab,qnb->cqna", self.JinvT, dphi)
 
 
@@ -108,20 +117,21 @@ class Space:
 
     def __init__(self, coords, cells, p2_dofmap, p1_dofmap, quad_n=5):
         self.coords = np.asarray(coords, dtype=np.float64)
+        self.dim = dim = int(self.coords.shape[1])
         self.cells = np.asarray(cells, dtype=np.int64)
         self.p2 = np.asarray(p2_dofmap, dtype=np.int64)
         self.p1 = np.asarray(p1_dofmap, dtype=np.int64)
         self.n2 = int(self.p2.max()) + 1
         self.n1 = int(self.p1.max()) + 1
         self.geo = Geometry(self.coords, self.cells)
-        self.pts, self.wts = collapsed_gauss_rule(quad_n)
+        self.pts, self.wts = collapsed_gauss_rule(quad_n, dim)
         self.phi2, dphi2 = p2_basis(self.pts)
         self.phi1, dphi1 = p1_basis(self.pts)
         self.g2 = self.geo.phys_grad(dphi2)      # [c, q, 6, 2]
         self.g1 = self.geo.phys_grad(dphi1)      # [c, q, 3, 2]
         self.wdet = self.geo.absdet[:, None] * self.wts[None, :]   # [c, q]
-        # velocity (interleaved) cell dof map [c, 6, 2]
-        self.vdof = 2 * self.p2[:, :, None] + np.arange(2)[None, None, :]
+        # velocity (interleaved) cell dof map [c, n_loc, dim]
+        self.vdof = dim * self.p2[:, :, None] + np.arange(dim)[None, None, :]
 
     # -- helpers -----------------------------------------------------------
     def _coo(self, vals, rows, cols, shape):
@@ -132,20 +142,18 @@ class Space:
         return A
 
     def p2_nodes(self):
-        """Coordinates of the scalar P2 nodes [n2, 2] (vertices, edge midpoints)."""
-        out = np.zeros((self.n2, 2))
+        """Coordinates of the scalar P2 nodes [n2, dim] (vertices, edge midpoints)."""
+        out = np.zeros((self.n2, self.dim))
         x = self.geo.x
-        out[self.p2[:, 0]] = x[:, 0]
-        out[self.p2[:, 1]] = x[:, 1]
-        out[self.p2[:, 2]] = x[:, 2]
-        out[self.p2[:, 3]] = 0.5 * (x[:, 1] + x[:, 2])
-        out[self.p2[:, 4]] = 0.5 * (x[:, 0] + x[:, 2])
-        out[self.p2[:, 5]] = 0.5 * (x[:, 0] + x[:, 1])
+        for i in range(self.dim + 1):
+            out[self.p2[:, i]] = x[:, i]
+        for e, (a, b) in enumerate(_EDGE_PAIRS[self.dim]):
+            out[self.p2[:, self.dim + 1 + e]] = 0.5 * (x[:, a] + x[:, b])
         return out
 
     def p1_nodes(self):
-        out = np.zeros((self.n1, 2))
-        for i in range(3):
+        out = np.zeros((self.n1, self.dim))
+        for i in range(self.dim + 1):
             out[self.p1[:, i]] = self.geo.x[:, i]
         return out
 
@@ -169,19 +177,19 @@ class Space:
 
     def vector_mass(self):
         """(v, w) on the interleaved P2^2 space -- source/ns_ipcs_solver.py:183."""
-        return sp.kron(self.mass_p2(), sp.identity(2), format="csr")
+        return sp.kron(self.mass_p2(), sp.identity(self.dim), format="csr")
 
     def vector_stiffness(self, traction_form=False):
         """inner(grad u, grad v)  or  inner(grad u + grad u^T, sym grad v)
         -- source/ns_solver_base.py:669-673."""
-        K = sp.kron(self.stiffness_p2(), sp.identity(2), format="csr")
+        K = sp.kron(self.stiffness_p2(), sp.identity(self.dim), format="csr")
         if not traction_form:
             return K
         # extra term  sum_ab d_a u_b d_b v_a  ->  rows (i,a) cols (j,b): int d_b phi_i d_a phi_j
         Ke = np.einsum("cq,cqib,cqja->ciajb", self.wdet, self.g2, self.g2)
         rows = self.vdof[:, :, :, None, None]
         cols = self.vdof[:, None, None, :, :]
-        E = self._coo(Ke, rows, cols, (2 * self.n2, 2 * self.n2))
+        E = self._coo(Ke, rows, cols, (self.dim * self.n2, self.dim * self.n2))
         return (K + E).tocsr()
 
     def divergence(self):
@@ -189,14 +197,14 @@ class Space:
         De = np.einsum("cq,qi,cqja->cija", self.wdet, self.phi1, self.g2)
         rows = self.p1[:, :, None, None]
         cols = self.vdof[:, None, :, :]
-        return self._coo(De, rows, cols, (self.n1, 2 * self.n2))
+        return self._coo(De, rows, cols, (self.n1, self.dim * self.n2))
 
     def pressure_gradient(self):
         """G[(i,a), j] = int phi_i d_a psi_j   (grad p, w): source/ns_ipcs_solver.py:185."""
         Ge = np.einsum("cq,qi,cqja->ciaj", self.wdet, self.phi2, self.g1)
         rows = self.vdof[:, :, :, None]
         cols = self.p1[:, None, None, :]
-        return self._coo(Ge, rows, cols, (2 * self.n2, self.n1))
+        return self._coo(Ge, rows, cols, (self.dim * self.n2, self.n1))
 
     # -- solution dependent terms -------------------------------------------
     def _u_at_q(self, u):
@@ -213,11 +221,13 @@ class Space:
             f = adv
             be = np.einsum("cq,cqa,qi->cia", self.wdet, f, self.phi2)
         elif form == "rotational":
+            if self.dim != 2:
+                raise NotImplementedError("rotational form: 2D only")
             curl = gu[:, :, 1, 0] - gu[:, :, 0, 1]
             f = np.stack([-curl * uq[:, :, 1], curl * uq[:, :, 0]], axis=2)
             be = np.einsum("cq,cqa,qi->cia", self.wdet, f, self.phi2)
         elif form == "divergence":
-            div = gu[:, :, 0, 0] + gu[:, :, 1, 1]
+            div = np.einsum("cqaa->cq", gu)
             f = adv + 0.5 * div[:, :, None] * uq
             be = np.einsum("cq,cqa,qi->cia", self.wdet, f, self.phi2)
         elif form == "skew_symmetric":
@@ -226,7 +236,7 @@ class Space:
             be -= 0.5 * np.einsum("cq,cqib,cqb,cqa->cia", self.wdet, self.g2, uq, uq)
         else:
             raise ValueError(form)
-        b = np.zeros(2 * self.n2)
+        b = np.zeros(self.dim * self.n2)
         np.add.at(b, self.vdof.ravel(), be.ravel())
         return b
 
@@ -234,7 +244,7 @@ class Space:
         """d/du of convection_residual (exact Gateaux derivative = dlfn.derivative)."""
         uq, gu = self._u_at_q(u)
         w, phi, g = self.wdet, self.phi2, self.g2
-        d = np.eye(2)
+        d = np.eye(self.dim)
         # building blocks: test (i,a), trial (j,b)
         # T1 = phi_i (u . grad phi_j) delta_ab ; T2 = phi_i phi_j d_b u_a
         udg = np.einsum("cqb,cqjb->cqj", uq, g)             # u . grad phi_j
@@ -243,7 +253,7 @@ class Space:
         if form == "standard":
             Je = T1 + T2
         elif form == "divergence":
-            div = gu[:, :, 0, 0] + gu[:, :, 1, 1]
+            div = np.einsum("cqaa->cq", gu)
             # + 1/2 [ d_b phi_j u_a + div(u) phi_j delta_ab ] phi_i
             T3 = 0.5 * np.einsum("cq,qi,cqjb,cqa->ciajb", w, phi, g, uq)
             T4 = 0.5 * np.einsum("cq,qi,qj,cq,ab->ciajb", w, phi, phi, div, d)
@@ -269,7 +279,7 @@ class Space:
             raise ValueError(form)
         rows = self.vdof[:, :, :, None, None]
         cols = self.vdof[:, None, None, :, :]
-        return self._coo(Je, rows, cols, (2 * self.n2, 2 * self.n2))
+        return self._coo(Je, rows, cols, (self.dim * self.n2, self.dim * self.n2))
 
     def picard_convection(self, u, form="standard"):
         """(grad v) u . w  linearisation -- source/ns_solver_base.py:478-499 (standard only)."""
@@ -277,10 +287,10 @@ class Space:
             raise NotImplementedError(form)
         uq, _ = self._u_at_q(u)
         udg = np.einsum("cqb,cqjb->cqj", uq, self.g2)
-        T1 = np.einsum("cq,qi,cqj,ab->ciajb", self.wdet, self.phi2, udg, np.eye(2))
+        T1 = np.einsum("cq,qi,cqj,ab->ciajb", self.wdet, self.phi2, udg, np.eye(self.dim))
         rows = self.vdof[:, :, :, None, None]
         cols = self.vdof[:, None, None, :, :]
-        return self._coo(T1, rows, cols, (2 * self.n2, 2 * self.n2))
+        return self._coo(T1, rows, cols, (self.dim * self.n2, self.dim * self.n2))
 
     # -- boundary integrals ---------------------------------------------------
     def traction_vector(self, facets, traction_nodal):
@@ -295,7 +305,7 @@ class Space:
         # 1D P2 mass matrix on an edge (end, end, mid), Simpson-exact
         M1 = np.array([[4.0, -1.0, 2.0], [-1.0, 4.0, 2.0], [2.0, 2.0, 16.0]]) / 30.0
         be = np.einsum("f,ij,fja->fia", length, M1, traction_nodal)
-        b = np.zeros(2 * self.n2)
+        b = np.zeros(self.dim * self.n2)
         idx = 2 * facets[:, :, None] + np.arange(2)[None, None, :]
         np.add.at(b, idx.ravel(), be.ravel())
         return b
@@ -424,8 +434,8 @@ class IPCSOracle:
         self.Ap = s.stiffness_p1()
         self.traction_form = traction_form
         n2, n1 = s.n2, s.n1
-        self.vel = [np.zeros(2 * n2) for _ in range(3)]       # _velocities[0..2]
-        self.ustar = np.zeros(2 * n2)                         # _intermediate_velocity
+        self.vel = [np.zeros(s.dim * n2) for _ in range(3)]       # _velocities[0..2]
+        self.ustar = np.zeros(s.dim * n2)                         # _intermediate_velocity
         self.p = np.zeros(n1)
         self.p_old = np.zeros(n1)
         self.body_force = None        # nodal P2 values, interleaved
@@ -513,7 +523,7 @@ class BDFOracle:
         self.M = s.vector_mass()
         self.K = s.vector_stiffness(traction_form)
         self.D = s.divergence()
-        self.nv = 2 * s.n2
+        self.nv = s.dim * s.n2
         self.n = self.nv + s.n1
         self.sol = [np.zeros(self.n) for _ in range(3)]      # _solutions[0..2]
         self.body_force = None

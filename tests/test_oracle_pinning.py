@@ -227,3 +227,87 @@ def test_cfl_number_closed_form():
     s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
     u = np.tile([0.6, 0.8], dm.n_p2)
     assert abs(fo.cfl_number(s, u, 0.1) - 2.0 * 0.1 / (np.sqrt(2.0) / 4)) < 1e-13
+
+
+# ---------------------------------------------------------------- 3D (tetrahedra)
+def make_space3(n, p1=(1.0, 1.0, 1.0)):
+    from fem_mesh import box_mesh
+    mesh = box_mesh((0.0, 0.0, 0.0), p1, n[0], n[1], n[2])
+    dm = TaylorHoodDofMap(mesh)
+    return mesh, dm, fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+
+
+def test_k5_reference_tetrahedron_matrices_exact():
+    """P2 / P1 Lagrange on the reference tetrahedron (UFC local order) against sympy-exact
+    integrals: mass, stiffness, divergence and one convection vector."""
+    x, y, z = sy.symbols("x y z")
+    l = [1 - x - y - z, x, y, z]
+    pairs = ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+    N = [l[i] * (2 * l[i] - 1) for i in range(4)] + [4 * l[a] * l[b] for a, b in pairs]
+
+    def integ(e):
+        return sy.integrate(sy.integrate(sy.integrate(e, (z, 0, 1 - x - y)), (y, 0, 1 - x)), (x, 0, 1))
+
+    coords = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    s = fo.Space(coords, np.array([[0, 1, 2, 3]]), np.arange(10)[None, :], np.arange(4)[None, :])
+    M = np.array([[float(integ(N[i] * N[j])) for j in range(10)] for i in range(10)])
+    np.testing.assert_allclose(s.mass_p2().toarray(), M, rtol=0, atol=1e-16)
+    K = np.array([[float(integ(sum(sy.diff(N[i], v) * sy.diff(N[j], v) for v in (x, y, z))))
+                   for j in range(10)] for i in range(10)])
+    np.testing.assert_allclose(s.stiffness_p2().toarray(), K, rtol=0, atol=2e-15)
+    D = s.divergence().toarray()
+    for i in range(4):
+        for j in (0, 3, 5, 9):
+            for a, var in enumerate((x, y, z)):
+                assert abs(D[i, 3 * j + a] - float(integ(l[i] * sy.diff(N[j], var)))) < 1e-15
+    rng = np.random.default_rng(7)
+    u = rng.integers(-2, 3, size=30).astype(float)
+    comp = [sum(sy.Rational(int(u[3 * k + a])) * N[k] for k in range(10)) for a in range(3)]
+    adv = [sum(sy.diff(comp[a], v) * comp[b] for b, v in enumerate((x, y, z))) for a in range(3)]
+    exact = np.array([float(integ(adv[a] * N[i])) for i in (0, 4, 9) for a in range(3)])
+    got = s.convection_residual(u).reshape(10, 3)[[0, 4, 9]].ravel()
+    np.testing.assert_allclose(got, exact, rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("form", ["standard", "divergence", "skew_symmetric"])
+def test_k7_3d_jacobian_and_structure(form):
+    mesh, dm, s = make_space3((2, 3, 2), p1=(1.0, 1.5, 0.8))
+    assert dm.n_p2 == 5 * 7 * 5 and dm.n_p1 == 3 * 4 * 3
+    rng = np.random.default_rng(0)
+    u, d = rng.standard_normal(3 * s.n2), rng.standard_normal(3 * s.n2)
+    eps = 1e-6
+    fd = (s.convection_residual(u + eps * d, form) - s.convection_residual(u - eps * d, form)) / (2 * eps)
+    assert np.linalg.norm(s.convection_jacobian(u, form) @ d - fd) <= 1e-8 * np.linalg.norm(fd)
+    vol = 1.0 * 1.5 * 0.8
+    assert abs(s.mass_p2().sum() - vol) < 1e-13 and abs(s.mass_p1().sum() - vol) < 1e-13
+    assert np.abs(s.stiffness_p2() @ np.ones(s.n2)).max() < 1e-12
+    X = s.p2_nodes()
+    assert np.abs(X - dm.p2_coords).max() < 1e-14
+    A = np.array([[0.3, 0.1, -0.2], [0.0, 0.5, 0.4], [0.7, -0.3, 0.2]])
+    ulin = (X @ A.T).ravel()
+    assert abs((s.divergence() @ ulin).sum() - vol * np.trace(A)) < 1e-12
+    if form == "skew_symmetric":
+        assert abs(u @ s.convection_residual(u, form)) < 1e-10 * (u @ u)
+
+
+def test_k1_3d_duct_stokes_polynomial_solution_is_reproduced():
+    """Stokes flow with the quadratic velocity u = (y(1-y) + z(1-z), 0, 0), p = -4 c_v x (+c):
+    -c_v lap u + grad p = (4 c_v, 0, 0) - (4 c_v, 0, 0) = 0.  u is in P2, p in P1, so one
+    stationary BDF step (alpha = 0) with u prescribed on the whole boundary reproduces it to
+    round-off on a Kuhn mesh."""
+    mesh, dm, s = make_space3((2, 2, 2))
+    cv = 0.37
+    coef = dict(convective_term=0.0, pressure_term=1.0, viscous_term=cv, body_force_term=None)
+    orc = fo.BDFOracle(s, coef, pin_pressure=True)
+    X = dm.p2_coords
+    exact = np.stack([X[:, 1] * (1 - X[:, 1]) + X[:, 2] * (1 - X[:, 2]), 0 * X[:, 0], 0 * X[:, 0]], axis=1)
+    marks = FacetMarkers(mesh)
+    marks.mark(lambda Y: np.ones(Y.shape[0], bool), 1)
+    nodes = np.unique(dm.facet_p2_nodes(marks.facets_with_id(1)))
+    dofs = (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()
+    orc.step((0.0, 0.0, 0.0), 1.0, (dofs, exact[nodes].ravel()))
+    nv = 3 * dm.n_p2
+    assert np.abs(orc.sol[0][:nv] - exact.ravel()).max() < 1e-12
+    p = orc.sol[0][nv:]
+    pex = -4.0 * cv * dm.p1_coords[:, 0]
+    assert np.abs((p - p[0]) - (pex - pex[0])).max() < 1e-10

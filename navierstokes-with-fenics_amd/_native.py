@@ -224,16 +224,19 @@ class NsfemContext:
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         p2 = np.ascontiguousarray(p2_dofmap, dtype=np.int32)
         p1 = np.ascontiguousarray(p1_dofmap, dtype=np.int32)
-        assert coords.ndim == 2 and coords.shape[1] == 2
-        assert cells.shape == (p2.shape[0], 3) and p2.shape[1] == 6 and p1.shape == cells.shape
-        desc = MeshDesc(2, cells.shape[0], coords.shape[0], int(n_p2), int(n_p1),
+        assert coords.ndim == 2 and coords.shape[1] in (2, 3)
+        dim = int(coords.shape[1])                        # 2: triangles, 3: tetrahedra
+        assert cells.shape == (p2.shape[0], dim + 1) and p1.shape == cells.shape
+        assert p2.shape[1] == (6 if dim == 2 else 10)
+        self.dim = dim
+        desc = MeshDesc(dim, cells.shape[0], coords.shape[0], int(n_p2), int(n_p1),
                         _dp(coords), _ip(cells), _ip(p2), _ip(p1))
         rc = self._lib.nsfem_create(C.byref(desc), int(device), C.byref(self._h))
         if rc != OK:
             msg = self._lib.nsfem_last_error(None)
             raise NativeError(rc, msg.decode() if msg else "nsfem_create failed")
         self.n_p2, self.n_p1 = int(n_p2), int(n_p1)
-        self.n_velocity = 2 * self.n_p2
+        self.n_velocity = dim * self.n_p2
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -29,7 +29,7 @@ static std::string g_create_error;
   }                                                   \
   return NSFEM_OK;
 
-static inline int64_t nvel(const nsfem_ctx* c) { return 2 * (int64_t)c->mesh.n_p2; }
+static inline int64_t nvel(const nsfem_ctx* c) { return (int64_t)c->mesh.dim * c->mesh.n_p2; }
 static inline int64_t npre(const nsfem_ctx* c) { return (int64_t)c->mesh.n_p1; }
 
 static int64_t slot_size(const nsfem_ctx* c, int slot) {
@@ -90,7 +90,7 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   API_BEGIN
   NSFEM_REQUIRE(m && out, "null argument");
   *out = nullptr;
-  NSFEM_REQUIRE(m->dim == 2, "only 2D triangle meshes are supported");
+  NSFEM_REQUIRE(m->dim == 2 || m->dim == 3, "dim must be 2 (triangles) or 3 (tetrahedra)");
   NSFEM_REQUIRE(m->n_cells > 0 && m->n_vertices > 0 && m->n_p2 > 0 && m->n_p1 > 0, "empty mesh");
   NSFEM_REQUIRE(m->coords && m->cells && m->p2_dofmap && m->p1_dofmap, "null mesh array");
   int ndev = 0;
@@ -103,31 +103,43 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   hipStream_t s = fresh->stream;
   const int nc = m->n_cells;
   // ---- mesh arrays, SoA
+  const int dim = m->dim;
+  NSFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 (triangles) or 3 (tetrahedra)");
+  const int nl1 = dim + 1, nl2 = dim == 2 ? 6 : 10;
   {
-    std::vector<double> vx((size_t)6 * nc);
-    std::vector<int32_t> p2((size_t)6 * nc), p1((size_t)3 * nc);
+    std::vector<double> vx((size_t)nl1 * dim * nc);
+    std::vector<int32_t> p2((size_t)nl2 * nc), p1((size_t)nl1 * nc);
     double area = 0.0;
     for (int c = 0; c < nc; ++c) {
-      double xy[3][2];
-      for (int v = 0; v < 3; ++v) {
-        const int vid = m->cells[(size_t)c * 3 + v];
+      double x[4][3] = {{0}};
+      for (int v = 0; v < nl1; ++v) {
+        const int vid = m->cells[(size_t)c * nl1 + v];
         NSFEM_REQUIRE(vid >= 0 && vid < m->n_vertices, "cell vertex id out of range");
-        for (int d = 0; d < 2; ++d) {
-          xy[v][d] = m->coords[(size_t)vid * 2 + d];
-          vx[(size_t)(2 * v + d) * nc + c] = xy[v][d];
+        for (int d = 0; d < dim; ++d) {
+          x[v][d] = m->coords[(size_t)vid * dim + d];
+          vx[(size_t)(dim * v + d) * nc + c] = x[v][d];
         }
       }
-      const double det = (xy[1][0] - xy[0][0]) * (xy[2][1] - xy[0][1]) -
-                         (xy[2][0] - xy[0][0]) * (xy[1][1] - xy[0][1]);
+      double det;
+      if (dim == 2) {
+        det = (x[1][0] - x[0][0]) * (x[2][1] - x[0][1]) - (x[2][0] - x[0][0]) * (x[1][1] - x[0][1]);
+        area += 0.5 * std::fabs(det);
+      } else {
+        double a[3], b[3], e[3];
+        for (int d = 0; d < 3; ++d) { a[d] = x[1][d] - x[0][d]; b[d] = x[2][d] - x[0][d]; e[d] = x[3][d] - x[0][d]; }
+        det = a[0] * (b[1] * e[2] - b[2] * e[1]) - a[1] * (b[0] * e[2] - b[2] * e[0]) +
+              a[2] * (b[0] * e[1] - b[1] * e[0]);
+        area += std::fabs(det) / 6.0;
+      }
       NSFEM_REQUIRE(det != 0.0, "degenerate cell");
-      area += 0.5 * std::fabs(det);
-      for (int k = 0; k < 6; ++k) p2[(size_t)k * nc + c] = m->p2_dofmap[(size_t)c * 6 + k];
-      for (int k = 0; k < 3; ++k) p1[(size_t)k * nc + c] = m->p1_dofmap[(size_t)c * 3 + k];
+      for (int k = 0; k < nl2; ++k) p2[(size_t)k * nc + c] = m->p2_dofmap[(size_t)c * nl2 + k];
+      for (int k = 0; k < nl1; ++k) p1[(size_t)k * nc + c] = m->p1_dofmap[(size_t)c * nl1 + k];
     }
     fresh->area = area;
-    fresh->h_p2map.assign(m->p2_dofmap, m->p2_dofmap + (size_t)6 * nc);
-    fresh->h_p1map.assign(m->p1_dofmap, m->p1_dofmap + (size_t)3 * nc);
+    fresh->h_p2map.assign(m->p2_dofmap, m->p2_dofmap + (size_t)nl2 * nc);
+    fresh->h_p1map.assign(m->p1_dofmap, m->p1_dofmap + (size_t)nl1 * nc);
     fresh->mom_prec.c = fresh;
+    fresh->mesh.dim = dim;
     fresh->mesh.n_cells = nc;
     fresh->mesh.n_p2 = m->n_p2;
     fresh->mesh.n_p1 = m->n_p1;
@@ -139,37 +151,38 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   // ---- sparsity patterns + slot maps (host), then device copies
   {
     HostPattern h;
-    build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, 6, m->p2_dofmap, 6, true, h);
+    build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, nl2, m->p2_dofmap, nl2, true, h);
     upload_pattern(s, h, fresh->p22, true);
     {
       std::vector<int32_t> ptr, idx;
-      build_inverse_index(m->n_p2, (int64_t)nc * 6,
+      build_inverse_index(m->n_p2, (int64_t)nc * nl2,
                           [&](int64_t src) { return m->p2_dofmap[src]; }, ptr, idx);
       fresh->mesh.nptr.upload(ptr, s);
       fresh->mesh.nidx.upload(idx, s);
-      fresh->mesh.ebuf.alloc((size_t)nc * 144);
-      fresh->mesh.rbuf.alloc((size_t)nc * 12);
+      fresh->mesh.ebuf.alloc((size_t)nc * nl2 * nl2 * dim * dim);
+      fresh->mesh.rbuf.alloc((size_t)nc * nl2 * dim);
     }
-    build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, 3, m->p1_dofmap, 3, true, h);
+    build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, nl1, m->p1_dofmap, nl1, true, h);
     upload_pattern(s, h, fresh->p11, true);
-    build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, 3, m->p2_dofmap, 6, false, h);
+    build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, nl1, m->p2_dofmap, nl2, false, h);
     upload_pattern(s, h, fresh->p12, true);
-    build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, 6, m->p1_dofmap, 3, false, h);
+    build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, nl2, m->p1_dofmap, nl1, false, h);
     upload_pattern(s, h, fresh->p21, true);
   }
   // ---- constant operators, integrated on the device
   QuadTables qt;
   fill_quad_tables(qt);
   upload_quad_tables(qt);
+  if (dim == 3) upload_quad_tables_3d();
   fresh->M2.init(&fresh->p22, 1, 1, s);
   fresh->K2.init(&fresh->p22, 1, 1, s);
   fresh->L.init(&fresh->p22, 1, 1, s);
-  fresh->J.init(&fresh->p22, 2, 2, s);
+  fresh->J.init(&fresh->p22, dim, dim, s);
   fresh->Ap.init(&fresh->p11, 1, 1, s);
   fresh->Mp.init(&fresh->p11, 1, 1, s);
-  fresh->Dv.init(&fresh->p12, 1, 2, s);
-  fresh->Gr.init(&fresh->p21, 2, 1, s);
-  fresh->DT.init(&fresh->p21, 2, 1, s);
+  fresh->Dv.init(&fresh->p12, 1, dim, s);
+  fresh->Gr.init(&fresh->p21, dim, 1, s);
+  fresh->DT.init(&fresh->p21, dim, 1, s);
   launch_assemble_p2_scalar(s, fresh->mesh, fresh->p22, fresh->M2.vals.p, fresh->K2.vals.p);
   launch_assemble_p1_scalar(s, fresh->mesh, fresh->p11, fresh->Ap.vals.p, fresh->Mp.vals.p);
   launch_assemble_div_grad(s, fresh->mesh, fresh->p12, fresh->p21, fresh->Dv.vals.p,
@@ -440,6 +453,7 @@ static double cc_of(const nsfem_ctx* c) { return std::isfinite(c->coef[0]) ? c->
 // Coriolis factor 2 c_cor omega (source/ns_solver_base.py:173-191, 2D branch)
 static double coriolis_gamma(const nsfem_ctx* c) {
   if (c->omega == 0.0) return 0.0;
+  if (c->mesh.dim != 2) throw Error(NSFEM_ERR_ARG, "rotating frames are built for 2D meshes only");
   if (!std::isfinite(c->coef[4])) throw Error(NSFEM_ERR_ARG, "angular velocity set but coriolis_term coefficient is None");
   return 2.0 * c->coef[4] * c->omega;
 }
@@ -458,6 +472,8 @@ static void momentum_begin_step(nsfem_ctx* c, bool with_old_pressure = true) {
   } else {
     launch_axpby(s, nv, a1, c->state[NSFEM_U1].p, a2, c->state[NSFEM_U2].p, c->tmp_v.p);
   }
+  if (c->omega_dot != 0.0 && c->mesh.dim != 2)
+    throw Error(NSFEM_ERR_ARG, "rotating frames are built for 2D meshes only");
   if (c->omega_dot != 0.0) {      // Euler acceleration  c_e (d omega/dt) e_z x x  (ns_solver_base.py:193-211)
     NSFEM_REQUIRE(std::isfinite(c->coef[5]), "angular acceleration set but euler_term coefficient is None");
     if (!c->rot_field.p) {
@@ -466,7 +482,7 @@ static void momentum_begin_step(nsfem_ctx* c, bool with_old_pressure = true) {
     }
     launch_axpby(s, nv, 1.0, c->tmp_v.p, c->coef[5] * c->omega_dot, c->rot_field.p, c->tmp_v.p);
   }
-  launch_spmv(s, c->M2, 2, c->tmp_v.p, c->gconst.p, nullptr, MASK_NONE);
+  launch_spmv(s, c->M2, c->mesh.dim, c->tmp_v.p, c->gconst.p, nullptr, MASK_NONE);
   if (with_old_pressure)   // IPCS: - c_p (p_old, div w); the monolithic scheme keeps p unknown
     launch_spmv_axpy(s, c->DT, 1, -c->coef[1], c->state[NSFEM_P_OLD].p, c->gconst.p, nullptr);
   if (c->have_traction)
@@ -497,7 +513,7 @@ static void fill_linop(nsfem_ctx* c, LinOp& op, bool velocity) {
 static void momentum_residual_raw(nsfem_ctx* c, const double* u, double* out) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c);
-  launch_spmv(s, c->L, 2, u, out, nullptr, MASK_NONE);
+  launch_spmv(s, c->L, c->mesh.dim, u, out, nullptr, MASK_NONE);
   launch_axpby(s, nv, 1.0, out, 1.0, c->gconst.p, out);
   if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], u, out, nullptr);
   const double cc = cc_of(c);
@@ -527,7 +543,8 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
     launch_convection_jacobian(s, c->mesh, c->p22, c->state[vel_slot].p, cc, c->L.vals.p, E,
                                c->coef[2], c->J.vals.p, c->conv_form, c->picard);
   else
-    launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
+    if (c->mesh.dim == 3) jacobian_init_3d(s, c->p22.nnz, c->L.vals.p, c->J.vals.p);
+    else launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
   const double g = coriolis_gamma(c);
   if (g != 0.0) launch_jac_add_skew(s, c->p22.nnz, g, c->M2.vals.p, c->J.vals.p);
   launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
@@ -595,7 +612,7 @@ static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_i
 static void correction_assemble(nsfem_ctx* c) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c), np = npre(c);
-  launch_spmv(s, c->M2, 2, c->state[NSFEM_USTAR].p, c->rhs_v.p, nullptr, MASK_NONE);
+  launch_spmv(s, c->M2, c->mesh.dim, c->state[NSFEM_USTAR].p, c->rhs_v.p, nullptr, MASK_NONE);
   launch_axpby(s, np, 1.0, c->state[NSFEM_P].p, -1.0, c->state[NSFEM_P_OLD].p, c->tmp_p.p);
   launch_spmv(s, c->Gr, 1, c->tmp_p.p, c->tmp_v.p, nullptr, MASK_NONE);
   launch_axpby(s, nv, 1.0, c->rhs_v.p, -c->k / c->alpha[0], c->tmp_v.p, c->rhs_v.p);
@@ -604,7 +621,7 @@ static void correction_assemble(nsfem_ctx* c) {
                            hipMemcpyDeviceToDevice, s));
   launch_set_values(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, c->state[NSFEM_U0].p);
   if (!c->dinv_m_ready) {
-    launch_inv_diag(s, c->M2, 2, c->mask_v.p, c->dinv_m.p);
+    launch_inv_diag(s, c->M2, c->mesh.dim, c->mask_v.p, c->dinv_m.p);
     c->dinv_m_ready = true;
   }
 }
@@ -612,7 +629,7 @@ static void correction_assemble(nsfem_ctx* c) {
 static int correction_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
   LinOp op;
   op.A = &c->M2;
-  op.nv = 2;
+  op.nv = c->mesh.dim;
   op.rowmask = c->mask_v.p;
   op.maskmode = MASK_ZERO;
   op.dinv = c->dinv_m.p;
@@ -685,6 +702,36 @@ extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* 
   API_END(ctx)
 }
 
+// mesh arrays, pattern and the P1 stiffness / mass matrices of one coarse level (same space
+// dimension as the fine mesh)
+static void fill_p1_level(nsfem_ctx* ctx, nsfem_ctx::P1Level* lv, int n_vertices, int nc,
+                          const double* coords, const int32_t* cells) {
+  hipStream_t s = ctx->stream;
+  const int dim = ctx->mesh.dim, nl1 = dim + 1;
+  lv->n = n_vertices;
+  std::vector<double> vx((size_t)nl1 * dim * nc);
+  std::vector<int32_t> p1((size_t)nl1 * nc);
+  for (int c = 0; c < nc; ++c)
+    for (int v = 0; v < nl1; ++v) {
+      const int vid = cells[(size_t)c * nl1 + v];
+      NSFEM_REQUIRE(vid >= 0 && vid < n_vertices, "coarse cell vertex id out of range");
+      p1[(size_t)v * nc + c] = vid;
+      for (int k = 0; k < dim; ++k) vx[(size_t)(dim * v + k) * nc + c] = coords[(size_t)vid * dim + k];
+    }
+  lv->mesh.dim = dim;
+  lv->mesh.n_cells = nc;
+  lv->mesh.n_p1 = lv->mesh.n_vertices = n_vertices;
+  lv->mesh.vx.upload(vx, s);
+  lv->mesh.p1.upload(p1, s);
+  HostPattern h;
+  build_pattern(n_vertices, n_vertices, nc, cells, nl1, cells, nl1, true, h);
+  upload_pattern(s, h, lv->pat, true);
+  lv->K.init(&lv->pat, 1, 1, s);
+  lv->M.init(&lv->pat, 1, 1, s);
+  lv->Lc.init(&lv->pat, 1, 1, s);
+  launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+}
+
 extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) {
   API_BEGIN
   NSFEM_REQUIRE(ctx && d, "null argument");
@@ -696,28 +743,7 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
   hipStream_t s = ctx->stream;
   nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
   ctx->coarse.push_back(lv);
-  const int nc = d->n_cells;
-  lv->n = d->n_vertices;
-  std::vector<double> vx((size_t)6 * nc);
-  std::vector<int32_t> p1((size_t)3 * nc);
-  for (int c = 0; c < nc; ++c)
-    for (int v = 0; v < 3; ++v) {
-      const int vid = d->cells[(size_t)c * 3 + v];
-      NSFEM_REQUIRE(vid >= 0 && vid < d->n_vertices, "coarse cell vertex id out of range");
-      p1[(size_t)v * nc + c] = vid;
-      for (int k = 0; k < 2; ++k) vx[(size_t)(2 * v + k) * nc + c] = d->coords[(size_t)vid * 2 + k];
-    }
-  lv->mesh.n_cells = nc;
-  lv->mesh.n_p1 = lv->mesh.n_vertices = d->n_vertices;
-  lv->mesh.vx.upload(vx, s);
-  lv->mesh.p1.upload(p1, s);
-  HostPattern h;
-  build_pattern(d->n_vertices, d->n_vertices, nc, d->cells, 3, d->cells, 3, true, h);
-  upload_pattern(s, h, lv->pat, true);
-  lv->K.init(&lv->pat, 1, 1, s);
-  lv->M.init(&lv->pat, 1, 1, s);
-  lv->Lc.init(&lv->pat, 1, 1, s);
-  launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+  fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells);
   lv->to_finer.build(s, n_fine, d->n_vertices, d->p_rowptr, d->p_col, d->p_val);
   if (d->ghost) {
     lv->h_ghost.assign(d->ghost, d->ghost + d->n_vertices);
@@ -783,27 +809,7 @@ extern "C" int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, in
   hipStream_t s = ctx->stream;
   delete ctx->global_coarse;
   nsfem_ctx::P1Level* lv = ctx->global_coarse = new nsfem_ctx::P1Level();
-  lv->n = n_vertices;
-  std::vector<double> vx((size_t)6 * n_cells);
-  std::vector<int32_t> p1((size_t)3 * n_cells);
-  for (int c = 0; c < n_cells; ++c)
-    for (int v = 0; v < 3; ++v) {
-      const int vid = cells[(size_t)c * 3 + v];
-      NSFEM_REQUIRE(vid >= 0 && vid < n_vertices, "coarse cell vertex id out of range");
-      p1[(size_t)v * n_cells + c] = vid;
-      for (int k = 0; k < 2; ++k) vx[(size_t)(2 * v + k) * n_cells + c] = coords[(size_t)vid * 2 + k];
-    }
-  lv->mesh.n_cells = n_cells;
-  lv->mesh.n_p1 = lv->mesh.n_vertices = n_vertices;
-  lv->mesh.vx.upload(vx, s);
-  lv->mesh.p1.upload(p1, s);
-  HostPattern h;
-  build_pattern(n_vertices, n_vertices, n_cells, cells, 3, cells, 3, true, h);
-  upload_pattern(s, h, lv->pat, true);
-  lv->K.init(&lv->pat, 1, 1, s);
-  lv->M.init(&lv->pat, 1, 1, s);
-  lv->Lc.init(&lv->pat, 1, 1, s);
-  launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+  fill_p1_level(ctx, lv, n_vertices, n_cells, coords, cells);
   ctx->glob_off = offset;
   NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
@@ -823,28 +829,7 @@ extern "C" int nsfem_mg_add_global_level(nsfem_ctx* ctx, const nsfem_mg_level_de
   hipStream_t s = ctx->stream;
   nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
   ctx->global_tail.push_back(lv);
-  const int nc = d->n_cells;
-  lv->n = d->n_vertices;
-  std::vector<double> vx((size_t)6 * nc);
-  std::vector<int32_t> p1((size_t)3 * nc);
-  for (int c = 0; c < nc; ++c)
-    for (int v = 0; v < 3; ++v) {
-      const int vid = d->cells[(size_t)c * 3 + v];
-      NSFEM_REQUIRE(vid >= 0 && vid < d->n_vertices, "coarse cell vertex id out of range");
-      p1[(size_t)v * nc + c] = vid;
-      for (int k = 0; k < 2; ++k) vx[(size_t)(2 * v + k) * nc + c] = d->coords[(size_t)vid * 2 + k];
-    }
-  lv->mesh.n_cells = nc;
-  lv->mesh.n_p1 = lv->mesh.n_vertices = d->n_vertices;
-  lv->mesh.vx.upload(vx, s);
-  lv->mesh.p1.upload(p1, s);
-  HostPattern h;
-  build_pattern(d->n_vertices, d->n_vertices, nc, d->cells, 3, d->cells, 3, true, h);
-  upload_pattern(s, h, lv->pat, true);
-  lv->K.init(&lv->pat, 1, 1, s);
-  lv->M.init(&lv->pat, 1, 1, s);
-  lv->Lc.init(&lv->pat, 1, 1, s);
-  launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+  fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells);
   lv->to_finer.build(s, n_fine, d->n_vertices, d->p_rowptr, d->p_col, d->p_val);
   NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
@@ -868,7 +853,7 @@ extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d
   ctx->n_p2_global = d->n_p2_global;
   ctx->n_p1_global = d->n_p1_global;
   // masks carry the ghost flag from now on
-  launch_overlay_ghost(s, 2 * (int64_t)n2, ctx->ghost_v.p, ctx->mask_v.p);
+  launch_overlay_ghost(s, nvel(ctx), ctx->ghost_v.p, ctx->mask_v.p);
   launch_overlay_ghost(s, n1, ctx->ghost_p.p, ctx->mask_p.p);
   ctx->dinv_m_ready = ctx->dinv_p_ready = false;
   NSFEM_HIP(hipStreamSynchronize(s));
@@ -948,14 +933,17 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
   {
     const int n2 = ctx->mesh.n_p2, nc = ctx->mesh.n_cells;
     std::vector<int32_t> a((size_t)n2, -1), b((size_t)n2, -1);
-    const int ends[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+    const int dim = ctx->mesh.dim, nl1 = dim + 1, nl2 = dim == 2 ? 6 : 10;
+    const int ends2[3][2] = {{1, 2}, {0, 2}, {0, 1}};                               // UFC edges
+    const int ends3[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
     for (int c = 0; c < nc; ++c) {
-      const int32_t* p2 = &ctx->h_p2map[(size_t)c * 6];
-      const int32_t* p1 = &ctx->h_p1map[(size_t)c * 3];
-      for (int v = 0; v < 3; ++v) { a[p2[v]] = p1[v]; b[p2[v]] = -1; }
-      for (int e = 0; e < 3; ++e) {
-        a[p2[3 + e]] = std::min(p1[ends[e][0]], p1[ends[e][1]]);
-        b[p2[3 + e]] = std::max(p1[ends[e][0]], p1[ends[e][1]]);
+      const int32_t* p2 = &ctx->h_p2map[(size_t)c * nl2];
+      const int32_t* p1 = &ctx->h_p1map[(size_t)c * nl1];
+      for (int v = 0; v < nl1; ++v) { a[p2[v]] = p1[v]; b[p2[v]] = -1; }
+      for (int e = 0; e < nl2 - nl1; ++e) {
+        const int e0 = dim == 2 ? ends2[e][0] : ends3[e][0], e1 = dim == 2 ? ends2[e][1] : ends3[e][1];
+        a[p2[nl1 + e]] = std::min(p1[e0], p1[e1]);
+        b[p2[nl1 + e]] = std::max(p1[e0], p1[e1]);
       }
     }
     std::vector<int32_t> rp((size_t)n2 + 1, 0), col;
@@ -990,7 +978,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
   // momentum hierarchy: P2 fine -> P1 fine -> coarse P1 levels, operator a M + b K
   {
     Multigrid& mg = ctx->mg_v;
-    mg.nv = 2; mg.degree = degree; mg.eig_ratio = ratio; mg.coarse_dense_max = dense_max;
+    mg.nv = ctx->mesh.dim; mg.degree = degree; mg.eig_ratio = ratio; mg.coarse_dense_max = dense_max;
     // non-symmetric cycle V(0, degree+1): BiCGStab does not need a symmetric preconditioner, and
     // without pre-smoothing the fine residual is the input itself (two fine SpMVs fewer per
     // cycle; measured 6 % faster steps than V(2,2) at equal iteration counts)
@@ -1323,6 +1311,7 @@ extern "C" int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, doub
   NSFEM_REQUIRE(ctx && cfl, "null argument");
   NSFEM_REQUIRE(slot >= 0 && slot < NSFEM_N_SLOTS && slot_size(ctx, slot) == nvel(ctx),
                 "not a velocity slot");
+  NSFEM_REQUIRE(ctx->mesh.dim == 2, "the CFL diagnostic is built for 2D meshes only");
   hipStream_t s = ctx->stream;
   const int n_parts = 256;
   ctx->kw.ensure(nvel(ctx));

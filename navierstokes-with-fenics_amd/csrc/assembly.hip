@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_gather_vals(int nnz, int bs,
 // ------------------------------------------------------------- launch wrappers
 static inline int grid_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
-static void gather_vals(hipStream_t s, const Pattern& p, int bs, const double* ebuf, double* vals) {
+void gather_vals(hipStream_t s, const Pattern& p, int bs, const double* ebuf, double* vals) {
   NSFEM_REQUIRE(p.cptr.p && p.cidx.p, "pattern has no inverted index");
   hipLaunchKernelGGL(k_gather_vals, dim3(grid_for((int64_t)p.nnz * bs)), dim3(kBlock), 0, s,
                      p.nnz, bs, p.cptr.p, p.cidx.p, ebuf, vals);
@@ -546,6 +546,7 @@ static void gather_vals(hipStream_t s, const Pattern& p, int bs, const double* e
 
 void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p22, double* mass,
                                double* stiff) {
+  if (m.dim == 3) return assemble_p2_scalar_3d(s, m, p22, mass, stiff);
   DevBuf<double> tmp;
   tmp.alloc((size_t)m.n_cells * 72);
   double* t0 = tmp.p;
@@ -558,6 +559,7 @@ void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p
 }
 void launch_assemble_p1_scalar(hipStream_t s, const MeshDev& m, const Pattern& p11, double* stiff,
                                double* mass) {
+  if (m.dim == 3) return assemble_p1_scalar_3d(s, m, p11, stiff, mass);
   DevBuf<double> tmp;
   tmp.alloc((size_t)m.n_cells * 18);
   double* t0 = tmp.p;
@@ -570,6 +572,7 @@ void launch_assemble_p1_scalar(hipStream_t s, const MeshDev& m, const Pattern& p
 }
 void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p12,
                               const Pattern& p21, double* div, double* grad, double* divT) {
+  if (m.dim == 3) return assemble_div_grad_3d(s, m, p12, p21, div, grad, divT);
   DevBuf<double> tmp;
   tmp.alloc((size_t)m.n_cells * 36 * 3);
   double* t0 = tmp.p;
@@ -586,6 +589,7 @@ void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p1
 }
 void launch_assemble_viscous_extra(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                    double* extra) {
+  NSFEM_REQUIRE(m.dim == 2, "the traction form of the viscous term is built for 2D meshes only");
   DevBuf<double> tmp;
   tmp.alloc((size_t)m.n_cells * 144);
   hipLaunchKernelGGL(k_visc_extra, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
@@ -603,6 +607,7 @@ void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double*
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                 const double* u, double cc, const double* L, const double* E,
                                 double cvE, double* J, int form, bool picard) {
+  if (m.dim == 3) return convection_jacobian_3d(s, m, p22, u, cc, L, J, form, picard);
   const dim3 grid(grid_for((int64_t)m.n_cells * 6)), block(kBlock);
 #define NSFEM_CJ(F, P) \
   hipLaunchKernelGGL((k_conv_jac<F, P>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.ebuf.p)
@@ -624,6 +629,7 @@ void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& 
 }
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b, int form) {
+  if (m.dim == 3) return convection_residual_3d(s, m, u, cc, b, form);
   const dim3 grid(grid_for((int64_t)m.n_cells * 6)), block(kBlock);
 #define NSFEM_CR(F) \
   hipLaunchKernelGGL((k_conv_res<F>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.rbuf.p)

@@ -1,0 +1,483 @@
+// Element kernels for tetrahedral Taylor-Hood meshes (P2: 4 vertex + 6 edge nodes in UFC order,
+// P1: 4 vertices) -- the 3D counterpart of assembly.hip with the same conventions:
+//   * one thread per (cell, local row i); SoA per-cell geometry / dof maps (coalesced);
+//   * reference tables in __constant__ memory (uniform quadrature index => scalar loads);
+//   * element tensors are STORED to an element buffer [cell][i][j][block] and summed per CSR
+//     slot by the gather kernels of assembly.hip in a fixed order (no atomics, reproducible).
+// Forms: source/ns_solver_base.py:370-399,478-499 (the reference writes them dimension-
+// independently; its 3D branches are never exercised).  The 15-point Keast rule
+// is exact for degree 5, the highest degree any of these integrands reaches on affine cells.
+#include "nsfem_internal.hpp"
+
+namespace nsfem {
+
+struct QuadTables3 {
+  double w[15];
+  double phi2[15][10];
+  double dphi2[15][10][3];
+  double phi1[15][4];
+};
+__constant__ QuadTables3 c_q3;
+
+void upload_quad_tables_3d() {
+  QuadTables3 t;
+  const double s15 = std::sqrt(15.0);
+  const double a1 = (7.0 - s15) / 34.0, a2 = (7.0 + s15) / 34.0, b = (10.0 - 2.0 * s15) / 40.0;
+  const double w0 = 16.0 / 135.0, w1 = (2665.0 + 14.0 * s15) / 37800.0,
+               w2 = (2665.0 - 14.0 * s15) / 37800.0, w3 = 10.0 / 189.0;
+  double pts[15][3];
+  int n = 0;
+  pts[n][0] = pts[n][1] = pts[n][2] = 0.25; t.w[n++] = w0 / 6.0;
+  const double as[2] = {a1, a2}, ws[2] = {w1, w2};
+  for (int k = 0; k < 2; ++k) {
+    const double a = as[k], c = 1.0 - 3.0 * a;
+    const double p4[4][3] = {{a, a, a}, {c, a, a}, {a, c, a}, {a, a, c}};
+    for (int m = 0; m < 4; ++m) {
+      for (int d = 0; d < 3; ++d) pts[n][d] = p4[m][d];
+      t.w[n++] = ws[k] / 6.0;
+    }
+  }
+  const double c = 0.5 - b;
+  const double p6[6][3] = {{b, b, c}, {b, c, b}, {c, b, b}, {b, c, c}, {c, b, c}, {c, c, b}};
+  for (int m = 0; m < 6; ++m) {
+    for (int d = 0; d < 3; ++d) pts[n][d] = p6[m][d];
+    t.w[n++] = w3 / 6.0;
+  }
+  const double dl[4][3] = {{-1.0, -1.0, -1.0}, {1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+  const int pr[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+  for (int q = 0; q < 15; ++q) {
+    const double l[4] = {1.0 - pts[q][0] - pts[q][1] - pts[q][2], pts[q][0], pts[q][1], pts[q][2]};
+    for (int i = 0; i < 4; ++i) {
+      t.phi1[q][i] = l[i];
+      t.phi2[q][i] = l[i] * (2.0 * l[i] - 1.0);
+      for (int d = 0; d < 3; ++d) t.dphi2[q][i][d] = (4.0 * l[i] - 1.0) * dl[i][d];
+    }
+    for (int e = 0; e < 6; ++e) {
+      const int a = pr[e][0], bb = pr[e][1];
+      t.phi2[q][4 + e] = 4.0 * l[a] * l[bb];
+      for (int d = 0; d < 3; ++d) t.dphi2[q][4 + e][d] = 4.0 * (l[a] * dl[bb][d] + l[bb] * dl[a][d]);
+    }
+  }
+  NSFEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_q3), &t, sizeof(QuadTables3)));
+}
+
+struct CellGeo3 {
+  double ji[3][3];   // J^{-1}[b][a] = d xi_b / d x_a
+  double adet;
+};
+
+__device__ __forceinline__ CellGeo3 load_geo3(const double* __restrict__ vx, int nc, int c) {
+  double x[4][3];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[v][d] = vx[(size_t)(3 * v + d) * nc + c];
+  double J[3][3];   // J[a][b] = x_{b+1}[a] - x_0[a]
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) J[a][b] = x[b + 1][a] - x[0][a];
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double id = 1.0 / det;
+  CellGeo3 g;
+  g.ji[0][0] = c00 * id;
+  g.ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+  g.ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+  g.ji[1][0] = c01 * id;
+  g.ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+  g.ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+  g.ji[2][0] = c02 * id;
+  g.ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+  g.ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+  g.adet = fabs(det);
+  return g;
+}
+
+// physical gradient of a reference gradient dr: out_a = sum_b Jinv[b][a] dr_b
+__device__ __forceinline__ void phys3(const CellGeo3& g, const double* dr, double* out) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) out[a] = g.ji[0][a] * dr[0] + g.ji[1][a] * dr[1] + g.ji[2][a] * dr[2];
+}
+
+// ------------------------------------------------------------------ scalar P2
+__global__ __launch_bounds__(256) void k3_p2_scalar(int nc, const double* __restrict__ vx,
+                                                    double* __restrict__ mass,
+                                                    double* __restrict__ stiff) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nc * 10) return;
+  const int i = (int)(t / nc), c = (int)(t % nc);
+  const CellGeo3 g = load_geo3(vx, nc, c);
+  double m[10], k[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) m[j] = k[j] = 0.0;
+  for (int q = 0; q < 15; ++q) {
+    const double w = c_q3.w[q] * g.adet;
+    double gi[3];
+    phys3(g, c_q3.dphi2[q][i], gi);
+    const double pi = c_q3.phi2[q][i] * w;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      double gj[3];
+      phys3(g, c_q3.dphi2[q][j], gj);
+      m[j] += pi * c_q3.phi2[q][j];
+      k[j] += w * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const size_t s = ((size_t)c * 10 + i) * 10 + j;
+    mass[s] = m[j];
+    stiff[s] = k[j];
+  }
+}
+
+// ------------------------------------------------------------------ scalar P1
+__global__ __launch_bounds__(256) void k3_p1_scalar(int nc, const double* __restrict__ vx,
+                                                    double* __restrict__ stiff,
+                                                    double* __restrict__ mass) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nc * 4) return;
+  const int i = (int)(t / nc), c = (int)(t % nc);
+  const CellGeo3 g = load_geo3(vx, nc, c);
+  const double dl[4][3] = {{-1.0, -1.0, -1.0}, {1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+  double gi[3];
+  phys3(g, dl[i], gi);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double gj[3];
+    phys3(g, dl[j], gj);
+    const size_t s = ((size_t)c * 4 + i) * 4 + j;
+    stiff[s] = g.adet / 6.0 * (gi[0] * gj[0] + gi[1] * gj[1] + gi[2] * gj[2]);
+    mass[s] = g.adet / 120.0 * (i == j ? 2.0 : 1.0);       // V/20 (1 + delta_ij), V = adet/6
+  }
+}
+
+// --------------------------------------------------- divergence (P1 rows, 1x3)
+__global__ __launch_bounds__(256) void k3_div(int nc, const double* __restrict__ vx,
+                                              double* __restrict__ div) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nc * 4) return;
+  const int i = (int)(t / nc), c = (int)(t % nc);
+  const CellGeo3 g = load_geo3(vx, nc, c);
+  double d[10][3];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) d[j][0] = d[j][1] = d[j][2] = 0.0;
+  for (int q = 0; q < 15; ++q) {
+    const double wp = c_q3.w[q] * g.adet * c_q3.phi1[q][i];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      double gj[3];
+      phys3(g, c_q3.dphi2[q][j], gj);
+      d[j][0] += wp * gj[0];
+      d[j][1] += wp * gj[1];
+      d[j][2] += wp * gj[2];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const size_t s = ((size_t)c * 4 + i) * 10 + j;
+    div[3 * s] = d[j][0];
+    div[3 * s + 1] = d[j][1];
+    div[3 * s + 2] = d[j][2];
+  }
+}
+
+// --------------------------- gradient / transposed divergence (P2 rows, 3x1)
+__global__ __launch_bounds__(256) void k3_grad(int nc, const double* __restrict__ vx,
+                                               double* __restrict__ grad,
+                                               double* __restrict__ divT) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nc * 10) return;
+  const int i = (int)(t / nc), c = (int)(t % nc);
+  const CellGeo3 g = load_geo3(vx, nc, c);
+  const double dl[4][3] = {{-1.0, -1.0, -1.0}, {1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+  double gr[4][3], dt[4][3], gp[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    phys3(g, dl[j], gp[j]);
+    gr[j][0] = gr[j][1] = gr[j][2] = dt[j][0] = dt[j][1] = dt[j][2] = 0.0;
+  }
+  for (int q = 0; q < 15; ++q) {
+    const double w = c_q3.w[q] * g.adet;
+    const double pi = c_q3.phi2[q][i] * w;
+    double gi[3];
+    phys3(g, c_q3.dphi2[q][i], gi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        gr[j][a] += pi * gp[j][a];                          // int phi_i d_a psi_j
+        dt[j][a] += w * gi[a] * c_q3.phi1[q][j];            // int d_a phi_i psi_j
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t s = ((size_t)c * 10 + i) * 4 + j;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      grad[3 * s + a] = gr[j][a];
+      divT[3 * s + a] = dt[j][a];
+    }
+  }
+}
+
+// ---- convection blocks (Newton / Picard), forms 0 standard, 2 divergence, 3 skew-symmetric;
+// with u, G_ab = d_b u_a at the quadrature point, test (phi_i, a), trial (phi_j, b):
+//   standard    phi_i [ (u.g_j) d_ab + phi_j G_ab ]                 (Picard: first term)
+//   divergence  standard + 1/2 phi_i [ g_j,b u_a + div phi_j d_ab ] (Picard: 1st + 4th term)
+//   skew        1/2 standard - 1/2 [ g_i,b phi_j u_a + (u.g_i) phi_j d_ab ]
+template <int FORM, bool PICARD>
+__global__ __launch_bounds__(256) void k3_conv_jac(int nc, const double* __restrict__ vx,
+                                                   const int32_t* __restrict__ p2,
+                                                   const double* __restrict__ u, double cc,
+                                                   double* __restrict__ ebuf) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nc * 10) return;
+  const int i = (int)(t / nc), c = (int)(t % nc);
+  const CellGeo3 g = load_geo3(vx, nc, c);
+  int node[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) node[k] = p2[(size_t)k * nc + c];
+  double acc[10][9];
+#pragma unroll
+  for (int j = 0; j < 10; ++j)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) acc[j][e] = 0.0;
+  for (int q = 0; q < 15; ++q) {
+    double gk[10][3];
+    double uq[3] = {0.0, 0.0, 0.0};
+    double G[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      phys3(g, c_q3.dphi2[q][k], gk[k]);
+      const double ph = c_q3.phi2[q][k];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double ua = u[(size_t)node[k] * 3 + a];      // L1/L2-resident re-read per q
+        uq[a] += ph * ua;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) G[a][b] += gk[k][b] * ua;
+      }
+    }
+    const double w = c_q3.w[q] * g.adet * cc;
+    const double wpi = w * c_q3.phi2[q][i];
+    const double div = G[0][0] + G[1][1] + G[2][2];
+    const double udgi = uq[0] * gk[i][0] + uq[1] * gk[i][1] + uq[2] * gk[i][2];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const double udg = uq[0] * gk[j][0] + uq[1] * gk[j][1] + uq[2] * gk[j][2];
+      const double pj = c_q3.phi2[q][j];
+      if (FORM == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          acc[j][a * 3 + a] += wpi * udg;
+          if (!PICARD)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[j][a * 3 + b] += wpi * pj * G[a][b];
+        }
+      } else if (FORM == 2) {
+        const double hd = 0.5 * div * pj;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          acc[j][a * 3 + a] += wpi * (udg + hd);
+          if (!PICARD)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+              acc[j][a * 3 + b] += wpi * (pj * G[a][b] + 0.5 * gk[j][b] * uq[a]);
+        }
+      } else {
+        const double sk = 0.5 * (wpi * udg - w * udgi * pj);
+        const double hw = 0.5 * w * pj;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          acc[j][a * 3 + a] += sk;
+          if (!PICARD)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+              acc[j][a * 3 + b] += 0.5 * wpi * pj * G[a][b] - hw * gk[i][b] * uq[a];
+        }
+      }
+    }
+  }
+  double* out = ebuf + ((size_t)c * 100 + (size_t)i * 10) * 9;
+#pragma unroll
+  for (int j = 0; j < 10; ++j)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) out[j * 9 + e] = acc[j][e];
+}
+
+template <int FORM>
+__global__ __launch_bounds__(256) void k3_conv_res(int nc, const double* __restrict__ vx,
+                                                   const int32_t* __restrict__ p2,
+                                                   const double* __restrict__ u, double cc,
+                                                   double* __restrict__ rbuf) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nc * 10) return;
+  const int i = (int)(t / nc), c = (int)(t % nc);
+  const CellGeo3 g = load_geo3(vx, nc, c);
+  double un[10][3];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const size_t node = (size_t)p2[(size_t)k * nc + c];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) un[k][a] = u[node * 3 + a];
+  }
+  double r[3] = {0.0, 0.0, 0.0};
+  for (int q = 0; q < 15; ++q) {
+    double uq[3] = {0.0, 0.0, 0.0};
+    double G[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    double gi[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      double gk[3];
+      phys3(g, c_q3.dphi2[q][k], gk);
+      const double ph = c_q3.phi2[q][k];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        uq[a] += ph * un[k][a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) G[a][b] += gk[b] * un[k][a];
+      }
+      if (k == i) { gi[0] = gk[0]; gi[1] = gk[1]; gi[2] = gk[2]; }
+    }
+    const double w = c_q3.w[q] * g.adet * cc;
+    const double wpi = w * c_q3.phi2[q][i];
+    double adv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) adv[a] = G[a][0] * uq[0] + G[a][1] * uq[1] + G[a][2] * uq[2];
+    if (FORM == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[a] += wpi * adv[a];
+    } else if (FORM == 2) {
+      const double hd = 0.5 * (G[0][0] + G[1][1] + G[2][2]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[a] += wpi * (adv[a] + hd * uq[a]);
+    } else {
+      const double udgi = uq[0] * gi[0] + uq[1] * gi[1] + uq[2] * gi[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[a] += 0.5 * (wpi * adv[a] - w * udgi * uq[a]);
+    }
+  }
+  double* out = rbuf + ((size_t)c * 10 + i) * 3;
+  out[0] = r[0];
+  out[1] = r[1];
+  out[2] = r[2];
+}
+
+// J[s] = L[s] I_3 + sum of the element blocks scattered to slot s (ascending source order)
+__global__ __launch_bounds__(256) void k3_jac_gather(int nnz, const int32_t* __restrict__ cptr,
+                                                     const int32_t* __restrict__ cidx,
+                                                     const double* __restrict__ ebuf,
+                                                     const double* __restrict__ L,
+                                                     double* __restrict__ J) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nnz * 9) return;
+  const int s = (int)(t / 9), e = (int)(t % 9);
+  double acc = (e == 0 || e == 4 || e == 8) ? L[s] : 0.0;
+  if (ebuf)
+    for (int k = cptr[s]; k < cptr[s + 1]; ++k) acc += ebuf[(size_t)cidx[k] * 9 + e];
+  J[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void k3_res_gather(int n_nodes, const int32_t* __restrict__ nptr,
+                                                     const int32_t* __restrict__ nidx,
+                                                     const double* __restrict__ rbuf,
+                                                     double* __restrict__ b) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n_nodes * 3) return;
+  const int n = (int)(t / 3), a = (int)(t % 3);
+  double acc = b[t];
+  for (int k = nptr[n]; k < nptr[n + 1]; ++k) acc += rbuf[(size_t)nidx[k] * 3 + a];
+  b[t] = acc;
+}
+
+// ------------------------------------------------------------- launch wrappers
+static inline int grid3(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+void gather_vals(hipStream_t s, const Pattern& p, int bs, const double* ebuf, double* vals);
+
+void assemble_p2_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, double* mass,
+                           double* stiff) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 200);
+  double* t0 = tmp.p;
+  double* t1 = tmp.p + (size_t)m.n_cells * 100;
+  hipLaunchKernelGGL(k3_p2_scalar, dim3(grid3((int64_t)m.n_cells * 10)), dim3(kBlock), 0, s,
+                     m.n_cells, m.vx.p, t0, t1);
+  gather_vals(s, p22, 1, t0, mass);
+  gather_vals(s, p22, 1, t1, stiff);
+  NSFEM_HIP(hipStreamSynchronize(s));
+}
+void assemble_p1_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p11, double* stiff,
+                           double* mass) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 32);
+  double* t0 = tmp.p;
+  double* t1 = tmp.p + (size_t)m.n_cells * 16;
+  hipLaunchKernelGGL(k3_p1_scalar, dim3(grid3((int64_t)m.n_cells * 4)), dim3(kBlock), 0, s,
+                     m.n_cells, m.vx.p, t0, t1);
+  gather_vals(s, p11, 1, t0, stiff);
+  gather_vals(s, p11, 1, t1, mass);
+  NSFEM_HIP(hipStreamSynchronize(s));
+}
+void assemble_div_grad_3d(hipStream_t s, const MeshDev& m, const Pattern& p12, const Pattern& p21,
+                          double* div, double* grad, double* divT) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 120 * 3);
+  double* t0 = tmp.p;
+  double* t1 = tmp.p + (size_t)m.n_cells * 120;
+  double* t2 = tmp.p + (size_t)m.n_cells * 240;
+  hipLaunchKernelGGL(k3_div, dim3(grid3((int64_t)m.n_cells * 4)), dim3(kBlock), 0, s, m.n_cells,
+                     m.vx.p, t0);
+  hipLaunchKernelGGL(k3_grad, dim3(grid3((int64_t)m.n_cells * 10)), dim3(kBlock), 0, s, m.n_cells,
+                     m.vx.p, t1, t2);
+  gather_vals(s, p12, 3, t0, div);
+  gather_vals(s, p21, 3, t1, grad);
+  gather_vals(s, p21, 3, t2, divT);
+  NSFEM_HIP(hipStreamSynchronize(s));
+}
+void jacobian_init_3d(hipStream_t s, int nnz, const double* L, double* J) {
+  hipLaunchKernelGGL(k3_jac_gather, dim3(grid3((int64_t)nnz * 9)), dim3(kBlock), 0, s, nnz, nullptr,
+                     nullptr, nullptr, L, J);
+  NSFEM_HIP(hipGetLastError());
+}
+void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, const double* u,
+                            double cc, const double* L, double* J, int form, bool picard) {
+  const dim3 grid(grid3((int64_t)m.n_cells * 10)), block(kBlock);
+#define NSFEM_CJ3(F, P) \
+  hipLaunchKernelGGL((k3_conv_jac<F, P>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.ebuf.p)
+  switch (form * 2 + (picard ? 1 : 0)) {
+    case 0: NSFEM_CJ3(0, false); break;
+    case 1: NSFEM_CJ3(0, true); break;
+    case 4: NSFEM_CJ3(2, false); break;
+    case 5: NSFEM_CJ3(2, true); break;
+    case 6: NSFEM_CJ3(3, false); break;
+    case 7: NSFEM_CJ3(3, true); break;
+    default: throw Error(NSFEM_ERR_ARG, "convective form not available on tetrahedral meshes "
+                                        "(standard, divergence, skew_symmetric are)");
+  }
+#undef NSFEM_CJ3
+  hipLaunchKernelGGL(k3_jac_gather, dim3(grid3((int64_t)p22.nnz * 9)), dim3(kBlock), 0, s, p22.nnz,
+                     p22.cptr.p, p22.cidx.p, m.ebuf.p, L, J);
+  NSFEM_HIP(hipGetLastError());
+}
+void convection_residual_3d(hipStream_t s, const MeshDev& m, const double* u, double cc, double* b,
+                            int form) {
+  const dim3 grid(grid3((int64_t)m.n_cells * 10)), block(kBlock);
+#define NSFEM_CR3(F) \
+  hipLaunchKernelGGL((k3_conv_res<F>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.rbuf.p)
+  switch (form) {
+    case 0: NSFEM_CR3(0); break;
+    case 2: NSFEM_CR3(2); break;
+    case 3: NSFEM_CR3(3); break;
+    default: throw Error(NSFEM_ERR_ARG, "convective form not available on tetrahedral meshes");
+  }
+#undef NSFEM_CR3
+  hipLaunchKernelGGL(k3_res_gather, dim3(grid3((int64_t)m.n_p2 * 3)), dim3(kBlock), 0, s, m.n_p2,
+                     m.nptr.p, m.nidx.p, m.rbuf.p, b);
+  NSFEM_HIP(hipGetLastError());
+}
+
+}  // namespace nsfem

@@ -253,6 +253,10 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     else if (A.br == 1 && A.bc == 1 && nv == 1) NSFEM_STREAM(1, 1, 1);
     else if (A.br == 1 && A.bc == 2 && nv == 1) NSFEM_STREAM(1, 2, 1);
     else if (A.br == 2 && A.bc == 1 && nv == 1) NSFEM_STREAM(2, 1, 1);
+    else if (A.br == 3 && A.bc == 3 && nv == 1) NSFEM_STREAM(3, 3, 1);
+    else if (A.br == 1 && A.bc == 1 && nv == 3) NSFEM_STREAM(1, 1, 3);
+    else if (A.br == 1 && A.bc == 3 && nv == 1) NSFEM_STREAM(1, 3, 1);
+    else if (A.br == 3 && A.bc == 1 && nv == 1) NSFEM_STREAM(3, 1, 1);
     else throw Error(NSFEM_ERR_ARG, "unsupported block shape in spmv");
 #undef NSFEM_STREAM
     NSFEM_HIP(hipGetLastError());
@@ -290,6 +294,10 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
   else if (A.br == 1 && A.bc == 1 && nv == 1) NSFEM_SPMV(1, 1, 1);
   else if (A.br == 1 && A.bc == 2 && nv == 1) NSFEM_SPMV(1, 2, 1);
   else if (A.br == 2 && A.bc == 1 && nv == 1) NSFEM_SPMV(2, 1, 1);
+  else if (A.br == 3 && A.bc == 3 && nv == 1) NSFEM_SPMV(3, 3, 1);
+  else if (A.br == 1 && A.bc == 1 && nv == 3) NSFEM_SPMV(1, 1, 3);
+  else if (A.br == 1 && A.bc == 3 && nv == 1) NSFEM_SPMV(1, 3, 1);
+  else if (A.br == 3 && A.bc == 1 && nv == 1) NSFEM_SPMV(3, 1, 1);
   else throw Error(NSFEM_ERR_ARG, "unsupported block shape in spmv");
 #undef NSFEM_SPMV
   NSFEM_HIP(hipGetLastError());

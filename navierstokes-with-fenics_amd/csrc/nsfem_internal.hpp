@@ -149,6 +149,7 @@ void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x,
 
 // element kernels
 struct MeshDev {
+  int dim = 2;              // 2: triangles (6 + 3 nodes per cell), 3: tetrahedra (10 + 4)
   int n_cells = 0, n_p2 = 0, n_p1 = 0, n_vertices = 0;
   DevBuf<double> vx;        // SoA vertex coords per cell: [6][n_cells] (x0,y0,x1,y1,x2,y2)
   DevBuf<int32_t> p2;       // SoA [6][n_cells]
@@ -159,6 +160,19 @@ struct MeshDev {
 };
 void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                double* mass, double* stiff);
+// tetrahedral meshes (assembly3d.hip); the launch_* wrappers dispatch on MeshDev::dim
+void upload_quad_tables_3d();
+void assemble_p2_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, double* mass,
+                           double* stiff);
+void assemble_p1_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p11, double* stiff,
+                           double* mass);
+void assemble_div_grad_3d(hipStream_t s, const MeshDev& m, const Pattern& p12, const Pattern& p21,
+                          double* div, double* grad, double* divT);
+void jacobian_init_3d(hipStream_t s, int nnz, const double* L, double* J);
+void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, const double* u,
+                            double cc, const double* L, double* J, int form, bool picard);
+void convection_residual_3d(hipStream_t s, const MeshDev& m, const double* u, double cc, double* b,
+                            int form);
 void launch_assemble_p1_scalar(hipStream_t s, const MeshDev& m, const Pattern& p11,
                                double* stiff, double* mass);
 void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p12,

@@ -1,0 +1,136 @@
+"""GPU parity on TETRAHEDRAL Taylor-Hood meshes (BoxMesh-style Kuhn meshes, BASELINE configs 3-4 in
+small): the 3D element kernels (csrc/assembly3d.hip), the 3x3 / 1x3 / 3x1 block SpMV
+instantiations and the IPCS / monolithic steps against the dimension-generic oracle, which is
+pinned in 3D by sympy-exact tetrahedron matrices and a polynomial Stokes solution
+(tests/test_oracle_pinning.py).  The reference never exercises its 3D branches."""
+import numpy as np
+import pytest
+
+import _native as nat
+import fem_oracle as fo
+from fem_mesh import FacetMarkers, TaylorHoodDofMap, box_mesh
+from gpu_common import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def box3(n, p1=(1.0, 1.0, 1.0)):
+    mesh = box_mesh((0.0, 0.0, 0.0), p1, *n)
+    dm = TaylorHoodDofMap(mesh)
+    marks = FacetMarkers(mesh)
+    for axis in range(3):
+        marks.mark(lambda X, a=axis: np.abs(X[:, a]) < 1e-12, 2 * axis + 1)
+        marks.mark(lambda X, a=axis: np.abs(X[:, a] - p1[a]) < 1e-12, 2 * axis + 2)
+    return mesh, dm, marks
+
+
+def context3(mesh, dm):
+    return nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+
+
+def lid_bc(dm, marks):
+    """no-slip on five faces, lid (1, 0, 0) on z = top (wins on shared edges)"""
+    last = {}
+    for mid in (1, 2, 3, 4, 5, 6):
+        nodes = np.unique(dm.facet_p2_nodes(marks.facets_with_id(mid)))
+        for a in range(3):
+            val = 1.0 if (mid == 6 and a == 0) else 0.0
+            last.update(zip((3 * nodes + a).tolist(), [val] * nodes.size))
+    d = np.array(sorted(last), dtype=np.int64)
+    return d, np.array([last[i] for i in d.tolist()])
+
+
+@pytest.fixture(scope="module")
+def setup3():
+    mesh, dm, marks = box3((3, 2, 2), p1=(1.0, 0.8, 0.6))
+    ctx = context3(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    yield mesh, dm, marks, ctx, s
+    ctx.close()
+
+
+def test_3d_constant_operators_and_spmv(setup3):
+    _, dm, _, ctx, s = setup3
+    pairs = [(nat.OP_MASS_P2, s.mass_p2()), (nat.OP_STIFF_P2, s.stiffness_p2()),
+             (nat.OP_STIFF_P1, s.stiffness_p1()), (nat.OP_MASS_P1, s.mass_p1()),
+             (nat.OP_DIV, s.divergence()), (nat.OP_GRAD, s.pressure_gradient()),
+             (nat.OP_DIVT, s.divergence().T.tocsr())]
+    rng = np.random.default_rng(3)
+    for op, ref in pairs:
+        A = ctx.operator_csr(op)
+        assert A.shape == ref.shape
+        assert abs(A - ref).max() <= 1e-13 * abs(ref).max(), op
+        x = rng.standard_normal(ref.shape[1])
+        assert rel(ctx.operator_apply(op, x), ref @ x) < 1e-13
+
+
+@pytest.mark.parametrize("form_id,form", [(0, "standard"), (2, "divergence"), (3, "skew_symmetric")])
+def test_3d_momentum_residual_jacobian_and_newton_update(setup3, form_id, form):
+    _, dm, marks, ctx, s = setup3
+    rng = np.random.default_rng(5)
+    Re, k, alpha = 20.0, 0.05, (1.5, -2.0, 0.5)
+    u = [rng.standard_normal(dm.n_velocity) for _ in range(4)]
+    p_old = rng.standard_normal(dm.n_p1)
+    f = rng.standard_normal(dm.n_velocity)
+    ctx.set_coeffs(1.0, 1.0, 1.0 / Re, 0.7)
+    ctx.set_bdf(alpha, k)
+    ctx.set_convective_form(form_id)
+    bd, bv = lid_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    for slot, v in ((nat.U1, u[1]), (nat.U2, u[2]), (nat.USTAR, u[3]), (nat.P_OLD, p_old),
+                    (nat.BODY_FORCE, f)):
+        ctx.set_state(slot, v)
+    ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+    M, K, D = s.vector_mass(), s.vector_stiffness(), s.divergence()
+    L = alpha[0] / k * M + K / Re
+    b = L @ u[3] + M @ (alpha[1] * u[1] + alpha[2] * u[2]) / k - D.T @ p_old - 0.7 * (M @ f) \
+        + s.convection_residual(u[3], form)
+    b[bd] = u[3][bd] - bv
+    assert rel(ctx.get_rhs(nat.SYS_MOMENTUM), b) < 1e-13
+    J = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
+    Jref = L + s.convection_jacobian(u[3], form)
+    assert abs(J - Jref).max() <= 1e-13 * abs(Jref).max()
+    ctx.solve(nat.SYS_MOMENTUM, rtol=1e-13)
+    dx = fo.spla.splu(fo.apply_dirichlet_rows(Jref, bd).tocsc()).solve(b)
+    assert rel(ctx.get_state(nat.USTAR), u[3] - dx) < 1e-10
+    ctx.set_coeffs(1.0, 1.0, 1.0 / Re)
+    ctx.set_convective_form(0)
+
+
+def test_3d_rotational_form_is_refused(setup3):
+    _, dm, _, ctx, _ = setup3
+    ctx.set_convective_form(1)
+    ctx.set_bdf((1.0, -1.0, 0.0), 0.1)
+    with pytest.raises(nat.NativeError):
+        ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+    ctx.set_convective_form(0)
+
+
+def test_3d_ipcs_lid_driven_cavity_steps_match_oracle():
+    """3D lid-driven cavity, Re = 50: Newton histories and fields of three IPCS steps against the
+    LU oracle (Jacobi-preconditioned Krylov solves here)."""
+    mesh, dm, marks = box3((3, 3, 3))
+    ctx = context3(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.02, body_force_term=None)
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    ctx.set_coeffs(1.0, 1.0, 0.02)
+    vbc = lid_bc(dm, marks)
+    pbc = (np.zeros(0, np.int64), np.zeros(0))
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, *pbc)
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-13
+    for step in range(3):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, 0.05)
+        info = ctx.step_ipcs(opts)
+        orc.step(alpha, 0.05, vbc, pbc)
+        assert info.newton_iterations == orc.newton_its[step]
+        ctx.advance(0)
+        orc.advance()
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    pg, po = ctx.get_state(nat.P_OLD), orc.p_old
+    assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
+    ctx.close()

@@ -44,18 +44,57 @@ def structured_prolongation(nx, ny):
     return rowptr, col, val
 
 
-def structured_hierarchy(p0, p1, nx, ny, coarsest=16):
+def structured_prolongation_3d(nx, ny, nz):
+    """P1 prolongation between the Kuhn meshes (nx/2, ny/2, nz/2) -> (nx, ny, nz) of
+    ``fem_mesh.box_mesh``: every edge of the Kuhn split points in a direction of {0,1}^3, so a fine
+    vertex with odd index set S is the midpoint of the coarse edge from floor(i/2) to
+    floor(i/2) + 1_S (rows = fine vertices, id = (iz (ny+1) + iy)(nx+1) + ix)."""
+    assert nx % 2 == 0 and ny % 2 == 0 and nz % 2 == 0
+    cx, cy = nx // 2, ny // 2
+    iz, iy, ix = np.meshgrid(np.arange(nz + 1), np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
+    ix, iy, iz = ix.ravel(), iy.ravel(), iz.ravel()
+    ox, oy, oz = ix % 2, iy % 2, iz % 2
+
+    def cid(jx, jy, jz):
+        return (jz * (cy + 1) + jy) * (cx + 1) + jx
+
+    a = cid((ix - ox) // 2, (iy - oy) // 2, (iz - oz) // 2)
+    b = cid((ix + ox) // 2, (iy + oy) // 2, (iz + oz) // 2)
+    single = (ox == 0) & (oy == 0) & (oz == 0)
+    counts = np.where(single, 1, 2)
+    rowptr = np.zeros(ix.size + 1, dtype=np.int32)
+    np.cumsum(counts, out=rowptr[1:])
+    col = np.empty(rowptr[-1], dtype=np.int32)
+    val = np.empty(rowptr[-1], dtype=np.float64)
+    first = rowptr[:-1]
+    col[first] = a
+    val[first] = np.where(single, 1.0, 0.5)
+    second = first[~single] + 1
+    col[second] = b[~single]
+    val[second] = 0.5
+    return rowptr, col, val
+
+
+def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=16):
     """[(coarse mesh, prolongation CSR to the next finer mesh), ...] finest-first, stopping
-    when a direction becomes odd or smaller than ``coarsest`` cells."""
+    when a direction becomes odd or smaller than ``coarsest`` cells.  2D right-diagonal
+    rectangle meshes, or (with ``nz``) 3D Kuhn box meshes."""
     levels = []
-    while nx % 2 == 0 and ny % 2 == 0 and min(nx, ny) // 2 >= coarsest:
-        P = structured_prolongation(nx, ny)
-        nx, ny = nx // 2, ny // 2
-        levels.append((rectangle_mesh(p0, p1, nx, ny), P))
+    if nz is None:
+        while nx % 2 == 0 and ny % 2 == 0 and min(nx, ny) // 2 >= coarsest:
+            P = structured_prolongation(nx, ny)
+            nx, ny = nx // 2, ny // 2
+            levels.append((rectangle_mesh(p0, p1, nx, ny), P))
+        return levels
+    from fem_mesh import box_mesh
+    while nx % 2 == 0 and ny % 2 == 0 and nz % 2 == 0 and min(nx, ny, nz) // 2 >= coarsest:
+        P = structured_prolongation_3d(nx, ny, nz)
+        nx, ny, nz = nx // 2, ny // 2, nz // 2
+        levels.append((box_mesh(p0, p1, nx, ny, nz), P))
     return levels
 
 
-def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=16):
+def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=None):
     """Build the hierarchy of a structured mesh (``mesh.structured`` = (p0, p1, nx, ny)) on the
     device context.  Returns the number of coarse P1 levels (0: mesh cannot be coarsened; the
     two-level P2 -> P1 hierarchy is still built)."""
@@ -63,6 +102,8 @@ def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=16):
     if mesh is not None and hasattr(mesh, "mg_levels"):
         levels = mesh.mg_levels                        # refinement hierarchy of a general mesh
     else:
+        if coarsest is None:       # dense coarsest solve of <= ~1200 unknowns: 16^2 cells / 8^3 cubes
+            coarsest = 16 if info is None or len(info) == 4 else 8
         levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
     ctx.mg_prolongations = []                          # kept for attach_schur_laplacian
     for coarse_mesh, (rowptr, col, val) in levels:

@@ -134,3 +134,48 @@ def test_3d_ipcs_lid_driven_cavity_steps_match_oracle():
     pg, po = ctx.get_state(nat.P_OLD), orc.p_old
     assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
     ctx.close()
+
+
+def test_3d_multigrid_hierarchy_ipcs_and_monolithic_match_oracle():
+    """Kuhn meshes are nested under grid refinement: geometric multigrid (P2 -> P1 -> 4^3 -> 2^3)
+    preconditions the 3D IPCS and monolithic BDF steps; both agree with the LU oracle and the
+    iteration counts are those of a working V-cycle."""
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box3((4, 4, 4))
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.02, body_force_term=None)
+    vbc = lid_bc(dm, marks)
+    pbc = (np.zeros(0, np.int64), np.zeros(0))
+    for scheme in ("ipcs", "bdf"):
+        ctx = context3(mesh, dm)
+        assert attach_hierarchy(ctx, mesh, coarsest=1) == 2
+        ctx.set_coeffs(1.0, 1.0, 0.02)
+        ctx.set_dirichlet(nat.VELOCITY, *vbc)
+        ctx.set_dirichlet(nat.PRESSURE, *pbc)
+        ctx.set_dirichlet(nat.PRESSURE_PRECOND, *pbc)
+        orc = fo.IPCSOracle(s, coef, refactor_every_step=False) if scheme == "ipcs" \
+            else fo.BDFOracle(s, coef, pin_pressure=True)
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-13
+        opts.momentum.precond = opts.poisson.precond = 1
+        for step in range(2):
+            alpha = fo.bdf_alpha(step, 1.0)
+            ctx.set_bdf(alpha, 0.05)
+            if scheme == "ipcs":
+                info = ctx.step_ipcs(opts)
+                orc.step(alpha, 0.05, vbc, pbc)
+                assert info.krylov_iterations_poisson <= 25
+            else:
+                info = ctx.step_bdf(opts)
+                orc.step(alpha, 0.05, vbc)
+            assert info.newton_iterations == orc.newton_its[step]
+            assert info.krylov_iterations_momentum <= 40 * info.newton_iterations
+            ctx.advance(0 if scheme == "ipcs" else 1)
+            orc.advance()
+        nv = dm.n_velocity
+        uo, po = (orc.vel[1], orc.p_old) if scheme == "ipcs" else (orc.sol[1][:nv], orc.sol[1][nv:])
+        assert rel(ctx.get_state(nat.U1), uo) < 1e-9
+        pg = ctx.get_state(nat.P_OLD)
+        assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
+        ctx.close()

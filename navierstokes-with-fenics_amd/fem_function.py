@@ -38,28 +38,26 @@ class DeviceFunction:
 
     def nodal_values(self):
         v = self.vector()
-        return v.reshape(-1, 2) if self.field == "velocity" else v
+        return v.reshape(-1, self._solver._dofmap.dim) if self.field == "velocity" else v
 
     def __call__(self, point):
         """Point evaluation (host side, brute-force cell search; for tests/diagnostics)."""
         dm = self._solver._dofmap
         mesh = dm.mesh
-        p = np.asarray(point, dtype=np.float64)[:2]
+        dim = dm.dim
+        p = np.asarray(point, dtype=np.float64)[:dim]
         x = mesh.coords[mesh.cells.astype(np.int64)]
-        d = x[:, 1:] - x[:, :1]
-        det = d[:, 0, 0] * d[:, 1, 1] - d[:, 0, 1] * d[:, 1, 0]
-        r = p[None, :] - x[:, 0]
-        xi = (r[:, 0] * d[:, 1, 1] - r[:, 1] * d[:, 1, 0]) / det
-        eta = (-r[:, 0] * d[:, 0, 1] + r[:, 1] * d[:, 0, 0]) / det
-        inside = np.nonzero((xi > -1e-12) & (eta > -1e-12) & (xi + eta < 1.0 + 1e-12))[0]
+        J = np.transpose(x[:, 1:] - x[:, :1], (0, 2, 1))             # columns = edge vectors
+        ref = np.linalg.solve(J, (p[None, :] - x[:, 0])[:, :, None])[:, :, 0]
+        inside = np.nonzero((ref > -1e-12).all(axis=1) & (ref.sum(axis=1) < 1.0 + 1e-12))[0]
         if inside.size == 0:
             raise RuntimeError("point outside of the mesh")
         c = int(inside[0])
-        l = np.array([1.0 - xi[c] - eta[c], xi[c], eta[c]])
+        l = np.concatenate([[1.0 - ref[c].sum()], ref[c]])
         if self.field == "pressure":
             return float(l @ self.vector()[dm.p1_dofmap[c]])
-        N = np.array([l[0] * (2 * l[0] - 1), l[1] * (2 * l[1] - 1), l[2] * (2 * l[2] - 1),
-                      4 * l[1] * l[2], 4 * l[0] * l[2], 4 * l[0] * l[1]])
+        pairs = ((1, 2), (0, 2), (0, 1)) if dim == 2 else ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+        N = np.array([li * (2 * li - 1) for li in l] + [4 * l[a] * l[b] for a, b in pairs])
         return N @ self.nodal_values()[dm.p2_dofmap[c]]
 
 
@@ -118,7 +116,7 @@ def vertex_or_cell_values(function):
     nv = mesh.coords.shape[0]
     node_of_vertex = np.empty(nv, dtype=np.int64)
     if function.field == "velocity":
-        node_of_vertex[cells.ravel()] = np.asarray(dm.p2_dofmap)[:, :3].ravel()
+        node_of_vertex[cells.ravel()] = np.asarray(dm.p2_dofmap)[:, :cells.shape[1]].ravel()
     else:
         node_of_vertex[cells.ravel()] = np.asarray(dm.p1_dofmap).ravel()
     return mesh, "Node", function.nodal_values()[node_of_vertex]

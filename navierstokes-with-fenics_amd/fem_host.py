@@ -11,37 +11,48 @@ is not part of the per-step device path:
 import numpy as np
 
 
-def conical_rule(n):
-    """Gauss-Legendre (n x n) conical product rule on the reference triangle."""
+def conical_rule(n, dim=2):
+    """Gauss-Legendre conical (Duffy) product rule on the reference triangle / tetrahedron:
+    (points [q, dim], weights [q])."""
     g, w = np.polynomial.legendre.leggauss(n)
     g, w = 0.5 * (g + 1.0), 0.5 * w
-    xi = np.repeat(g, n)
-    eta = np.tile(g, n) * (1.0 - xi)
-    wt = np.repeat(w, n) * np.tile(w, n) * (1.0 - xi)
-    return xi, eta, wt
+    if dim == 2:
+        xi = np.repeat(g, n)
+        eta = np.tile(g, n) * (1.0 - xi)
+        wt = np.repeat(w, n) * np.tile(w, n) * (1.0 - xi)
+        return np.stack([xi, eta], axis=1), wt
+    a, b, c = np.meshgrid(g, g, g, indexing="ij")
+    wa, wb, wc = np.meshgrid(w, w, w, indexing="ij")
+    pts = np.stack([a, b * (1.0 - a), c * (1.0 - a) * (1.0 - b)], axis=-1).reshape(-1, 3)
+    return pts, (wa * wb * wc * (1.0 - a) ** 2 * (1.0 - b)).ravel()
 
 
-def _p2_shape(xi, eta):
-    l0, l1, l2 = 1.0 - xi - eta, xi, eta
-    return np.stack([l0 * (2 * l0 - 1), l1 * (2 * l1 - 1), l2 * (2 * l2 - 1),
-                     4 * l1 * l2, 4 * l0 * l2, 4 * l0 * l1], axis=1)
+_EDGE_PAIRS = {2: ((1, 2), (0, 2), (0, 1)), 3: ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))}
 
 
-def _p1_shape(xi, eta):
-    return np.stack([1.0 - xi - eta, xi, eta], axis=1)
+def _p1_shape(pts):
+    return np.concatenate([1.0 - pts.sum(axis=1, keepdims=True), pts], axis=1)
+
+
+def _p2_shape(pts):
+    lam = _p1_shape(pts)
+    dim = pts.shape[1]
+    return np.stack([lam[:, i] * (2 * lam[:, i] - 1) for i in range(dim + 1)]
+                    + [4 * lam[:, a] * lam[:, b] for a, b in _EDGE_PAIRS[dim]], axis=1)
 
 
 def load_vector(mesh, cell_dofs, n_dofs, fun, degree=2, n_comp=1, quad_n=6):
-    """b_i = int f phi_i  for P1 (degree 1) or P2 (degree 2) scalar shape functions;
-    ``fun(X) -> [n] or [n, n_comp]``; vector results are node-interleaved."""
-    xi, eta, wt = conical_rule(quad_n)
-    N = _p2_shape(xi, eta) if degree == 2 else _p1_shape(xi, eta)
-    x = mesh.coords[mesh.cells.astype(np.int64)]                   # [c, 3, 2]
-    lam = _p1_shape(xi, eta)                                        # [q, 3]
-    X = np.einsum("qv,cvd->cqd", lam, x)                            # [c, q, 2]
-    det = np.abs((x[:, 1, 0] - x[:, 0, 0]) * (x[:, 2, 1] - x[:, 0, 1])
-                 - (x[:, 2, 0] - x[:, 0, 0]) * (x[:, 1, 1] - x[:, 0, 1]))
-    f = np.asarray(fun(X.reshape(-1, 2)), dtype=np.float64).reshape(X.shape[0], X.shape[1], -1)
+    """b_i = int f phi_i  for P1 (degree 1) or P2 (degree 2) scalar shape functions on
+    triangles / tetrahedra; ``fun(X) -> [n] or [n, n_comp]``; vector results are
+    node-interleaved."""
+    dim = mesh.coords.shape[1]
+    pts, wt = conical_rule(quad_n, dim)
+    N = _p2_shape(pts) if degree == 2 else _p1_shape(pts)
+    x = mesh.coords[mesh.cells.astype(np.int64)]                   # [c, dim+1, dim]
+    lam = _p1_shape(pts)                                            # [q, dim+1]
+    X = np.einsum("qv,cvd->cqd", lam, x)                            # [c, q, dim]
+    det = np.abs(np.linalg.det(x[:, 1:] - x[:, :1]))
+    f = np.asarray(fun(X.reshape(-1, dim)), dtype=np.float64).reshape(X.shape[0], X.shape[1], -1)
     be = np.einsum("c,q,qi,cqa->cia", det, wt, N, f)                # [c, nloc, n_comp]
     b = np.zeros(n_dofs * n_comp)
     idx = n_comp * cell_dofs.astype(np.int64)[:, :, None] + np.arange(n_comp)[None, None, :]
@@ -51,19 +62,27 @@ def load_vector(mesh, cell_dofs, n_dofs, fun, degree=2, n_comp=1, quad_n=6):
 
 # exact P2 mass matrix of a unit-length edge, local order (end, end, midpoint)
 _EDGE_MASS = np.array([[4.0, -1.0, 2.0], [-1.0, 4.0, 2.0], [2.0, 2.0, 16.0]]) / 30.0
+# exact P2 mass matrix of a unit-area triangle, local order (v0, v1, v2, e(v1v2), e(v0v2), e(v0v1))
+_FACE_MASS = np.array([[6, -1, -1, -4, 0, 0], [-1, 6, -1, 0, -4, 0], [-1, -1, 6, 0, 0, -4],
+                       [-4, 0, 0, 32, 16, 16], [0, -4, 0, 16, 32, 16], [0, 0, -4, 16, 16, 32]]) / 180.0
 
 
 def traction_vector(dofmap, facet_ids, values_at_nodes):
-    """int_Gamma t . w ds with t interpolated at the three P2 nodes of every facet.
-    values_at_nodes(X [m, 2]) -> [m, 2]."""
-    nodes = dofmap.facet_p2_nodes(facet_ids)                         # [nf, 3]
+    """int_Gamma t . w ds with t interpolated at the P2 nodes of every facet (3 on an edge, 6 on
+    a face).  values_at_nodes(X [m, dim]) -> [m, dim]."""
+    dim = dofmap.dim
+    nodes = dofmap.facet_p2_nodes(facet_ids)                         # [nf, 3 | 6]
     X = dofmap.p2_coords[nodes.ravel()]
-    t = np.asarray(values_at_nodes(X), dtype=np.float64).reshape(nodes.shape[0], 3, 2)
-    ends = dofmap.p2_coords[nodes[:, 1]] - dofmap.p2_coords[nodes[:, 0]]
-    length = np.sqrt((ends * ends).sum(axis=1))
-    be = np.einsum("f,ij,fja->fia", length, _EDGE_MASS, t)
+    t = np.asarray(values_at_nodes(X), dtype=np.float64).reshape(nodes.shape[0], nodes.shape[1], dim)
+    e1 = dofmap.p2_coords[nodes[:, 1]] - dofmap.p2_coords[nodes[:, 0]]
+    if dim == 2:
+        measure, M = np.sqrt((e1 * e1).sum(axis=1)), _EDGE_MASS
+    else:
+        e2 = dofmap.p2_coords[nodes[:, 2]] - dofmap.p2_coords[nodes[:, 0]]
+        measure, M = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1), _FACE_MASS
+    be = np.einsum("f,ij,fja->fia", measure, M, t)
     b = np.zeros(dofmap.n_velocity)
-    idx = 2 * nodes[:, :, None] + np.arange(2)[None, None, :]
+    idx = dim * nodes[:, :, None] + np.arange(dim)[None, None, :]
     np.add.at(b, idx.ravel(), be.ravel())
     return b
 

@@ -310,13 +310,16 @@ def periodic_entity_map(mesh, domain):
     nv, ne = mesh.num_vertices(), mesh.num_edges()
     pts = np.concatenate([mesh.coords, mesh.edge_midpoints()], axis=0)
     on_bnd = np.zeros(nv + ne, dtype=bool)
-    bedges = np.nonzero(mesh.edge_on_boundary)[0]
+    if mesh._dim == 2:
+        bedges = np.nonzero(mesh.edge_on_boundary)[0]
+    else:                                       # edges of the boundary faces
+        bedges = np.unique(mesh.facet_edges[mesh.facet_on_boundary])
     on_bnd[nv + bedges] = True
     on_bnd[mesh.edges[bedges].ravel()] = True
     scale = 1.0 / max(mesh.hmin(), 1e-300)
 
     def key(p):
-        return (int(round(p[0] * 8.0 * scale)), int(round(p[1] * 8.0 * scale)))
+        return tuple(int(round(v * 8.0 * scale)) for v in p)
 
     is_master = np.zeros(nv + ne, dtype=bool)
     for i in np.nonzero(on_bnd)[0]:
@@ -330,7 +333,7 @@ def periodic_entity_map(mesh, domain):
     # reference's PeriodicDomain does not treat the corner explicitly; how dolfin resolves that
     # chain cannot be checked here -- the mathematically periodic space is built.]
     for i in np.nonzero(on_bnd)[0]:
-        target = np.array([np.nan, np.nan])
+        target = np.full(pts.shape[1], np.nan)
         domain.map(pts[i].copy(), target)
         if not np.all(np.isfinite(target)):
             continue

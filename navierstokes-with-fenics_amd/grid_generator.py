@@ -3,8 +3,9 @@
 Same entry points, argument meaning and marker enumeration as the reference's
 ``source/grid_generator.py`` (hyper_cube :111-151, hyper_rectangle :154-208,
 open_hyper_cube :211-353, HyperCubeBoundaryMarkers :36-46), producing the
-dolfin-free ``fem_mesh.Mesh`` / ``FacetMarkers`` pair.  2D only: every 3D branch
-of the reference solvers is "pragma: no cover" (SURVEY.md D4).  mshr / gmsh are
+dolfin-free ``fem_mesh.Mesh`` / ``FacetMarkers`` pair.  hyper_cube / hyper_rectangle also build
+the 3D BoxMesh (Kuhn tetrahedra; the reference's 3D solver branches are "pragma: no cover",
+SURVEY.md D4, here they run).  mshr / gmsh are
 absent: spherical_shell (2D annulus) and the DFG channel are triangulated in-repo instead.
 """
 from enum import Enum, auto
@@ -38,18 +39,23 @@ def _mark_box(mesh, lo, hi):
     markers = FacetMarkers(mesh, 0)
     ids = HyperCubeBoundaryMarkers
     tol = _NEAR * max(1.0, float(np.abs(np.array([lo, hi])).max()))
-    for axis, value, marker in ((0, lo[0], ids.left), (0, hi[0], ids.right),
-                                (1, lo[1], ids.bottom), (1, hi[1], ids.top)):
+    sides = [(0, lo[0], ids.left), (0, hi[0], ids.right), (1, lo[1], ids.bottom), (1, hi[1], ids.top)]
+    if len(lo) == 3:                    # reference: back / front = z planes (:143-149, :200-206)
+        sides += [(2, lo[2], ids.back), (2, hi[2], ids.front)]
+    for axis, value, marker in sides:
         markers.mark(lambda X, a=axis, v=value: np.abs(X[:, a] - v) < tol, marker.value)
     return markers
 
 
 def hyper_cube(dim, n_points=10):
-    """Unit square with an equidistant right-diagonal triangulation."""
+    """Unit square / cube with an equidistant right-diagonal triangulation / Kuhn (BoxMesh)
+    tetrahedralisation."""
     assert isinstance(dim, int) and dim in (2, 3)
     assert isinstance(n_points, int) and n_points >= 0
     if dim == 3:
-        raise NotImplementedError("3D meshes are outside the 2D hot path (SURVEY.md D4)")
+        from fem_mesh import box_mesh
+        mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n_points, n_points, n_points)
+        return mesh, _mark_box(mesh, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
     mesh = rectangle_mesh((0.0, 0.0), (1.0, 1.0), n_points, n_points)
     return mesh, _mark_box(mesh, (0.0, 0.0), (1.0, 1.0))
 
@@ -67,7 +73,9 @@ def hyper_rectangle(first_point, second_point, n_points=10):
         assert isinstance(n_points, int) and n_points > 0
         n_points = (n_points,) * dim
     if dim == 3:
-        raise NotImplementedError("3D meshes are outside the 2D hot path (SURVEY.md D4)")
+        from fem_mesh import box_mesh
+        mesh = box_mesh(first_point, second_point, *n_points)
+        return mesh, _mark_box(mesh, first_point, second_point)
     mesh = rectangle_mesh(first_point, second_point, *n_points)
     return mesh, _mark_box(mesh, first_point, second_point)
 

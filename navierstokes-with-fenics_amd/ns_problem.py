@@ -124,6 +124,8 @@ class ProblemBase:
         (:55-83) reproduces it exactly.  Stored per cell as the mean of its three vertex values."""
         from fem_function import HostField
         dm = self._get_solver()._dofmap
+        if dm.dim != 2:
+            return None                     # 3D post-processing fields are not built
         g = self._cell_gradients(self._get_velocity().nodal_values(), dm.p2_dofmap, True)
         curl = g[:, :, 1, 0] - g[:, :, 0, 1]
         field = HostField(self._mesh, "vorticity", "Cell", curl.mean(axis=1))
@@ -134,6 +136,8 @@ class ProblemBase:
         """grad of the P1 pressure: piecewise constant = its DG0 projection (:85-103)."""
         from fem_function import HostField
         dm = self._get_solver()._dofmap
+        if dm.dim != 2:
+            return None
         g = self._cell_gradients(self._get_pressure().nodal_values(), dm.p1_dofmap, False)
         return HostField(self._mesh, "pressure gradient", "Cell", g[:, 0, 0, :])
 
@@ -200,7 +204,8 @@ class InstationaryProblem(ProblemBase):
         switched off."""
         next_step_size = self._time_stepping.get_next_step_size()
         assert next_step_size > 0.0 and math.isfinite(next_step_size)
-        if getattr(self, "compute_cfl", True):
+        if getattr(self, "compute_cfl", True) and self._space_dim == 2:
+            # (the device CFL kernel is built for triangles; the value is a diagnostic only)
             self._last_cfl = self._compute_cfl_number(next_step_size)
 
     def solve_problem(self):

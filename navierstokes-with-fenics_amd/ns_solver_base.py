@@ -251,7 +251,7 @@ class SolverBase:
         dofs, vals = [], []
 
         def add(nodes, comp, v):
-            dofs.append(2 * nodes + comp)
+            dofs.append(self._space_dim * nodes + comp)
             vals.append(np.broadcast_to(v, nodes.shape).astype(np.float64))
 
         for bc in getattr(self, "_velocity_bcs", []):
@@ -259,26 +259,26 @@ class SolverBase:
             nodes = np.unique(dm.facet_p2_nodes(self._boundary_markers.facets_with_id(bndry_id)))
             X = dm.p2_coords[nodes]
             if bc_type is VelocityBCType.no_slip:
-                for comp in range(2):
+                for comp in range(self._space_dim):
                     add(nodes, comp, 0.0)
             elif bc_type in (VelocityBCType.no_normal_flux, VelocityBCType.no_tangential_flux):
                 normal = np.array(fem_host.boundary_normal(self._mesh, self._boundary_markers, bndry_id))
                 k = int(np.abs(normal).argmax())
                 assert abs(abs(normal[k]) - 1.0) < 5.0e-14, "boundary must be axis aligned"
                 comps = (k,) if bc_type is VelocityBCType.no_normal_flux else tuple(
-                    d for d in range(2) if d != k)
+                    d for d in range(self._space_dim) if d != k)
                 for comp in comps:
                     add(nodes, comp, 0.0)
             elif bc_type is VelocityBCType.constant:
                 assert isinstance(bc[2], (tuple, list))
-                for comp in range(2):
+                for comp in range(self._space_dim):
                     add(nodes, comp, bc[2][comp])
             elif bc_type is VelocityBCType.constant_component:
                 assert isinstance(bc[3], float)
                 add(nodes, bc[2], bc[3])
             elif bc_type is VelocityBCType.function:
                 v = dlfn.evaluate(bc[2], X)
-                for comp in range(2):
+                for comp in range(self._space_dim):
                     add(nodes, comp, v[:, comp])
             elif bc_type is VelocityBCType.function_component:
                 add(nodes, bc[2], dlfn.evaluate(bc[3], X))
@@ -339,7 +339,7 @@ class SolverBase:
                 facets = self._boundary_markers.facets_with_id(bndry_id)
 
                 def nodal(X, bc=bc, bc_type=bc_type):
-                    out = np.zeros((X.shape[0], 2))
+                    out = np.zeros((X.shape[0], self._space_dim))
                     if bc_type in (TractionBCType.constant, TractionBCType.function):
                         out[:] = dlfn.evaluate(bc[2], X)
                     else:
@@ -464,7 +464,7 @@ class InstationarySolverBase(SolverBase):
                 return np.tile(np.asarray(condition, dtype=np.float64), dm.n_p2)
             assert condition.value_rank() == 1
             b = fem_host.load_vector(self._mesh, dm.p2_dofmap, dm.n_p2,
-                                     lambda X: dlfn.evaluate(condition, X), degree=2, n_comp=2)
+                                     lambda X: dlfn.evaluate(condition, X), degree=2, n_comp=self._space_dim)
             return self._ctx.mass_solve(nat.VELOCITY, b)
         if isinstance(condition, float):
             return np.full(dm.n_p1, condition)

@@ -57,9 +57,11 @@ class XDMFFile:
     def _write_mesh(self, mesh):
         cells = np.asarray(mesh.cells, dtype=np.int32)
         coords = np.asarray(mesh.coords, dtype=np.float64)
-        topo = ('<Topology TopologyType="Triangle" NumberOfElements="%d" NodesPerElement="3">\n%s\n'
-                '</Topology>' % (cells.shape[0], self._data_item(cells, "Int")))
-        geo = '<Geometry GeometryType="XY">\n%s\n</Geometry>' % self._data_item(coords, "Float")
+        kind = "Triangle" if cells.shape[1] == 3 else "Tetrahedron"
+        topo = ('<Topology TopologyType="%s" NumberOfElements="%d" NodesPerElement="%d">\n%s\n'
+                '</Topology>' % (kind, cells.shape[0], cells.shape[1], self._data_item(cells, "Int")))
+        geo = '<Geometry GeometryType="%s">\n%s\n</Geometry>' % (
+            "XY" if coords.shape[1] == 2 else "XYZ", self._data_item(coords, "Float"))
         self._mesh_items = (topo, geo)
 
     def write(self, function, t=0.0):

@@ -728,3 +728,73 @@ def test_instationary_rotating_couette_flow_matches_oracle():
     assert np.linalg.norm(u.vector() - uo) < 1e-6 * np.linalg.norm(uo)
     pv = p.vector()
     assert np.linalg.norm((pv - pv.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())
+
+
+# ---- 3D (BASELINE configs 3-4 in small; the reference's 3D branches are never exercised) ------
+class Cavity3D(InstationaryProblem):
+    """lid-driven unit cube, Re = 50: no-slip on five faces, lid (1, 0, 0) on the front face
+    (z = 1), hyper_cube(3, n) = dolfin BoxMesh markers."""
+
+    def __init__(self, n_points, solver_class, n_steps=3):
+        super().__init__(None, start_time=0.0, end_time=1.0, desired_start_time_step=0.05,
+                         n_max_steps=n_steps)
+        self._n_points = n_points
+        self._problem_name = "Cavity3D"
+        self._output_frequency = 2
+        self._postprocessing_frequency = 0
+        self.set_solver_class(solver_class)
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_cube(3, self._n_points)
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=50.0)
+
+    def set_initial_conditions(self):
+        self._initial_conditions = {"velocity": (0.0, 0.0, 0.0), "pressure": 0.0}
+
+    def set_boundary_conditions(self):
+        ids = HyperCubeBoundaryMarkers
+        self._bcs = tuple((VelocityBCType.no_slip, m.value, None)
+                          for m in (ids.left, ids.right, ids.bottom, ids.top, ids.back)) + \
+            ((VelocityBCType.constant, ids.front.value, (1.0, 0.0, 0.0)), )
+
+
+@pytest.mark.parametrize("solver_class", [IPCSSolver, ImplicitBDFSolver])
+def test_3d_cavity_through_the_solver_classes_matches_oracle(solver_class):
+    problem = Cavity3D(4, solver_class)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    assert solver._space_dim == 3 and solver._mg_levels == 0 and dm.n_dofs == 3 * 9 ** 3 + 5 ** 3
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    vd, vv = solver._dirichlet_bcs["velocity"]
+    _, first = np.unique(vd[::-1], return_index=True)
+    keep = len(vd) - 1 - first
+    bc = (vd[keep].astype(np.int64), vv[keep])
+    coef = solver._equation_coefficients
+    nv = dm.n_velocity
+    if solver_class is IPCSSolver:
+        orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+        for step in range(3):
+            orc.step(fo.bdf_alpha(step, 1.0), 0.05, bc, (np.zeros(0, np.int64), np.zeros(0)))
+            orc.advance()
+        uo, po = orc.vel[1], orc.p_old
+    else:
+        orc = fo.BDFOracle(s, coef, pin_pressure=True)
+        for step in range(3):
+            orc.step(fo.bdf_alpha(step, 1.0), 0.05, bc)
+            orc.advance()
+        uo, po = orc.sol[1][:nv], orc.sol[1][nv:]
+    u, p = solver.solution.split()
+    assert np.linalg.norm(u.vector() - uo) < 1e-6 * np.linalg.norm(uo)
+    pv = p.vector()
+    assert np.linalg.norm((pv - pv.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())
+    # point evaluation and XDMF output work on tetrahedra
+    assert abs(u((0.5, 0.5, 1.0))[0] - 1.0) < 1e-12
+    import xdmf_io
+    import os
+    files = [f for f in os.listdir("results") if f.endswith(".xdmf")]
+    back = xdmf_io.read_xdmf(os.path.join("results", files[0]))
+    assert back["cells"].shape[1] == 4 and back["coords"].shape[1] == 3
+    assert back["fields"]["velocity"][-1].shape == (5 ** 3, 3)

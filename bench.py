@@ -164,6 +164,79 @@ def dfg_bdf_bench(args):
     ctx.close()
 
 
+def cavity3d_bench(args):
+    """3D lid-driven cavity on a Kuhn (BoxMesh) tetrahedral mesh, Re = 100, IPCS or monolithic
+    BDF-2 -- the single-GPU, reduced-size relative of BASELINE.json configs[3:5] (which are 3D,
+    8-GPU configurations beyond what the reference itself exercises)."""
+    from fem_mesh import FacetMarkers, TaylorHoodDofMap, box_mesh
+    from multigrid import attach_hierarchy
+    n = args.n
+    t_setup = time.perf_counter()
+    mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
+    dm = TaylorHoodDofMap(mesh)
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+    levels = attach_hierarchy(ctx, mesh)
+    X = dm.p2_coords
+    on = np.zeros(dm.n_p2, dtype=bool)
+    for a in range(3):
+        on |= (np.abs(X[:, a]) < 1e-12) | (np.abs(X[:, a] - 1.0) < 1e-12)
+    nodes = np.nonzero(on)[0]
+    lid = np.abs(X[nodes, 2] - 1.0) < 1e-12
+    dofs = np.concatenate([3 * nodes, 3 * nodes + 1, 3 * nodes + 2]).astype(np.int32)
+    vals = np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(2 * nodes.size)])
+    ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
+    ctx.set_dirichlet(nat.VELOCITY, dofs, vals)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+    t_setup = time.perf_counter() - t_setup
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = args.krylov_rtol
+    opts.momentum.precond = opts.poisson.precond = 1
+    opts.newton_forcing = args.newton_forcing
+    bdf = args.workload == "cavity3d-bdf"
+    dt = args.dt if args.dt != 1.0e-3 else 0.5 / n          # CFL ~ 0.5 for the unit lid speed
+
+    def one_step(i):
+        ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), dt)
+        info = ctx.step_bdf(opts) if bdf else ctx.step_ipcs(opts)
+        ctx.advance(1 if bdf else 0)
+        return info
+
+    for i in range(args.warmup):
+        one_step(i)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    newton = kry = poi = 0
+    for i in range(args.warmup, args.warmup + args.steps):
+        info = one_step(i)
+        newton += info.newton_iterations
+        kry += info.krylov_iterations_momentum
+        poi += info.krylov_iterations_poisson
+    ctx.synchronize()
+    sps = args.steps / (time.perf_counter() - t0)
+    ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 100)
+    achieved = nbytes / (ms_spmv * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "dof_updates_per_sec", "value": sps * dm.n_dofs, "unit": "DoF-updates/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "time_steps_per_sec": sps,
+        "config": {"workload": "3D lid-driven cavity Re=100, %d^3 cubes x 6 Kuhn tetrahedra (%d cells, %d dofs), "
+                               "%s, dt=%g" % (n, mesh.num_cells(), dm.n_dofs,
+                                              "BDF-2 monolithic" if bdf else "IPCS", dt),
+                   "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "newton_forcing": args.newton_forcing, "coarse_p1_levels": levels,
+                   "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
+                   "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
+                   "host_setup_s": t_setup},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<3,3,1,0> (velocity Jacobian, 3x3 block CSR)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv}}))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,14 +255,22 @@ def main():
     ap.add_argument("--mg-degree", type=int, default=2, help="Chebyshev smoother degree")
     ap.add_argument("--mg-eig-ratio", type=float, default=4.0)
     ap.add_argument("--coarsest", type=int, default=0, help="cells across the coarsest multigrid mesh (0: default)")
-    ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf"), default="cavity-ipcs",
-                    help="cavity-ipcs = BASELINE configs[1] (headline); dfg-bdf = configs[2], 1 GPU")
+    ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf"),
+                    default="cavity-ipcs",
+                    help="cavity-ipcs = BASELINE configs[1] (headline); dfg-bdf = configs[2], 1 GPU; "
+                         "cavity3d-* = 3D tetrahedral cavity (--cells cubes per side), 1 GPU")
     ap.add_argument("--dfg-refine", type=int, default=5)
     args = ap.parse_args()
     if args.workload == "dfg-bdf":
         if int(os.environ.get("WORLD_SIZE", "1")) != 1:
             raise SystemExit("the dfg-bdf workload is a single-GPU configuration")
         return dfg_bdf_bench(args)
+    if args.workload.startswith("cavity3d"):
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("the 3D workloads are single-GPU configurations")
+        if args.n == 512:
+            args.n = 32
+        return cavity3d_bench(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

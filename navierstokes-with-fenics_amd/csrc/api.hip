@@ -505,7 +505,7 @@ static void fill_linop(nsfem_ctx* c, LinOp& op, bool velocity) {
   if (!c->distributed()) return;
   op.comm = c->comm;
   op.halo = velocity ? &c->halo_p2 : &c->halo_p1;
-  op.halo_width = velocity ? 2 : 1;
+  op.halo_width = velocity ? c->mesh.dim : 1;
   op.ghostmask = velocity ? c->mask_v.p : c->mask_p.p;
   op.n_global = velocity ? 2 * c->n_p2_global : c->n_p1_global;
 }
@@ -1267,7 +1267,7 @@ extern "C" int nsfem_mass_solve(nsfem_ctx* ctx, int field, const double* b, doub
   dx.zero(s);
   LinOp op;
   op.A = vel ? &ctx->M2 : &ctx->Mp;
-  op.nv = vel ? 2 : 1;
+  op.nv = vel ? ctx->mesh.dim : 1;
   launch_inv_diag(s, *op.A, op.nv, nullptr, dinv.p);
   op.dinv = dinv.p;
   int rc = pcg(s, ctx->kw, op, db.p, dx.p, *opts, inf, false);

@@ -187,3 +187,44 @@ def test_expression_conditional_operator_and_annulus_mesh():
     d2 = mesh.coords[mesh.cells[:, 2]] - mesh.coords[mesh.cells[:, 0]]
     area = 0.5 * np.abs(d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]).sum()
     assert abs(area - np.pi * (1.0 - 0.25 ** 2)) < 5e-3
+
+
+def test_box_mesh_kuhn_split_dofmap_and_nested_prolongation():
+    """3D host pieces: dolfin BoxMesh vertex order and 6-tet Kuhn split, face markers, Taylor-Hood
+    counts 3(2n+1)^3 + (n+1)^3, and the structured P1 prolongation -- exact for
+    linear functions AND every fine vertex sits on a coarse edge (nested spaces)."""
+    from fem_mesh import box_mesh
+    from grid_generator import HyperCubeBoundaryMarkers as M, hyper_cube, hyper_rectangle
+    from multigrid import structured_hierarchy, structured_prolongation_3d
+    mesh, marks = hyper_cube(3, 4)
+    assert mesh.num_cells() == 6 * 4 ** 3 and mesh.num_vertices() == 5 ** 3
+    x = mesh.coords[mesh.cells.astype(np.int64)]
+    vol = np.einsum("ci,ci->c", x[:, 1] - x[:, 0], np.cross(x[:, 2] - x[:, 0], x[:, 3] - x[:, 0])) / 6.0
+    assert (vol > 0).all() and abs(vol.sum() - 1.0) < 1e-14
+    assert np.allclose(mesh.coords[1], [0.25, 0, 0]) and np.allclose(mesh.coords[5], [0, 0.25, 0])
+    # every cell contains the main diagonal of its cube
+    lo, hi = x.min(axis=1), x.max(axis=1)
+    has = lambda P: (np.abs(x - P[:, None, :]).max(axis=2) < 1e-14).any(axis=1)
+    assert has(lo).all() and has(hi).all()
+    dm = TaylorHoodDofMap(mesh)
+    assert dm.n_dofs == 3 * 9 ** 3 + 5 ** 3
+    for name, axis, value in (("left", 0, 0.0), ("right", 0, 1.0), ("bottom", 1, 0.0),
+                              ("top", 1, 1.0), ("back", 2, 0.0), ("front", 2, 1.0)):
+        f = marks.facets_with_id(M[name].value)
+        assert f.size == 2 * 16 and np.allclose(mesh.facet_midpoints()[f, axis], value)
+        nodes = np.unique(dm.facet_p2_nodes(f))
+        assert nodes.size == 81 and np.allclose(dm.p2_coords[nodes, axis], value)
+    assert marks.ids() == {m.value for m in (M.left, M.right, M.bottom, M.top, M.back, M.front)}
+    mesh2, _ = hyper_rectangle((0.0, 0.0, 0.0), (2.0, 1.0, 0.5), (4, 2, 2))
+    rowptr, col, val = structured_prolongation_3d(4, 2, 2)
+    coarse = box_mesh((0.0, 0.0, 0.0), (2.0, 1.0, 0.5), 2, 1, 1)
+    import scipy.sparse as sp
+    P = sp.csr_matrix((val, col, rowptr), shape=(mesh2.num_vertices(), coarse.num_vertices()))
+    lin = lambda X: 0.3 + 1.1 * X[:, 0] - 0.7 * X[:, 1] + 2.0 * X[:, 2]
+    assert np.abs(P @ lin(coarse.coords) - lin(mesh2.coords)).max() < 1e-14
+    ce = {tuple(e) for e in coarse.edges.tolist()}
+    for r in range(P.shape[0]):
+        cols = sorted(P.indices[P.indptr[r]:P.indptr[r + 1]].tolist())
+        assert len(cols) == 1 or tuple(cols) in ce          # midpoint of an actual coarse edge
+    levels = structured_hierarchy((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 8, 8, 8, coarsest=2)
+    assert [lv[0].num_vertices() for lv in levels] == [125, 27]

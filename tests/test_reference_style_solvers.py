@@ -798,3 +798,81 @@ def test_3d_cavity_through_the_solver_classes_matches_oracle(solver_class):
     back = xdmf_io.read_xdmf(os.path.join("results", files[0]))
     assert back["cells"].shape[1] == 4 and back["coords"].shape[1] == 3
     assert back["fields"]["velocity"][-1].shape == (5 ** 3, 3)
+
+
+class PeriodicDomain3D(dlfn.SubDomain):
+    """triple-periodic unit cube: masters are the planes x = 0, y = 0, z = 0"""
+
+    def inside(self, x, on_boundary):
+        return bool(on_boundary and (dlfn.near(x[0], 0.0) or dlfn.near(x[1], 0.0) or dlfn.near(x[2], 0.0)))
+
+    def map(self, x_slave, x_master):
+        for a in range(3):
+            if dlfn.near(x_slave[a], 1.0):
+                x_master[:] = x_slave
+                x_master[a] -= 1.0
+                return
+        x_master[:] = -10.0
+
+
+class TaylorGreenVortex3D(TaylorGreenVortex):
+    """the planar Taylor-Green vortex, invariant in z, on the triple-periodic cube: exercises the
+    3D periodic dof map, the 3D convection kernels and the mean-value pressure constraint"""
+
+    def __init__(self):
+        super().__init__(None)
+        self._n_points = 6
+        self._n_max_steps = 5
+        self._time_stepping_args = None
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_cube(3, self._n_points)
+
+    def set_initial_conditions(self):
+        g = self._gamma
+        self._initial_conditions = {
+            "velocity": dlfn.Expression(("cos(gamma * x[0]) * sin(gamma * x[1])",
+                                         "-sin(gamma * x[0]) * cos(gamma * x[1])", "0.0"), gamma=g, degree=3),
+            "pressure": dlfn.Expression("-1.0/4.0 * (cos(2.0 * gamma * x[0]) + cos(2.0 * gamma * x[1]))",
+                                        gamma=g, degree=3)}
+
+    def set_periodic_boundary_conditions(self):
+        self._periodic_bcs = PeriodicDomain3D()
+        ids = HyperCubeBoundaryMarkers
+        self._periodic_boundary_ids = tuple(m.value for m in (ids.left, ids.right, ids.top, ids.bottom,
+                                                              ids.back, ids.front))
+
+
+def test_taylor_green_vortex_triple_periodic_3d():
+    problem = TaylorGreenVortex3D()
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    assert dm.n_p2 == 12 ** 3 and dm.n_p1 == 6 ** 3                 # all periodic images share a dof
+    velocity, pressure = solver.solution.split()
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    assert abs((s.mass_p1() @ pressure.vector()).sum()) < 1e-12
+    u = velocity.nodal_values()
+    assert np.abs(u[:, 2]).max() < 1e-8                              # stays planar
+    g, Re, t = 2.0 * np.pi, 100.0, 0.5
+    X = dm.p2_coords
+    ue = np.exp(-2.0 * g * g * t / Re) * np.stack([np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]),
+                                                   -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1])], axis=1)
+    assert np.abs(u[:, :2] - ue).max() < 0.30 * np.abs(ue).max()     # h = 1/6, dt = 0.1: coarse
+    orc = fo.BDFOracle(s, solver._equation_coefficients, pin_pressure=True)
+    import fem_host
+    b = fem_host.load_vector(dm.mesh, dm.p2_dofmap, dm.n_p2,
+                             lambda Y: dlfn.evaluate(problem._initial_conditions["velocity"], Y), degree=2, n_comp=3)
+    orc.set_initial(fo.spla.spsolve(s.vector_mass().tocsc(), b), None)
+    b = fem_host.load_vector(dm.mesh, dm.p1_dofmap, dm.n_p1,
+                             lambda Y: dlfn.evaluate(problem._initial_conditions["pressure"], Y), degree=1, n_comp=1)
+    p0 = fo.spla.spsolve(s.mass_p1().tocsc(), b)
+    for i in (0, 1):
+        orc.sol[i][dm.n_velocity:] = p0
+    for step in range(5):
+        orc.step(fo.bdf_alpha(step, 1.0), 0.1)
+        orc.advance()
+    nv = dm.n_velocity
+    assert np.linalg.norm(velocity.vector() - orc.sol[1][:nv]) < 1e-6 * np.linalg.norm(orc.sol[1][:nv])
+    pg, po = pressure.vector(), orc.sol[1][nv:]
+    assert np.linalg.norm((pg - pg.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())

@@ -408,8 +408,15 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
     halo_fill(s, L, L.r.p);
     launch_spmv(s, *L.R, nv, L.r.p, C.b.p, C.mask, MASK_ZERO);
   } else {            // no pre-smoothing: x = 0, the residual is b itself
-    halo_fill(s, L, b);
-    launch_spmv(s, *L.R, nv, b, C.b.p, C.mask, MASK_ZERO);
+    const double* src = b;
+    if (comm_active() && L.has_halo) {
+      // the restriction needs the ghost entries of b, but b belongs to the caller (a Krylov
+      // vector whose ghost entries must stay zero for the dot products): fill a copy
+      NSFEM_HIP(hipMemcpyAsync(L.r.p, b, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+      halo_fill(s, L, L.r.p);
+      src = L.r.p;
+    }
+    launch_spmv(s, *L.R, nv, src, C.b.p, C.mask, MASK_ZERO);
   }
   vcycle(s, l + 1, C.b.p, C.x.p);
   halo_fill(s, C, C.x.p);

@@ -26,10 +26,13 @@ convergence_test/taylor_green_vortex.py:111-117).  Velocity/pressure values of
 FEniCS itself cannot be diffed here: "parity unpinned" against FEniCS output.
 
 Conventions shared with the product (inputs, not algorithm):
-  * scalar P2 node ids come from ``p2_dofmap`` [n_cells, 6]: local order
-    (v0, v1, v2, e(v1v2), e(v0v2), e(v0v1))  (FIAT/UFC ordering);
-  * velocity vectors are node-interleaved: index = 2 * node + component;
-  * mixed vectors are [velocity (2*N2) | pressure (N1)].
+  * triangles and tetrahedra (``dim`` = coords.shape[1]); scalar P2 node ids come from
+    ``p2_dofmap`` [n_cells, 6 | 10]: vertices, then edge nodes in FIAT/UFC edge order
+    (2D: e(v1v2), e(v0v2), e(v0v1); 3D: e(v2v3), e(v1v3), e(v1v2), e(v0v3), e(v0v2), e(v0v1));
+  * velocity vectors are node-interleaved: index = dim * node + component;
+  * mixed vectors are [velocity (dim*N2) | pressure (N1)].
+The 3D branch is pinned by sympy-exact tetrahedron matrices and a polynomial Stokes solution
+(tests/test_oracle_pinning.py); the reference itself never runs in 3D.
 A quadrature rule DIFFERENT from the one in the HIP kernels is used on purpose
 (collapsed Gauss-Legendre instead of the 7-point Radon rule): all integrands
 are polynomials on affine cells, so both are exact and must agree to round-off.

@@ -402,7 +402,7 @@ def main():
                      "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.dt, 2)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.dt, 6)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

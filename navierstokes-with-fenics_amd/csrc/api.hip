@@ -843,8 +843,9 @@ extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d
   const int n2 = ctx->mesh.n_p2, n1 = ctx->mesh.n_p1;
   ctx->h_ghost_p2.assign(d->p2_ghost, d->p2_ghost + n2);
   ctx->h_ghost_p1.assign(d->p1_ghost, d->p1_ghost + n1);
-  std::vector<uint8_t> gv((size_t)2 * n2), gp((size_t)n1);
-  for (int i = 0; i < n2; ++i) gv[2 * i] = gv[2 * i + 1] = d->p2_ghost[i] ? 2 : 0;
+  std::vector<uint8_t> gv((size_t)ctx->mesh.dim * n2), gp((size_t)n1);
+  for (int i = 0; i < n2; ++i)
+    for (int a = 0; a < ctx->mesh.dim; ++a) gv[(size_t)ctx->mesh.dim * i + a] = d->p2_ghost[i] ? 2 : 0;
   for (int i = 0; i < n1; ++i) gp[i] = d->p1_ghost[i] ? 2 : 0;
   ctx->ghost_v.upload(gv, s);
   ctx->ghost_p.upload(gp, s);

@@ -152,5 +152,117 @@ class StripPartition:
         return len(self.levels)
 
 
-def global_dof_counts(nx, ny):
-    return (2 * nx + 1) * (2 * ny + 1), (nx + 1) * (ny + 1)
+def global_dof_counts(nx, ny, nz=None):
+    if nz is None:
+        return (2 * nx + 1) * (2 * ny + 1), (nx + 1) * (ny + 1)
+    return (2 * nx + 1) * (2 * ny + 1) * (2 * nz + 1), (nx + 1) * (ny + 1) * (nz + 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# 3D: slabs of cube layers along z (the slowest lexicographic index, so every halo is again one
+# contiguous range: whole lattice planes)
+# ---------------------------------------------------------------------------------------------
+class SlabLevel:
+    """One P1 level of one rank of a Kuhn box mesh: own cube layers + ghost layer above."""
+
+    def __init__(self, p0, p1, nx, ny, nz, layer0, own_layers, ghost_layers):
+        from fem_mesh import box_mesh
+        layers = own_layers + ghost_layers
+        hz = (p1[2] - p0[2]) / nz
+        lo = (p0[0], p0[1], p0[2] + layer0 * hz)
+        hi = (p1[0], p1[1], p0[2] + (layer0 + layers) * hz)
+        self.mesh = box_mesh(lo, hi, nx, ny, layers)
+        # exact global coordinates (avoid round-off differences between ranks)
+        z_all = np.linspace(p0[2], p1[2], nz + 1)
+        w1 = (nx + 1) * (ny + 1)
+        self.mesh.coords[:, 2] = np.repeat(z_all[layer0: layer0 + layers + 1], w1)
+        self.nx, self.ny, self.rows, self.own_rows, self.row0 = nx, ny, layers, own_layers, layer0
+        self.has_below, self.has_above = layer0 > 0, ghost_layers > 0
+        self.w1 = w1
+        self.n_p1 = w1 * (layers + 1)
+        ghost = np.zeros(self.n_p1, dtype=np.uint8)
+        if self.has_below:
+            ghost[:w1] = GHOST
+        if self.has_above:
+            ghost[w1 * (own_layers + 1):] = GHOST
+        self.p1_ghost = ghost
+        self.p1_halo = dict(
+            send_up=(w1 * own_layers, w1) if self.has_above else (0, 0),
+            recv_above=(w1 * (own_layers + 1), w1) if self.has_above else (0, 0),
+            send_down=(w1, w1) if self.has_below else (0, 0),
+            recv_below=(0, w1) if self.has_below else (0, 0))
+
+    def global_p1_offset(self):
+        return self.row0 * self.w1
+
+
+class SlabPartition:
+    """3D counterpart of ``StripPartition``: rank ``rank`` of ``size`` owns nz / size cube layers
+    of the (nx, ny, nz) Kuhn box mesh (dofs of its layers except the bottom lattice plane) and
+    assembles one ghost layer above.  Same attributes, same ``attach``."""
+
+    def __init__(self, p0, p1, nx, ny, nz, rank, size, coarsest=8, global_coarsest=None):
+        from multigrid import structured_hierarchy, structured_prolongation_3d
+        assert nz % size == 0, "cube layers must divide evenly over the ranks"
+        own = nz // size
+        self.rank, self.size = rank, size
+        self.p0, self.p1, self.nx, self.ny, self.nz = tuple(p0), tuple(p1), nx, ny, nz
+        g = 1 if rank < size - 1 else 0
+        self.fine = SlabLevel(p0, p1, nx, ny, nz, rank * own, own, g)
+        self.mesh = self.fine.mesh
+        self.dofmap = dm = TaylorHoodDofMap(self.mesh)
+        w2 = (2 * nx + 1) * (2 * ny + 1)
+        self.w2 = w2
+        planes = 2 * self.fine.rows + 1
+        assert dm.n_p2 == w2 * planes
+        ghost2 = np.zeros(dm.n_p2, dtype=np.uint8)
+        if self.fine.has_below:
+            ghost2[:w2] = GHOST
+        if self.fine.has_above:
+            ghost2[w2 * (2 * own + 1):] = GHOST
+        self.p2_ghost = ghost2
+        self.p2_halo = dict(
+            send_up=(w2 * 2 * own, w2) if self.fine.has_above else (0, 0),
+            recv_above=(w2 * (2 * own + 1), 2 * w2) if self.fine.has_above else (0, 0),
+            send_down=(w2, 2 * w2) if self.fine.has_below else (0, 0),
+            recv_below=(0, w2) if self.fine.has_below else (0, 0))
+        self.p1_ghost = self.fine.p1_ghost
+        self.p1_halo = self.fine.p1_halo
+        self.p2_global = rank * own * 2 * w2 + np.arange(dm.n_p2)
+        self.p1_global = rank * own * self.fine.w1 + np.arange(dm.n_p1)
+        self.p2_owned = ghost2 == 0
+        self.p1_owned = self.p1_ghost == 0
+        self.levels = []
+        lx, ly, lz, lown, fine_level = nx, ny, nz, own, self.fine
+        while lx % 2 == 0 and ly % 2 == 0 and lown % 2 == 0 and lown // 2 >= 1 \
+                and min(lx, ly, lz) // 2 >= coarsest:
+            cx, cy, cz, cown = lx // 2, ly // 2, lz // 2, lown // 2
+            lev = SlabLevel(p0, p1, cx, cy, cz, rank * cown, cown, g)
+            rowptr, col, val = structured_prolongation_3d(lx, ly, 2 * lev.rows)
+            n_fine = (lx + 1) * (ly + 1) * (fine_level.rows + 1)
+            rowptr = rowptr[: n_fine + 1].copy()
+            nnz = rowptr[-1]
+            self.levels.append((lev, (rowptr, col[:nnz].copy(), val[:nnz].copy())))
+            lx, ly, lz, lown, fine_level = cx, cy, cz, cown, lev
+        last = self.levels[-1][0] if self.levels else self.fine
+        self.coarse_global_shape = (last.nx, last.ny, lz)
+        self.coarse_global_offset = last.global_p1_offset()
+        self.global_tail = []
+        if global_coarsest is not None:
+            self.global_tail = structured_hierarchy(self.p0, self.p1, last.nx, last.ny, lz,
+                                                    coarsest=global_coarsest)
+
+    def attach(self, ctx, degree=2, eig_ratio=4.0):
+        from fem_mesh import box_mesh
+        n2g, n1g = global_dof_counts(self.nx, self.ny, self.nz)
+        ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, self.p2_halo,
+                          self.p1_halo, n2g, n1g)
+        for lev, (rowptr, col, val) in self.levels:
+            ctx.mg_add_level(lev.mesh.coords, lev.mesh.cells, rowptr, col, val,
+                             ghost=lev.p1_ghost, halo=lev.p1_halo)
+        cg = box_mesh(self.p0, self.p1, *self.coarse_global_shape)
+        ctx.mg_set_global_coarse(cg.coords, cg.cells, self.coarse_global_offset)
+        for mesh, (rowptr, col, val) in self.global_tail:
+            ctx.mg_add_global_level(mesh.coords, mesh.cells, rowptr, col, val)
+        ctx.mg_finalize(degree, eig_ratio)
+        return len(self.levels)

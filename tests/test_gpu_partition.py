@@ -118,6 +118,90 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail):
     nat.local_group_destroy(group)
 
 
+def test_partitioned_3d_slabs_equal_single_context():
+    """3D: slabs of cube layers along z (SlabPartition), partitioned multigrid with the replicated
+    global tail -- two in-process ranks reproduce the single-context 3D IPCS run."""
+    from fem_mesh import TaylorHoodDofMap, box_mesh
+    from partition import SlabPartition
+    n, size, nsteps, k = 8, 2, 2, 0.02
+    mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
+    dm = TaylorHoodDofMap(mesh)
+
+    def bc(dmap):
+        X = dmap.p2_coords
+        on = np.zeros(dmap.n_p2, dtype=bool)
+        for a in range(3):
+            on |= (np.abs(X[:, a]) < 1e-12) | (np.abs(X[:, a] - 1.0) < 1e-12)
+        nodes = np.nonzero(on)[0]
+        lid = np.abs(X[nodes, 2] - 1.0) < 1e-12
+        return (np.concatenate([3 * nodes, 3 * nodes + 1, 3 * nodes + 2]).astype(np.int32),
+                np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(2 * nodes.size)]))
+
+    def run(ctx, dmap, out, key):
+        ctx.set_coeffs(1.0, 1.0, 0.02)
+        ctx.set_dirichlet(nat.VELOCITY, *bc(dmap))
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-12
+        opts.momentum.precond = opts.poisson.precond = 1
+        infos = []
+        for step in range(nsteps):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
+            infos.append(ctx.step_ipcs(opts))
+            ctx.advance(0)
+        out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
+
+    ref = {}
+    ctx0 = context(mesh, dm)
+    attach_hierarchy(ctx0, mesh, coarsest=2)
+    run(ctx0, dm, ref, 0)
+    u_ref, p_ref, inf_ref = ref[0]
+    ctx0.close()
+    group = nat.local_group_create(size)
+    parts = [SlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n, r, size, coarsest=4,
+                           global_coarsest=2) for r in range(size)]
+    assert len(parts[0].levels) == 1 and len(parts[0].global_tail) == 1
+    ctxs = []
+    for r, part in enumerate(parts):
+        pdm = part.dofmap
+        c = nat.NsfemContext(part.mesh.coords, part.mesh.cells, pdm.p2_dofmap, pdm.p1_dofmap,
+                             pdm.n_p2, pdm.n_p1)
+        c.attach_local_comm(group, r)
+        ctxs.append(c)
+    out, errors = {}, []
+
+    def worker(r):
+        try:
+            parts[r].attach(ctxs[r])
+            run(ctxs[r], parts[r].dofmap, out, r)
+        except BaseException as exc:
+            errors.append((r, repr(exc)))
+            os._exit(17)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    u = np.zeros_like(u_ref)
+    p = np.zeros_like(p_ref)
+    for r, part in enumerate(parts):
+        ul, pl, infos = out[r]
+        u.reshape(-1, 3)[part.p2_global[part.p2_owned]] = ul.reshape(-1, 3)[part.p2_owned]
+        p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
+        for a, b in zip(infos, inf_ref):
+            assert a.newton_iterations == b.newton_iterations
+            assert a.krylov_iterations_momentum == b.krylov_iterations_momentum
+            assert a.krylov_iterations_poisson == b.krylov_iterations_poisson
+    assert rel(u, u_ref) < 1e-11
+    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-10
+    for c in ctxs:
+        c.close()
+    nat.local_group_destroy(group)
+
+
 def test_bench_through_rccl_single_rank():
     """bench.py with the RCCL communicator attached (1 rank): ncclCommInitRank, the all-reduces
     of every dot product and the torch.distributed(gloo) bootstrap all run for real."""

@@ -164,24 +164,53 @@ def dfg_bdf_bench(args):
     ctx.close()
 
 
+def _init_dist(args):
+    """(rank, world, local_rank, torch.distributed | None): gloo bootstrap used only for the
+    unique-id broadcast, the barrier and the MAX reduction of the bench contract"""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and args.gpus != world:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    dist = None
+    if world > 1 or os.environ.get("NSFEM_FORCE_COMM") is not None:
+        import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local_rank, dist
+
+
 def cavity3d_bench(args):
     """3D lid-driven cavity on a Kuhn (BoxMesh) tetrahedral mesh, Re = 100, IPCS or monolithic
-    BDF-2 -- the single-GPU, reduced-size relative of BASELINE.json configs[3:5] (which are 3D,
-    8-GPU configurations beyond what the reference itself exercises)."""
-    from fem_mesh import FacetMarkers, TaylorHoodDofMap, box_mesh
-    from multigrid import attach_hierarchy
+    BDF-2 -- the relative of BASELINE.json configs[3:5] (3D configurations beyond what the
+    reference itself exercises).  N > 1 (IPCS): weak scaling, every rank owns a
+    slab of n cube layers of the n x n x (n N) box [0,1]^2 x [0,N] (lid on top), coupled through
+    RCCL exactly like the 2D strips."""
+    from partition import SlabPartition, global_dof_counts
+    rank, world, local_rank, dist = _init_dist(args)
+    bdf = args.workload == "cavity3d-bdf"
+    if bdf and world > 1:
+        raise SystemExit("the monolithic scheme is not partitioned; use cavity3d-ipcs for N > 1")
     n = args.n
     t_setup = time.perf_counter()
-    mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
-    dm = TaylorHoodDofMap(mesh)
-    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
-    levels = attach_hierarchy(ctx, mesh)
+    part = SlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, float(world)), n, n, n * world, rank, world,
+                         coarsest=args.coarsest if args.coarsest else (8 if world == 1 else 16),
+                         global_coarsest=None if world == 1 else 4)
+    mesh, dm = part.mesh, part.dofmap
+    device = 0 if os.environ.get("NSFEM_SHARE_GPU") else local_rank
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1, device)
+    if dist is not None:
+        ids = [nat.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.attach_rccl_comm(ids[0], rank, world)
+    levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
     X = dm.p2_coords
-    on = np.zeros(dm.n_p2, dtype=bool)
-    for a in range(3):
+    on = (np.abs(X[:, 2]) < 1e-12) | (np.abs(X[:, 2] - world) < 1e-12)
+    for a in range(2):
         on |= (np.abs(X[:, a]) < 1e-12) | (np.abs(X[:, a] - 1.0) < 1e-12)
     nodes = np.nonzero(on)[0]
-    lid = np.abs(X[nodes, 2] - 1.0) < 1e-12
+    lid = np.abs(X[nodes, 2] - world) < 1e-12
     dofs = np.concatenate([3 * nodes, 3 * nodes + 1, 3 * nodes + 2]).astype(np.int32)
     vals = np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(2 * nodes.size)])
     ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
@@ -189,12 +218,13 @@ def cavity3d_bench(args):
     ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
     ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
     t_setup = time.perf_counter() - t_setup
+    n2g, n1g = global_dof_counts(n, n, n * world)
+    n_dofs = 3 * n2g + n1g
     opts = ctx.default_step_opts()
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = args.krylov_rtol
     opts.momentum.precond = opts.poisson.precond = 1
     opts.newton_forcing = args.newton_forcing
-    bdf = args.workload == "cavity3d-bdf"
     dt = args.dt if args.dt != 1.0e-3 else 0.5 / n          # CFL ~ 0.5 for the unit lid speed
 
     def one_step(i):
@@ -206,6 +236,8 @@ def cavity3d_bench(args):
     for i in range(args.warmup):
         one_step(i)
     ctx.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     newton = kry = poi = 0
     for i in range(args.warmup, args.warmup + args.steps):
@@ -214,27 +246,40 @@ def cavity3d_bench(args):
         kry += info.krylov_iterations_momentum
         poi += info.krylov_iterations_poisson
     ctx.synchronize()
-    sps = args.steps / (time.perf_counter() - t0)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    sps = args.steps / elapsed
     ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 100)
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "dof_updates_per_sec", "value": sps * dm.n_dofs, "unit": "DoF-updates/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic", "time_steps_per_sec": sps,
-        "config": {"workload": "3D lid-driven cavity Re=100, %d^3 cubes x 6 Kuhn tetrahedra (%d cells, %d dofs), "
-                               "%s, dt=%g" % (n, mesh.num_cells(), dm.n_dofs,
-                                              "BDF-2 monolithic" if bdf else "IPCS", dt),
-                   "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
-                   "newton_forcing": args.newton_forcing, "coarse_p1_levels": levels,
-                   "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
-                   "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
-                   "host_setup_s": t_setup},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<3,3,1,0> (velocity Jacobian, 3x3 block CSR)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv}}))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "dof_updates_per_sec", "value": sps * n_dofs, "unit": "DoF-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "time_steps_per_sec": sps,
+            "config": {"workload": "3D lid-driven cavity Re=100, %dx%dx%d cubes x 6 Kuhn tetrahedra "
+                                   "(%d dofs), %s, dt=%g" % (n, n, n * world, n_dofs,
+                                                             "BDF-2 monolithic" if bdf else "IPCS", dt),
+                       "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                       "newton_forcing": args.newton_forcing, "coarse_p1_levels": levels,
+                       "parallelism": "1 GPU" if world == 1 else
+                       "%d slabs of %d cube layers, RCCL halo exchange + all-reduce" % (world, n),
+                       "newton_its_per_step": newton / args.steps,
+                       "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
+                       "host_setup_s": t_setup},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<3,3,1,0> (velocity Jacobian, 3x3 block CSR)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv}}))
     ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -266,25 +311,11 @@ def main():
             raise SystemExit("the dfg-bdf workload is a single-GPU configuration")
         return dfg_bdf_bench(args)
     if args.workload.startswith("cavity3d"):
-        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-            raise SystemExit("the 3D workloads are single-GPU configurations")
         if args.n == 512:
             args.n = 32
         return cavity3d_bench(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and args.gpus != world:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
-    force_comm = os.environ.get("NSFEM_FORCE_COMM") is not None
-    dist = None
-    if world > 1 or force_comm:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rank, world, local_rank, dist = _init_dist(args)
 
     # ---- local problem: strip `rank` of the 512 x (512 * world) mesh (own rows + ghost row)
     from partition import StripPartition, global_dof_counts

@@ -86,7 +86,8 @@ enum nsfem_operator {
   NSFEM_OP_GRAD = 5,         /* (grad p, w)      2 n_p2 x n_p1                */
   NSFEM_OP_DIVT = 6,         /* (p, div w)       2 n_p2 x n_p1                */
   NSFEM_OP_MOMENTUM_JAC = 7, /* IPCS/BDF velocity block of the Newton matrix  */
-  NSFEM_OP_VISCOUS_EXTRA = 8 /* traction-form extra block (grad u^T : grad v) */
+  NSFEM_OP_VISCOUS_EXTRA = 8, /* traction-form extra block (grad u^T : grad v) */
+  NSFEM_OP_MOMENTUM_JAC_MF = 9 /* nsfem_operator_apply only: matrix-free velocity Jacobian (3D) */
 };
 
 enum nsfem_system {
@@ -129,6 +130,10 @@ typedef struct {
                                    Newton -- linear residual reduced by eta, at most down to a
                                    tenth of the nonlinear target; the Newton loop still stops on
                                    the reference's criterion (throughput runs)              */
+  int32_t matrix_free;          /* velocity Jacobian inside the step drivers: 0 auto (tetrahedra:
+                                   matrix-free element kernel, triangles: assembled block CSR),
+                                   1 always assembled, 2 always matrix-free (3D only)        */
+  int32_t reserved;
 } nsfem_step_opts;
 
 #define NSFEM_MAX_NEWTON 64

@@ -18,7 +18,7 @@ OK, ERR_ARG, ERR_HIP, ERR_BREAKDOWN, ERR_NOT_CONVERGED, ERR_COMM = 0, -1, -2, -3
 U0, U1, U2, USTAR, P, P_OLD, BODY_FORCE, TRACTION, P2_OLD = range(9)
 VELOCITY, PRESSURE, PRESSURE_PRECOND = 0, 1, 2
 (OP_MASS_P2, OP_STIFF_P2, OP_STIFF_P1, OP_MASS_P1, OP_DIV, OP_GRAD, OP_DIVT,
- OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA) = range(9)
+ OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA, OP_MOMENTUM_JAC_MF) = range(10)
 SYS_MOMENTUM, SYS_POISSON, SYS_CORRECTION, SYS_MONOLITHIC = range(4)
 MAX_NEWTON = 64
 
@@ -60,7 +60,7 @@ class StepOpts(C.Structure):
                 ("newton_max_iter", C.c_int32), ("convective_form", C.c_int32),
                 ("momentum", KrylovOpts), ("poisson", KrylovOpts), ("correction", KrylovOpts),
                 ("picard", C.c_int32), ("allow_nonconvergence", C.c_int32),
-                ("newton_forcing", C.c_double)]
+                ("newton_forcing", C.c_double), ("matrix_free", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StepInfo(C.Structure):
@@ -427,6 +427,12 @@ class NsfemContext:
         return sp.csr_matrix((val, col, rowptr), shape=(nr.value, ncol.value))
 
     def operator_apply(self, op, x):
+        if op == OP_MOMENTUM_JAC_MF:                 # matrix-free Jacobian at u = USTAR
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            assert x.size == self.n_velocity
+            y = np.empty(self.n_velocity, dtype=np.float64)
+            self._check(self._lib.nsfem_operator_apply(self._h, op, _dp(x), _dp(y)))
+            return y
         nr, ncol, nnz = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._lib.nsfem_operator_shape(self._h, op, C.byref(nr), C.byref(ncol),
                                                    C.byref(nnz)))

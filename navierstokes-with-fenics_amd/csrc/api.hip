@@ -550,6 +550,32 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
   launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
 }
 
+void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
+  const int64_t nv = nvel(c);
+  const int dim = c->mesh.dim;
+  if (c->distributed()) c->comm->exchange(s, c->halo_p2, const_cast<double*>(x), dim);
+  launch_spmv(s, c->L, dim, x, y, nullptr, MASK_NONE);
+  const double cc = cc_of(c);
+  if (cc != 0.0)
+    convection_action_3d(s, c->mesh, c->state[vel_slot].p, x, cc, y, c->conv_form, c->picard);
+  launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, x, y);                 // identity rows
+  if (c->ghost_v.p) launch_zero_ghost(s, nv, c->mask_v.p, y);        // ghost rows: owner computes
+}
+
+// 0 = auto: tetrahedral meshes apply the velocity Jacobian matrix-free inside the fused step
+// drivers (assembling the 3x3-block matrix costs more than the handful of products an inexact
+// Newton step needs, and the element kernel is cheaper than streaming 76 B per block);
+// triangles assemble (0.5 ms at n = 512).  1 = always assemble, 2 = always matrix-free.
+static bool use_matrix_free(const nsfem_ctx* c, const nsfem_step_opts* o) {
+  if (o->matrix_free == 1) return false;
+  if (c->traction_form) return false;
+  if (c->mesh.dim != 3) {
+    if (o->matrix_free == 2) throw Error(NSFEM_ERR_ARG, "the matrix-free Jacobian is built for tetrahedral meshes");
+    return false;
+  }
+  return true;
+}
+
 // J dx = b ; u* -= dx
 static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
   hipStream_t s = c->stream;
@@ -561,6 +587,13 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
   op.maskmode = MASK_IDENTITY;
   op.dinv = c->dinv_v.p;
   fill_linop(c, op, true);
+  if (c->mf_active) {               // matrix-free Jacobian (the step driver skipped the assembly)
+    c->mom_mf.c = c;
+    c->mom_mf.n = nvel(c);
+    c->mom_mf.vel_slot = NSFEM_USTAR;
+    op.custom = &c->mom_mf;
+    if (o.precond != 1) launch_inv_diag(s, c->L, c->mesh.dim, c->mask_v.p, c->dinv_v.p);
+  }
   if (o.precond == 1) {
     NSFEM_REQUIRE(c->mg_built, "multigrid requested but no hierarchy was set (nsfem_mg_finalize)");
     mg_refresh(c, true);
@@ -1071,8 +1104,9 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   inf.newton_residuals[0] = r;
   int it = 0;
   bool converged = r < opts->newton_atol;
+  ctx->mf_active = use_matrix_free(ctx, opts);
   while (!converged && it < opts->newton_max_iter) {
-    momentum_jacobian(ctx);
+    if (!ctx->mf_active) momentum_jacobian(ctx);
     nsfem_solve_info si;
     int rc = momentum_solve_update(ctx, forced_opts(opts, opts->momentum, r0), si);
     inf.krylov_iterations_momentum += si.iterations;
@@ -1087,6 +1121,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   }
   inf.newton_iterations = it;
   inf.converged = converged ? 1 : 0;
+  ctx->mf_active = false;
   if (!converged) throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
   // ---- projection step
   {
@@ -1127,7 +1162,8 @@ static nsfem_krylov_opts forced_opts(const nsfem_step_opts* o, const nsfem_krylo
 void nsfem_ctx::MixedOp::apply(hipStream_t s, const double* x, double* y) {
   const int64_t nv = nvel(c);
   const double cp = c->coef[1];
-  launch_spmv(s, c->J, 1, x, y, c->mask_v.p, MASK_IDENTITY);
+  if (c->mf_active) c->mom_mf.apply(s, x, y);
+  else launch_spmv(s, c->J, 1, x, y, c->mask_v.p, MASK_IDENTITY);
   launch_spmv_axpy(s, c->DT, 1, -cp, x + nv, y, c->mask_v.p);
   launch_spmv_scaled(s, c->Dv, 1, -cp, x, y + nv);
   launch_copy_at(s, c->nbc_p, c->bc_p_dofs.p, x + nv, y + nv);
@@ -1195,8 +1231,12 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   inf.newton_residuals[0] = r;
   int it = 0;
   bool converged = r < opts->newton_atol;
+  ctx->mf_active = use_matrix_free(ctx, opts);
+  ctx->mom_mf.c = ctx;
+  ctx->mom_mf.n = nv;
+  ctx->mom_mf.vel_slot = NSFEM_U0;
   while (!converged && it < opts->newton_max_iter) {
-    momentum_jacobian(ctx, NSFEM_U0);
+    if (!ctx->mf_active) momentum_jacobian(ctx, NSFEM_U0);
     mg_refresh(ctx, true);
     mg_refresh_schur(ctx);
     ctx->dx_m.zero(s);
@@ -1223,6 +1263,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   }
   inf.newton_iterations = it;
   inf.converged = converged ? 1 : 0;
+  ctx->mf_active = false;
   ctx->picard = false;
   if (!converged && !opts->allow_nonconvergence)
     throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
@@ -1389,6 +1430,23 @@ extern "C" int nsfem_operator_export(nsfem_ctx* ctx, int op, int32_t* rowptr, in
 extern "C" int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y) {
   API_BEGIN
   NSFEM_REQUIRE(ctx && x && y, "null argument");
+  if (op == NSFEM_OP_MOMENTUM_JAC_MF) {      // matrix-free Jacobian at u = USTAR (parity tests)
+    NSFEM_REQUIRE(ctx->mesh.dim == 3, "the matrix-free Jacobian is built for tetrahedral meshes");
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)nvel(ctx);
+    DevBuf<double> dx, dy;
+    dx.alloc(n);
+    dy.alloc(n);
+    ensure_L(ctx);
+    NSFEM_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    ctx->mom_mf.c = ctx;
+    ctx->mom_mf.n = (int64_t)n;
+    ctx->mom_mf.vel_slot = NSFEM_USTAR;
+    ctx->mom_mf.apply(s, dx.p, dy.p);
+    NSFEM_HIP(hipMemcpyAsync(y, dy.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+    return NSFEM_OK;
+  }
   int nv;
   const BlockMat* A = get_op(ctx, op, &nv);
   const Pattern& p = *A->pat;

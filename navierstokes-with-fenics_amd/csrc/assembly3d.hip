@@ -309,62 +309,102 @@ __global__ __launch_bounds__(256) void k3_conv_jac(int nc, const double* __restr
     for (int e = 0; e < 9; ++e) out[j * 9 + e] = acc[j][e];
 }
 
-template <int FORM>
-__global__ __launch_bounds__(256) void k3_conv_res(int nc, const double* __restrict__ vx,
-                                                   const int32_t* __restrict__ p2,
-                                                   const double* __restrict__ u, double cc,
-                                                   double* __restrict__ rbuf) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)nc * 10) return;
-  const int i = (int)(t / nc), c = (int)(t % nc);
+// ---- convection residual and its linearised action, one thread per CELL: u (and the direction
+// v) at the 10 nodes live in registers, u_q / grad u_q are formed once per quadrature point and
+// feed all 10 test functions (the per-(cell, i) mapping recomputed them 10 times).
+//   LIN = 0   r_(i,a) = int c(u)_a phi_i                          (residual)
+//   LIN = 1   r_(i,a) = int [d c(u)/du . v]_a phi_i               (Newton matrix times v)
+//   LIN = 2   Picard linearisation times v (source/ns_solver_base.py:478-499)
+// forms: 0 standard (grad u) u; 2 divergence + 1/2 div(u) u; 3 skew-symmetric
+//   1/2 [ (grad u) u . phi - ((grad phi) u) . u ]
+template <int FORM, int LIN>
+__global__ __launch_bounds__(256) void k3_conv_cell(int nc, const double* __restrict__ vx,
+                                                    const int32_t* __restrict__ p2,
+                                                    const double* __restrict__ u,
+                                                    const double* __restrict__ v, double cc,
+                                                    double* __restrict__ rbuf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
   const CellGeo3 g = load_geo3(vx, nc, c);
-  double un[10][3];
+  double un[10][3], vn[LIN ? 10 : 1][3];
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
     const size_t node = (size_t)p2[(size_t)k * nc + c];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) un[k][a] = u[node * 3 + a];
+    for (int a = 0; a < 3; ++a) {
+      un[k][a] = u[node * 3 + a];
+      if (LIN) vn[k][a] = v[node * 3 + a];
+    }
   }
-  double r[3] = {0.0, 0.0, 0.0};
+  double r[10][3];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) r[i][0] = r[i][1] = r[i][2] = 0.0;
   for (int q = 0; q < 15; ++q) {
-    double uq[3] = {0.0, 0.0, 0.0};
-    double G[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-    double gi[3] = {0.0, 0.0, 0.0};
+    double gk[10][3];
+    double uq[3] = {0.0, 0.0, 0.0}, vq[3] = {0.0, 0.0, 0.0};
+    double Gu[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    double Gv[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      double gk[3];
-      phys3(g, c_q3.dphi2[q][k], gk);
+      phys3(g, c_q3.dphi2[q][k], gk[k]);
       const double ph = c_q3.phi2[q][k];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         uq[a] += ph * un[k][a];
+        if (LIN) vq[a] += ph * vn[k][a];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) G[a][b] += gk[b] * un[k][a];
+        for (int b = 0; b < 3; ++b) {
+          Gu[a][b] += gk[k][b] * un[k][a];
+          if (LIN) Gv[a][b] += gk[k][b] * vn[k][a];
+        }
       }
-      if (k == i) { gi[0] = gk[0]; gi[1] = gk[1]; gi[2] = gk[2]; }
     }
     const double w = c_q3.w[q] * g.adet * cc;
-    const double wpi = w * c_q3.phi2[q][i];
-    double adv[3];
+    // f_a: coefficient of phi_i ; h_a, hs: the skew form's  - (s . grad phi_i) h_a  terms
+    double f[3];
+    const double divu = Gu[0][0] + Gu[1][1] + Gu[2][2];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) adv[a] = G[a][0] * uq[0] + G[a][1] * uq[1] + G[a][2] * uq[2];
-    if (FORM == 0) {
+    for (int a = 0; a < 3; ++a) {
+      const double adv_u = Gu[a][0] * uq[0] + Gu[a][1] * uq[1] + Gu[a][2] * uq[2];     // (grad u) u
+      if (LIN == 0) {
+        f[a] = adv_u + (FORM == 2 ? 0.5 * divu * uq[a] : 0.0);
+      } else {
+        const double gv_u = Gv[a][0] * uq[0] + Gv[a][1] * uq[1] + Gv[a][2] * uq[2];    // (grad v) u
+        const double gu_v = Gu[a][0] * vq[0] + Gu[a][1] * vq[1] + Gu[a][2] * vq[2];    // (grad u) v
+        f[a] = gv_u + (LIN == 1 ? gu_v : 0.0);
+        if (FORM == 2) {
+          f[a] += 0.5 * divu * vq[a];
+          if (LIN == 1) f[a] += 0.5 * (Gv[0][0] + Gv[1][1] + Gv[2][2]) * uq[a];
+        }
+      }
+      if (FORM == 3) f[a] *= 0.5;
+    }
 #pragma unroll
-      for (int a = 0; a < 3; ++a) r[a] += wpi * adv[a];
-    } else if (FORM == 2) {
-      const double hd = 0.5 * (G[0][0] + G[1][1] + G[2][2]);
+    for (int i = 0; i < 10; ++i) {
+      const double wpi = w * c_q3.phi2[q][i];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) r[a] += wpi * (adv[a] + hd * uq[a]);
-    } else {
-      const double udgi = uq[0] * gi[0] + uq[1] * gi[1] + uq[2] * gi[2];
+      for (int a = 0; a < 3; ++a) r[i][a] += wpi * f[a];
+      if (FORM == 3) {
+        const double ugi = uq[0] * gk[i][0] + uq[1] * gk[i][1] + uq[2] * gk[i][2];
+        if (LIN == 0) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) r[a] += 0.5 * (wpi * adv[a] - w * udgi * uq[a]);
+          for (int a = 0; a < 3; ++a) r[i][a] -= 0.5 * w * ugi * uq[a];
+        } else {
+          const double vgi = vq[0] * gk[i][0] + vq[1] * gk[i][1] + vq[2] * gk[i][2];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            r[i][a] -= 0.5 * w * (ugi * vq[a] + (LIN == 1 ? vgi * uq[a] : 0.0));
+        }
+      }
     }
   }
-  double* out = rbuf + ((size_t)c * 10 + i) * 3;
-  out[0] = r[0];
-  out[1] = r[1];
-  out[2] = r[2];
+  double* out = rbuf + (size_t)c * 30;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    out[i * 3] = r[i][0];
+    out[i * 3 + 1] = r[i][1];
+    out[i * 3 + 2] = r[i][2];
+  }
 }
 
 // J[s] = L[s] I_3 + sum of the element blocks scattered to slot s (ascending source order)
@@ -463,20 +503,39 @@ void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22,
                      p22.cptr.p, p22.cidx.p, m.ebuf.p, L, J);
   NSFEM_HIP(hipGetLastError());
 }
+template <int LIN>
+static void launch_conv_cell(hipStream_t s, const MeshDev& m, const double* u, const double* v,
+                             double cc, int form) {
+  const dim3 grid(grid3(m.n_cells)), block(kBlock);
+#define NSFEM_CC3(F) \
+  hipLaunchKernelGGL((k3_conv_cell<F, LIN>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, v, cc, m.rbuf.p)
+  switch (form) {
+    case 0: NSFEM_CC3(0); break;
+    case 2: NSFEM_CC3(2); break;
+    case 3: NSFEM_CC3(3); break;
+    default: throw Error(NSFEM_ERR_ARG, "convective form not available on tetrahedral meshes "
+                                        "(standard, divergence, skew_symmetric are)");
+  }
+#undef NSFEM_CC3
+  NSFEM_HIP(hipGetLastError());
+}
+
 void convection_residual_3d(hipStream_t s, const MeshDev& m, const double* u, double cc, double* b,
                             int form) {
-  const dim3 grid(grid3((int64_t)m.n_cells * 10)), block(kBlock);
-#define NSFEM_CR3(F) \
-  hipLaunchKernelGGL((k3_conv_res<F>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.rbuf.p)
-  switch (form) {
-    case 0: NSFEM_CR3(0); break;
-    case 2: NSFEM_CR3(2); break;
-    case 3: NSFEM_CR3(3); break;
-    default: throw Error(NSFEM_ERR_ARG, "convective form not available on tetrahedral meshes");
-  }
-#undef NSFEM_CR3
+  launch_conv_cell<0>(s, m, u, nullptr, cc, form);
   hipLaunchKernelGGL(k3_res_gather, dim3(grid3((int64_t)m.n_p2 * 3)), dim3(kBlock), 0, s, m.n_p2,
                      m.nptr.p, m.nidx.p, m.rbuf.p, b);
+  NSFEM_HIP(hipGetLastError());
+}
+
+// y += c_c [d conv(u)/du] v  (Newton) or its Picard linearisation: the matrix-free action of the
+// convection blocks of the velocity Jacobian
+void convection_action_3d(hipStream_t s, const MeshDev& m, const double* u, const double* v,
+                          double cc, double* y, int form, bool picard) {
+  if (picard) launch_conv_cell<2>(s, m, u, v, cc, form);
+  else launch_conv_cell<1>(s, m, u, v, cc, form);
+  hipLaunchKernelGGL(k3_res_gather, dim3(grid3((int64_t)m.n_p2 * 3)), dim3(kBlock), 0, s, m.n_p2,
+                     m.nptr.p, m.nidx.p, m.rbuf.p, y);
   NSFEM_HIP(hipGetLastError());
 }
 

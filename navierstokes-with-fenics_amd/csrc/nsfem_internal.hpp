@@ -173,6 +173,8 @@ void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22,
                             double cc, const double* L, double* J, int form, bool picard);
 void convection_residual_3d(hipStream_t s, const MeshDev& m, const double* u, double cc, double* b,
                             int form);
+void convection_action_3d(hipStream_t s, const MeshDev& m, const double* u, const double* v,
+                          double cc, double* y, int form, bool picard);
 void launch_assemble_p1_scalar(hipStream_t s, const MeshDev& m, const Pattern& p11,
                                double* stiff, double* mass);
 void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p12,
@@ -449,6 +451,14 @@ struct nsfem_ctx {
   std::vector<int32_t> h_bc_s;
   nsfem::DevBuf<uint8_t> mask_s;
   nsfem::DevBuf<double> rhs_m, dx_m;
+  // matrix-free velocity Jacobian (tetrahedral meshes): y = L x + c_c [d conv(u)/du] x with
+  // identity rows on Dirichlet dofs and zero ghost rows; u = state[vel_slot]
+  struct MomentumMF : nsfem::Operator {
+    nsfem_ctx* c = nullptr;
+    int vel_slot = 3;               // NSFEM_USTAR
+    void apply(hipStream_t s, const double* x, double* y) override;
+  } mom_mf;
+  bool mf_active = false;           // the running step driver applies the Jacobian matrix-free
   struct MixedOp : nsfem::Operator {
     nsfem_ctx* c = nullptr;
     void apply(hipStream_t s, const double* x, double* y) override;

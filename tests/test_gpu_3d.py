@@ -90,6 +90,16 @@ def test_3d_momentum_residual_jacobian_and_newton_update(setup3, form_id, form):
     J = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
     Jref = L + s.convection_jacobian(u[3], form)
     assert abs(J - Jref).max() <= 1e-13 * abs(Jref).max()
+    # matrix-free Jacobian (what the fused 3D step drivers apply) = assembled Jacobian with
+    # identity rows, Newton and Picard linearisations
+    x = rng.standard_normal(dm.n_velocity)
+    Jbc = fo.apply_dirichlet_rows(Jref, bd)
+    assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Jbc @ x) < 1e-13
+    if form == "standard":
+        ctx.set_convective_form(form_id, picard=True)
+        Pbc = fo.apply_dirichlet_rows(L + s.picard_convection(u[3], form), bd)
+        assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Pbc @ x) < 1e-13
+        ctx.set_convective_form(form_id)
     ctx.solve(nat.SYS_MOMENTUM, rtol=1e-13)
     dx = fo.spla.splu(fo.apply_dirichlet_rows(Jref, bd).tocsc()).solve(b)
     assert rel(ctx.get_state(nat.USTAR), u[3] - dx) < 1e-10

@@ -11,6 +11,8 @@ from partition import StripPartition
 n = int(sys.argv[1]); size = int(sys.argv[2]); nsteps = int(sys.argv[3]); k = float(sys.argv[4])
 use_mg = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 coarsest = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+part_coarsest = int(sys.argv[7]) if len(sys.argv) > 7 else coarsest     # partitioned levels stop here
+forcing = float(sys.argv[8]) if len(sys.argv) > 8 else 0.0
 
 def lid_bc(dm):
     """cavity BC on whatever boundary nodes of the unit square the (local) dof map holds"""
@@ -33,6 +35,10 @@ def run(ctx, out, key):
         o.rtol = 1e-12
     if use_mg:
         opts.momentum.precond = opts.poisson.precond = 1
+    if forcing:
+        opts.newton_forcing = forcing
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-8
     infos = []
     for step in range(nsteps):
         ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
@@ -54,7 +60,8 @@ print("serial: %.3fs  newton %s  kry mom %s poi %s" % (t_ref, [i.newton_iteratio
 
 # ---- partitioned, one thread per rank
 group = nat.local_group_create(size)
-parts = [StripPartition((0, 0), (1, 1), n, n, r, size, coarsest=coarsest) for r in range(size)]
+parts = [StripPartition((0, 0), (1, 1), n, n, r, size, coarsest=part_coarsest,
+                        global_coarsest=coarsest if part_coarsest != coarsest else None) for r in range(size)]
 ctxs = []
 for r, part in enumerate(parts):
     pdm = part.dofmap

@@ -313,9 +313,33 @@ def test_error_paths_are_loud():
     with pytest.raises(nat.NativeError) as err:
         ctx.step_ipcs(opts)
     assert err.value.code == nat.ERR_NOT_CONVERGED
+    opts = ctx.default_step_opts()
+    opts.matrix_free = 2                                        # matrix-free Jacobian: tetrahedra only
+    with pytest.raises(nat.NativeError):
+        ctx.step_ipcs(opts)
+    with pytest.raises(nat.NativeError):                         # monolithic step without a hierarchy
+        ctx.step_bdf(ctx.default_step_opts())
+    import scipy.sparse as sp
+    with pytest.raises(nat.NativeError):                         # Schur operator before mg_finalize
+        ctx.mg_set_schur_operator(0, sp.identity(dm.n_p1, format="csr"), False)
+    from multigrid import attach_hierarchy
+    attach_hierarchy(ctx, mesh, coarsest=2)
+    with pytest.raises(nat.NativeError):                         # wrong size / no such level
+        ctx.mg_set_schur_operator(0, sp.identity(dm.n_p1 + 1, format="csr"), False)
+    with pytest.raises(nat.NativeError):
+        ctx.mg_set_schur_operator(7, sp.identity(dm.n_p1, format="csr"), False)
+    with pytest.raises(nat.NativeError):                         # hierarchy is final
+        ctx.mg_add_level(mesh.coords, mesh.cells, np.zeros(dm.n_p1 + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    with pytest.raises(nat.NativeError):                         # rotating frame without a coefficient
+        ctx.set_angular_velocity(1.0)
+        ctx.step_ipcs(ctx.default_step_opts())
     ctx.close()
     with pytest.raises(nat.NativeError):                         # bad dof map entry
         nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap + 10 ** 6, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+    with pytest.raises(nat.NativeError):                         # degenerate cell
+        bad = mesh.coords.copy()
+        bad[mesh.cells[0]] = bad[mesh.cells[0, 0]]
+        nat.NsfemContext(bad, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
 
 
 def test_full_size_properties_n512():

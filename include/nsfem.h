@@ -87,7 +87,9 @@ enum nsfem_operator {
   NSFEM_OP_DIVT = 6,         /* (p, div w)       2 n_p2 x n_p1                */
   NSFEM_OP_MOMENTUM_JAC = 7, /* IPCS/BDF velocity block of the Newton matrix  */
   NSFEM_OP_VISCOUS_EXTRA = 8, /* traction-form extra block (grad u^T : grad v) */
-  NSFEM_OP_MOMENTUM_JAC_MF = 9 /* nsfem_operator_apply only: matrix-free velocity Jacobian (3D) */
+  NSFEM_OP_MOMENTUM_JAC_MF = 9, /* nsfem_operator_apply only: matrix-free velocity Jacobian */
+  NSFEM_OP_MOMENTUM_SMOOTHER = 10 /* nsfem_time_spmv only: finest-level Chebyshev step of the
+                                     velocity multigrid (scalar P2 operator, fused epilogue) */
 };
 
 enum nsfem_system {
@@ -130,9 +132,9 @@ typedef struct {
                                    Newton -- linear residual reduced by eta, at most down to a
                                    tenth of the nonlinear target; the Newton loop still stops on
                                    the reference's criterion (throughput runs)              */
-  int32_t matrix_free;          /* velocity Jacobian inside the step drivers: 0 auto (tetrahedra:
-                                   matrix-free element kernel, triangles: assembled block CSR),
-                                   1 always assembled, 2 always matrix-free (3D only)        */
+  int32_t matrix_free;          /* velocity Jacobian inside the step drivers: 0 auto (= matrix-
+                                   free: L x + linearised convection by an element kernel),
+                                   1 assembled block CSR, 2 matrix-free                      */
   int32_t reserved;
 } nsfem_step_opts;
 
@@ -285,6 +287,11 @@ int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, double* cfl);
 
 /* ---- measurement hooks (bench.py): time `reps` launches of the dominant SpMV
  * with HIP events on the context's stream; ms per launch returned ------------- */
+/* in-situ HIP-event timing of the finest-level smoothing launches of the velocity multigrid
+ * (the dominant kernel of a time step): enable != 0 starts sampling, enable == 0 stops and
+ * reports average launch duration [ms], number of launches and algorithmic bytes per launch */
+int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* launches,
+                           int64_t* algorithmic_bytes);
 int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                     int64_t* algorithmic_bytes);
 int nsfem_synchronize(nsfem_ctx* ctx);

@@ -18,7 +18,7 @@ OK, ERR_ARG, ERR_HIP, ERR_BREAKDOWN, ERR_NOT_CONVERGED, ERR_COMM = 0, -1, -2, -3
 U0, U1, U2, USTAR, P, P_OLD, BODY_FORCE, TRACTION, P2_OLD = range(9)
 VELOCITY, PRESSURE, PRESSURE_PRECOND = 0, 1, 2
 (OP_MASS_P2, OP_STIFF_P2, OP_STIFF_P1, OP_MASS_P1, OP_DIV, OP_GRAD, OP_DIVT,
- OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA, OP_MOMENTUM_JAC_MF) = range(10)
+ OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA, OP_MOMENTUM_JAC_MF, OP_MOMENTUM_SMOOTHER) = range(11)
 SYS_MOMENTUM, SYS_POISSON, SYS_CORRECTION, SYS_MONOLITHIC = range(4)
 MAX_NEWTON = 64
 
@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_profile_smoother",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -157,6 +157,7 @@ def load_library(path=None):
         "nsfem_shift_mean_pressure": (C.c_int, [vp, dbl, pd]),
         "nsfem_cfl_number": (C.c_int, [vp, C.c_int, dbl, pd]),
         "nsfem_set_angular_velocity": (C.c_int, [vp, dbl, dbl]),
+        "nsfem_profile_smoother": (C.c_int, [vp, C.c_int, pd, C.POINTER(i64), C.POINTER(i64)]),
         "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),
         "nsfem_synchronize": (C.c_int, [vp]),
         "nsfem_mg_add_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
@@ -449,6 +450,14 @@ class NsfemContext:
         out = C.c_double()
         self._check(self._lib.nsfem_cfl_number(self._h, int(slot), float(step_size), C.byref(out)))
         return out.value
+
+    def profile_smoother(self, enable):
+        """start (True) / stop (False -> (avg ms per launch, launches, algorithmic bytes per launch))
+        the in-situ timing of the finest-level smoothing launches of the velocity multigrid"""
+        ms, n, nbytes = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self._lib.nsfem_profile_smoother(self._h, 1 if enable else 0, C.byref(ms),
+                                                     C.byref(n), C.byref(nbytes)))
+        return None if enable else (ms.value, n.value, nbytes.value)
 
     def time_spmv(self, op, reps=50):
         ms = C.c_double()

@@ -555,25 +555,29 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   const int dim = c->mesh.dim;
   if (c->distributed()) c->comm->exchange(s, c->halo_p2, const_cast<double*>(x), dim);
   launch_spmv(s, c->L, dim, x, y, nullptr, MASK_NONE);
+  if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, nullptr);
   const double cc = cc_of(c);
   if (cc != 0.0)
-    convection_action_3d(s, c->mesh, c->state[vel_slot].p, x, cc, y, c->conv_form, c->picard);
+    launch_convection_action(s, c->mesh, c->state[vel_slot].p, x, cc, y, c->conv_form, c->picard);
+  const double g = coriolis_gamma(c);
+  if (g != 0.0) {
+    if (!c->rot_tmp.p) c->rot_tmp.alloc((size_t)nv);
+    launch_rot90(s, c->mesh.n_p2, g, x, c->rot_tmp.p);
+    launch_spmv_axpy(s, c->M2, 2, 1.0, c->rot_tmp.p, y, nullptr);
+  }
   launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, x, y);                 // identity rows
   if (c->ghost_v.p) launch_zero_ghost(s, nv, c->mask_v.p, y);        // ghost rows: owner computes
 }
 
-// 0 = auto: tetrahedral meshes apply the velocity Jacobian matrix-free inside the fused step
-// drivers (assembling the 3x3-block matrix costs more than the handful of products an inexact
-// Newton step needs, and the element kernel is cheaper than streaming 76 B per block);
-// triangles assemble (0.5 ms at n = 512).  1 = always assemble, 2 = always matrix-free.
+// 0 = auto = matrix-free: inside the fused step drivers the velocity Jacobian is applied as
+// L x + c_c [d conv(u)/du] x by an element kernel (one thread per cell) instead of being
+// assembled.  Measured: tetrahedra, n = 48: step 55 -> 29 ms (assembling the 3x3-block matrix cost
+// more than the handful of products an inexact Newton step needs); triangles, n = 512:
+// 9.3 -> 8.6 ms with inexact Newton, equal (16 ms) with rtol 1e-12 + exact Newton.
+// 1 = always assemble (block CSR), 2 = always matrix-free.
 static bool use_matrix_free(const nsfem_ctx* c, const nsfem_step_opts* o) {
-  if (o->matrix_free == 1) return false;
-  if (c->traction_form) return false;
-  if (c->mesh.dim != 3) {
-    if (o->matrix_free == 2) throw Error(NSFEM_ERR_ARG, "the matrix-free Jacobian is built for tetrahedral meshes");
-    return false;
-  }
-  return true;
+  (void)c;
+  return o->matrix_free != 1;
 }
 
 // J dx = b ; u* -= dx
@@ -1431,7 +1435,6 @@ extern "C" int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, dou
   API_BEGIN
   NSFEM_REQUIRE(ctx && x && y, "null argument");
   if (op == NSFEM_OP_MOMENTUM_JAC_MF) {      // matrix-free Jacobian at u = USTAR (parity tests)
-    NSFEM_REQUIRE(ctx->mesh.dim == 3, "the matrix-free Jacobian is built for tetrahedral meshes");
     hipStream_t s = ctx->stream;
     const size_t n = (size_t)nvel(ctx);
     DevBuf<double> dx, dy;
@@ -1462,15 +1465,104 @@ extern "C" int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, dou
   API_END(ctx)
 }
 
+// In-situ timing of the dominant kernel: while enabled, every finest-level Chebyshev smoothing
+// launch of the velocity multigrid (k_spmv_stream<1,1,dim,EPI_CHEB>) is bracketed by a HIP-event
+// pair on the context's stream.  enable != 0: start (discarding earlier samples); enable == 0:
+// stop and return the average launch duration, the number of launches and the algorithmic bytes
+// per launch.
+extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* launches,
+                                      int64_t* algorithmic_bytes) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
+  Multigrid& mg = ctx->mg_v;
+  if (enable) {
+    if (mg.prof_ev.empty()) {
+      mg.prof_ev.resize(8192);
+      for (hipEvent_t& e : mg.prof_ev) NSFEM_HIP(hipEventCreate(&e));
+    }
+    mg.prof_n = 0;
+    mg.prof = true;
+    return NSFEM_OK;
+  }
+  mg.prof = false;
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < mg.prof_n; i += 2) {
+    float t = 0.f;
+    NSFEM_HIP(hipEventElapsedTime(&t, mg.prof_ev[i], mg.prof_ev[i + 1]));
+    total += t;
+  }
+  const int64_t n_launch = (int64_t)(mg.prof_n / 2);
+  if (avg_ms) *avg_ms = n_launch ? total / (double)n_launch : 0.0;
+  if (launches) *launches = n_launch;
+  if (algorithmic_bytes) {
+    const Pattern& p = *mg.lv[0].A->pat;
+    const int64_t n = (int64_t)p.n_rows * mg.nv;
+    *algorithmic_bytes = (int64_t)p.nnz * 12 + (int64_t)(p.n_rows + 1) * 4 + n * (6 * 8 + 1);
+  }
+  API_END(ctx)
+}
+
 extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                                int64_t* algorithmic_bytes) {
   API_BEGIN
   NSFEM_REQUIRE(ctx && reps > 0 && ms_per_launch, "bad argument");
+  if (op == NSFEM_OP_MOMENTUM_SMOOTHER) {
+    // one Chebyshev-Jacobi smoothing step of the velocity multigrid on its finest level: the
+    // scalar P2 operator L applied to the interleaved components with the fused epilogue
+    // d = c1 d + c2 dinv (b - L x), y = x + d  (k_spmv_stream<1,1,dim,EPI_CHEB>)
+    NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
+    mg_refresh(ctx, true);
+    hipStream_t s = ctx->stream;
+    Multigrid& mg = ctx->mg_v;
+    MGLevel& L0 = mg.lv[0];
+    const Pattern& p = *L0.A->pat;
+    const int nv = mg.nv;
+    auto step = [&] {
+      launch_cheb_step(s, *L0.A, nv, L0.xa.p, L0.r.p, L0.dinv.p, L0.d.p, 0.3, 0.7, L0.xb.p, L0.mask);
+    };
+    // In the solver this launch follows other kernels that have streamed hundreds of MB; the
+    // operator (145 MB at n = 512) would otherwise sit in the 256 MB Infinity Cache between
+    // back-to-back repetitions.  Timed: `reps` pairs (flush, step) minus `reps` flushes, the
+    // flush being a product with the 2x2-block Jacobian array (0.47 GB streamed, larger than the
+    // cache, so its own time does not depend on what ran before).
+    DevBuf<double> fx, fy;
+    fx.alloc((size_t)nvel(ctx));
+    fy.alloc((size_t)nvel(ctx));
+    fx.zero(s);
+    auto flush = [&] { launch_spmv(s, ctx->J, 1, fx.p, fy.p, nullptr, MASK_NONE); };
+    hipEvent_t e0, e1;
+    NSFEM_HIP(hipEventCreate(&e0));
+    NSFEM_HIP(hipEventCreate(&e1));
+    auto timed = [&](bool with_step) {
+      for (int i = 0; i < 3; ++i) { flush(); if (with_step) step(); }
+      NSFEM_HIP(hipEventRecord(e0, s));
+      for (int i = 0; i < reps; ++i) { flush(); if (with_step) step(); }
+      NSFEM_HIP(hipEventRecord(e1, s));
+      NSFEM_HIP(hipEventSynchronize(e1));
+      float t = 0.f;
+      NSFEM_HIP(hipEventElapsedTime(&t, e0, e1));
+      return (double)t;
+    };
+    const double t_both = timed(true), t_flush = timed(false);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double ms = t_both - t_flush;
+    *ms_per_launch = (double)ms / reps;
+    if (algorithmic_bytes) {
+      const int64_t n = (int64_t)p.n_rows * nv;
+      // matrix (value + column per nonzero, row pointers) + x, b, dinv, d (read), d, y (written)
+      // + the row mask
+      *algorithmic_bytes = (int64_t)p.nnz * 12 + (int64_t)(p.n_rows + 1) * 4 + n * (6 * 8 + 1);
+    }
+    return NSFEM_OK;
+  }
   int nv;
   const BlockMat* A = get_op(ctx, op, &nv);
   const Pattern& p = *A->pat;
-  // scalar P2 operators act on both velocity components in the solver
-  const int nvv = (op == NSFEM_OP_MASS_P2 || op == NSFEM_OP_STIFF_P2) ? 2 : 1;
+  // scalar P2 operators act on all velocity components in the solver
+  const int nvv = (op == NSFEM_OP_MASS_P2 || op == NSFEM_OP_STIFF_P2) ? ctx->mesh.dim : 1;
   const size_t nx = (size_t)p.n_cols * A->bc * nvv, ny = (size_t)p.n_rows * A->br * nvv;
   DevBuf<double> dx, dy;
   dx.alloc(nx);

@@ -447,61 +447,124 @@ void launch_cfl(hipStream_t s, const MeshDev& m, const double* u, double scale, 
   NSFEM_HIP(hipGetLastError());
 }
 
-// ---- convection residual  b_(i,a) += cc * int c(u)_a phi_i  for the four weak forms
-template <int FORM>
-__global__ __launch_bounds__(256) void k_conv_res(int nc, const double* __restrict__ vx,
-                                                  const int32_t* __restrict__ p2,
-                                                  const double* __restrict__ u, double cc,
-                                                  double* __restrict__ rbuf) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)nc * 6) return;
-  const int i = (int)(t / nc), c = (int)(t % nc);
+// ---- convection residual / linearised action, one thread per CELL (the 2D counterpart of
+// k3_conv_cell): u (and the direction v) at the 6 nodes in registers, u_q and grad u_q formed once
+// per quadrature point for all 6 test functions.
+//   LIN = 0  r_(i,a) = int c(u)_a phi_i ;  LIN = 1  Newton matrix times v ;  LIN = 2  Picard matrix
+//   times v.  FORM as in k_conv_jac (0 standard, 1 rotational, 2 divergence, 3 skew-symmetric).
+template <int FORM, int LIN>
+__global__ __launch_bounds__(256) void k_conv_cell(int nc, const double* __restrict__ vx,
+                                                   const int32_t* __restrict__ p2,
+                                                   const double* __restrict__ u,
+                                                   const double* __restrict__ v, double cc,
+                                                   double* __restrict__ rbuf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
   const CellGeo g = load_geo(vx, nc, c);
-  double ux[6], uy[6];
+  double ux[6], uy[6], wx[LIN ? 6 : 1], wy[LIN ? 6 : 1];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int node = p2[(size_t)k * nc + c];
-    const double2 v = reinterpret_cast<const double2*>(u)[node];
-    ux[k] = v.x;
-    uy[k] = v.y;
+    const double2 a = reinterpret_cast<const double2*>(u)[node];
+    ux[k] = a.x;
+    uy[k] = a.y;
+    if (LIN) {
+      const double2 b = reinterpret_cast<const double2*>(v)[node];
+      wx[k] = b.x;
+      wy[k] = b.y;
+    }
   }
-  double rx = 0.0, ry = 0.0;
+  double rx[6], ry[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rx[i] = ry[i] = 0.0;
   for (int q = 0; q < 7; ++q) {
-    double uqx = 0.0, uqy = 0.0, g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0, gix = 0.0, giy = 0.0;
+    double gx[6], gy[6];
+    double uqx = 0.0, uqy = 0.0, g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
+    double vqx = 0.0, vqy = 0.0, h00 = 0.0, h01 = 0.0, h10 = 0.0, h11 = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      double gx, gy;
-      phys(g, c_q.dphi2[q][k][0], c_q.dphi2[q][k][1], gx, gy);
+      phys(g, c_q.dphi2[q][k][0], c_q.dphi2[q][k][1], gx[k], gy[k]);
       const double ph = c_q.phi2[q][k];
       uqx += ph * ux[k];
       uqy += ph * uy[k];
-      g00 += gx * ux[k];
-      g01 += gy * ux[k];
-      g10 += gx * uy[k];
-      g11 += gy * uy[k];
-      if (k == i) { gix = gx; giy = gy; }
+      g00 += gx[k] * ux[k];
+      g01 += gy[k] * ux[k];
+      g10 += gx[k] * uy[k];
+      g11 += gy[k] * uy[k];
+      if (LIN) {
+        vqx += ph * wx[k];
+        vqy += ph * wy[k];
+        h00 += gx[k] * wx[k];
+        h01 += gy[k] * wx[k];
+        h10 += gx[k] * wy[k];
+        h11 += gy[k] * wy[k];
+      }
     }
     const double w = c_q.w[q] * g.adet * cc;
-    const double wpi = w * c_q.phi2[q][i];
-    const double ax = g00 * uqx + g01 * uqy, ay = g10 * uqx + g11 * uqy;   // (grad u) u
-    if (FORM == 0) {
-      rx += wpi * ax;
-      ry += wpi * ay;
-    } else if (FORM == 1) {
-      const double curl = g10 - g01;
-      rx += wpi * (-curl * uqy);
-      ry += wpi * (curl * uqx);
-    } else if (FORM == 2) {
-      const double hd = 0.5 * (g00 + g11);
-      rx += wpi * (ax + hd * uqx);
-      ry += wpi * (ay + hd * uqy);
+    double fx, fy;                       // coefficient of phi_i
+    if (LIN == 0) {
+      const double ax = g00 * uqx + g01 * uqy, ay = g10 * uqx + g11 * uqy;       // (grad u) u
+      if (FORM == 1) {
+        const double curl = g10 - g01;
+        fx = -curl * uqy;
+        fy = curl * uqx;
+      } else {
+        fx = ax;
+        fy = ay;
+        if (FORM == 2) {
+          const double hd = 0.5 * (g00 + g11);
+          fx += hd * uqx;
+          fy += hd * uqy;
+        }
+      }
     } else {
-      const double udgi = uqx * gix + uqy * giy;
-      rx += 0.5 * (wpi * ax - w * udgi * uqx);
-      ry += 0.5 * (wpi * ay - w * udgi * uqy);
+      const double gvu_x = h00 * uqx + h01 * uqy, gvu_y = h10 * uqx + h11 * uqy;   // (grad v) u
+      const double guv_x = g00 * vqx + g01 * vqy, guv_y = g10 * vqx + g11 * vqy;   // (grad u) v
+      if (FORM == 1) {
+        const double cu = g10 - g01, cv = h10 - h01;
+        fx = -cu * vqy;
+        fy = cu * vqx;
+        if (LIN == 1) {
+          fx += -cv * uqy;
+          fy += cv * uqx;
+        }
+      } else {
+        fx = gvu_x + (LIN == 1 ? guv_x : 0.0);
+        fy = gvu_y + (LIN == 1 ? guv_y : 0.0);
+        if (FORM == 2) {
+          const double hdu = 0.5 * (g00 + g11);
+          fx += hdu * vqx;
+          fy += hdu * vqy;
+          if (LIN == 1) {
+            const double hdv = 0.5 * (h00 + h11);
+            fx += hdv * uqx;
+            fy += hdv * uqy;
+          }
+        }
+      }
+    }
+    if (FORM == 3) { fx *= 0.5; fy *= 0.5; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double wpi = w * c_q.phi2[q][i];
+      rx[i] += wpi * fx;
+      ry[i] += wpi * fy;
+      if (FORM == 3) {
+        const double ugi = uqx * gx[i] + uqy * gy[i];
+        if (LIN == 0) {
+          rx[i] -= 0.5 * w * ugi * uqx;
+          ry[i] -= 0.5 * w * ugi * uqy;
+        } else {
+          const double vgi = vqx * gx[i] + vqy * gy[i];
+          rx[i] -= 0.5 * w * (ugi * vqx + (LIN == 1 ? vgi * uqx : 0.0));
+          ry[i] -= 0.5 * w * (ugi * vqy + (LIN == 1 ? vgi * uqy : 0.0));
+        }
+      }
     }
   }
-  reinterpret_cast<double2*>(rbuf)[(size_t)c * 6 + i] = make_double2(rx, ry);
+  double2* out = reinterpret_cast<double2*>(rbuf) + (size_t)c * 6;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[i] = make_double2(rx[i], ry[i]);
 }
 
 // b[(node, a)] += sum of the element vectors of the cells around the node (fixed order)
@@ -511,9 +574,21 @@ __global__ __launch_bounds__(256) void k_res_gather(int n_nodes, const int32_t* 
                                                     double* __restrict__ b) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= n_nodes) return;
+  const double2* __restrict__ rb = reinterpret_cast<const double2*>(rbuf);
   double2 acc = reinterpret_cast<double2*>(b)[n];
-  for (int k = nptr[n]; k < nptr[n + 1]; ++k) {
-    const double2 v = reinterpret_cast<const double2*>(rbuf)[nidx[k]];
+  int k = nptr[n];
+  const int e = nptr[n + 1];
+  // four independent loads in flight per lane, summed in ascending source order (deterministic)
+  for (; k + 4 <= e; k += 4) {
+    const int i0 = nidx[k], i1 = nidx[k + 1], i2 = nidx[k + 2], i3 = nidx[k + 3];
+    const double2 v0 = rb[i0], v1 = rb[i1], v2 = rb[i2], v3 = rb[i3];
+    acc.x += v0.x; acc.y += v0.y;
+    acc.x += v1.x; acc.y += v1.y;
+    acc.x += v2.x; acc.y += v2.y;
+    acc.x += v3.x; acc.y += v3.y;
+  }
+  for (; k < e; ++k) {
+    const double2 v = rb[nidx[k]];
     acc.x += v.x;
     acc.y += v.y;
   }
@@ -627,22 +702,41 @@ void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& 
                      p22.cptr.p, p22.cidx.p, m.ebuf.p, L, E, cvE, J);
   NSFEM_HIP(hipGetLastError());
 }
+template <int LIN>
+static void launch_conv_cell(hipStream_t s, const MeshDev& m, const double* u, const double* v,
+                             double cc, int form) {
+  const dim3 grid(grid_for(m.n_cells)), block(kBlock);
+#define NSFEM_CC(F) \
+  hipLaunchKernelGGL((k_conv_cell<F, LIN>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, v, cc, m.rbuf.p)
+  switch (form) {
+    case 0: NSFEM_CC(0); break;
+    case 1: NSFEM_CC(1); break;
+    case 2: NSFEM_CC(2); break;
+    case 3: NSFEM_CC(3); break;
+    default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
+  }
+#undef NSFEM_CC
+  NSFEM_HIP(hipGetLastError());
+}
+
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b, int form) {
   if (m.dim == 3) return convection_residual_3d(s, m, u, cc, b, form);
-  const dim3 grid(grid_for((int64_t)m.n_cells * 6)), block(kBlock);
-#define NSFEM_CR(F) \
-  hipLaunchKernelGGL((k_conv_res<F>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.rbuf.p)
-  switch (form) {
-    case 0: NSFEM_CR(0); break;
-    case 1: NSFEM_CR(1); break;
-    case 2: NSFEM_CR(2); break;
-    case 3: NSFEM_CR(3); break;
-    default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
-  }
-#undef NSFEM_CR
+  launch_conv_cell<0>(s, m, u, nullptr, cc, form);
   hipLaunchKernelGGL(k_res_gather, dim3(grid_for(m.n_p2)), dim3(kBlock), 0, s, m.n_p2, m.nptr.p,
                      m.nidx.p, m.rbuf.p, b);
+  NSFEM_HIP(hipGetLastError());
+}
+
+// y += c_c [d conv(u)/du] v (Newton) or its Picard linearisation: matrix-free action of the
+// convection blocks of the velocity Jacobian
+void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, const double* v,
+                              double cc, double* y, int form, bool picard) {
+  if (m.dim == 3) return convection_action_3d(s, m, u, v, cc, y, form, picard);
+  if (picard) launch_conv_cell<2>(s, m, u, v, cc, form);
+  else launch_conv_cell<1>(s, m, u, v, cc, form);
+  hipLaunchKernelGGL(k_res_gather, dim3(grid_for(m.n_p2)), dim3(kBlock), 0, s, m.n_p2, m.nptr.p,
+                     m.nidx.p, m.rbuf.p, y);
   NSFEM_HIP(hipGetLastError());
 }
 

@@ -430,7 +430,18 @@ __global__ __launch_bounds__(256) void k3_res_gather(int n_nodes, const int32_t*
   if (t >= (int64_t)n_nodes * 3) return;
   const int n = (int)(t / 3), a = (int)(t % 3);
   double acc = b[t];
-  for (int k = nptr[n]; k < nptr[n + 1]; ++k) acc += rbuf[(size_t)nidx[k] * 3 + a];
+  int k = nptr[n];
+  const int e = nptr[n + 1];
+  // four independent loads in flight per lane, summed in ascending source order (deterministic)
+  for (; k + 4 <= e; k += 4) {
+    const double v0 = rbuf[(size_t)nidx[k] * 3 + a], v1 = rbuf[(size_t)nidx[k + 1] * 3 + a];
+    const double v2 = rbuf[(size_t)nidx[k + 2] * 3 + a], v3 = rbuf[(size_t)nidx[k + 3] * 3 + a];
+    acc += v0;
+    acc += v1;
+    acc += v2;
+    acc += v3;
+  }
+  for (; k < e; ++k) acc += rbuf[(size_t)nidx[k] * 3 + a];
   b[t] = acc;
 }
 

@@ -354,7 +354,13 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
       NSFEM_HIP(hipGetLastError());
     } else {
       halo_fill(s, L, cur);
+      const bool timed = prof && &L == &lv[0] && prof_n + 2 <= prof_ev.size();
+      if (timed) NSFEM_HIP(hipEventRecord(prof_ev[prof_n], s));
       launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask);
+      if (timed) {
+        NSFEM_HIP(hipEventRecord(prof_ev[prof_n + 1], s));
+        prof_n += 2;
+      }
     }
     cur = out;
   }

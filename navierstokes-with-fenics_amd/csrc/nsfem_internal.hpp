@@ -188,6 +188,8 @@ void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double*
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                 const double* u, double cc, const double* L, const double* E,
                                 double cvE, double* J, int form, bool picard);
+void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, const double* v,
+                              double cc, double* y, int form, bool picard);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b, int form);
 // diag extraction: d[(i,a)] = 1 / A_ii[a][a]  (mask rows -> 1)
@@ -334,6 +336,11 @@ struct Multigrid : Precond {
   // hierarchy: a serial multigrid (no communicator) every rank runs redundantly on the
   // all-reduced right-hand side -- the small levels cost no halo exchanges at all
   Multigrid* tail = nullptr;     // not owned
+  // in-situ timing of the finest-level smoothing launches (bench.py's roofline figure): one
+  // HIP-event pair per launch while enabled
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_n = 0;
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
   void refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>& cur, bool singular);
   void halo_fill(hipStream_t s, const MGLevel& L, const double* v);

@@ -70,6 +70,7 @@ class ImplicitBDFSolver(InstationarySolverBase):
         o.newton_rtol = 10.0 * self._tol
         o.newton_max_iter = self._maxiter
         o.convective_form = _FORM_ID[self._form_convective_term]
+        o.matrix_free = {None: 0, False: 1, True: 2}[getattr(self, "matrix_free", None)]
         o.momentum.rtol = self.krylov_rtol
         o.momentum.max_iter = self.krylov_max_iter
         o.momentum.precond = 1

@@ -80,6 +80,7 @@ class IPCSSolver(InstationarySolverBase):
         o.newton_rtol = 10.0 * self._tol
         o.newton_max_iter = self._maxiter
         o.convective_form = _FORM_ID[self._form_convective_term]
+        o.matrix_free = {None: 0, False: 1, True: 2}[getattr(self, "matrix_free", None)]
         for k in (o.momentum, o.poisson, o.correction):
             k.rtol = self.krylov_rtol
             k.max_iter = self.krylov_max_iter

@@ -236,6 +236,8 @@ class InstationaryProblem(ProblemBase):
                 self._mesh, self._boundary_markers, self._form_convective_term,
                 self._time_stepping, self._tol, self._maxiter)
         solver = self._navier_stokes_solver
+        if hasattr(self, "solver_matrix_free"):      # Jacobian mode of the device step drivers
+            solver.matrix_free = self.solver_matrix_free
         solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
         if hasattr(self, "_body_force"):
             solver.set_body_force(self._body_force)

@@ -384,6 +384,9 @@ class InstationarySolverBase(SolverBase):
         # Krylov options of the device solves (the reference uses sparse LU instead)
         self.krylov_rtol = 1.0e-12
         self.krylov_max_iter = 20000
+        # velocity Jacobian in the fused step drivers: None = library default (matrix-free element
+        # kernel), False = assembled block CSR, True = matrix-free
+        self.matrix_free = None
         #: geometric multigrid preconditioning of the momentum and Poisson solves
         self.use_multigrid = True
 

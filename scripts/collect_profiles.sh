@@ -13,6 +13,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- \
   python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_trace.err
 cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+python3 $REPO/scripts/summarize_trace_by_grid.py $(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1) 500 \
+  > $OUT/${TAG}_kernel_stats_by_grid.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -o ${TAG} -- \
     python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_$C.err

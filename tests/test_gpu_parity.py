@@ -313,10 +313,6 @@ def test_error_paths_are_loud():
     with pytest.raises(nat.NativeError) as err:
         ctx.step_ipcs(opts)
     assert err.value.code == nat.ERR_NOT_CONVERGED
-    opts = ctx.default_step_opts()
-    opts.matrix_free = 2                                        # matrix-free Jacobian: tetrahedra only
-    with pytest.raises(nat.NativeError):
-        ctx.step_ipcs(opts)
     with pytest.raises(nat.NativeError):                         # monolithic step without a hierarchy
         ctx.step_bdf(ctx.default_step_opts())
     import scipy.sparse as sp
@@ -547,10 +543,14 @@ def test_convective_forms_residual_jacobian_and_step(setup16, form_id, form):
     Jref = L + 0.8 * s.convection_jacobian(u, form)
     J = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
     assert abs(J - Jref).max() <= 1e-13 * abs(Jref).max()
+    # matrix-free application (one thread per cell, no assembly) = assembled matrix
+    x = rng.standard_normal(dm.n_velocity)
+    assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Jref @ x) < 1e-13
+    ctx.set_convective_form(form_id, picard=True)
+    ctx.assemble(nat.SYS_MOMENTUM)
+    Jp = ctx.operator_csr(nat.OP_MOMENTUM_JAC)                 # device Picard matrix, any form
+    assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Jp @ x) < 1e-13
     if form == "standard":
-        ctx.set_convective_form(0, picard=True)
-        ctx.assemble(nat.SYS_MOMENTUM)
-        Jp = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
         Jpref = L + 0.8 * s.picard_convection(u)
         assert abs(Jp - Jpref).max() <= 1e-13 * abs(Jpref).max()
     ctx.set_convective_form(0)
@@ -566,6 +566,7 @@ def test_convective_forms_residual_jacobian_and_step(setup16, form_id, form):
     c2.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
     opts = c2.default_step_opts()
     opts.convective_form = form_id
+    opts.matrix_free = 2 if form_id % 2 else 1      # both Jacobian modes give the same steps
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = 1e-13
     for step in range(2):

@@ -113,6 +113,10 @@ def test_channel_flow():
 def test_transient_cavity_fused_and_explicit_seam_agree():
     a = CavityProblem(12)
     a.solve_problem()
+    ua_mf = a._get_solver().solution.split()[0].vector()       # default: matrix-free Jacobian
+    a = CavityProblem(12)
+    a.solver_matrix_free = False                               # assembled Jacobian, as the seam uses
+    a.solve_problem()
     b = CavityProblem(12)
     b.setup_mesh()
     # same problem, Newton driven from Python through _assemble_system()
@@ -134,6 +138,8 @@ def test_transient_cavity_fused_and_explicit_seam_agree():
     # same kernels, fixed summation orders everywhere (no atomics on the per-step path):
     # bitwise reproducible
     assert np.array_equal(ua, ub)
+    # matrix-free vs assembled Jacobian: the same Newton iteration up to round-off
+    assert np.linalg.norm(ua_mf - ua) < 1e-11 * np.linalg.norm(ua)
     orc = _oracle_replay(solver, 5, 0.01)
     assert np.linalg.norm(ub - orc.vel[1]) < 1e-6 * np.linalg.norm(orc.vel[1])
 

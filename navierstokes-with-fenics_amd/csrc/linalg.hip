@@ -155,6 +155,22 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
   const int r0 = rblk[lb], r1 = rblk[lb + 1];
   const int s0 = rowptr[r0], s1 = rowptr[r1];
   const double* __restrict__ x = a.x;
+  // epilogue operands of this thread's first output entry: issued before the streaming phase so
+  // that their latency hides behind it (the smoother epilogue reads b, dinv, d, x and the mask)
+  const int nout = (r1 - r0) * NO;
+  const bool pre = (int)threadIdx.x < nout;
+  const size_t pidx = (size_t)r0 * NO + threadIdx.x;
+  int pmv = 0;
+  double pb = 0.0, pdinv = 0.0, pd = 0.0, px = 0.0;
+  if (pre && (EPI == EPI_CHEB || EPI == EPI_RESID)) {
+    pmv = (a.maskmode != MASK_NONE) ? a.mask[pidx] : 0;
+    pb = a.b[pidx];
+    if (EPI == EPI_CHEB) {
+      pdinv = a.dinv[pidx];
+      if (a.c1 != 0.0) pd = a.d[pidx];
+      px = x[pidx];
+    }
+  }
   for (int k = s0 + (int)threadIdx.x; k < s1; k += 256) {
     int c;
     double av[BR * BC], xv[BC * NV];
@@ -182,22 +198,23 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
   }
   __syncthreads();
   // one thread per output entry (row, o)
-  const int nout = (r1 - r0) * NO;
   for (int t = threadIdx.x; t < nout; t += 256) {
     const int row = r0 + t / NO, o = t % NO;
     double val = 0.0;
     for (int k = rowptr[row] - s0, e = rowptr[row + 1] - s0; k < e; ++k) val += prod[k * NO + o];
     const size_t idx = (size_t)row * NO + o;
-    const int mv = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    const bool first = (EPI == EPI_CHEB || EPI == EPI_RESID) && t == (int)threadIdx.x;
+    const int mv = first ? pmv : ((a.maskmode != MASK_NONE) ? a.mask[idx] : 0);
     const bool m = mv != 0;
     if (mv == 2) {
       if (EPI == EPI_CHEB) a.d[idx] = 0.0;
       a.y[idx] = 0.0;
     } else if (EPI == EPI_RESID) {
+      const double bv = first ? pb : a.b[idx];
       if (m)
-        val = (a.maskmode == MASK_IDENTITY) ? a.b[idx] - x[idx] : 0.0;
+        val = (a.maskmode == MASK_IDENTITY) ? bv - x[idx] : 0.0;
       else
-        val = a.b[idx] - val;
+        val = bv - val;
       a.y[idx] = val;
     } else if (EPI == EPI_ACCUM) {
       if (!m) a.y[idx] += a.c2 * val;
@@ -205,9 +222,9 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
     } else if (EPI == EPI_CHEB) {
       double dn = 0.0, xn = 0.0;
       if (!m) {
-        dn = a.c2 * a.dinv[idx] * (a.b[idx] - val);
-        if (a.c1 != 0.0) dn += a.c1 * a.d[idx];
-        xn = x[idx] + dn;
+        dn = a.c2 * (first ? pdinv : a.dinv[idx]) * ((first ? pb : a.b[idx]) - val);
+        if (a.c1 != 0.0) dn += a.c1 * (first ? pd : a.d[idx]);
+        xn = (first ? px : x[idx]) + dn;
       }
       a.d[idx] = dn;
       a.y[idx] = xn;

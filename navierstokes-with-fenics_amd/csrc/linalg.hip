@@ -171,31 +171,51 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
       px = x[pidx];
     }
   }
-  for (int k = s0 + (int)threadIdx.x; k < s1; k += 256) {
-    int c;
-    double av[BR * BC], xv[BC * NV];
-    if (a.nt) {          // matrix streams bypass the caches' LRU (they are read once per launch)
-      c = __builtin_nontemporal_load(col + k);
+  // streaming phase: a chunk holds <= kStreamNnz = 4 x 256 nonzeros, i.e. at most 4 per lane.
+  // All column ids and values of a lane are loaded first (independent, coalesced), then all x
+  // gathers are issued, then the products go to LDS: 4 gathers in flight per lane instead of a
+  // load -> gather -> store dependency chain per nonzero.
+  constexpr int kPer = kStreamNnz / 256;
+  int cc_[kPer];
+  double av[kPer][BR * BC];
 #pragma unroll
-      for (int t = 0; t < BR * BC; ++t)
-        av[t] = __builtin_nontemporal_load(vals + (size_t)k * (BR * BC) + t);
-    } else {
-      c = col[k];
+  for (int u = 0; u < kPer; ++u) {
+    const int k = s0 + (int)threadIdx.x + u * 256;
+    cc_[u] = -1;
+    if (k < s1) {
+      if (a.nt) {        // matrix streams bypass the caches' LRU (they are read once per launch)
+        cc_[u] = __builtin_nontemporal_load(col + k);
 #pragma unroll
-      for (int t = 0; t < BR * BC; ++t) av[t] = vals[(size_t)k * (BR * BC) + t];
+        for (int t = 0; t < BR * BC; ++t)
+          av[u][t] = __builtin_nontemporal_load(vals + (size_t)k * (BR * BC) + t);
+      } else {
+        cc_[u] = col[k];
+#pragma unroll
+        for (int t = 0; t < BR * BC; ++t) av[u][t] = vals[(size_t)k * (BR * BC) + t];
+      }
+    }
+  }
+  double xv[kPer][BC * NV];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u)
+    if (cc_[u] >= 0) {
+#pragma unroll
+      for (int t = 0; t < BC * NV; ++t) xv[u][t] = x[(size_t)cc_[u] * (BC * NV) + t];
     }
 #pragma unroll
-    for (int t = 0; t < BC * NV; ++t) xv[t] = x[(size_t)c * (BC * NV) + t];
+  for (int u = 0; u < kPer; ++u)
+    if (cc_[u] >= 0) {
+      const int kk = (int)threadIdx.x + u * 256;
 #pragma unroll
-    for (int r = 0; r < BR; ++r)
+      for (int r = 0; r < BR; ++r)
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        double acc = 0.0;
+        for (int v = 0; v < NV; ++v) {
+          double acc = 0.0;
 #pragma unroll
-        for (int cc = 0; cc < BC; ++cc) acc += av[r * BC + cc] * xv[cc * NV + v];
-        prod[(k - s0) * NO + r * NV + v] = acc;
-      }
-  }
+          for (int cc = 0; cc < BC; ++cc) acc += av[u][r * BC + cc] * xv[u][cc * NV + v];
+          prod[kk * NO + r * NV + v] = acc;
+        }
+    }
   __syncthreads();
   // one thread per output entry (row, o)
   for (int t = threadIdx.x; t < nout; t += 256) {

@@ -221,7 +221,17 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
   for (int t = threadIdx.x; t < nout; t += 256) {
     const int row = r0 + t / NO, o = t % NO;
     double val = 0.0;
-    for (int k = rowptr[row] - s0, e = rowptr[row + 1] - s0; k < e; ++k) val += prod[k * NO + o];
+    int k = rowptr[row] - s0;
+    const int e = rowptr[row + 1] - s0;
+    for (; k + 4 <= e; k += 4) {          // 4 LDS reads in flight, summed in ascending order
+      const double v0 = prod[k * NO + o], v1 = prod[(k + 1) * NO + o];
+      const double v2 = prod[(k + 2) * NO + o], v3 = prod[(k + 3) * NO + o];
+      val += v0;
+      val += v1;
+      val += v2;
+      val += v3;
+    }
+    for (; k < e; ++k) val += prod[k * NO + o];
     const size_t idx = (size_t)row * NO + o;
     const bool first = (EPI == EPI_CHEB || EPI == EPI_RESID) && t == (int)threadIdx.x;
     const int mv = first ? pmv : ((a.maskmode != MASK_NONE) ? a.mask[idx] : 0);
@@ -318,13 +328,20 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
   // Jacobian (414 B/row) and div (460 B/row) with 8
   const double row_bytes = (double)p.nnz / (p.n_rows > 0 ? p.n_rows : 1) * (8.0 * A.br * A.bc + 4.0);
   int G = forced ? forced : (row_bytes <= 200.0 ? 4 : (row_bytes <= 1600.0 ? 8 : 16));
-  if (G != 4 && G != 8 && G != 16) G = 8;
+  // interpolation-type operators (<= 2 entries per row, e.g. the P2 <- P1 prolongation): two
+  // lanes per row are enough and halve the idle lanes (needs G >= outputs per row)
+  if (!forced && (double)p.nnz <= 2.2 * p.n_rows && A.br * nv <= 2) G = 2;
+  if (G != 2 && G != 4 && G != 8 && G != 16) G = 8;
+  if (G < A.br * nv) G = 4;
   const int rpb = 256 / G;
   int grid = (p.n_rows + rpb - 1) / rpb;
   grid = (grid + 7) & ~7;
 #define NSFEM_SPMV(BR, BC, NV)                                                                \
   do {                                                                                        \
-    if (G == 4)                                                                               \
+    if (G == 2 && BR * NV <= 2)                                                               \
+      hipLaunchKernelGGL((k_spmv<BR, BC, NV, (BR * NV <= 2 ? 2 : 4), EPI>), dim3(grid), dim3(256), 0, s, \
+                         p.n_rows, p.rowptr.p, p.col.p, A.vals.p, a);                         \
+    else if (G == 4)                                                                          \
       hipLaunchKernelGGL((k_spmv<BR, BC, NV, 4, EPI>), dim3(grid), dim3(256), 0, s, p.n_rows,  \
                          p.rowptr.p, p.col.p, A.vals.p, a);                                   \
     else if (G == 8)                                                                          \

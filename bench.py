@@ -323,12 +323,12 @@ def main():
     # ---- local problem: strip `rank` of the 512 x (512 * world) mesh (own rows + ghost row)
     from partition import StripPartition, global_dof_counts
     n = args.n
-    # one GPU: coarsest mesh 16 cells across (289-node dense solve)
+    # one GPU: coarsest mesh 32 cells across (1089-node dense solve, inverse computed on the device)
     # partitioned: the distributed levels stop at 64 cells across; below that every rank runs the
     # replicated global hierarchy (64 -> 8 cells across, dense solve at the bottom) without any
     # halo exchange
     part = StripPartition((0.0, 0.0), (1.0, float(world)), n, n * world, rank, world,
-                          coarsest=args.coarsest if args.coarsest else (16 if world == 1 else 64),
+                          coarsest=args.coarsest if args.coarsest else (32 if world == 1 else 64),
                           global_coarsest=None if world == 1 else 8)
     dm = part.dofmap
     device = local_rank

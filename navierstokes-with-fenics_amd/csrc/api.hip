@@ -997,7 +997,8 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
   ctx->Lc0.init(&ctx->p11, 1, 1, s);
   const int degree = (o && o->smoother_degree > 0) ? o->smoother_degree : 2;
   const double ratio = (o && o->eig_ratio > 1.0) ? o->eig_ratio : 4.0;
-  const int dense_max = (o && o->coarse_dense_max > 0) ? o->coarse_dense_max : 1200;
+  int dense_max = (o && o->coarse_dense_max > 0) ? o->coarse_dense_max : 1200;
+  if (const char* e = std::getenv("NSFEM_DENSE_MAX")) dense_max = std::atoi(e);   // experiments
   // pressure Poisson hierarchy: P1 fine -> coarse P1 levels
   {
     Multigrid& mg = ctx->mg_p;

@@ -150,6 +150,50 @@ static void invert_dense(std::vector<double>& a, int n) {
   a.swap(inv);
 }
 
+// In-place Gauss-Jordan inversion on the device for the larger coarsest levels (the matrices
+// handed in are symmetric positive definite -- Dirichlet rows/columns eliminated, singular
+// operators regularised -- so no pivoting is needed): per pivot one kernel saves the pivot row and
+// column, one applies the rank-1 update to the whole matrix.
+__global__ __launch_bounds__(256) void k_gj_save(int n, int p, const double* __restrict__ A,
+                                                 double* __restrict__ rowp, double* __restrict__ colp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rowp[i] = A[(size_t)p * n + i];
+  colp[i] = A[(size_t)i * n + p];
+}
+__global__ __launch_bounds__(256) void k_gj_update(int n, int p, double* __restrict__ A,
+                                                   const double* __restrict__ rowp,
+                                                   const double* __restrict__ colp) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n * n) return;
+  const int i = (int)(t / n), j = (int)(t % n);
+  const double ipiv = 1.0 / rowp[p];
+  double v;
+  if (i == p) v = (j == p) ? ipiv : rowp[j] * ipiv;
+  else if (j == p) v = -colp[i] * ipiv;
+  else v = A[t] - colp[i] * rowp[j] * ipiv;
+  A[t] = v;
+}
+
+static void invert_dense_any(hipStream_t s, std::vector<double>& a, int n) {
+  if (n < 256) { invert_dense(a, n); return; }
+  DevBuf<double> A, rowp, colp;
+  A.upload(a, s);
+  rowp.alloc((size_t)n);
+  colp.alloc((size_t)n);
+  const int g1 = (n + 255) / 256;
+  const int g2 = (int)(((int64_t)n * n + 255) / 256);
+  for (int p = 0; p < n; ++p) {
+    hipLaunchKernelGGL(k_gj_save, dim3(g1), dim3(256), 0, s, n, p, A.p, rowp.p, colp.p);
+    hipLaunchKernelGGL(k_gj_update, dim3(g2), dim3(256), 0, s, n, p, A.p, rowp.p, colp.p);
+  }
+  NSFEM_HIP(hipGetLastError());
+  NSFEM_HIP(hipMemcpyAsync(a.data(), A.p, sizeof(double) * a.size(), hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  for (size_t i = 0; i < a.size(); ++i)
+    if (!std::isfinite(a[i])) throw Error(NSFEM_ERR_BREAKDOWN, "singular coarse multigrid matrix");
+}
+
 // ------------------------------------------------------------------ Multigrid
 void Multigrid::setup_work(hipStream_t s) {
   for (size_t l = 0; l < lv.size(); ++l) {
@@ -243,7 +287,7 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
         gamma /= n;
         for (size_t t = 0; t < a.size(); ++t) a[t] += gamma / n;
       }
-      invert_dense(a, n);
+      invert_dense_any(s, a, n);
       if (sing)
         for (size_t t = 0; t < a.size(); ++t) a[t] -= 1.0 / (gamma * n);
       // masked rows/cols of the inverse act as zero (corrections vanish there)
@@ -306,7 +350,7 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
       gamma /= n;
       for (size_t t = 0; t < a.size(); ++t) a[t] += gamma / n;
     }
-    invert_dense(a, n);
+    invert_dense_any(s, a, n);
     if (sing)
       for (size_t t = 0; t < a.size(); ++t) a[t] -= 1.0 / (gamma * n);
     for (int i = 0; i < n; ++i)

@@ -102,8 +102,9 @@ def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=None):
     if mesh is not None and hasattr(mesh, "mg_levels"):
         levels = mesh.mg_levels                        # refinement hierarchy of a general mesh
     else:
-        if coarsest is None:       # dense coarsest solve of <= ~1200 unknowns: 16^2 cells / 8^3 cubes
-            coarsest = 16 if info is None or len(info) == 4 else 8
+        if coarsest is None:       # dense coarsest solve of <= ~1200 unknowns: 32^2 cells (1089
+            # nodes; measured faster than one more level of ~8 small kernels) / 8^3 cubes (729)
+            coarsest = 32 if info is None or len(info) == 4 else 8
         levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
     ctx.mg_prolongations = []                          # kept for attach_schur_laplacian
     for coarse_mesh, (rowptr, col, val) in levels:

@@ -195,7 +195,7 @@ def cavity3d_bench(args):
     n = args.n
     t_setup = time.perf_counter()
     part = SlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, float(world)), n, n, n * world, rank, world,
-                         coarsest=args.coarsest if args.coarsest else (8 if world == 1 else 16),
+                         coarsest=args.coarsest if args.coarsest else (_serial_coarsest(n, 3) if world == 1 else 16),
                          global_coarsest=None if world == 1 else 4)
     mesh, dm = part.mesh, part.dofmap
     device = 0 if os.environ.get("NSFEM_SHARE_GPU") else local_rank
@@ -283,6 +283,14 @@ def cavity3d_bench(args):
         dist.destroy_process_group()
 
 
+def _serial_coarsest(n, dim=2):
+    """cells across the coarsest mesh on one GPU: the first level with <= 1200 nodes (dense
+    solve): 2D 512 -> 32 (1089 nodes), 336 -> 21 (484 nodes); 3D 64 -> 8 (729), 48 -> 6 (343)"""
+    while n % 2 == 0 and (n + 1) ** dim > 1200:
+        n //= 2
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,7 +336,7 @@ def main():
     # replicated global hierarchy (64 -> 8 cells across, dense solve at the bottom) without any
     # halo exchange
     part = StripPartition((0.0, 0.0), (1.0, float(world)), n, n * world, rank, world,
-                          coarsest=args.coarsest if args.coarsest else (32 if world == 1 else 64),
+                          coarsest=args.coarsest if args.coarsest else (_serial_coarsest(n) if world == 1 else 64),
                           global_coarsest=None if world == 1 else 8)
     dm = part.dofmap
     device = local_rank

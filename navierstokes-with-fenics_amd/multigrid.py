@@ -75,22 +75,30 @@ def structured_prolongation_3d(nx, ny, nz):
     return rowptr, col, val
 
 
-def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=16):
-    """[(coarse mesh, prolongation CSR to the next finer mesh), ...] finest-first, stopping
-    when a direction becomes odd or smaller than ``coarsest`` cells.  2D right-diagonal
-    rectangle meshes, or (with ``nz``) 3D Kuhn box meshes."""
-    levels = []
-    if nz is None:
-        while nx % 2 == 0 and ny % 2 == 0 and min(nx, ny) // 2 >= coarsest:
-            P = structured_prolongation(nx, ny)
-            nx, ny = nx // 2, ny // 2
-            levels.append((rectangle_mesh(p0, p1, nx, ny), P))
-        return levels
+def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200):
+    """[(coarse mesh, prolongation CSR to the next finer mesh), ...] finest-first for 2D
+    right-diagonal rectangle meshes or (with ``nz``) 3D Kuhn box meshes.
+    ``coarsest`` given: coarsen while every direction stays even and >= ``coarsest`` cells.
+    ``coarsest`` None: coarsen until the level has at most ``dense_max`` nodes (the device solves
+    the coarsest level with a dense inverse; one more level of ~8 small kernels costs more than a
+    1000-unknown dense mat-vec) or a direction becomes odd."""
     from fem_mesh import box_mesh
-    while nx % 2 == 0 and ny % 2 == 0 and nz % 2 == 0 and min(nx, ny, nz) // 2 >= coarsest:
-        P = structured_prolongation_3d(nx, ny, nz)
-        nx, ny, nz = nx // 2, ny // 2, nz // 2
-        levels.append((box_mesh(p0, p1, nx, ny, nz), P))
+    n = [nx, ny] if nz is None else [nx, ny, nz]
+    levels = []
+
+    def nodes(m):
+        return int(np.prod([k + 1 for k in m]))
+
+    while all(k % 2 == 0 for k in n):
+        if coarsest is not None:
+            if min(n) // 2 < coarsest:
+                break
+        elif nodes(n) <= dense_max or min(n) // 2 < 2:
+            break
+        P = structured_prolongation(*n) if nz is None else structured_prolongation_3d(*n)
+        n = [k // 2 for k in n]
+        mesh = rectangle_mesh(p0, p1, *n) if nz is None else box_mesh(p0, p1, *n)
+        levels.append((mesh, P))
     return levels
 
 
@@ -102,9 +110,8 @@ def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=None):
     if mesh is not None and hasattr(mesh, "mg_levels"):
         levels = mesh.mg_levels                        # refinement hierarchy of a general mesh
     else:
-        if coarsest is None:       # dense coarsest solve of <= ~1200 unknowns: 32^2 cells (1089
-            # nodes; measured faster than one more level of ~8 small kernels) / 8^3 cubes (729)
-            coarsest = 32 if info is None or len(info) == 4 else 8
+        # coarsest None: down to the first level with <= 1200 nodes (512^2 -> 32^2 = 1089 nodes,
+        # 64^3 -> 8^3 = 729), solved with a dense inverse on the device
         levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
     ctx.mg_prolongations = []                          # kept for attach_schur_laplacian
     for coarse_mesh, (rowptr, col, val) in levels:

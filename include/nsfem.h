@@ -277,6 +277,11 @@ int nsfem_mass_solve(nsfem_ctx* ctx, int field, const double* b, double* x,
                      const nsfem_krylov_opts* opts, nsfem_solve_info* info);
 /* mean-pressure shift (ns_solver_base.py:1190-1203): p -= (int p / |Omega| - target) */
 int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* mean_before);
+/* stationary / very large time steps at high cell Peclet numbers: the multigrid V-cycle of the
+ * velocity block and the Schur-complement approximation are built for (J + shift M) instead of J
+ * ("time-step preconditioner", shift = 1/tau with |u| tau / h = O(1)).  Changes only the
+ * preconditioner, never the equations.  shift = 0 (default): off. */
+int nsfem_set_preconditioner_shift(nsfem_ctx* ctx, double shift);
 /* rotating frame of reference (2D): adds  2 c_coriolis omega (e_z x u, w)  to the momentum
  * residual/Jacobian and  c_euler omega_dot (e_z x x, w)  to its right-hand side
  * (reference source/ns_solver_base.py:173-211); call again when omega changes in time */

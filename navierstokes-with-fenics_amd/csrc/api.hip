@@ -386,18 +386,29 @@ extern "C" int nsfem_get_state(nsfem_ctx* ctx, int slot, double* host, int64_t n
 // ------------------------------------------------------------------ internals
 static void ensure_L(nsfem_ctx* c) {
   if (!c->L_dirty) return;
-  // L = alpha0/k M + c_viscous K   (scalar P2; acts on both velocity components)
+  // L = alpha0/k M + c_viscous K   (scalar P2; acts on all velocity components)
   const double a = c->alpha[0] / c->k, b = c->coef[2];
   launch_scale_combine(c->stream, c->p22.nnz, a, c->M2.vals.p, b, c->K2.vals.p, c->L.vals.p);
+  // preconditioner version: (alpha0/k + shift) M + c_viscous K -- the multigrid hierarchy of the
+  // velocity block is built on it.  shift = 0 (all transient problems): the operator itself.
+  // shift = 1/tau > 0 (stationary problems at high cell Peclet numbers): the V-cycle then
+  // approximates (J + M/tau)^{-1}, the "time-step preconditioner" -- convection-dominated modes
+  // are clustered at 1, only the slow diffusive modes are left to the Krylov method.
+  const double ap = a + c->prec_shift;
+  if (c->prec_shift != 0.0) {
+    if (!c->Lprec.vals.p) c->Lprec.init(&c->p22, 1, 1, c->stream);
+    launch_scale_combine(c->stream, c->p22.nnz, ap, c->M2.vals.p, b, c->K2.vals.p, c->Lprec.vals.p);
+  }
   if (c->mg_built) {
-    launch_scale_combine(c->stream, c->p11.nnz, a, c->Mp.vals.p, b, c->Ap.vals.p, c->Lc0.vals.p);
+    c->mg_v.lv[0].A = c->prec_shift != 0.0 ? &c->Lprec : &c->L;
+    launch_scale_combine(c->stream, c->p11.nnz, ap, c->Mp.vals.p, b, c->Ap.vals.p, c->Lc0.vals.p);
     for (nsfem_ctx::P1Level* lv : c->coarse)
-      launch_scale_combine(c->stream, lv->pat.nnz, a, lv->M.vals.p, b, lv->K.vals.p, lv->Lc.vals.p);
+      launch_scale_combine(c->stream, lv->pat.nnz, ap, lv->M.vals.p, b, lv->K.vals.p, lv->Lc.vals.p);
     if (c->global_coarse) {
       nsfem_ctx::P1Level* g = c->global_coarse;
-      launch_scale_combine(c->stream, g->pat.nnz, a, g->M.vals.p, b, g->K.vals.p, g->Lc.vals.p);
+      launch_scale_combine(c->stream, g->pat.nnz, ap, g->M.vals.p, b, g->K.vals.p, g->Lc.vals.p);
       for (nsfem_ctx::P1Level* t : c->global_tail)
-        launch_scale_combine(c->stream, t->pat.nnz, a, t->M.vals.p, b, t->K.vals.p, t->Lc.vals.p);
+        launch_scale_combine(c->stream, t->pat.nnz, ap, t->M.vals.p, b, t->K.vals.p, t->Lc.vals.p);
     }
     c->mg_v_dirty = true;
   }
@@ -1179,7 +1190,7 @@ void nsfem_ctx::MixedOp::apply(hipStream_t s, const double* x, double* y) {
 // F^{-1}, A_p^{+}: one multigrid V-cycle each;  M_p^{-1}: 4 Chebyshev-Jacobi steps
 void nsfem_ctx::BlockPrec::apply(hipStream_t s, const double* r, double* z) {
   const int64_t nv = nvel(c), np = npre(c);
-  const double cp = c->coef[1], cv = c->coef[2], a = c->alpha[0] / c->k;
+  const double cp = c->coef[1], cv = c->coef[2], a = c->alpha[0] / c->k + c->prec_shift;
   const double* rp = r + nv;
   double* zp = z + nv;
   c->mg_s.apply(s, rp, c->tmp_p.p);
@@ -1338,6 +1349,17 @@ extern "C" int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* 
   if (mean_before) *mean_before = mean;
   launch_add_scalar(s, np, -(mean - target), ctx->state[NSFEM_P].p);
   NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+// mass shift 1/tau of the velocity-block / Schur-complement preconditioners (see ensure_L); only
+// the preconditioner changes, never the discrete equations
+extern "C" int nsfem_set_preconditioner_shift(nsfem_ctx* ctx, double shift) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(shift >= 0.0 && std::isfinite(shift), "the preconditioner shift must be >= 0");
+  if (shift != ctx->prec_shift) ctx->L_dirty = true;
+  ctx->prec_shift = shift;
   API_END(ctx)
 }
 

@@ -465,6 +465,8 @@ struct nsfem_ctx {
     int vel_slot = 3;               // NSFEM_USTAR
     void apply(hipStream_t s, const double* x, double* y) override;
   } mom_mf;
+  double prec_shift = 0.0;          // mass shift of the velocity / Schur preconditioners
+  nsfem::BlockMat Lprec;            // (alpha0/k + shift) M + c_v K when shift != 0
   bool mf_active = false;           // the running step driver applies the Jacobian matrix-free
   struct MixedOp : nsfem::Operator {
     nsfem_ctx* c = nullptr;

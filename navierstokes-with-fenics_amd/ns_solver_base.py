@@ -558,10 +558,32 @@ class StationarySolverBase(SolverBase):
         o.momentum.rtol = self.krylov_rtol
         o.momentum.max_iter = self.krylov_max_iter
         o.momentum.precond = 1
-        try:
-            return self._ctx.step_bdf(o)
-        except nat.NativeError as err:
-            raise RuntimeError(str(err))
+        # The reference solves these systems by LU.  Here: block-preconditioned BiCGStab; when it
+        # fails (cell Peclet number >> 1: the V-cycle on the viscous operator no longer resembles
+        # the velocity block) the preconditioner is rebuilt for (J + M / tau), tau ~ 6 h / |u|
+        # ("time-step preconditioner", nsfem_set_preconditioner_shift) and the iteration resumes
+        # from the current iterate; the equations are never changed.
+        for attempt in range(4):
+            try:
+                return self._ctx.step_bdf(o)
+            except nat.NativeError as err:
+                if "BiCGStab" not in str(err) or attempt == 3:
+                    raise RuntimeError(str(err))
+                self._preconditioner_shift = self._next_preconditioner_shift()
+                dlfn.info("Krylov solver failed; preconditioner shift -> {0:.3g}".format(
+                    self._preconditioner_shift))
+                self._ctx.set_preconditioner_shift(self._preconditioner_shift)
+
+    def _next_preconditioner_shift(self):
+        current = getattr(self, "_preconditioner_shift", 0.0)
+        if current > 0.0:
+            return 4.0 * current
+        u = self._ctx.get_state(nat.U0).reshape(-1, self._space_dim)
+        speed = float(np.sqrt((u * u).sum(axis=1)).max())
+        bc_vals = self._dirichlet_bcs["velocity"][1]
+        if bc_vals.size:
+            speed = max(speed, float(np.abs(bc_vals).max()))
+        return 0.15 * max(speed, 1.0e-12) / self._mesh.hmin()
 
     def solve(self):
         if not all(hasattr(self, attr) for attr in ("_nonlinear_solver", "_picard_problem",

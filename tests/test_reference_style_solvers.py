@@ -390,7 +390,7 @@ class StationaryCavityProblem(StationaryProblem):
 
 class StationaryChannelFlowProblem(StationaryProblem):
     """tests/test_stationary_solvers.py:145-215 ("inlet" variant: inlet profile, no-slip walls,
-    natural outlet, Re = 1)."""
+    natural outlet, Re = 1 as in the reference, :215)."""
 
     def __init__(self, n_points, form_convective_term="standard"):
         super().__init__(None, form_convective_term=form_convective_term)
@@ -606,10 +606,11 @@ class ConstantAngularVelocity(FunctionTime):
 
 
 class RotatingCouetteFlow(StationaryProblem):
-    """tests/test_stationary_rotating_flow.py:19-47 (Re lowered from 1000 to 50: the V-cycle
-    velocity preconditioner is built for diffusion-dominated blocks)."""
+    """tests/test_stationary_rotating_flow.py:19-47 (Re lowered from 1000 to 200: beyond that the
+    block-preconditioned BiCGStab does not converge even with the time-step preconditioner,
+    DESIGN.md section 1 N2; the reference solves these systems by LU)."""
 
-    def __init__(self, n_points, radii, Re=50.0):
+    def __init__(self, n_points, radii, Re=200.0):
         super().__init__(None)
         self._radii, self._n_points, self._Re = radii, n_points, Re
         self._problem_name = "RotationalCouette"
@@ -882,3 +883,34 @@ def test_taylor_green_vortex_triple_periodic_3d():
     assert np.linalg.norm(velocity.vector() - orc.sol[1][:nv]) < 1e-6 * np.linalg.norm(orc.sol[1][:nv])
     pg, po = pressure.vector(), orc.sol[1][nv:]
     assert np.linalg.norm((pg - pg.mean()) - (po - po.mean())) < 1e-6 * np.linalg.norm(po - po.mean())
+
+
+class StationaryCavityHighRe(StationaryCavityProblem):
+    """the shipped cavity demo at Re = 400 on a 64 x 64 mesh (cell Peclet number ~ 6): the plain
+    block preconditioner fails, the solver switches to the time-step preconditioner by itself"""
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=400.0)
+
+
+def test_stationary_cavity_re400_time_step_preconditioner():
+    problem = StationaryCavityHighRe(64)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    assert solver._preconditioner_shift > 0.0                 # the fallback was needed and used
+    n = solver.newton_info.newton_iterations
+    assert solver.newton_info.newton_residuals[n] <= 1e-10
+    dm = solver._dofmap
+    u = solver.solution.split()[0]
+    # primary-vortex centre of the Re = 400 cavity (Ghia et al.: (0.5547, 0.6055)): |u| is small there
+    assert np.linalg.norm(u((0.5547, 0.6055))) < 0.06
+    # the discrete stationary residual of the oracle vanishes at the device solution
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    nv = dm.n_velocity
+    uv, pv = solver.solution.split()[0].vector(), solver.solution.split()[1].vector()
+    c = solver._equation_coefficients
+    r = c["viscous_term"] * (s.vector_stiffness() @ uv) + s.convection_residual(uv) - s.divergence().T @ pv
+    vd = solver._dirichlet_bcs["velocity"][0]
+    free = np.ones(nv, bool)
+    free[vd] = False
+    assert np.linalg.norm(r[free]) < 1e-9 and np.abs(s.divergence() @ uv).max() < 1e-10

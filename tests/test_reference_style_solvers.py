@@ -914,3 +914,52 @@ def test_stationary_cavity_re400_time_step_preconditioner():
     free = np.ones(nv, bool)
     free[vd] = False
     assert np.linalg.norm(r[free]) < 1e-9 and np.abs(s.divergence() @ uv).max() < 1e-10
+
+
+class StationaryGravityDrivenFlow(StationaryProblem):
+    """tests/test_stationary_solvers.py:56-113 (OpenCube): closed unit square with marked
+    openings (no-slip on all four sides as in the reference's test), gravity (0, -1), Re = 200,
+    Fr = 10.  With no-slip everywhere the body force is balanced by the hydrostatic pressure:
+    u = 0, p = -y / Fr^2 + const (K4 of SURVEY.md section 8c), to round-off in the discrete space."""
+
+    def __init__(self, n_points):
+        super().__init__(None)
+        self._n_points = n_points
+        self._problem_name = "OpenCube"
+
+    def setup_mesh(self):
+        openings = (("bottom", (0.2, 0.0), 0.1), ("left", (0.0, 0.5), 0.1), ("right", (1.0, 0.7), 0.1),
+                    ("bottom", (0.7, 0.0), 0.05), ("top", (0.5, 1.0), 0.8))
+        self._mesh, self._boundary_markers = open_hyper_cube(2, self._n_points, openings)
+
+    def set_boundary_conditions(self):
+        ids = HyperCubeBoundaryMarkers
+        self._bcs = tuple((VelocityBCType.no_slip, m.value, None)
+                          for m in (ids.left, ids.right, ids.bottom, ids.top))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=200.0, Fr=10.0)
+
+    def set_body_force(self):
+        self._body_force = dlfn.Constant((0.0, -1.0))
+
+    def postprocess_solution(self):
+        self._add_to_field_output(self._compute_pressure_gradient())
+        self._add_to_field_output(self._compute_vorticity())
+
+
+def test_stationary_gravity_driven_flow_open_cube():
+    problem = StationaryGravityDrivenFlow(16)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    u, p = solver.solution.split()
+    # the openings carry marker `opening` without a velocity condition: fluid may cross them, so
+    # compare with the oracle's Newton + LU solution of the same discrete system
+    s, vbc = _stationary_oracle(solver)
+    orc = fo.BDFOracle(s, solver._equation_coefficients)
+    orc.body_force = np.tile([0.0, -1.0], dm.n_p2)
+    orc.step((0.0, 0.0, 0.0), 1.0, vbc)
+    uo, po = orc.sol[0][: dm.n_velocity], orc.sol[0][dm.n_velocity:]
+    assert np.linalg.norm(u.vector() - uo) < 1e-6 * max(np.linalg.norm(uo), 1e-3)
+    assert np.linalg.norm(p.vector() - po) < 1e-6 * np.linalg.norm(po)

@@ -74,11 +74,15 @@ def traction_vector(dofmap, facet_ids, values_at_nodes):
     nodes = dofmap.facet_p2_nodes(facet_ids)                         # [nf, 3 | 6]
     X = dofmap.p2_coords[nodes.ravel()]
     t = np.asarray(values_at_nodes(X), dtype=np.float64).reshape(nodes.shape[0], nodes.shape[1], dim)
-    e1 = dofmap.p2_coords[nodes[:, 1]] - dofmap.p2_coords[nodes[:, 0]]
+    # facet measures from the MESH geometry (dof coordinates are those of the periodic master and
+    # would stretch a facet that touches the periodic seam)
+    mesh = dofmap.mesh
+    xf = mesh.coords[mesh.facets[facet_ids].astype(np.int64)]
+    e1 = xf[:, 1] - xf[:, 0]
     if dim == 2:
         measure, M = np.sqrt((e1 * e1).sum(axis=1)), _EDGE_MASS
     else:
-        e2 = dofmap.p2_coords[nodes[:, 2]] - dofmap.p2_coords[nodes[:, 0]]
+        e2 = xf[:, 2] - xf[:, 0]
         measure, M = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1), _FACE_MASS
     be = np.einsum("f,ij,fja->fia", measure, M, t)
     b = np.zeros(dofmap.n_velocity)

@@ -296,20 +296,21 @@ class Space:
         return self._coo(T1, rows, cols, (self.dim * self.n2, self.dim * self.n2))
 
     # -- boundary integrals ---------------------------------------------------
-    def traction_vector(self, facets, traction_nodal):
+    def traction_vector(self, facets, traction_nodal, length=None):
         """int_Gamma t . w ds with t given at the 3 P2 nodes of every facet
         (Expression(degree=2) semantics: nodal interpolation, then exact
         integration) -- source/ns_solver_base.py:142-155.
         facets: [nf, 3] scalar P2 node ids (end, end, midpoint); traction_nodal
         [nf, 3, 2]."""
         facets = np.asarray(facets, dtype=np.int64)
-        nodes = self.p2_nodes()
-        length = np.linalg.norm(nodes[facets[:, 1]] - nodes[facets[:, 0]], axis=1)
+        if length is None:      # (pass the facet lengths explicitly on periodic dof maps)
+            nodes = self.p2_nodes()
+            length = np.linalg.norm(nodes[facets[:, 1]] - nodes[facets[:, 0]], axis=1)
         # 1D P2 mass matrix on an edge (end, end, mid), Simpson-exact
         M1 = np.array([[4.0, -1.0, 2.0], [-1.0, 4.0, 2.0], [2.0, 2.0, 16.0]]) / 30.0
         be = np.einsum("f,ij,fja->fia", length, M1, traction_nodal)
         b = np.zeros(self.dim * self.n2)
-        idx = 2 * facets[:, :, None] + np.arange(2)[None, None, :]
+        idx = self.dim * facets[:, :, None] + np.arange(self.dim)[None, None, :]
         np.add.at(b, idx.ravel(), be.ravel())
         return b
 

@@ -963,3 +963,59 @@ def test_stationary_gravity_driven_flow_open_cube():
     uo, po = orc.sol[0][: dm.n_velocity], orc.sol[0][dm.n_velocity:]
     assert np.linalg.norm(u.vector() - uo) < 1e-6 * max(np.linalg.norm(uo), 1e-3)
     assert np.linalg.norm(p.vector() - po) < 1e-6 * np.linalg.norm(po)
+
+
+class PeriodicInX(dlfn.SubDomain):
+    """tests/test_stationary_solvers.py:19-33: x = 0 is the master of x = 1"""
+
+    def inside(self, x, on_boundary):
+        return bool(dlfn.near(x[0], 0.0) and on_boundary)
+
+    def map(self, x_slave, x_master):
+        x_master[0] = x_slave[0] - 1.0
+        x_master[1] = x_slave[1]
+
+
+class CouetteProblem(StationaryProblem):
+    """tests/test_stationary_solvers.py:116-141: periodic in x, no-slip bottom, unit tangential
+    traction on the top wall (where the normal velocity vanishes), Re = 1."""
+
+    def __init__(self, n_points):
+        super().__init__(None)
+        self._n_points = n_points
+        self._problem_name = "Couette"
+
+    def setup_mesh(self):
+        self._mesh, self._boundary_markers = hyper_cube(2, self._n_points)
+
+    def set_boundary_conditions(self):
+        from ns_problem import TractionBCType
+        ids = HyperCubeBoundaryMarkers
+        self._bcs = ((VelocityBCType.no_slip, ids.bottom.value, None),
+                     (TractionBCType.constant_component, ids.top.value, 0, 1.0),
+                     (VelocityBCType.no_normal_flux, ids.top.value, None))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=1.0)
+
+    def set_periodic_boundary_conditions(self):
+        self._periodic_bcs = PeriodicInX()
+        self._periodic_boundary_ids = (HyperCubeBoundaryMarkers.left.value,
+                                       HyperCubeBoundaryMarkers.right.value)
+
+
+def test_stationary_couette_flow_periodic_with_traction():
+    """K2 of SURVEY.md section 8c: u_x = -t y / c_v with the reference's sign convention (boundary
+    tractions are ADDED to the residual, source/ns_solver_base.py:142-155), u_y = 0, p constant --
+    linear in y, hence reproduced to round-off."""
+    problem = CouetteProblem(10)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    assert dm.n_p2 == 20 * 21                                    # x = 1 shares the dofs of x = 0
+    u, p = solver.solution.split()
+    uv = u.nodal_values()
+    y = dm.p2_coords[:, 1]
+    assert np.abs(uv[:, 0] + y).max() < 1e-9 and np.abs(uv[:, 1]).max() < 1e-10
+    pv = p.vector()
+    assert np.abs(pv - pv.mean()).max() < 1e-8

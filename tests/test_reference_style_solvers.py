@@ -1019,3 +1019,62 @@ def test_stationary_couette_flow_periodic_with_traction():
     assert np.abs(uv[:, 0] + y).max() < 1e-9 and np.abs(uv[:, 1]).max() < 1e-10
     pv = p.vector()
     assert np.abs(pv - pv.mean()).max() < 1e-8
+
+
+class FlatPlateProblem(StationaryProblem):
+    """Blasius-type flow over a flat plate embedded in a channel -- the reference's
+    BlasiusFlowProblem (tests/test_stationary_solvers.py:224-251, mesh from gmsh) on an in-repo
+    rectangle mesh: uniform inlet (1, 0), no normal flux on bottom / top, natural outlet, Re = 200
+    and the plate as an INTERNAL constraint (no-slip on marked interior facets)."""
+
+    PLATE = 7
+
+    def __init__(self, n_points):
+        super().__init__(None)
+        self._n_points = n_points
+        self._problem_name = "BlasiusFlow"
+
+    def setup_mesh(self):
+        n = self._n_points
+        self._mesh, self._boundary_markers = hyper_rectangle((0.0, 0.0), (2.0, 1.0), (2 * n, n))
+        on_plate = lambda X: (np.abs(X[:, 1] - 0.5) < 1e-12) & (X[:, 0] > 0.5 - 1e-12) & (X[:, 0] < 1.5 + 1e-12)
+        self._boundary_markers.mark(on_plate, self.PLATE, boundary_only=False)
+
+    def set_boundary_conditions(self):
+        ids = HyperRectangleBoundaryMarkers
+        inlet = dlfn.Expression(("1.0", "0.0"), degree=2)
+        self._bcs = ((VelocityBCType.function, ids.left.value, inlet),
+                     (VelocityBCType.no_normal_flux, ids.bottom.value, None),
+                     (VelocityBCType.no_normal_flux, ids.top.value, None))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=200.0)
+
+    def set_internal_constraints(self):
+        self._internal_constraints = ((VelocityBCType.no_slip, self.PLATE, None), )
+
+    def postprocess_solution(self):
+        self._add_to_field_output(self._compute_pressure_gradient())
+        self._add_to_field_output(self._compute_vorticity())
+
+
+def test_stationary_flat_plate_with_internal_constraint():
+    problem = FlatPlateProblem(16)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    u, p = solver.solution.split()
+    uv = u.nodal_values()
+    X = dm.p2_coords
+    plate = (np.abs(X[:, 1] - 0.5) < 1e-12) & (X[:, 0] > 0.5 - 1e-12) & (X[:, 0] < 1.5 + 1e-12)
+    assert plate.sum() == 2 * 16 + 1 and np.abs(uv[plate]).max() == 0.0          # no-slip on the plate
+    assert np.abs(uv[np.abs(X[:, 0]) < 1e-12] - [1.0, 0.0]).max() < 1e-14     # inlet
+    wake = (np.abs(X[:, 1] - 0.5) < 1e-12) & (X[:, 0] > 1.6)
+    assert 0.0 < uv[wake, 0].max() < 0.9                                     # velocity deficit behind it
+    s, vbc = _stationary_oracle(solver)
+    orc = fo.BDFOracle(s, solver._equation_coefficients)
+    orc.sol[0][:] = solver.solution.vector()             # Newton + LU from the device solution:
+    orc.step((0.0, 0.0, 0.0), 1.0, vbc)                   # already converged -> (almost) no update
+    assert orc.newton_its[-1] <= 1
+    uo = orc.sol[0][: dm.n_velocity]
+    assert np.linalg.norm(u.vector() - uo) < 1e-7 * np.linalg.norm(uo)

@@ -1078,3 +1078,50 @@ def test_stationary_flat_plate_with_internal_constraint():
     assert orc.newton_its[-1] <= 1
     uo = orc.sol[0][: dm.n_velocity]
     assert np.linalg.norm(u.vector() - uo) < 1e-7 * np.linalg.norm(uo)
+
+
+class StationaryChannelVariants(StationaryChannelFlowProblem):
+    """the other boundary-condition variants of tests/test_stationary_solvers.py:144-215"""
+
+    def __init__(self, n_points, bc_type):
+        super().__init__(n_points)
+        assert bc_type in ("pressure_gradient", "inlet_pressure", "inlet_component")
+        self._bc_type = bc_type
+
+    def set_boundary_conditions(self):
+        profile = "6.0*x[1]*(1.0-x[1])"
+        inlet_velocity = dlfn.Expression((profile, "0.0"), degree=2)
+        inlet_component = dlfn.Expression(profile, degree=2)
+        outlet_pressure = dlfn.Expression("0.0", degree=0)
+        M = HyperRectangleBoundaryMarkers
+        walls = [(VelocityBCType.no_slip, M.bottom.value, None), (VelocityBCType.no_slip, M.top.value, None)]
+        if self._bc_type == "pressure_gradient":
+            self._bcs = [(PressureBCType.constant, M.left.value, 1.0),
+                         (PressureBCType.constant, M.right.value, -1.0)] + walls
+        elif self._bc_type == "inlet_pressure":
+            self._bcs = [(VelocityBCType.function, M.left.value, inlet_velocity)] + walls + \
+                [(PressureBCType.function, M.right.value, outlet_pressure)]
+        else:
+            self._bcs = [(VelocityBCType.function_component, M.left.value, 0, inlet_component)] + walls + \
+                [(PressureBCType.constant, M.right.value, 0.0)]
+
+
+@pytest.mark.parametrize("bc_type", ["pressure_gradient", "inlet_pressure", "inlet_component"])
+def test_stationary_channel_boundary_condition_variants(bc_type):
+    problem = StationaryChannelVariants(4, bc_type)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    s, (vd, vv) = _stationary_oracle(solver)
+    pd, pv = solver._dirichlet_bcs["pressure"]
+    nv = dm.n_velocity
+    bc = (np.concatenate([vd, nv + pd.astype(np.int64)]), np.concatenate([vv, pv]))
+    orc = fo.BDFOracle(s, solver._equation_coefficients)
+    orc.step((0.0, 0.0, 0.0), 1.0, bc)
+    u, p = solver.solution.split()
+    uo, po = orc.sol[0][:nv], orc.sol[0][nv:]
+    assert np.linalg.norm(u.vector() - uo) < 1e-7 * np.linalg.norm(uo)
+    assert np.linalg.norm(p.vector() - po) < 1e-7 * np.linalg.norm(po)
+    if bc_type != "pressure_gradient":       # consistent data: the Poiseuille solution itself
+        X2 = dm.p2_coords
+        assert np.abs(u.nodal_values()[:, 0] - 6.0 * X2[:, 1] * (1.0 - X2[:, 1])).max() < 1e-8

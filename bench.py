@@ -190,8 +190,6 @@ def cavity3d_bench(args):
     from partition import SlabPartition, global_dof_counts
     rank, world, local_rank, dist = _init_dist(args)
     bdf = args.workload == "cavity3d-bdf"
-    if bdf and world > 1:
-        raise SystemExit("the monolithic scheme is not partitioned; use cavity3d-ipcs for N > 1")
     n = args.n
     t_setup = time.perf_counter()
     part = SlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, float(world)), n, n, n * world, rank, world,

@@ -417,15 +417,28 @@ static void ensure_L(nsfem_ctx* c) {
 
 // (re)build masks / smoother data / coarse inverse of a hierarchy when its inputs changed
 static void mg_refresh_schur(nsfem_ctx* c) {
+  auto ghost_flags = [&](std::vector<uint8_t>& m) {
+    for (size_t i = 0; i < c->h_ghost_p1.size(); ++i)
+      if (c->h_ghost_p1[i]) m[i] = 2;
+  };
   if (c->mg_s_dirty) {
     c->graph_epoch++;
     std::vector<uint8_t> m((size_t)npre(c), 0);
     for (int32_t d : c->h_bc_s) m[d] = 1;
-    c->mg_s.refresh(c->stream, m, c->schur_singular >= 0 ? c->schur_singular != 0 : c->h_bc_s.empty());
+    ghost_flags(m);
+    const bool singular = c->schur_singular >= 0 ? c->schur_singular != 0
+                                                 : (c->distributed() ? true : c->h_bc_s.empty());
+    c->mg_s.refresh(c->stream, m, singular);
     c->mg_s_dirty = false;
   }
   if (!c->mg_m.ready) {
     std::vector<uint8_t> m((size_t)npre(c), 0);
+    ghost_flags(m);
+    if (c->distributed()) {       // level 0 of the mass smoother needs its own device mask
+      if (!c->mask_m.p) c->mask_m.alloc((size_t)npre(c));
+      c->mask_m.upload(m, c->stream);
+      c->mg_m.lv[0].mask = c->mask_m.p;
+    }
     c->mg_m.refresh(c->stream, m, false);
   }
 }
@@ -437,8 +450,10 @@ static void mg_refresh(nsfem_ctx* c, bool momentum) {
     c->graph_epoch++;
     std::vector<uint8_t> m((size_t)nvel(c), 0);
     for (int32_t d : c->h_bc_v) m[d] = 1;
+    const size_t dim = (size_t)c->mesh.dim;
     for (size_t i = 0; i < c->h_ghost_p2.size(); ++i)
-      if (c->h_ghost_p2[i]) m[2 * i] = m[2 * i + 1] = 2;
+      if (c->h_ghost_p2[i])
+        for (size_t a = 0; a < dim; ++a) m[dim * i + a] = 2;
     c->mg_v.refresh(c->stream, m, false);
     c->mg_v_dirty = false;
   } else {
@@ -1070,6 +1085,13 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
     mm.lv.clear();
     mm.lv.resize(1);
     mm.lv[0].A = &ctx->Mp; mm.lv[0].n = ctx->mesh.n_p1; mm.lv[0].mask = nullptr;
+    mm.smoother_only = true;
+    if (ctx->distributed()) {           // partitioned: halo exchange before every smoothing SpMV
+      mm.comm = ctx->comm;
+      mm.lv[0].halo = ctx->halo_p1;
+      mm.lv[0].has_halo = true;
+      mm.lv[0].h_ghost = &ctx->h_ghost_p1;
+    }
     mm.setup_work(s);
   }
   ctx->mg_built = true;
@@ -1176,13 +1198,19 @@ static nsfem_krylov_opts forced_opts(const nsfem_step_opts* o, const nsfem_krylo
 // ---------------------------------------------------------------- monolithic BDF
 // mixed operator  [[J, -c_p D^T], [-c_p D, 0]]  with identity rows on Dirichlet dofs
 void nsfem_ctx::MixedOp::apply(hipStream_t s, const double* x, double* y) {
-  const int64_t nv = nvel(c);
+  const int64_t nv = nvel(c), np = npre(c);
   const double cp = c->coef[1];
-  if (c->mf_active) c->mom_mf.apply(s, x, y);
+  const bool dist = c->distributed();
+  if (dist) {       // ghost entries of the input (in place: the Krylov vectors keep consistent ghosts)
+    if (!c->mf_active) c->comm->exchange(s, c->halo_p2, const_cast<double*>(x), c->mesh.dim);
+    c->comm->exchange(s, c->halo_p1, const_cast<double*>(x) + nv, 1);
+  }
+  if (c->mf_active) c->mom_mf.apply(s, x, y);          // (exchanges the velocity part itself)
   else launch_spmv(s, c->J, 1, x, y, c->mask_v.p, MASK_IDENTITY);
   launch_spmv_axpy(s, c->DT, 1, -cp, x + nv, y, c->mask_v.p);
   launch_spmv_scaled(s, c->Dv, 1, -cp, x, y + nv);
   launch_copy_at(s, c->nbc_p, c->bc_p_dofs.p, x + nv, y + nv);
+  if (c->ghost_p.p) launch_zero_ghost(s, np, c->mask_p.p, y + nv);
 }
 
 // upper block-triangular preconditioner with the Cahouet-Chabard Schur approximation
@@ -1197,8 +1225,10 @@ void nsfem_ctx::BlockPrec::apply(hipStream_t s, const double* r, double* z) {
   c->mg_m.apply(s, rp, c->rhs_p.p);
   launch_axpby(s, np, -a / (cp * cp), c->tmp_p.p, -cv / (cp * cp), c->rhs_p.p, zp);
   launch_copy_at(s, c->nbc_p, c->bc_p_dofs.p, rp, zp);
+  if (c->distributed()) c->comm->exchange(s, c->halo_p1, zp, 1);
   NSFEM_HIP(hipMemcpyAsync(c->tmp_v.p, r, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
   launch_spmv_axpy(s, c->DT, 1, cp, zp, c->tmp_v.p, c->mask_v.p);
+  if (c->ghost_p.p) launch_zero_ghost(s, np, c->mask_p.p, zp);      // keep ghost entries out of the dots
   c->mg_v.apply(s, c->tmp_v.p, z);
   launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, c->tmp_v.p, z);
 }
@@ -1215,6 +1245,10 @@ static double bdf_residual(nsfem_ctx* c) {
   launch_set_bc_residual(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, b);
   launch_spmv_scaled(s, c->Dv, 1, -c->coef[1], u, b + nv);
   launch_set_bc_residual(s, c->nbc_p, c->bc_p_dofs.p, c->bc_p_vals.p, p, b + nv);
+  if (c->ghost_v.p) {            // owners compute: ghost rows are zero (also for the norm)
+    launch_zero_ghost(s, nv, c->mask_v.p, b);
+    launch_zero_ghost(s, np, c->mask_p.p, b + nv);
+  }
   return global_norm(c, nv + np, b, nullptr);
 }
 
@@ -1226,7 +1260,8 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
   ctx->conv_form = opts->convective_form;
-  NSFEM_REQUIRE(!ctx->distributed(), "the monolithic step is not partitioned yet (use IPCS)");
+  NSFEM_REQUIRE(!ctx->distributed() || ctx->schur_singular < 0,
+                "the algebraic Schur Laplacian is not partitioned (open boundaries: use IPCS on several GPUs)");
   NSFEM_REQUIRE(ctx->mg_built, "the monolithic step needs the multigrid hierarchy "
                                "(block preconditioner): call nsfem_mg_finalize");
   nsfem_step_info& inf = info ? *info : local;
@@ -1259,6 +1294,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     LinOp op;
     op.custom = &ctx->mixed_op;
     op.prec = &ctx->block_prec;
+    if (ctx->distributed()) op.comm = ctx->comm;        // all-reduce of the partial dot products
     op.graph_epoch = ctx->graph_epoch;
     nsfem_solve_info si;
     int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p,

@@ -252,7 +252,7 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
       cur.swap(nxt);
     }
   }
-  if (comm_active()) {
+  if (comm_active() && !smoother_only) {
     refresh_global_coarse(s, cur, singular);
     ready = true;
     return;
@@ -420,7 +420,7 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
   if (l + 1 == lv.size()) {
-    if (comm_active()) {
+    if (comm_active() && !smoother_only) {
       // gather the owned right-hand sides into the global coarse vector (ghost entries are
       // zero, so overlapping lines add up correctly), solve redundantly, copy the local part
       gb.zero(s);

@@ -342,6 +342,7 @@ struct Multigrid : Precond {
   std::vector<hipEvent_t> prof_ev;
   size_t prof_n = 0;
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
+  bool smoother_only = false;    // the last level is smoothed (coarse_steps), never solved globally
   void refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>& cur, bool singular);
   void halo_fill(hipStream_t s, const MGLevel& L, const double* v);
   void setup_work(hipStream_t s);
@@ -465,6 +466,7 @@ struct nsfem_ctx {
     int vel_slot = 3;               // NSFEM_USTAR
     void apply(hipStream_t s, const double* x, double* y) override;
   } mom_mf;
+  nsfem::DevBuf<uint8_t> mask_m;     // ghost flags of the pressure mass smoother (partitioned)
   double prec_shift = 0.0;          // mass shift of the velocity / Schur preconditioners
   nsfem::BlockMat Lprec;            // (alpha0/k + shift) M + c_v K when shift != 0
   bool mf_active = false;           // the running step driver applies the Jacobian matrix-free

@@ -118,9 +118,80 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail):
     nat.local_group_destroy(group)
 
 
-def test_partitioned_3d_slabs_equal_single_context():
+@pytest.mark.parametrize("n,size,tail", [(32, 2, False), (64, 4, True)])
+def test_partitioned_monolithic_bdf_equals_single_context(n, size, tail):
+    """The monolithic BDF step on strips: halo-exchanged mixed operator (matrix-free velocity
+    block), partitioned block preconditioner (Schur Laplacian and velocity V-cycles, pressure-mass
+    smoother), all-reduced dots -- same Newton / BiCGStab counts and fields as one context."""
+    nsteps, k, coarsest = 3, 0.01, 2
+    mesh, dm, _ = box(n, n)
+
+    def run(ctx, dmap, out, key):
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, *_cavity_bc(dmap))
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        opts.momentum.rtol, opts.momentum.precond = 1e-12, 1
+        infos = []
+        for step in range(nsteps):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
+            infos.append(ctx.step_bdf(opts))
+            ctx.advance(1)
+        out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
+
+    ref = {}
+    ctx0 = context(mesh, dm)
+    attach_hierarchy(ctx0, mesh, coarsest=coarsest)
+    run(ctx0, dm, ref, 0)
+    u_ref, p_ref, inf_ref = ref[0]
+    ctx0.close()
+    group = nat.local_group_create(size)
+    parts = [StripPartition((0.0, 0.0), (1.0, 1.0), n, n, r, size, coarsest=16 if tail else coarsest,
+                            global_coarsest=coarsest if tail else None) for r in range(size)]
+    ctxs = []
+    for r, part in enumerate(parts):
+        pdm = part.dofmap
+        c = nat.NsfemContext(part.mesh.coords, part.mesh.cells, pdm.p2_dofmap, pdm.p1_dofmap,
+                             pdm.n_p2, pdm.n_p1)
+        c.attach_local_comm(group, r)
+        ctxs.append(c)
+    out, errors = {}, []
+
+    def worker(r):
+        try:
+            parts[r].attach(ctxs[r])
+            run(ctxs[r], parts[r].dofmap, out, r)
+        except BaseException as exc:
+            errors.append((r, repr(exc)))
+            os._exit(17)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    u = np.zeros_like(u_ref)
+    p = np.zeros_like(p_ref)
+    for r, part in enumerate(parts):
+        ul, pl, infos = out[r]
+        u.reshape(-1, 2)[part.p2_global[part.p2_owned]] = ul.reshape(-1, 2)[part.p2_owned]
+        p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
+        for a, b in zip(infos, inf_ref):
+            assert a.newton_iterations == b.newton_iterations
+            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= 1
+    assert rel(u, u_ref) < 1e-10
+    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-9
+    for c in ctxs:
+        c.close()
+    nat.local_group_destroy(group)
+
+
+@pytest.mark.parametrize("scheme", ["ipcs", "bdf"])
+def test_partitioned_3d_slabs_equal_single_context(scheme):
     """3D: slabs of cube layers along z (SlabPartition), partitioned multigrid with the replicated
-    global tail -- two in-process ranks reproduce the single-context 3D IPCS run."""
+    global tail -- two in-process ranks reproduce the single-context 3D IPCS / monolithic runs."""
     from fem_mesh import TaylorHoodDofMap, box_mesh
     from partition import SlabPartition
     n, size, nsteps, k = 8, 2, 2, 0.02
@@ -141,6 +212,7 @@ def test_partitioned_3d_slabs_equal_single_context():
         ctx.set_coeffs(1.0, 1.0, 0.02)
         ctx.set_dirichlet(nat.VELOCITY, *bc(dmap))
         ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
         opts = ctx.default_step_opts()
         for o in (opts.momentum, opts.poisson, opts.correction):
             o.rtol = 1e-12
@@ -148,8 +220,8 @@ def test_partitioned_3d_slabs_equal_single_context():
         infos = []
         for step in range(nsteps):
             ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
-            infos.append(ctx.step_ipcs(opts))
-            ctx.advance(0)
+            infos.append(ctx.step_ipcs(opts) if scheme == "ipcs" else ctx.step_bdf(opts))
+            ctx.advance(0 if scheme == "ipcs" else 1)
         out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
 
     ref = {}
@@ -193,10 +265,10 @@ def test_partitioned_3d_slabs_equal_single_context():
         p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
         for a, b in zip(infos, inf_ref):
             assert a.newton_iterations == b.newton_iterations
-            assert a.krylov_iterations_momentum == b.krylov_iterations_momentum
+            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= (0 if scheme == "ipcs" else 1)
             assert a.krylov_iterations_poisson == b.krylov_iterations_poisson
-    assert rel(u, u_ref) < 1e-11
-    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-10
+    assert rel(u, u_ref) < 1e-10
+    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-9
     for c in ctxs:
         c.close()
     nat.local_group_destroy(group)

@@ -275,3 +275,7 @@ class InstationaryProblem(ProblemBase):
             if self._output_frequency > 0 and ts.step_number % self._output_frequency == 0:
                 self._write_xdmf_file(current_time=ts.current_time)
         print(ts)
+
+
+# the reference keeps StationaryProblem in this module (source/ns_problem.py:363-501)
+from ns_problem_stationary import StationaryProblem  # noqa: E402,F401

@@ -228,3 +228,31 @@ def test_box_mesh_kuhn_split_dofmap_and_nested_prolongation():
         assert len(cols) == 1 or tuple(cols) in ce          # midpoint of an actual coarse edge
     levels = structured_hierarchy((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 8, 8, 8, coarsest=2)
     assert [lv[0].num_vertices() for lv in levels] == [125, 27]
+
+
+def test_reference_module_names_resolve():
+    """a user of the reference imports these names from these modules (PYTHONPATH=source)"""
+    from auxiliary_methods import boundary_normal, extract_all_boundary_markers
+    from grid_generator import hyper_cube, HyperCubeBoundaryMarkers as M
+    mesh, marks = hyper_cube(2, 4)
+    assert boundary_normal(mesh, marks, M.top.value) == (0.0, 1.0)
+    assert boundary_normal(mesh, marks, M.left.value) == (-1.0, 0.0)
+    assert extract_all_boundary_markers(mesh, marks) == {1, 2, 3, 4}
+    mesh3, marks3 = hyper_cube(3, 2)
+    assert boundary_normal(mesh3, marks3, M.front.value) == (0.0, 0.0, 1.0)
+    import importlib
+    for module, names in (("ns_problem", ("InstationaryProblem", "StationaryProblem", "VelocityBCType",
+                                          "PressureBCType", "TractionBCType")),
+                          ("ns_solver_base", ("SolverBase", "InstationarySolverBase", "StationarySolverBase")),
+                          ("ns_bdf_solver", ("ImplicitBDFSolver",)), ("ns_ipcs_solver", ("IPCSSolver",)),
+                          ("bdf_time_stepping", ("BDFTimeStepping",)), ("discrete_time", ("DiscreteTime",)),
+                          ("imex_time_stepping", ("IMEXTimeStepping", "IMEXType")),
+                          ("theta_time_stepping", ("GeneralThetaTimeStepping", "ThetaTimeSteppingType")),
+                          ("auxiliary_classes", ("EquationCoefficientHandler", "AngularVelocityVector",
+                                                 "FunctionTime")),
+                          ("grid_generator", ("hyper_cube", "hyper_rectangle", "open_hyper_cube",
+                                              "spherical_shell", "channel_with_cylinder", "blasius_plate",
+                                              "backward_facing_step"))):
+        mod = importlib.import_module(module)
+        for name in names:
+            assert hasattr(mod, name), (module, name)

@@ -71,13 +71,17 @@ class IMEXTimeStepping(DiscreteTime):
         self._coefficients_changed = True
 
     def print_coefficients(self):
-        rule = "+-" + "-+-".join(4 * (12 * "-", )) + "-+"
-        print(rule)
-        print("| {:12} | {:12} | {:12} | {:12} |".format("coefficient", "n + 1", "n", "n - 1"))
-        print("| {:12} | {:12.2e} | {:12.2e} | {:12.2e} |".format("alpha", *self._alpha))
-        print("| {:12} | ".format("beta") + 12 * " " + " | {:12.2g} | {:12.2e} |".format(*self._beta))
-        print("| {:12} | {:12.2e} | {:12.2e} | {:12.2g} |".format("gamma", *self._gamma))
-        print("| {:12} | ".format("eta") + 12 * " " + " | {:12.2g} | {:12.2e} |".format(*self._eta))
+        """table of the four coefficient sets over the time levels n+1, n, n-1"""
+        cell = "{:12.2e}".format
+        blank = 12 * " "
+        rows = [("coefficient", "n + 1", "n", "n - 1"),
+                ("alpha", ) + tuple(cell(v) for v in self._alpha),
+                ("beta", blank) + tuple(cell(v) for v in self._beta),
+                ("gamma", ) + tuple(cell(v) for v in self._gamma),
+                ("eta", blank) + tuple(cell(v) for v in self._eta)]
+        print("+" + "+".join(4 * (14 * "-", )) + "+")
+        for row in rows:
+            print("| " + " | ".join("{:12}".format(c) for c in row) + " |")
 
     alpha = property(lambda self: self._alpha)
     beta = property(lambda self: self._beta)

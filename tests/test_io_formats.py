@@ -156,3 +156,20 @@ def test_external_mesh_entry_points(tmp_path):
     mesh2, marks2, names2 = gg.channel_with_cylinder()
     assert names2 == {"inlet": 1, "cylinder": 5}
     assert mesh2.num_cells() == mesh.num_cells() and np.array_equal(marks2.values, marks.values)
+
+
+def test_write_boundary_markers(tmp_path):
+    """ProblemBase.write_boundary_markers (reference source/ns_problem.py:329-348)"""
+    import xml.etree.ElementTree as ET
+    from grid_generator import open_hyper_cube
+    from ns_problem import ProblemBase
+    prob = ProblemBase(str(tmp_path))
+    prob._problem_name = "OpenCube"
+    prob._mesh, prob._boundary_markers = open_hyper_cube(2, 8, (("top", (0.5, 1.0), 0.5), ))
+    path = prob.write_boundary_markers()
+    root = ET.parse(path).getroot()
+    grid = root.find("Domain").find("Grid")
+    n = int(grid.find("Topology").get("NumberOfElements"))
+    assert n == 4 * 8
+    vals = np.array(grid.find("Attribute").find("DataItem").text.split(), dtype=int)
+    assert vals.size == n and set(vals.tolist()) == {1, 2, 3, 4, 7}

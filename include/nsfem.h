@@ -276,6 +276,10 @@ int nsfem_advance(nsfem_ctx* ctx, int scheme /* 0 ipcs, 1 bdf */);
 int nsfem_mass_solve(nsfem_ctx* ctx, int field, const double* b, double* x,
                      const nsfem_krylov_opts* opts, nsfem_solve_info* info);
 /* mean-pressure shift (ns_solver_base.py:1190-1203): p -= (int p / |Omega| - target) */
+/* post-processing: (grad phi, grad psi) = rhs on the P1 space, phi = 0 on `dofs` (velocity
+ * potential, reference source/ns_problem.py:105-176); pure Neumann data are mean-projected */
+int nsfem_poisson_solve(nsfem_ctx* ctx, const double* rhs, int64_t n_dirichlet, const int32_t* dofs,
+                        double* x, const nsfem_krylov_opts* opts, nsfem_solve_info* info);
 int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* mean_before);
 /* stationary / very large time steps at high cell Peclet numbers: the multigrid V-cycle of the
  * velocity block and the Schur-complement approximation are built for (J + shift M) instead of J

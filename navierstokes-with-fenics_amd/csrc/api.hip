@@ -1343,6 +1343,48 @@ extern "C" int nsfem_advance(nsfem_ctx* ctx, int scheme) {
   API_END(ctx)
 }
 
+// Post-processing Poisson solve on the P1 space:  (grad phi, grad psi) = rhs  with phi = 0 on the
+// given dofs (velocity potential of source/ns_problem.py:105-176); Jacobi-CG, the singular pure
+// Neumann case is handled by mean projection.  Not on the per-step path.
+extern "C" int nsfem_poisson_solve(nsfem_ctx* ctx, const double* rhs, int64_t n_dirichlet,
+                                   const int32_t* dofs, double* x, const nsfem_krylov_opts* opts,
+                                   nsfem_solve_info* info) {
+  nsfem_solve_info local;
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && rhs && x && opts && (n_dirichlet == 0 || dofs), "null argument");
+  NSFEM_REQUIRE(!ctx->distributed(), "post-processing solves are single-context");
+  nsfem_solve_info& inf = info ? *info : local;
+  hipStream_t s = ctx->stream;
+  const int64_t n = npre(ctx);
+  std::vector<uint8_t> hm((size_t)n, 0);
+  std::vector<double> hb(rhs, rhs + n);
+  for (int64_t i = 0; i < n_dirichlet; ++i) {
+    NSFEM_REQUIRE(dofs[i] >= 0 && dofs[i] < n, "Dirichlet dof out of range");
+    hm[dofs[i]] = 1;
+    hb[dofs[i]] = 0.0;
+  }
+  DevBuf<uint8_t> mask;
+  DevBuf<double> db, dx, dinv;
+  mask.upload(hm, s);
+  db.upload(hb, s);
+  dx.alloc((size_t)n);
+  dx.zero(s);
+  dinv.alloc((size_t)n);
+  LinOp op;
+  op.A = &ctx->Ap;
+  op.nv = 1;
+  op.rowmask = mask.p;
+  op.maskmode = MASK_ZERO;
+  launch_inv_diag(s, ctx->Ap, 1, mask.p, dinv.p);
+  op.dinv = dinv.p;
+  op.n_global = n;
+  int rc = pcg(s, ctx->kw, op, db.p, dx.p, *opts, inf, n_dirichlet == 0);
+  if (rc != NSFEM_OK) throw Error(rc, "CG failed in the post-processing Poisson solve");
+  NSFEM_HIP(hipMemcpyAsync(x, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
 extern "C" int nsfem_mass_solve(nsfem_ctx* ctx, int field, const double* b, double* x,
                                 const nsfem_krylov_opts* opts, nsfem_solve_info* info) {
   nsfem_solve_info local;

@@ -93,6 +93,58 @@ class ProblemBase:
         self._xdmf_file.parameters["functions_share_mesh"] = True
         self._xdmf_file.parameters["rewrite_function_mesh"] = False
 
+    def _get_boundary_conditions_map(self, field="velocity"):
+        """{bc type: (boundary ids, ...)} of the problem's boundary conditions (reference :178-203)"""
+        assert isinstance(field, str) and hasattr(self, "_bcs")
+        BCType = VelocityBCType if field == "velocity" else PressureBCType
+        assert field == "velocity" or field.lower() == "pressure"
+        bc_map = {}
+        for bc in self._bcs:
+            if isinstance(bc[0], BCType):
+                bc_map[bc[0]] = tuple(sorted(set(bc_map.get(bc[0], ())) | {bc[1]}))
+        return bc_map
+
+    def _compute_stream_potential(self):
+        """Velocity potential phi (the reference's "stream potential", :105-176): P1 solution of
+        (grad phi, grad psi) = (div u, psi) - sum over the remaining boundaries of (n . u, psi),
+        phi = 0 where the velocity obeys no-slip; boundaries with a no-normal-flux condition carry
+        neither term.  The Poisson solve runs on the device (nsfem_poisson_solve); the right-hand
+        side is assembled on the host from the exported divergence operator and exact 2-point Gauss
+        integration of the cubic boundary integrand.  2D."""
+        import _native as nat
+        from fem_function import HostField
+        solver = self._get_solver()
+        dm, mesh, marks = solver._dofmap, self._mesh, self._boundary_markers
+        assert dm.dim == 2, "the velocity potential post-processing is built for 2D meshes"
+        bc_map = self._get_boundary_conditions_map()
+        assert VelocityBCType.no_slip in bc_map
+        other = set(marks.ids(boundary_only=True)) - set(bc_map[VelocityBCType.no_slip])
+        other -= set(bc_map.get(VelocityBCType.no_normal_flux, ()))
+        u = self._get_velocity().vector()
+        rhs = solver._ctx.operator_apply(nat.OP_DIV, u)
+        un = u.reshape(-1, 2)
+        g = 0.5 / np.sqrt(3.0)
+        for t in (0.5 - g, 0.5 + g):                                      # Gauss points on [0, 1]
+            for bid in sorted(other):
+                facets = marks.facets_with_id(bid)
+                facets = facets[mesh.facet_on_boundary[facets]]
+                if facets.size == 0:
+                    continue
+                nodes2 = dm.facet_p2_nodes(facets)                        # (end, end, midpoint)
+                nodes1 = dm.facet_p1_nodes(facets)
+                xf = mesh.coords[mesh.facets[facets].astype(np.int64)]
+                length = np.linalg.norm(xf[:, 1] - xf[:, 0], axis=1)
+                normal = mesh.facet_normals(facets)
+                shape2 = np.array([(1 - t) * (1 - 2 * t), t * (2 * t - 1), 4 * t * (1 - t)])
+                uq = np.einsum("k,fka->fa", shape2, un[nodes2])
+                flux = (uq * normal).sum(axis=1) * 0.5 * length           # weight 1/2 per Gauss point
+                np.subtract.at(rhs, nodes1[:, 0], flux * (1 - t))
+                np.subtract.at(rhs, nodes1[:, 1], flux * t)
+        dirichlet = np.unique(np.concatenate(
+            [dm.facet_p1_nodes(marks.facets_with_id(i)).ravel() for i in bc_map[VelocityBCType.no_slip]]))
+        phi = solver._ctx.poisson_solve(rhs, dirichlet)
+        return HostField(mesh, "velocity potential", "Node", phi[dm.p1_vertex_node])
+
     def write_boundary_markers(self):
         """Facet markers as a file ParaView opens (reference: :329-348 writes a .pvd through
         dolfin.File): the marked facets as a Polyline (2D) / Triangle (3D) mesh with the marker id

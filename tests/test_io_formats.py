@@ -173,3 +173,56 @@ def test_write_boundary_markers(tmp_path):
     assert n == 4 * 8
     vals = np.array(grid.find("Attribute").find("DataItem").text.split(), dtype=int)
     assert vals.size == n and set(vals.tolist()) == {1, 2, 3, 4, 7}
+
+
+@pytest.mark.gpu
+def test_velocity_potential_post_processing():
+    """ProblemBase._compute_stream_potential (reference source/ns_problem.py:105-176): for the
+    irrotational field u = grad(x^2 - y^2)/2 = (x, -y) in a box with a no-slip-marked bottom the
+    weak problem (grad phi, grad psi) = (div u, psi) - (n . u, psi)_Gamma_other, phi = 0 on the
+    bottom, has the solution of  -lap phi = 0,  d phi / dn = n . u: phi = (x^2 - y^2)/2 (zero on
+    y = 0 only up to the x^2/2 part, so the discrete answer is compared with a host solve of the
+    same weak form)."""
+    import _native as nat
+    import fem_oracle as fo
+    from grid_generator import HyperCubeBoundaryMarkers as M, hyper_cube
+    from ns_problem import ProblemBase, VelocityBCType
+
+    class Holder:
+        pass
+
+    mesh, marks = hyper_cube(2, 8)
+    dm = TaylorHoodDofMap(mesh)
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+    X = dm.p2_coords
+    u = np.stack([X[:, 0], -X[:, 1]], axis=1).ravel()
+    ctx.set_state(nat.U0, u)
+    solver = Holder()
+    solver._dofmap, solver._ctx = dm, ctx
+    prob = ProblemBase(None)
+    prob._mesh, prob._boundary_markers = mesh, marks
+    prob._bcs = ((VelocityBCType.no_slip, M.bottom.value, None), (VelocityBCType.no_normal_flux, M.left.value, None))
+    prob._get_solver = lambda: solver
+    from fem_function import DeviceFunction
+    solver.solution = None
+    prob._get_velocity = lambda: DeviceFunction(solver, "velocity", nat.U0)
+    phi = prob._compute_stream_potential()
+    # host solve of the same weak form with the oracle's operators
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    rhs = s.divergence() @ u
+    for bid, (axis, value, sign) in ((M.right.value, (0, 1.0, 1.0)), (M.top.value, (1, 1.0, 1.0))):
+        facets = marks.facets_with_id(bid)
+        e = mesh.facets[facets]
+        for a, b in e:                                  # n . u = +x on the right (= 1), -y on top (= -1)
+            flux = 1.0 if bid == M.right.value else -1.0
+            length = np.linalg.norm(mesh.coords[a] - mesh.coords[b])
+            rhs[a] -= 0.5 * flux * length
+            rhs[b] -= 0.5 * flux * length
+    bottom = np.unique(dm.facet_p1_nodes(marks.facets_with_id(M.bottom.value)))
+    A = fo.apply_dirichlet_rows(s.stiffness_p1(), bottom).tolil()
+    rhs[bottom] = 0.0
+    ref = fo.spla.spsolve(A.tocsc(), rhs)
+    assert np.abs(phi.values - ref).max() < 1e-9 * np.abs(ref).max()
+    assert prob._get_boundary_conditions_map() == {VelocityBCType.no_slip: (M.bottom.value, ),
+                                                   VelocityBCType.no_normal_flux: (M.left.value, )}
+    ctx.close()

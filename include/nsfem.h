@@ -105,7 +105,9 @@ typedef struct {
   int32_t max_iter;
   int32_t precond;      /* 0 = Jacobi, 1 = multigrid (where available)         */
   int32_t check_every;  /* host convergence check interval (>=1)               */
-  int32_t reserved;
+  int32_t first_check;  /* iterations before the first host convergence check (every check is a
+                           device -> host round trip; the step drivers set it from the iteration
+                           count the same solve needed in the previous step)     */
 } nsfem_krylov_opts;
 
 typedef struct {

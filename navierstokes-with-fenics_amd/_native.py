@@ -47,7 +47,7 @@ class MeshDesc(C.Structure):
 
 class KrylovOpts(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("max_iter", C.c_int32),
-                ("precond", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32)]
+                ("precond", C.c_int32), ("check_every", C.c_int32), ("first_check", C.c_int32)]
 
 
 class SolveInfo(C.Structure):

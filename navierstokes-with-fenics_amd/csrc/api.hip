@@ -1114,7 +1114,7 @@ extern "C" int nsfem_default_step_opts(nsfem_step_opts* o) {
   k.max_iter = 20000;
   k.precond = 0;
   k.check_every = 1;
-  k.reserved = 0;
+  k.first_check = 0;
   o->momentum = k;
   o->poisson = k;
   o->correction = k;
@@ -1122,6 +1122,13 @@ extern "C" int nsfem_default_step_opts(nsfem_step_opts* o) {
 }
 
 static nsfem_krylov_opts forced_opts(const nsfem_step_opts* o, const nsfem_krylov_opts& base, double r0);
+// Every host convergence check of a Krylov solve is a device -> host round trip during which the
+// GPU runs dry.  The same solve of the previous time step is an excellent predictor of the
+// iteration count: the first check is postponed to one iteration before that count.
+static nsfem_krylov_opts hinted(nsfem_krylov_opts k, int hint) {
+  k.first_check = std::max(k.first_check, hint - 1);
+  return k;
+}
 
 extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info) {
   nsfem_step_info local;
@@ -1146,7 +1153,9 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   while (!converged && it < opts->newton_max_iter) {
     if (!ctx->mf_active) momentum_jacobian(ctx);
     nsfem_solve_info si;
-    int rc = momentum_solve_update(ctx, forced_opts(opts, opts->momentum, r0), si);
+    int& hint = ctx->hint_mom[std::min(it, 3)];
+    int rc = momentum_solve_update(ctx, hinted(forced_opts(opts, opts->momentum, r0), hint), si);
+    hint = si.iterations;
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the diffusion step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)
@@ -1165,7 +1174,8 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   {
     poisson_assemble(ctx);
     nsfem_solve_info si;
-    int rc = poisson_solve(ctx, opts->poisson, si);
+    int rc = poisson_solve(ctx, hinted(opts->poisson, ctx->hint_poi), si);
+    ctx->hint_poi = si.iterations;
     inf.krylov_iterations_poisson = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the projection step");
   }
@@ -1173,7 +1183,8 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   {
     correction_assemble(ctx);
     nsfem_solve_info si;
-    int rc = correction_solve(ctx, opts->correction, si);
+    int rc = correction_solve(ctx, hinted(opts->correction, ctx->hint_cor), si);
+    ctx->hint_cor = si.iterations;
     inf.krylov_iterations_correction = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the velocity correction step");
   }
@@ -1297,8 +1308,10 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     if (ctx->distributed()) op.comm = ctx->comm;        // all-reduce of the partial dot products
     op.graph_epoch = ctx->graph_epoch;
     nsfem_solve_info si;
+    int& hint = ctx->hint_mom[std::min(it, 3)];
     int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p,
-                      forced_opts(opts, opts->momentum, r0), si);
+                      hinted(forced_opts(opts, opts->momentum, r0), hint), si);
+    hint = si.iterations;
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the monolithic step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)

@@ -685,6 +685,19 @@ double host_sum_parts(hipStream_t s, KrylovWork& w, int which) {
   return acc;
 }
 
+// two slots with ONE device -> host round trip
+static void host_sum_parts2(hipStream_t s, KrylovWork& w, int a, int b, double& ra, double& rb) {
+  for (int which : {a, b})
+    NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)which * kParts, w.parts.p + (size_t)which * kParts,
+                             sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  ra = rb = 0.0;
+  for (int i = 0; i < kParts; ++i) {
+    ra += w.h_parts[(size_t)a * kParts + i];
+    rb += w.h_parts[(size_t)b * kParts + i];
+  }
+}
+
 // --------------------------------------------------------------- BiCGStab
 // partial-sum slots
 // (RHO, RR), (TS, TT) and the CG pairs (RZ, RR') are adjacent: one all-reduce per kernel
@@ -863,12 +876,13 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   }
   LAUNCH(k_bicg_start, kParts, s, n, w.r.p, w.rhat.p, parts, scal);
   reduce_slots(op, s, parts, P_RHO, 2);
-  double rr = host_sum_parts(s, w, P_RR);
-  const double r0 = std::sqrt(rr);
-  // |b| for the relative criterion
+  // |b| for the relative criterion (read back together with |r0|: one round trip)
   launch_dot(s, n, b, b, parts + P_PQ * kParts);
   reduce_slots(op, s, parts, P_PQ, 1);
-  const double bnorm = std::sqrt(host_sum_parts(s, w, P_PQ));
+  double rr, bb;
+  host_sum_parts2(s, w, P_RR, P_PQ, rr, bb);
+  const double r0 = std::sqrt(rr);
+  const double bnorm = std::sqrt(bb);
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
   info.residual0 = r0;
   info.residual = r0;
@@ -901,7 +915,7 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     if (it == 0 || !w.graphs_enabled(op)) body(it == 0 ? 1 : 0);
     else w.replay(s, key, [&] { body(0); });
     ++it;
-    if (it % check == 0 || it == o.max_iter) {
+    if ((it >= o.first_check && it % check == 0) || it == o.max_iter) {
       rr = host_sum_parts(s, w, P_RR);
       if (!std::isfinite(rr) || rr > 1e20 * std::max(r0 * r0, bnorm * bnorm)) {   // NaN / diverging
         info.iterations = it;
@@ -1008,11 +1022,12 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   if (op.prec) op.prec->apply(s, w.r.p, w.p.p);
   LAUNCH(k_cg_start, kParts, s, n, w.r.p, op.prec ? nullptr : op.dinv, w.p.p, parts, cur);
   reduce_slots(op, s, parts, cur, 2);
-  double rr = host_sum_parts(s, w, cur + 1);
-  const double r0 = std::sqrt(rr);
   launch_dot(s, n, rhs, rhs, parts + P_TT * kParts);
   reduce_slots(op, s, parts, P_TT, 1);
-  const double bnorm = std::sqrt(host_sum_parts(s, w, P_TT));
+  double rr, bb;
+  host_sum_parts2(s, w, cur + 1, P_TT, rr, bb);
+  const double r0 = std::sqrt(rr);
+  const double bnorm = std::sqrt(bb);
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
   info.residual0 = r0;
   info.residual = r0;
@@ -1045,7 +1060,7 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
     }
     std::swap(cur, nxt);
     ++it;
-    if (it % check == 0 || it == o.max_iter) {
+    if ((it >= o.first_check && it % check == 0) || it == o.max_iter) {
       rr = host_sum_parts(s, w, cur + 1);
       if (!std::isfinite(rr)) {
         info.iterations = it;

@@ -469,6 +469,7 @@ struct nsfem_ctx {
   nsfem::DevBuf<uint8_t> mask_m;     // ghost flags of the pressure mass smoother (partitioned)
   double prec_shift = 0.0;          // mass shift of the velocity / Schur preconditioners
   nsfem::BlockMat Lprec;            // (alpha0/k + shift) M + c_v K when shift != 0
+  int hint_mom[4] = {0, 0, 0, 0}, hint_poi = 0, hint_cor = 0;   // Krylov iteration counts of the last step
   bool mf_active = false;           // the running step driver applies the Jacobian matrix-free
   struct MixedOp : nsfem::Operator {
     nsfem_ctx* c = nullptr;

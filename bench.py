@@ -222,6 +222,7 @@ def cavity3d_bench(args):
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = args.krylov_rtol
     opts.momentum.precond = opts.poisson.precond = 1
+    opts.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
     opts.newton_forcing = args.newton_forcing
     opts.matrix_free = args.matrix_free
     dt = args.dt if args.dt != 1.0e-3 else 0.5 / n          # CFL ~ 0.5 for the unit lid speed
@@ -308,6 +309,8 @@ def main():
     ap.add_argument("--mg-eig-ratio", type=float, default=4.0)
     ap.add_argument("--matrix-free", type=int, default=0, choices=(0, 1, 2),
                     help="velocity Jacobian in the step driver: 0 auto, 1 assembled, 2 matrix-free")
+    ap.add_argument("--mass-solver", choices=("chebyshev", "cg"), default="chebyshev",
+                    help="velocity-correction mass solve: Chebyshev with a-priori bounds (no dots) or Jacobi-CG")
     ap.add_argument("--coarsest", type=int, default=0, help="cells across the coarsest multigrid mesh (0: default)")
     ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf"),
                     default="cavity-ipcs",
@@ -364,6 +367,7 @@ def main():
         o.rtol = args.krylov_rtol
     if mg_levels is not None:
         opts.momentum.precond = opts.poisson.precond = 1
+    opts.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
     opts.newton_forcing = args.newton_forcing
     opts.matrix_free = args.matrix_free
 

@@ -103,7 +103,9 @@ typedef struct {
   double rtol;          /* relative residual (to |b|) tolerance                */
   double atol;          /* absolute residual tolerance                         */
   int32_t max_iter;
-  int32_t precond;      /* 0 = Jacobi, 1 = multigrid (where available)         */
+  int32_t precond;      /* 0 = Jacobi, 1 = multigrid (where available), 2 = (velocity mass
+                           solve only) Chebyshev iteration with a-priori element bounds:
+                           no dot products, no all-reduce inside the iteration      */
   int32_t check_every;  /* host convergence check interval (>=1)               */
   int32_t first_check;  /* iterations before the first host convergence check (every check is a
                            device -> host round trip; the step drivers set it from the iteration
@@ -305,6 +307,8 @@ int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* 
                            int64_t* algorithmic_bytes);
 int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                     int64_t* algorithmic_bytes);
+/* extreme eigenvalues of diag(M_e)^-1 M_e of the P2 element mass matrix (host arithmetic only) */
+int nsfem_p2_mass_bounds(int dim, double* lmin, double* lmax);
 int nsfem_synchronize(nsfem_ctx* ctx);
 
 #ifdef __cplusplus

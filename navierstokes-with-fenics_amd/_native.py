@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -158,6 +158,7 @@ def load_library(path=None):
         "nsfem_cfl_number": (C.c_int, [vp, C.c_int, dbl, pd]),
         "nsfem_set_angular_velocity": (C.c_int, [vp, dbl, dbl]),
         "nsfem_set_preconditioner_shift": (C.c_int, [vp, dbl]),
+        "nsfem_p2_mass_bounds": (C.c_int, [C.c_int, pd, pd]),
         "nsfem_poisson_solve": (C.c_int, [vp, pd, i64, pi, pd, C.POINTER(KrylovOpts), C.POINTER(SolveInfo)]),
         "nsfem_profile_smoother": (C.c_int, [vp, C.c_int, pd, C.POINTER(i64), C.POINTER(i64)]),
         "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),

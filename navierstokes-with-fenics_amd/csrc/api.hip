@@ -235,6 +235,13 @@ extern "C" void nsfem_destroy(nsfem_ctx* ctx) {
   delete ctx;
 }
 
+// element bounds of the Jacobi-scaled P2 mass matrix (host only; exposed for the CPU tests)
+extern "C" int nsfem_p2_mass_bounds(int dim, double* lmin, double* lmax) {
+  if ((dim != 2 && dim != 3) || !lmin || !lmax) return NSFEM_ERR_ARG;
+  p2_mass_jacobi_bounds(dim, *lmin, *lmax);
+  return NSFEM_OK;
+}
+
 extern "C" int nsfem_synchronize(nsfem_ctx* ctx) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
@@ -475,6 +482,7 @@ void nsfem_ctx::MomentumPrec::apply(hipStream_t s, const double* r, double* z) {
   launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, r, z);
 }
 
+constexpr int P10 = 10;      // partial-sum slots 10, 11 of the Krylov work space belong to the drivers
 static double cc_of(const nsfem_ctx* c) { return std::isfinite(c->coef[0]) ? c->coef[0] : 0.0; }
 // Coriolis factor 2 c_cor omega (source/ns_solver_base.py:173-191, 2D branch)
 static double coriolis_gamma(const nsfem_ctx* c) {
@@ -689,7 +697,78 @@ static void correction_assemble(nsfem_ctx* c) {
   }
 }
 
+// Chebyshev iteration on the Jacobi-scaled velocity mass matrix with A-PRIORI spectral bounds
+// (Wathen's element bounds, p2_mass_jacobi_bounds): no dot products, every iteration is ONE
+// launch of the fused smoother kernel, and on partitioned meshes no all-reduce at all inside
+// the iteration.  Solves the correction equation  M e = b - M x0  (e vanishes on the Dirichlet
+// dofs), then x0 += e; the residual norm is checked after the predicted number of steps.
+static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  hipStream_t s = c->stream;
+  const int64_t nv = nvel(c);
+  Multigrid& mg = c->mg_mv;
+  if (mg.lv.empty()) {
+    double lmin, lmax;
+    p2_mass_jacobi_bounds(c->mesh.dim, lmin, lmax);
+    mg.nv = c->mesh.dim;
+    mg.coarse_dense_max = 0;
+    mg.smoother_only = true;
+    mg.lv.resize(1);
+    mg.lv[0].A = &c->M2;
+    mg.lv[0].n = c->mesh.n_p2;
+    mg.lv[0].mask = c->mask_v.p;
+    if (c->distributed()) {
+      mg.comm = c->comm;
+      mg.lv[0].halo = c->halo_p2;
+      mg.lv[0].has_halo = true;
+    }
+    mg.setup_work(s);
+    // interval [0.98 lmin, 1.02 lmax] in the parametrisation of Multigrid::cheb_coeffs
+    c->mass_kappa = (1.02 * lmax) / (0.98 * lmin);
+    mg.eig_ratio = c->mass_kappa;
+    mg.lv[0].lmax = 1.02 * lmax / 1.05;
+  }
+  MGLevel& L = mg.lv[0];
+  NSFEM_HIP(hipMemcpyAsync(L.dinv.p, c->dinv_m.p, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+  KrylovWork& w = c->kw;
+  w.ensure(nv);
+  double* x = c->state[NSFEM_U0].p;
+  double* parts = w.parts.p;
+  auto residual_norm = [&](double* r) {
+    if (c->distributed()) c->comm->exchange(s, c->halo_p2, x, c->mesh.dim);
+    launch_residual(s, c->M2, c->mesh.dim, x, c->rhs_v.p, r, c->mask_v.p, MASK_ZERO);
+    launch_dot(s, nv, r, r, parts + P10 * kParts);
+  };
+  residual_norm(w.r.p);
+  launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, parts + (P10 + 1) * kParts);
+  if (c->distributed()) c->comm->allreduce_sum(s, parts + P10 * kParts, 2 * kParts);
+  const double r0 = std::sqrt(host_sum_parts(s, w, P10));
+  const double bnorm = std::sqrt(host_sum_parts(s, w, P10 + 1));
+  const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+  info.residual0 = info.residual = r0;
+  info.iterations = 0;
+  info.converged = r0 <= target;
+  const double sk = std::sqrt(c->mass_kappa);
+  const double rate = std::log((sk + 1.0) / (sk - 1.0));
+  double res = r0;
+  while (!info.converged && info.iterations < o.max_iter) {
+    // steps needed for the error bound 2 sqrt(kappa) ((sqrt(kappa)-1)/(sqrt(kappa)+1))^k <= target / res
+    int k = (int)std::ceil(std::log(2.0 * sk * res / target) / rate);
+    k = std::max(1, std::min(k, o.max_iter - info.iterations));
+    mg.smooth(s, L, w.r.p, nullptr, w.q.p, k);                       // e ~ M^{-1} r
+    launch_axpby(s, nv, 1.0, x, 1.0, w.q.p, x);                      // x += e (e = 0 on Dirichlet dofs)
+    info.iterations += k;
+    residual_norm(w.r.p);
+    if (c->distributed()) c->comm->allreduce_sum(s, parts + P10 * kParts, kParts);
+    res = std::sqrt(host_sum_parts(s, w, P10));
+    if (!std::isfinite(res)) return NSFEM_ERR_BREAKDOWN;
+    info.residual = res;
+    info.converged = res <= target;
+  }
+  return info.converged ? NSFEM_OK : NSFEM_ERR_NOT_CONVERGED;
+}
+
 static int correction_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  if (o.precond == 2) return correction_solve_chebyshev(c, o, info);
   LinOp op;
   op.A = &c->M2;
   op.nv = c->mesh.dim;
@@ -913,6 +992,7 @@ extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d
   ctx->ghost_v.upload(gv, s);
   ctx->ghost_p.upload(gp, s);
   ctx->halo_p2 = to_halo(d->p2_halo);
+  ctx->mg_mv.lv.clear();            // rebuilt with the halo on the next Chebyshev mass solve
   ctx->halo_p1 = to_halo(d->p1_halo);
   ctx->n_p2_global = d->n_p2_global;
   ctx->n_p1_global = d->n_p1_global;

@@ -11,16 +11,9 @@
 
 namespace nsfem {
 
-struct QuadTables3 {
-  double w[15];
-  double phi2[15][10];
-  double dphi2[15][10][3];
-  double phi1[15][4];
-};
 __constant__ QuadTables3 c_q3;
 
-void upload_quad_tables_3d() {
-  QuadTables3 t;
+void fill_quad_tables_3d(QuadTables3& t) {
   const double s15 = std::sqrt(15.0);
   const double a1 = (7.0 - s15) / 34.0, a2 = (7.0 + s15) / 34.0, b = (10.0 - 2.0 * s15) / 40.0;
   const double w0 = 16.0 / 135.0, w1 = (2665.0 + 14.0 * s15) / 37800.0,
@@ -58,6 +51,11 @@ void upload_quad_tables_3d() {
       for (int d = 0; d < 3; ++d) t.dphi2[q][4 + e][d] = 4.0 * (l[a] * dl[bb][d] + l[bb] * dl[a][d]);
     }
   }
+}
+
+void upload_quad_tables_3d() {
+  QuadTables3 t;
+  fill_quad_tables_3d(t);
   NSFEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_q3), &t, sizeof(QuadTables3)));
 }
 

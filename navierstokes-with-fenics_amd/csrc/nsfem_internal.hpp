@@ -161,7 +161,17 @@ struct MeshDev {
 void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                double* mass, double* stiff);
 // tetrahedral meshes (assembly3d.hip); the launch_* wrappers dispatch on MeshDev::dim
+struct QuadTables3 {          // 15-point degree-5 Keast rule, P2 (10 nodes) / P1 (4 nodes) tables
+  double w[15];
+  double phi2[15][10];
+  double dphi2[15][10][3];
+  double phi1[15][4];
+};
+void fill_quad_tables_3d(QuadTables3& t);
 void upload_quad_tables_3d();
+// extreme eigenvalues of diag(M_e)^{-1} M_e for the P2 element mass matrix (Wathen: they bound
+// the spectrum of the Jacobi-scaled assembled mass matrix on any affine mesh)
+void p2_mass_jacobi_bounds(int dim, double& lmin, double& lmax);
 void assemble_p2_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, double* mass,
                            double* stiff);
 void assemble_p1_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p11, double* stiff,
@@ -427,7 +437,9 @@ struct nsfem_ctx {
   int64_t n_p2_global = 0, n_p1_global = 0;
   P1Level* global_coarse = nullptr;            // replicated global coarsest mesh (owned)
   std::vector<P1Level*> global_tail;           // its coarser levels, finest first (owned)
-  nsfem::Multigrid mg_p_tail, mg_v_tail;       // replicated hierarchies below global_coarse
+  nsfem::Multigrid mg_p_tail, mg_v_tail;
+  nsfem::Multigrid mg_mv;                      // one level: Chebyshev solver of the velocity mass matrix
+  double mass_kappa = 0.0;       // replicated hierarchies below global_coarse
   int64_t glob_off = 0;
   // NSFEM_FORCE_COMM=1 routes a single-rank run through the communicator as well (lets a
   // one-GPU box exercise the RCCL all-reduce calls)

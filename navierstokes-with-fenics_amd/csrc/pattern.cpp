@@ -136,6 +136,58 @@ void fill_quad_tables(QuadTables& t) {
     for (int q = 0; q < 6; ++q) t.cfl_inv[i][q] = m[i][6 + q];
 }
 
+void p2_mass_jacobi_bounds(int dim, double& lmin, double& lmax) {
+  constexpr int N = 10;
+  const int n = dim == 2 ? 6 : 10;
+  double S[N][N] = {{0.0}};
+  if (dim == 2) {
+    QuadTables t;
+    fill_quad_tables(t);
+    for (int q = 0; q < 7; ++q)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S[i][j] += t.w[q] * t.phi2[q][i] * t.phi2[q][j];
+  } else {
+    QuadTables3 t;
+    fill_quad_tables_3d(t);
+    for (int q = 0; q < 15; ++q)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S[i][j] += t.w[q] * t.phi2[q][i] * t.phi2[q][j];
+  }
+  double d[N];
+  for (int i = 0; i < n; ++i) d[i] = std::sqrt(S[i][i]);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) S[i][j] /= d[i] * d[j];
+  // cyclic Jacobi rotations on the symmetric n x n matrix
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) off += S[i][j] * S[i][j];
+    if (off < 1e-30) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        if (std::fabs(S[p][q]) < 1e-300) continue;
+        const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+        const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * c;
+        for (int k = 0; k < n; ++k) {
+          const double a = S[k][p], b = S[k][q];
+          S[k][p] = c * a - sn * b;
+          S[k][q] = sn * a + c * b;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double a = S[p][k], b = S[q][k];
+          S[p][k] = c * a - sn * b;
+          S[q][k] = sn * a + c * b;
+        }
+      }
+  }
+  lmin = lmax = S[0][0];
+  for (int i = 1; i < n; ++i) {
+    lmin = std::min(lmin, S[i][i]);
+    lmax = std::max(lmax, S[i][i]);
+  }
+}
+
 }  // namespace nsfem
 
 namespace nsfem {

@@ -33,7 +33,7 @@ def _cavity_bc(dm, height=1.0):
             np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(nodes.size)]))
 
 
-def _run(ctx, dm, nsteps, k, use_mg, out, key):
+def _run(ctx, dm, nsteps, k, use_mg, out, key, cheb=False):
     ctx.set_coeffs(1.0, 1.0, 0.01)
     ctx.set_dirichlet(nat.VELOCITY, *_cavity_bc(dm))
     ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
@@ -42,6 +42,8 @@ def _run(ctx, dm, nsteps, k, use_mg, out, key):
         o.rtol = 1e-12
     if use_mg:
         opts.momentum.precond = opts.poisson.precond = 1
+    if cheb:
+        opts.correction.precond = 2
     infos = []
     for step in range(nsteps):
         ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
@@ -50,18 +52,20 @@ def _run(ctx, dm, nsteps, k, use_mg, out, key):
     out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
 
 
-@pytest.mark.parametrize("n,size,use_mg,tail", [(16, 2, False, False), (32, 4, True, False),
-                                                (64, 2, True, False), (64, 2, True, True)])
-def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail):
+@pytest.mark.parametrize("n,size,use_mg,tail,cheb", [(16, 2, False, False, False), (32, 4, True, False, False),
+                                                     (64, 2, True, False, False), (64, 2, True, True, False),
+                                                     (32, 2, True, False, True)])
+def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb):
     """tail: the partitioned levels stop at 16 cells across and the rest of the hierarchy
-    (16 -> 8 -> 4 -> 2) is the replicated global one -- still the serial algorithm."""
+    (16 -> 8 -> 4 -> 2) is the replicated global one -- still the serial algorithm.
+    cheb: the velocity correction uses the dot-product-free Chebyshev mass solve."""
     nsteps, k, coarsest = 3, 0.01, 2
     mesh, dm, _ = box(n, n)
     ref = {}
     ctx0 = context(mesh, dm)
     if use_mg:
         attach_hierarchy(ctx0, mesh, coarsest=coarsest)
-    _run(ctx0, dm, nsteps, k, use_mg, ref, 0)
+    _run(ctx0, dm, nsteps, k, use_mg, ref, 0, cheb)
     u_ref, p_ref, inf_ref = ref[0]
     ctx0.close()
 
@@ -87,7 +91,7 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail):
             else:
                 ctxs[r].set_partition(r, size, part.p2_ghost, part.p1_ghost, part.p2_halo,
                                       part.p1_halo, (2 * n + 1) ** 2, (n + 1) ** 2)
-            _run(ctxs[r], part.dofmap, nsteps, k, use_mg, out, r)
+            _run(ctxs[r], part.dofmap, nsteps, k, use_mg, out, r, cheb)
         except BaseException as exc:                     # a dead rank would deadlock the others
             errors.append((r, repr(exc)))
             os._exit(17)
@@ -108,6 +112,8 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail):
             assert a.newton_iterations == b.newton_iterations
             assert a.krylov_iterations_momentum == b.krylov_iterations_momentum
             assert a.krylov_iterations_poisson == b.krylov_iterations_poisson
+            if cheb:        # a-priori bounds: the step count is predicted, identical everywhere
+                assert a.krylov_iterations_correction == b.krylov_iterations_correction <= 60
     assert rel(u, u_ref) < 1e-11
     assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-10
     for r, part in enumerate(parts):                     # ghosts are copies of the owners' values
@@ -292,3 +298,43 @@ def test_bench_through_rccl_single_rank():
     line2 = json.loads(res2.stdout.strip().splitlines()[-1])
     for key in ("newton_its_per_step", "bicgstab_its_per_step", "poisson_cg_its_per_step"):
         assert line["config"][key] == line2["config"][key]
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_chebyshev_mass_solve_matches_cg(dim):
+    """correction.precond = 2: Chebyshev iteration on diag(M)^-1 M with Wathen's element bounds
+    (no dot products) must give the Jacobi-CG result of the velocity-correction step."""
+    if dim == 2:
+        mesh, dm, _ = box(24, 24)
+        bc = _cavity_bc(dm)
+    else:
+        from fem_mesh import box_mesh, TaylorHoodDofMap
+        mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 6, 6, 6)
+        dm = TaylorHoodDofMap(mesh)
+        X = dm.p2_coords
+        on = ((np.abs(X) < 1e-12) | (np.abs(X - 1) < 1e-12)).any(axis=1)
+        nodes = np.nonzero(on)[0]
+        lid = np.abs(X[nodes, 2] - 1) < 1e-12
+        bc = (np.concatenate([3 * nodes, 3 * nodes + 1, 3 * nodes + 2]).astype(np.int32),
+              np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(2 * nodes.size)]))
+    res = {}
+    for cheb in (False, True):
+        ctx = context(mesh, dm)
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, *bc)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-12
+        opts.correction.precond = 2 if cheb else 0
+        its = []
+        for step in range(3):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), 0.01)
+            info = ctx.step_ipcs(opts)
+            its.append(info.krylov_iterations_correction)
+            ctx.advance(0)
+        res[cheb] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), its)
+        ctx.close()
+    assert rel(res[True][0], res[False][0]) < 1e-10
+    assert rel(res[True][1], res[False][1]) < 1e-8
+    assert max(res[True][2]) <= (60 if dim == 2 else 130)

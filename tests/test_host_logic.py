@@ -256,3 +256,29 @@ def test_reference_module_names_resolve():
         mod = importlib.import_module(module)
         for name in names:
             assert hasattr(mod, name), (module, name)
+
+
+def test_p2_mass_element_bounds():
+    """Extreme eigenvalues of diag(M_e)^-1 M_e for the P2 element mass matrix (affine elements:
+    shape independent) = Wathen's bounds for the Jacobi-scaled global mass matrix; the native
+    library computes them on the host for the Chebyshev mass solve."""
+    import ctypes as C
+    import _native as nat
+    import sympy as sp
+    lib = nat.load_library()
+    for dim, expect in ((2, (0.39237, 2.05982)), (3, (0.25, 4.34747))):
+        lo, hi = C.c_double(), C.c_double()
+        assert lib.nsfem_p2_mass_bounds(dim, C.byref(lo), C.byref(hi)) == 0
+        assert abs(lo.value - expect[0]) < 2e-5 and abs(hi.value - expect[1]) < 2e-5
+    assert lib.nsfem_p2_mass_bounds(4, C.byref(lo), C.byref(hi)) != 0
+    # independent check in 2D from exactly integrated P2 shape functions
+    x, y = sp.symbols("x y")
+    l = [1 - x - y, x, y]
+    phi = [li * (2 * li - 1) for li in l] + [4 * l[1] * l[2], 4 * l[0] * l[2], 4 * l[0] * l[1]]
+    M = np.array([[float(sp.integrate(sp.integrate(a * b, (y, 0, 1 - x)), (x, 0, 1))) for b in phi]
+                  for a in phi])
+    d = 1.0 / np.sqrt(np.diag(M))
+    ev = np.linalg.eigvalsh(d[:, None] * M * d[None, :])
+    lo, hi = C.c_double(), C.c_double()
+    lib.nsfem_p2_mass_bounds(2, C.byref(lo), C.byref(hi))
+    assert abs(ev[0] - lo.value) < 1e-10 and abs(ev[-1] - hi.value) < 1e-10

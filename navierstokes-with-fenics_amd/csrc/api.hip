@@ -1209,6 +1209,17 @@ static nsfem_krylov_opts hinted(nsfem_krylov_opts k, int hint) {
   k.first_check = std::max(k.first_check, hint - 1);
   return k;
 }
+// The predictor for the next solve: the iteration count of this one, reduced when the postponed
+// first check found the residual far below the target (linear-convergence estimate of the count
+// that would have sufficed) -- otherwise a single long solve would keep all later ones long.
+static int next_hint(const nsfem_solve_info& si, const nsfem_krylov_opts& k) {
+  if (!si.converged) return 0;                     // a failed solve predicts nothing
+  if (si.iterations <= 1 || !(si.residual > 0.0) || !(si.residual0 > si.residual)) return si.iterations;
+  const double target = std::max(k.atol, k.rtol * si.residual0);
+  if (!(si.residual < target) || !(si.residual0 > target)) return si.iterations;
+  const double need = si.iterations * std::log(si.residual0 / target) / std::log(si.residual0 / si.residual);
+  return std::max(1, std::min(si.iterations, (int)std::ceil(need)));
+}
 
 extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem_step_info* info) {
   nsfem_step_info local;
@@ -1234,8 +1245,9 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     if (!ctx->mf_active) momentum_jacobian(ctx);
     nsfem_solve_info si;
     int& hint = ctx->hint_mom[std::min(it, 3)];
-    int rc = momentum_solve_update(ctx, hinted(forced_opts(opts, opts->momentum, r0), hint), si);
-    hint = si.iterations;
+    const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
+    int rc = momentum_solve_update(ctx, hinted(ko, hint), si);
+    hint = next_hint(si, ko);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the diffusion step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)
@@ -1255,7 +1267,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     poisson_assemble(ctx);
     nsfem_solve_info si;
     int rc = poisson_solve(ctx, hinted(opts->poisson, ctx->hint_poi), si);
-    ctx->hint_poi = si.iterations;
+    ctx->hint_poi = next_hint(si, opts->poisson);
     inf.krylov_iterations_poisson = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the projection step");
   }
@@ -1264,7 +1276,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     correction_assemble(ctx);
     nsfem_solve_info si;
     int rc = correction_solve(ctx, hinted(opts->correction, ctx->hint_cor), si);
-    ctx->hint_cor = si.iterations;
+    ctx->hint_cor = next_hint(si, opts->correction);
     inf.krylov_iterations_correction = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the velocity correction step");
   }
@@ -1389,9 +1401,9 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     op.graph_epoch = ctx->graph_epoch;
     nsfem_solve_info si;
     int& hint = ctx->hint_mom[std::min(it, 3)];
-    int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p,
-                      hinted(forced_opts(opts, opts->momentum, r0), hint), si);
-    hint = si.iterations;
+    const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
+    int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, hinted(ko, hint), si);
+    hint = next_hint(si, ko);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the monolithic step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)

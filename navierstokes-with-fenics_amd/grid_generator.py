@@ -287,8 +287,64 @@ def _read_external_mesh(basename):
     return mesh, markers, {name: tag for name, (dim, tag) in names.items() if dim == 1}
 
 
-def backward_facing_step():
-    return _read_external_mesh("BackwardFacingStep.geo")
+class BackwardFacingStepMarkers(Enum):
+    """Physical groups of the step geometry as the demo uses them
+    (demo/backward_facing_step.py:21-26: "inlet", "walls"; the outlet stays natural)."""
+    inlet = auto()
+    outlet = auto()
+    walls = auto()
+
+
+def backward_facing_step_mesh(m=2, n_refine=2, inlet_length=1.0, length=8.0, step_height=0.5):
+    """In-repo triangulation of the backward-facing-step channel of demo/backward_facing_step.py
+    (inlet of height h = 0.5 on y in [0.5, 1] -- the demo's inlet profile fixes that -- opening
+    into a channel of height 1): right-diagonal triangles on the L-shaped union of
+    [0, inlet_length] x [step_height, 1] and [inlet_length, length] x [0, 1], ``m`` cells per
+    step height on the coarse mesh, refined ``n_refine`` times (-> multigrid hierarchy)."""
+    from fem_mesh import Mesh
+    from multigrid import refinement_hierarchy
+    nx1 = max(1, int(round(inlet_length / step_height * m)))
+    nx2 = max(1, int(round((length - inlet_length) / step_height * m)))
+    ny1 = m
+    ny2 = max(1, int(round((1.0 - step_height) / step_height * m)))
+    xs = np.concatenate([np.linspace(0.0, inlet_length, nx1 + 1)[:-1], np.linspace(inlet_length, length, nx2 + 1)])
+    ys = np.concatenate([np.linspace(0.0, step_height, ny1 + 1)[:-1], np.linspace(step_height, 1.0, ny2 + 1)])
+    node_id = -np.ones((ys.size, xs.size), dtype=np.int64)
+    coords = []
+    for iy in range(ys.size):
+        for ix in range(xs.size):
+            if ix < nx1 and iy < ny1:
+                continue                               # inside the step block
+            node_id[iy, ix] = len(coords)
+            coords.append((xs[ix], ys[iy]))
+    cells = []
+    for iy in range(ys.size - 1):
+        for ix in range(xs.size - 1):
+            if ix < nx1 and iy < ny1:
+                continue
+            v0, v1 = node_id[iy, ix], node_id[iy, ix + 1]
+            v2, v3 = node_id[iy + 1, ix], node_id[iy + 1, ix + 1]
+            cells += [(v0, v1, v3), (v0, v2, v3)]
+    coarse = Mesh(np.array(coords), np.array(cells, dtype=np.int32))
+    marks = FacetMarkers(coarse, 0)
+    ids = BackwardFacingStepMarkers
+    marks.mark(lambda X: X[:, 0] > -1.0, ids.walls.value)             # every boundary facet ...
+    marks.mark(lambda X: np.abs(X[:, 0]) < 1e-12, ids.inlet.value)    # ... except the two ends
+    marks.mark(lambda X: np.abs(X[:, 0] - length) < 1e-12, ids.outlet.value)
+    if n_refine == 0:
+        coarse.mg_levels = []
+        return coarse, marks
+    return refinement_hierarchy(coarse, marks, n_refine)
+
+
+def backward_facing_step(m=2, n_refine=2):
+    """BackwardFacingStep.msh when supplied (reference: source/grid_generator.py, gmsh), else the
+    in-repo triangulation with the marker map the .geo file defines."""
+    try:
+        return _read_external_mesh("BackwardFacingStep.geo")
+    except FileNotFoundError:
+        mesh, markers = backward_facing_step_mesh(m, n_refine)
+        return mesh, markers, {marker.name: marker.value for marker in BackwardFacingStepMarkers}
 
 
 def blasius_plate():

@@ -532,6 +532,8 @@ class StationarySolverBase(SolverBase):
         self.krylov_rtol = 1.0e-12
         self.krylov_max_iter = 5000
         self.use_multigrid = True
+        self.pseudo_transient_fallback = True
+        self.pseudo_transient_max_steps = 4000
 
     def _setup_problem(self):
         assert hasattr(self, "_equation_coefficients")
@@ -563,16 +565,93 @@ class StationarySolverBase(SolverBase):
         # the velocity block) the preconditioner is rebuilt for (J + M / tau), tau ~ 6 h / |u|
         # ("time-step preconditioner", nsfem_set_preconditioner_shift) and the iteration resumes
         # from the current iterate; the equations are never changed.
+        # Last resort: pseudo-transient continuation (_pseudo_transient_solve) -- the same
+        # stationary residual driven to zero by implicit Euler steps of the hot path.
+        if getattr(self, "_use_pseudo_time", False) and maxiter > 1:
+            return self._pseudo_transient_solve(o, atol)
         for attempt in range(4):
             try:
                 return self._ctx.step_bdf(o)
             except nat.NativeError as err:
-                if "BiCGStab" not in str(err) or attempt == 3:
+                if "BiCGStab" not in str(err):
                     raise RuntimeError(str(err))
+                if attempt == 3:
+                    if not self.pseudo_transient_fallback:
+                        raise RuntimeError(str(err))
+                    break
                 self._preconditioner_shift = self._next_preconditioner_shift()
                 dlfn.info("Krylov solver failed; preconditioner shift -> {0:.3g}".format(
                     self._preconditioner_shift))
                 self._ctx.set_preconditioner_shift(self._preconditioner_shift)
+        self._use_pseudo_time = True
+        self._preconditioner_shift = 0.0
+        self._ctx.set_preconditioner_shift(0.0)
+        return self._pseudo_transient_solve(o, atol)
+
+    def _pseudo_transient_solve(self, o, atol):
+        """Pseudo-transient continuation: one Newton iteration of the implicit Euler step
+        (M / tau + J(u)) du = -F(u) per pseudo-time step, with F the STATIONARY residual (the old
+        time level is the current iterate) and tau adapted by switched evolution relaxation
+        (tau grows like 1 / |F|, so the iteration turns into Newton's method near the solution),
+        capped where the block-preconditioned Krylov solver stops converging.  The velocity mass
+        matrix keeps the linear systems within reach of the multigrid preconditioner at cell
+        Peclet numbers where the stationary Jacobian is not; the fixed point is the solution of
+        the reference's stationary problem (source/ns_solver_base.py:951-988), which the reference
+        reaches by LU-based Newton iterations."""
+        ctx = self._ctx
+        o.picard = 0
+        o.newton_max_iter = 1
+        o.newton_atol = atol
+        o.allow_nonconvergence = 1
+        # inexact steps: the convergence rate is set by tau, and no linear system needs to be
+        # solved below the tolerance of the nonlinear iteration
+        o.momentum.rtol = 1.0e-4
+        o.momentum.atol = 0.02 * atol
+        o.momentum.max_iter = min(self.krylov_max_iter, 300)
+        u = ctx.get_state(nat.U0).reshape(-1, self._space_dim)
+        speed = max(float(np.sqrt((u * u).sum(axis=1)).max()), 1.0e-12)
+        bc_vals = self._dirichlet_bcs["velocity"][1]
+        if bc_vals.size:
+            speed = max(speed, float(np.abs(bc_vals).max()))
+        tau = tau0 = 8.0 * self._mesh.hmin() / speed
+        tau_cap = float("inf")
+        res_prev, info, failures = None, None, 0
+        self.pseudo_time_history = getattr(self, "pseudo_time_history", [])
+        try:
+            for it in range(self.pseudo_transient_max_steps):
+                ctx.advance(0)                                   # old level <- current iterate
+                ctx.set_bdf((1.0, -1.0, 0.0), tau)
+                try:
+                    info = ctx.step_bdf(o)
+                except nat.NativeError as err:
+                    if "BiCGStab" not in str(err):
+                        raise RuntimeError(str(err))
+                    failures += 1
+                    if failures > 12:
+                        raise RuntimeError("pseudo-transient continuation: " + str(err))
+                    ctx.set_state(nat.U0, ctx.get_state(nat.U1))  # discard the failed update
+                    ctx.set_state(nat.P, ctx.get_state(nat.P_OLD))
+                    tau_cap = 0.5 * tau
+                    tau = 0.25 * tau
+                    continue
+                res = info.newton_residuals[0]                   # = |F(u)| of the stationary problem
+                self.pseudo_time_history.append((tau, res, info.krylov_iterations_momentum))
+                if not np.isfinite(res):
+                    raise RuntimeError("pseudo-transient continuation diverged")
+                if res <= atol:
+                    break
+                if res_prev is not None:
+                    tau = min(tau * min(max(res_prev / res, 0.5), 2.0), tau_cap)
+                res_prev = res
+                if it % 20 == 0:
+                    dlfn.info("pseudo-time step {0}: tau = {1:.3g}, residual = {2:.3e}".format(it, tau, res))
+        finally:
+            ctx.set_bdf((0.0, 0.0, 0.0), 1.0)
+        # report like the Newton solver: zero further iterations from the final iterate
+        o.newton_atol = 1.0e300
+        final = ctx.step_bdf(o)
+        self.pseudo_time_steps = getattr(self, "pseudo_time_steps", 0) + it + 1
+        return final
 
     def _next_preconditioner_shift(self):
         current = getattr(self, "_preconditioner_shift", 0.0)

@@ -606,11 +606,13 @@ class ConstantAngularVelocity(FunctionTime):
 
 
 class RotatingCouetteFlow(StationaryProblem):
-    """tests/test_stationary_rotating_flow.py:19-47 (Re lowered from 1000 to 200: beyond that the
-    block-preconditioned BiCGStab does not converge even with the time-step preconditioner,
-    DESIGN.md section 1 N2; the reference solves these systems by LU)."""
+    """tests/test_stationary_rotating_flow.py:19-47, Re = 1000 and Ro = 1 as shipped.  At this
+    Reynolds number the stationary Jacobian is out of reach of the block-preconditioned BiCGStab
+    (the reference uses LU); the solver falls back to pseudo-transient continuation
+    (StationarySolverBase._pseudo_transient_solve) and still drives the reference's stationary
+    residual below its tolerance."""
 
-    def __init__(self, n_points, radii, Re=200.0):
+    def __init__(self, n_points, radii, Re=1000.0):
         super().__init__(None)
         self._radii, self._n_points, self._Re = radii, n_points, Re
         self._problem_name = "RotationalCouette"
@@ -631,11 +633,15 @@ class RotatingCouetteFlow(StationaryProblem):
                      (VelocityBCType.function, ids.interior_boundary.value, velocity))
 
 
-def test_stationary_rotating_couette_flow_analytic_and_oracle():
+@pytest.mark.parametrize("Re", [200.0, 1000.0])
+def test_stationary_rotating_couette_flow_analytic_and_oracle(Re):
     ri, ro = 0.25, 1.0
-    problem = RotatingCouetteFlow(24, (ri, ro))
+    problem = RotatingCouetteFlow(24, (ri, ro), Re=Re)
     problem.solve_problem()
     solver = problem._get_solver()
+    n_it = solver.newton_info.newton_iterations
+    assert solver.newton_info.newton_residuals[n_it] <= 1e-10
+    assert (getattr(solver, "pseudo_time_steps", 0) > 0) == (Re == 1000.0)
     dm = solver._dofmap
     u = solver.solution.split()[0].nodal_values()
     X = dm.p2_coords
@@ -644,7 +650,8 @@ def test_stationary_rotating_couette_flow_analytic_and_oracle():
     B = -A * ro ** 2
     ut = A * r + B / r                                   # circular Couette in the rotating frame
     exact = np.stack([-ut * X[:, 1] / r, ut * X[:, 0] / r], axis=1)
-    assert np.abs(u - exact).max() < 2e-3                # discretisation error (polygonal circles)
+    # discretisation error (polygonal circles); larger at the higher cell Reynolds number
+    assert np.abs(u - exact).max() < (2e-3 if Re < 500.0 else 6e-3)
     # same discrete problem solved by the oracle (Newton + LU) from the device's solution
     s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
     orc = fo.BDFOracle(s, solver._equation_coefficients, pin_pressure=True)
@@ -652,6 +659,9 @@ def test_stationary_rotating_couette_flow_analytic_and_oracle():
     vd, vv = solver._dirichlet_bcs["velocity"]
     _, first = np.unique(vd[::-1], return_index=True)
     keep = len(vd) - 1 - first
+    if Re > 500.0:          # Newton + LU from zero does not converge either: start from the device's
+        orc.sol[0][:] = solver.solution.vector()
+        orc.sol[0][dm.n_velocity:] -= orc.sol[0][dm.n_velocity]      # the oracle pins p[0] = 0
     orc.step((0.0, 0.0, 0.0), 1.0, (vd[keep].astype(np.int64), vv[keep]))
     nv = dm.n_velocity
     assert np.linalg.norm(u.ravel() - orc.sol[0][:nv]) < 1e-7 * np.linalg.norm(orc.sol[0][:nv])
@@ -1125,3 +1135,79 @@ def test_stationary_channel_boundary_condition_variants(bc_type):
     if bc_type != "pressure_gradient":       # consistent data: the Poiseuille solution itself
         X2 = dm.p2_coords
         assert np.abs(u.nodal_values()[:, 0] - 6.0 * X2[:, 1] * (1.0 - X2[:, 1])).max() < 1e-8
+
+
+class BackwardFacingStepProblem(StationaryProblem):
+    """demo/backward_facing_step.py:12-35 as shipped (Re = 50, parabolic inlet on the upper half,
+    no-slip walls, natural outlet, pressure gradient + vorticity in the field output) on the
+    in-repo triangulation of the step channel (the gmsh file of the demo is not available)."""
+
+    def __init__(self, main_dir=None):
+        super().__init__(main_dir)
+        self._problem_name = "BackwardFacingStep"
+
+    def setup_mesh(self):
+        from grid_generator import backward_facing_step
+        self._mesh, self._boundary_markers, self._boundary_marker_map = backward_facing_step()
+
+    def set_boundary_conditions(self):
+        inlet_velocity = dlfn.Expression(("6.0*(x[1] - y0)/h*(1.0-(x[1] - y0)/h)", "0.0"),
+                                         h=0.5, y0=0.5, degree=2)
+        self._bcs = ((VelocityBCType.function, self._boundary_marker_map["inlet"], inlet_velocity),
+                     (VelocityBCType.no_slip, self._boundary_marker_map["walls"], None))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=50.0)
+
+    def postprocess_solution(self):
+        self._add_to_field_output(self._compute_pressure_gradient())
+        self._add_to_field_output(self._compute_vorticity())
+
+
+def test_stationary_backward_facing_step_demo():
+    problem = BackwardFacingStepProblem()
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    u, p = solver.solution.split()
+    uv = u.nodal_values()
+    X = dm.p2_coords
+    inlet = np.abs(X[:, 0]) < 1e-12
+    s_in = (X[inlet, 1] - 0.5) / 0.5
+    assert np.abs(uv[inlet, 0] - 6.0 * s_in * (1.0 - s_in)).max() < 1e-14
+    # a recirculation zone behind the step, none far downstream
+    behind = (np.abs(X[:, 1] - 0.125) < 1e-12) & (X[:, 0] > 1.05) & (X[:, 0] < 2.0)
+    far = (np.abs(X[:, 1] - 0.125) < 1e-12) & (X[:, 0] > 5.0)
+    assert uv[behind, 0].min() < -0.01 and uv[far, 0].min() > 0.0
+    # fully developed again at the outlet: Poiseuille profile of the full height with the inlet's
+    # flux (0.5): u = 3 y (1 - y)
+    out = np.abs(X[:, 0] - 8.0) < 1e-12
+    assert np.abs(uv[out, 0] - 3.0 * X[out, 1] * (1.0 - X[out, 1])).max() < 0.02
+    assert np.abs(uv[out, 1]).max() < 0.01
+    # discrete mass conservation: (div u, 1) = 0 because constants are in the pressure space
+    import _native as nat
+    div = solver._ctx.operator_apply(nat.OP_DIV, u.vector())
+    assert abs(div.sum()) < 1e-10
+    s, vbc = _stationary_oracle(solver)
+    orc = fo.BDFOracle(s, solver._equation_coefficients)
+    orc.sol[0][:] = solver.solution.vector()
+    orc.step((0.0, 0.0, 0.0), 1.0, vbc)
+    assert orc.newton_its[-1] <= 1
+    uo = orc.sol[0][: dm.n_velocity]
+    assert np.linalg.norm(u.vector() - uo) < 1e-7 * np.linalg.norm(uo)
+
+
+def test_stationary_rotating_couette_flow_as_shipped():
+    """tests/test_stationary_rotating_flow.py:50-52: n_points = 60, radii (0.25, 1), Re = 1000."""
+    problem = RotatingCouetteFlow(60, (0.25, 1.0))
+    problem.solve_problem()
+    solver = problem._get_solver()
+    n_it = solver.newton_info.newton_iterations
+    assert solver.newton_info.newton_residuals[n_it] <= 1e-10
+    u = solver.solution.split()[0].nodal_values()
+    X = solver._dofmap.p2_coords
+    r = np.hypot(X[:, 0], X[:, 1])
+    A = 0.25 ** 2 / (1.0 - 0.25 ** 2)
+    ut = A * r - A / r
+    exact = np.stack([-ut * X[:, 1] / r, ut * X[:, 0] / r], axis=1)
+    assert np.abs(u - exact).max() < 5e-4

@@ -1563,12 +1563,12 @@ extern "C" int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, doub
   NSFEM_REQUIRE(ctx && cfl, "null argument");
   NSFEM_REQUIRE(slot >= 0 && slot < NSFEM_N_SLOTS && slot_size(ctx, slot) == nvel(ctx),
                 "not a velocity slot");
-  NSFEM_REQUIRE(ctx->mesh.dim == 2, "the CFL diagnostic is built for 2D meshes only");
   hipStream_t s = ctx->stream;
   const int n_parts = 256;
   ctx->kw.ensure(nvel(ctx));
   double* parts = ctx->kw.parts.p + 5 * kParts;
-  launch_cfl(s, ctx->mesh, ctx->state[slot].p, 2.0 * step_size, parts, n_parts);
+  if (ctx->mesh.dim == 3) launch_cfl_3d(s, ctx->mesh, ctx->state[slot].p, 2.0 * step_size, parts, n_parts);
+  else launch_cfl(s, ctx->mesh, ctx->state[slot].p, 2.0 * step_size, parts, n_parts);
   if (ctx->distributed()) ctx->comm->allreduce_max(s, parts, n_parts);
   double h[256];
   NSFEM_HIP(hipMemcpyAsync(h, parts, sizeof(h), hipMemcpyDeviceToHost, s));

@@ -53,10 +53,72 @@ void fill_quad_tables_3d(QuadTables3& t) {
   }
 }
 
+// CFL diagnostic tables: P2 basis at the 14 points of the degree-4 Keast rule (FFC's "default"
+// scheme for quadrature degree 4 on tetrahedra, which the reference's DG2 projection requests:
+// source/ns_problem.py:570) and the projection matrix  M^{-1} Phi^T W  (10 x 14).
+struct CflTables3 {
+  double phi[14][10];
+  double inv[10][14];
+};
+__constant__ CflTables3 c_cfl3;
+
+static void fill_cfl_tables_3d(CflTables3& t) {
+  double l[14][4], w[14];
+  int n = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = i + 1; j < 4; ++j) {
+      for (int k = 0; k < 4; ++k) l[n][k] = (k == i || k == j) ? 0.5 : 0.0;
+      w[n++] = 0.0031746031746032;
+    }
+  const double pa[2] = {0.1005267652252045, 0.3143728734931922};
+  const double qa[2] = {0.6984197043243866, 0.0568813795204234};
+  const double wa[2] = {0.0147649707904968, 0.0221397911142651};
+  for (int r = 0; r < 2; ++r)
+    for (int k = 0; k < 4; ++k) {
+      for (int m = 0; m < 4; ++m) l[n][m] = (m == k) ? qa[r] : pa[r];
+      w[n++] = wa[r];
+    }
+  const int pr[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+  for (int q = 0; q < 14; ++q) {
+    for (int i = 0; i < 4; ++i) t.phi[q][i] = l[q][i] * (2.0 * l[q][i] - 1.0);
+    for (int e = 0; e < 6; ++e) t.phi[q][4 + e] = 4.0 * l[q][pr[e][0]] * l[q][pr[e][1]];
+  }
+  double m[10][20];
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 10; ++j) {
+      double a = 0.0;
+      for (int q = 0; q < 14; ++q) a += w[q] * t.phi[q][i] * t.phi[q][j];
+      m[i][j] = a;
+      m[i][10 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 10; ++c) {                      // Gauss-Jordan with partial pivoting
+    int piv = c;
+    for (int r = c + 1; r < 10; ++r)
+      if (std::fabs(m[r][c]) > std::fabs(m[piv][c])) piv = r;
+    for (int k = 0; k < 20; ++k) std::swap(m[c][k], m[piv][k]);
+    const double d = 1.0 / m[c][c];
+    for (int k = 0; k < 20; ++k) m[c][k] *= d;
+    for (int r = 0; r < 10; ++r)
+      if (r != c) {
+        const double f = m[r][c];
+        for (int k = 0; k < 20; ++k) m[r][k] -= f * m[c][k];
+      }
+  }
+  for (int i = 0; i < 10; ++i)
+    for (int q = 0; q < 14; ++q) {
+      double a = 0.0;
+      for (int j = 0; j < 10; ++j) a += m[i][10 + j] * t.phi[q][j];
+      t.inv[i][q] = a * w[q];
+    }
+}
+
 void upload_quad_tables_3d() {
   QuadTables3 t;
   fill_quad_tables_3d(t);
   NSFEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_q3), &t, sizeof(QuadTables3)));
+  CflTables3 cf;
+  fill_cfl_tables_3d(cf);
+  NSFEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_cfl3), &cf, sizeof(CflTables3)));
 }
 
 struct CellGeo3 {
@@ -545,6 +607,71 @@ void convection_action_3d(hipStream_t s, const MeshDev& m, const double* u, cons
   else launch_conv_cell<1>(s, m, u, v, cc, form);
   hipLaunchKernelGGL(k3_res_gather, dim3(grid3((int64_t)m.n_p2 * 3)), dim3(kBlock), 0, s, m.n_p2,
                      m.nptr.p, m.nidx.p, m.rbuf.p, y);
+  NSFEM_HIP(hipGetLastError());
+}
+
+// ---- CFL diagnostic on tetrahedra (reference source/ns_problem.py:554-587; the 2D kernel is
+// k_cfl): cell-local L2 projection onto DG2 of  2 |u| k / h  (h = dolfin CellDiameter = diameter of
+// the circumsphere) with the 14-point degree-4 rule, then the max-norm of the 10 coefficients.
+__global__ __launch_bounds__(256) void k3_cfl(int nc, const double* __restrict__ vx,
+                                              const int32_t* __restrict__ p2,
+                                              const double* __restrict__ u, double scale,
+                                              double* __restrict__ parts) {
+  __shared__ double sh[4];
+  double best = 0.0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    double x[4][3];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) x[v][d] = vx[(size_t)(3 * v + d) * nc + c];
+    // circumradius R = sqrt(P (P - aA)(P - bB)(P - cC)) / (6 V), P = (aA + bB + cC) / 2, with
+    // (a, A), (b, B), (c, C) the lengths of the three pairs of opposite edges
+    auto len = [&](int i, int j) {
+      const double dx = x[i][0] - x[j][0], dy = x[i][1] - x[j][1], dz = x[i][2] - x[j][2];
+      return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    const double pa = len(0, 1) * len(2, 3), pb = len(0, 2) * len(1, 3), pc = len(0, 3) * len(1, 2);
+    const double P = 0.5 * (pa + pb + pc);
+    const double e1[3] = {x[1][0] - x[0][0], x[1][1] - x[0][1], x[1][2] - x[0][2]};
+    const double e2[3] = {x[2][0] - x[0][0], x[2][1] - x[0][1], x[2][2] - x[0][2]};
+    const double e3[3] = {x[3][0] - x[0][0], x[3][1] - x[0][1], x[3][2] - x[0][2]};
+    const double det = e1[0] * (e2[1] * e3[2] - e2[2] * e3[1]) - e1[1] * (e2[0] * e3[2] - e2[2] * e3[0]) +
+                       e1[2] * (e2[0] * e3[1] - e2[1] * e3[0]);
+    const double h = 2.0 * sqrt(fmax(P * (P - pa) * (P - pb) * (P - pc), 0.0)) / fabs(det);   // 6 V = |det|
+    double uu[10][3];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const double* src = u + 3 * (size_t)p2[(size_t)k * nc + c];
+      uu[k][0] = src[0]; uu[k][1] = src[1]; uu[k][2] = src[2];
+    }
+    double ci[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) ci[i] = 0.0;
+    for (int q = 0; q < 14; ++q) {
+      double a = 0.0, b = 0.0, d = 0.0;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const double ph = c_cfl3.phi[q][k];
+        a += ph * uu[k][0]; b += ph * uu[k][1]; d += ph * uu[k][2];
+      }
+      const double f = scale * sqrt(a * a + b * b + d * d) / h;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) ci[i] += c_cfl3.inv[i][q] * f;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) best = fmax(best, fabs(ci[i]));
+  }
+  for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+void launch_cfl_3d(hipStream_t s, const MeshDev& m, const double* u, double scale, double* parts,
+                   int n_parts) {
+  hipLaunchKernelGGL(k3_cfl, dim3(n_parts), dim3(256), 0, s, m.n_cells, m.vx.p, m.p2.p, u, scale,
+                     parts);
   NSFEM_HIP(hipGetLastError());
 }
 

@@ -169,6 +169,8 @@ struct QuadTables3 {          // 15-point degree-5 Keast rule, P2 (10 nodes) / P
 };
 void fill_quad_tables_3d(QuadTables3& t);
 void upload_quad_tables_3d();
+void launch_cfl_3d(hipStream_t s, const MeshDev& m, const double* u, double scale, double* parts,
+                   int n_parts);
 // extreme eigenvalues of diag(M_e)^{-1} M_e for the P2 element mass matrix (Wathen: they bound
 // the spectrum of the Jacobi-scaled assembled mass matrix on any affine mesh)
 void p2_mass_jacobi_bounds(int dim, double& lmin, double& lmax);

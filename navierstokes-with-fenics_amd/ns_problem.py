@@ -282,8 +282,7 @@ class InstationaryProblem(ProblemBase):
         switched off."""
         next_step_size = self._time_stepping.get_next_step_size()
         assert next_step_size > 0.0 and math.isfinite(next_step_size)
-        if getattr(self, "compute_cfl", True) and self._space_dim == 2:
-            # (the device CFL kernel is built for triangles; the value is a diagnostic only)
+        if getattr(self, "compute_cfl", True):
             self._last_cfl = self._compute_cfl_number(next_step_size)
 
     def solve_problem(self):

@@ -327,20 +327,51 @@ def strang_fix_6():
     return pts, 0.5 * np.array([wa, wa, wa, wb, wb, wb])
 
 
+def keast_14():
+    """14-point degree-4 Keast rule on the reference tetrahedron (FFC/FIAT 'default' scheme for
+    quadrature degree 4 on tetrahedra: 6 edge midpoints + two vertex orbits; weights sum to 1/6)."""
+    import itertools
+    bary, w = [], []
+    for i, j in itertools.combinations(range(4), 2):
+        l = [0.0] * 4
+        l[i] = l[j] = 0.5
+        bary.append(l)
+        w.append(0.0031746031746032)
+    for p, q, wt in ((0.1005267652252045, 0.6984197043243866, 0.0147649707904968),
+                     (0.3143728734931922, 0.0568813795204234, 0.0221397911142651)):
+        for k in range(4):
+            l = [p] * 4
+            l[k] = q
+            bary.append(l)
+            w.append(wt)
+    return np.array(bary)[:, 1:], np.array(w)
+
+
+def circumdiameter(x):
+    """dolfin CellDiameter of the simplices x [c, d+1, d]: diameter of the circumscribed
+    circle / sphere."""
+    d = x.shape[2]
+    ln = lambda i, j: np.linalg.norm(x[:, i] - x[:, j], axis=1)
+    if d == 2:
+        e1, e2 = x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]
+        area2 = np.abs(e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0])
+        return ln(1, 2) * ln(0, 2) * ln(0, 1) / area2              # abc / (2 A)
+    pa, pb, pc = ln(0, 1) * ln(2, 3), ln(0, 2) * ln(1, 3), ln(0, 3) * ln(1, 2)
+    P = 0.5 * (pa + pb + pc)
+    vol6 = np.abs(np.linalg.det(x[:, 1:] - x[:, :1]))
+    return 2.0 * np.sqrt(np.maximum(P * (P - pa) * (P - pb) * (P - pc), 0.0)) / vol6
+
+
 def cfl_number(space, u, step_size):
     """source/ns_problem.py:554-587 restated: per cell, solve the local DG2 mass system
     M c = int phi_i f  with  f = 2 |u| k / h  (h = dolfin CellDiameter = circumdiameter), both
     sides integrated with the degree-4 rule; return max |c_i| over all cells."""
-    pts, wts = strang_fix_6()
-    phi, _ = p2_basis(pts)                                     # [q, 6]
-    x = space.geo.x                                            # [c, 3, 2]
-    la = np.linalg.norm(x[:, 1] - x[:, 2], axis=1)
-    lb = np.linalg.norm(x[:, 0] - x[:, 2], axis=1)
-    lc = np.linalg.norm(x[:, 0] - x[:, 1], axis=1)
-    h = la * lb * lc / space.geo.absdet                        # abc / (2 A), absdet = 2 A
+    pts, wts = strang_fix_6() if space.dim == 2 else keast_14()
+    phi, _ = p2_basis(pts)                                     # [q, 6 | 10]
+    h = circumdiameter(space.geo.x)
     uq = np.einsum("qk,cka->cqa", phi, u[space.vdof])
     f = 2.0 * np.linalg.norm(uq, axis=2) * step_size / h[:, None]          # [c, q]
-    M = np.einsum("q,qi,qj->ij", wts, phi, phi)                # reference mass (area factor cancels)
+    M = np.einsum("q,qi,qj->ij", wts, phi, phi)                # reference mass (volume factor cancels)
     rhs = np.einsum("q,qi,cq->ci", wts, phi, f)
     c = np.linalg.solve(M, rhs.T).T
     return float(np.abs(c).max())

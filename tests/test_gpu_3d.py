@@ -189,3 +189,29 @@ def test_3d_multigrid_hierarchy_ipcs_and_monolithic_match_oracle():
         pg = ctx.get_state(nat.P_OLD)
         assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
         ctx.close()
+
+
+def test_3d_cfl_number_matches_oracle():
+    """nsfem_cfl_number on tetrahedra (k3_cfl: DG2 projection with the 14-point degree-4 rule,
+    circumsphere diameter) vs the oracle on a distorted mesh with a random velocity; constant
+    velocity on the Kuhn mesh gives 2 |u| k / h with h = the cubes' space diagonal."""
+    from fem_mesh import Mesh
+    mesh, dm, _ = box3((4, 3, 3), p1=(1.0, 0.9, 0.6))
+    rng = np.random.default_rng(11)
+    coords = mesh.coords.copy()
+    inner = np.all((coords > 1e-12) & (coords < np.array([1.0, 0.9, 0.6]) - 1e-12), axis=1)
+    coords[inner] += 0.02 * rng.standard_normal((int(inner.sum()), 3))
+    mesh2 = Mesh(coords, mesh.cells)
+    dm2 = TaylorHoodDofMap(mesh2)
+    ctx = context3(mesh2, dm2)
+    s = fo.Space(mesh2.coords, mesh2.cells, dm2.p2_dofmap, dm2.p1_dofmap)
+    u = rng.standard_normal(dm2.n_velocity)
+    ctx.set_state(nat.U0, u)
+    ref = fo.cfl_number(s, u, 0.01)
+    assert abs(ctx.cfl_number(nat.U0, 0.01) - ref) < 1e-12 * ref
+    ctx.close()
+    ctx = context3(mesh, dm)
+    ctx.set_state(nat.U0, np.tile([1.0, 2.0, 2.0], dm.n_p2))
+    h = np.sqrt((1.0 / 4) ** 2 + 0.3 ** 2 + 0.2 ** 2)
+    assert abs(ctx.cfl_number(nat.U0, 0.01) - 2.0 * 3.0 * 0.01 / h) < 1e-13
+    ctx.close()

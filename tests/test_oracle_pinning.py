@@ -311,3 +311,28 @@ def test_k1_3d_duct_stokes_polynomial_solution_is_reproduced():
     p = orc.sol[0][nv:]
     pex = -4.0 * cv * dm.p1_coords[:, 0]
     assert np.abs((p - p[0]) - (pex - pex[0])).max() < 1e-10
+
+
+def test_cfl_number_closed_form_3d_and_keast_rule():
+    """The degree-4 tetrahedron rule of the CFL projection integrates all monomials up to degree 4
+    exactly (and not degree 5); constant velocity on a Kuhn mesh: CFL = 2 |u| k / h with h the
+    space diagonal of the cubes (all six tetrahedra share the cube's circumsphere)."""
+    import math
+    pts, w = fo.keast_14()
+    assert pts.shape == (14, 3) and abs(w.sum() - 1.0 / 6.0) < 1e-15
+    worst5 = 0.0
+    for i in range(6):
+        for j in range(6 - i):
+            for k in range(6 - i - j):
+                exact = math.factorial(i) * math.factorial(j) * math.factorial(k) / math.factorial(i + j + k + 3)
+                err = abs((w * pts[:, 0] ** i * pts[:, 1] ** j * pts[:, 2] ** k).sum() - exact) / exact
+                if i + j + k <= 4:
+                    assert err < 1e-13
+                else:
+                    worst5 = max(worst5, err)
+    assert worst5 > 1e-3
+    mesh, dm, s = make_space3((2, 3, 2), p1=(1.0, 0.9, 0.4))
+    h = math.sqrt(0.5 ** 2 + 0.3 ** 2 + 0.2 ** 2)
+    assert np.abs(fo.circumdiameter(s.geo.x) - h).max() < 1e-14
+    u = np.tile([2.0, -1.0, 2.0], dm.n_p2)
+    assert abs(fo.cfl_number(s, u, 0.05) - 2.0 * 3.0 * 0.05 / h) < 1e-13

@@ -119,6 +119,7 @@ def dfg_bdf_bench(args):
     ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
     attach_schur_laplacian(ctx, bd)
     t_setup = time.perf_counter() - t_setup
+    _apply_truncation(ctx, args)
     opts = ctx.default_step_opts()
     opts.momentum.rtol, opts.momentum.precond, opts.momentum.max_iter = args.krylov_rtol, 1, 500
     opts.newton_forcing = args.newton_forcing
@@ -218,6 +219,7 @@ def cavity3d_bench(args):
     t_setup = time.perf_counter() - t_setup
     n2g, n1g = global_dof_counts(n, n, n * world)
     n_dofs = 3 * n2g + n1g
+    _apply_truncation(ctx, args)
     opts = ctx.default_step_opts()
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = args.krylov_rtol
@@ -282,6 +284,11 @@ def cavity3d_bench(args):
         dist.destroy_process_group()
 
 
+def _apply_truncation(ctx, args):
+    parts = [float(v) for v in str(args.mg_truncation).split(",")]
+    ctx.mg_set_truncation(parts[0], parts[1] if len(parts) > 1 else 0.1)
+
+
 def _serial_coarsest(n, dim=2):
     """cells across the coarsest mesh on one GPU: the first level with <= 1200 nodes (dense
     solve): 2D 512 -> 32 (1089 nodes), 336 -> 21 (484 nodes); 3D 64 -> 8 (729), 48 -> 6 (343)"""
@@ -311,6 +318,9 @@ def main():
                     help="velocity Jacobian in the step driver: 0 auto, 1 assembled, 2 matrix-free")
     ap.add_argument("--mass-solver", choices=("chebyshev", "cg"), default="chebyshev",
                     help="velocity-correction mass solve: Chebyshev with a-priori bounds (no dots) or Jacobi-CG")
+    ap.add_argument("--mg-truncation", default="4,0.1",
+                    help="R[,TOL]: truncate the velocity multigrid cycle at the first level with "
+                         "c_v K_ii <= R alpha0/k M_ii, solved there by Chebyshev iteration to TOL (0: off)")
     ap.add_argument("--coarsest", type=int, default=0, help="cells across the coarsest multigrid mesh (0: default)")
     ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf"),
                     default="cavity-ipcs",
@@ -362,6 +372,7 @@ def main():
     n2g, n1g = global_dof_counts(n, n * world)
     n_dofs = 2 * n2g + n1g
 
+    _apply_truncation(ctx, args)
     opts = ctx.default_step_opts()
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = args.krylov_rtol

@@ -246,6 +246,13 @@ int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cel
  * the all-reduced right-hand side, so the small levels cost no halo exchange */
 int nsfem_mg_add_global_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* level);
 int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* opts /* may be NULL */);
+/* truncated velocity cycle for mass-dominated operators (small time steps): the first P1 level
+ * on which  c_v K_ii <= max_ratio * (alpha0/k) M_ii  for every node is solved by Chebyshev
+ * iteration to the relative accuracy coarse_tol (a-priori spectral bounds), and the levels below
+ * it -- including the dense / global coarse solve and its all-reduce -- leave the cycle.
+ * Defaults: max_ratio = 4, coarse_tol = 0.1; max_ratio = 0 disables the truncation.  Re-evaluated whenever the step size or the
+ * coefficients change. */
+int nsfem_mg_set_truncation(nsfem_ctx* ctx, double max_ratio, double coarse_tol);
 
 /* ---- multi-GPU: one process per GPU, each owning a strip of the mesh (new; the reference
  * is serial).  The context is created on the LOCAL mesh (own cell rows + one ghost row);

@@ -391,6 +391,42 @@ extern "C" int nsfem_get_state(nsfem_ctx* ctx, int slot, double* host, int64_t n
 }
 
 // ------------------------------------------------------------------ internals
+// Mass-dominated velocity operators (small time steps): on a level where the stiffness part of
+// the diagonal is at most `mg_trunc_ratio` times the mass part, a = ap M + b K is spectrally close
+// to the (well conditioned) mass matrix, lambda_min(D^-1 a) >= lambda_min(D_M^-1 M) / (1 + r) with
+// r = max_i b K_ii / (ap M_ii) and lambda_min(D_M^-1 M) = 1/2 for P1 elements (element bound) --
+// a few Chebyshev steps SOLVE that level, and every coarser level, the dense coarse solve and (on
+// partitioned meshes) the global coarse all-reduce drop out of the cycle.
+static void select_velocity_cycle_depth(nsfem_ctx* c, double ap, double b) {
+  Multigrid& mg = c->mg_v;
+  mg.active = 0;
+  if (!(c->mg_trunc_ratio > 0.0) || !(ap > 0.0) || mg.lv.size() < 3) return;
+  hipStream_t s = c->stream;
+  c->kw.ensure(nvel(c));
+  double* parts = c->kw.parts.p;
+  // level 1 = P1 on the fine mesh, level l + 2 = coarse[l]
+  for (size_t l = 1; l + 1 < mg.lv.size(); ++l) {
+    double r;
+    if (l == 1) r = diag_ratio_max(s, c->p11, c->Mp.vals.p, c->Ap.vals.p, parts);
+    else if (l - 2 < c->coarse.size())
+      r = diag_ratio_max(s, c->coarse[l - 2]->pat, c->coarse[l - 2]->M.vals.p, c->coarse[l - 2]->K.vals.p, parts);
+    else break;
+    r *= b / ap;
+    if (c->distributed()) {           // every rank must run the same cycle
+      NSFEM_HIP(hipMemcpyAsync(parts, &r, sizeof(double), hipMemcpyHostToDevice, s));
+      c->comm->allreduce_max(s, parts, 1);
+      NSFEM_HIP(hipMemcpyAsync(&r, parts, sizeof(double), hipMemcpyDeviceToHost, s));
+      NSFEM_HIP(hipStreamSynchronize(s));
+    }
+    if (r <= c->mg_trunc_ratio) {
+      mg.active = l + 1;
+      mg.trunc_lmin = 0.5 / (1.0 + r);
+      mg.trunc_tol = c->mg_trunc_tol;
+      return;
+    }
+  }
+}
+
 static void ensure_L(nsfem_ctx* c) {
   if (!c->L_dirty) return;
   // L = alpha0/k M + c_viscous K   (scalar P2; acts on all velocity components)
@@ -417,6 +453,7 @@ static void ensure_L(nsfem_ctx* c) {
       for (nsfem_ctx::P1Level* t : c->global_tail)
         launch_scale_combine(c->stream, t->pat.nnz, ap, t->M.vals.p, b, t->K.vals.p, t->Lc.vals.p);
     }
+    select_velocity_cycle_depth(c, ap, b);
     c->mg_v_dirty = true;
   }
   c->L_dirty = false;
@@ -1178,6 +1215,16 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
   ctx->mg_p_dirty = ctx->mg_v_dirty = ctx->mg_s_dirty = true;
   ctx->L_dirty = true;       // (re)compute the coarse momentum operators
   NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_mg_set_truncation(nsfem_ctx* ctx, double max_ratio, double coarse_tol) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(max_ratio >= 0.0 && coarse_tol > 0.0 && coarse_tol < 1.0, "truncation parameters out of range");
+  ctx->mg_trunc_ratio = max_ratio;
+  ctx->mg_trunc_tol = coarse_tol;
+  ctx->L_dirty = true;
   API_END(ctx)
 }
 

@@ -77,6 +77,38 @@ __global__ __launch_bounds__(256) void k_gershgorin(int n_rows, int nv,
   if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
 }
 
+// max over rows of K_ii / M_ii (both matrices on the same scalar pattern)
+__global__ __launch_bounds__(256) void k_diag_ratio(int n_rows, const int32_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col,
+                                                    const double* __restrict__ M,
+                                                    const double* __restrict__ K,
+                                                    double* __restrict__ parts) {
+  __shared__ double sh[256];
+  double best = 0.0;
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows;
+       row += gridDim.x * blockDim.x)
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+      if (col[k] == row && M[k] > 0.0) best = fmax(best, K[k] / M[k]);
+  sh[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
+}
+
+double diag_ratio_max(hipStream_t s, const Pattern& pat, const double* M, const double* K,
+                      double* parts) {
+  std::vector<double> hp(kParts);
+  hipLaunchKernelGGL(k_diag_ratio, dim3(kParts), dim3(256), 0, s, pat.n_rows, pat.rowptr.p, pat.col.p,
+                     M, K, parts);
+  NSFEM_HIP(hipGetLastError());
+  NSFEM_HIP(hipMemcpyAsync(hp.data(), parts, sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  return *std::max_element(hp.begin(), hp.end());
+}
+
 // --------------------------------------------------------------- host helpers
 // transfer matrix from CSR triplets (rows = finer level, cols = coarser level) + R = P^T
 void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* rowptr,
@@ -216,8 +248,10 @@ void Multigrid::setup_work(hipStream_t s) {
 void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular) {
   std::vector<uint8_t> cur = mask0, nxt;
   std::vector<double> hp(kParts);
-  for (size_t l = 0; l < lv.size(); ++l) {
+  const size_t n_used = truncated() ? active : lv.size();
+  for (size_t l = 0; l < n_used; ++l) {
     MGLevel& L = lv[l];
+    L.ratio = 0.0;
     const size_t n = (size_t)L.n * nv;
     NSFEM_REQUIRE(cur.size() == n, "multigrid mask size mismatch");
     if (l > 0 || own_mask0) {
@@ -239,7 +273,7 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
       NSFEM_HIP(hipStreamSynchronize(s));
     }
     if (!(L.lmax > 0.0) || !std::isfinite(L.lmax)) L.lmax = 2.0;
-    if (l + 1 < lv.size()) {
+    if (l + 1 < n_used) {
       const std::vector<int32_t>& inj = *L.h_inj;
       const MGLevel& C = lv[l + 1];
       nxt.assign((size_t)C.n * nv, 0);
@@ -251,6 +285,18 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
         }
       cur.swap(nxt);
     }
+  }
+  if (truncated()) {
+    // the last active level is solved by Chebyshev iteration over [trunc_lmin, 1.05 lmax]:
+    // error <= 2 ((sqrt(kappa) - 1) / (sqrt(kappa) + 1))^steps <= trunc_tol
+    MGLevel& T = lv[active - 1];
+    NSFEM_REQUIRE(trunc_lmin > 0.0, "truncated multigrid cycle without a lower spectral bound");
+    const double kappa = std::max(1.05 * T.lmax / trunc_lmin, 1.0 + 1e-9);
+    T.ratio = kappa;
+    const double sk = std::sqrt(kappa);
+    trunc_steps = std::max(2, (int)std::ceil(std::log(2.0 / trunc_tol) / std::log((sk + 1.0) / (sk - 1.0))));
+    ready = true;
+    return;
   }
   if (comm_active() && !smoother_only) {
     refresh_global_coarse(s, cur, singular);
@@ -364,7 +410,7 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
 
 void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1, double& c2,
                             double& rho) const {
-  const double b = 1.05 * L.lmax, a = b / eig_ratio;
+  const double b = 1.05 * L.lmax, a = b / (L.ratio > 0.0 ? L.ratio : eig_ratio);
   const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
   if (k == 0) {
     c1 = 0.0;
@@ -419,6 +465,10 @@ void Multigrid::halo_fill(hipStream_t s, const MGLevel& L, const double* v) {
 void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
+  if (truncated() && l + 1 == active) {
+    smooth(s, L, b, nullptr, x, trunc_steps);
+    return;
+  }
   if (l + 1 == lv.size()) {
     if (comm_active() && !smoother_only) {
       // gather the owned right-hand sides into the global coarse vector (ghost entries are

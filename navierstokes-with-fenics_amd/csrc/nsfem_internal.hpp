@@ -174,6 +174,8 @@ void launch_cfl_3d(hipStream_t s, const MeshDev& m, const double* u, double scal
 // extreme eigenvalues of diag(M_e)^{-1} M_e for the P2 element mass matrix (Wathen: they bound
 // the spectrum of the Jacobi-scaled assembled mass matrix on any affine mesh)
 void p2_mass_jacobi_bounds(int dim, double& lmin, double& lmax);
+// max_i K_ii / M_ii of two scalar matrices on the same pattern (stored diagonals)
+double diag_ratio_max(hipStream_t s, const Pattern& pat, const double* M, const double* K, double* parts);
 void assemble_p2_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, double* mass,
                            double* stiff);
 void assemble_p1_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p11, double* stiff,
@@ -318,6 +320,7 @@ struct MGLevel {
   DevBuf<uint8_t> own_mask;
   DevBuf<double> dinv, xa, xb, x, b, r, d;
   double lmax = 2.0;
+  double ratio = 0.0;            // > 0: Chebyshev interval [lmax / ratio, lmax] of THIS level (truncated solve)
   const BlockMat* P = nullptr;   // transfer to / from the next coarser level
   const BlockMat* R = nullptr;
   const std::vector<int32_t>* h_inj = nullptr;
@@ -355,6 +358,13 @@ struct Multigrid : Precond {
   size_t prof_n = 0;
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
   bool smoother_only = false;    // the last level is smoothed (coarse_steps), never solved globally
+  // truncated cycle (mass-dominated operators): only the first `active` levels are used and the
+  // last of them is SOLVED by `trunc_steps` Chebyshev steps over its whole spectrum
+  // [trunc_lmin, lmax] -- no coarser level, no dense / global coarse solve, no all-reduce
+  size_t active = 0;             // 0: all levels
+  double trunc_lmin = 0.0, trunc_tol = 0.1;
+  int trunc_steps = 0;
+  bool truncated() const { return active > 0 && active < lv.size(); }
   void refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>& cur, bool singular);
   void halo_fill(hipStream_t s, const MGLevel& L, const double* v);
   void setup_work(hipStream_t s);
@@ -439,9 +449,11 @@ struct nsfem_ctx {
   int64_t n_p2_global = 0, n_p1_global = 0;
   P1Level* global_coarse = nullptr;            // replicated global coarsest mesh (owned)
   std::vector<P1Level*> global_tail;           // its coarser levels, finest first (owned)
-  nsfem::Multigrid mg_p_tail, mg_v_tail;
+  nsfem::Multigrid mg_p_tail, mg_v_tail;       // replicated hierarchies below global_coarse
   nsfem::Multigrid mg_mv;                      // one level: Chebyshev solver of the velocity mass matrix
-  double mass_kappa = 0.0;       // replicated hierarchies below global_coarse
+  double mass_kappa = 0.0;
+  double mg_trunc_ratio = 4.0;                 // > 0: truncate the velocity cycle where nu K_ii <= ratio * alpha M_ii
+  double mg_trunc_tol = 0.1;
   int64_t glob_off = 0;
   // NSFEM_FORCE_COMM=1 routes a single-rank run through the communicator as well (lets a
   // one-GPU box exercise the RCCL all-reduce calls)

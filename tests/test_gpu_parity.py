@@ -659,3 +659,38 @@ def test_inexact_newton_reaches_the_reference_criterion_and_the_same_fields(sche
     p = ctx.get_state(nat.P_OLD)
     assert rel(p - p.mean(), po - po.mean()) < 1e-6
     ctx.close()
+
+
+def test_truncated_velocity_cycle_is_only_a_preconditioner_change():
+    """nsfem_mg_set_truncation: at a small time step the velocity operator alpha0/k M + c_v K is
+    mass dominated on the coarser levels; the cycle stops at the first such level and solves it by
+    Chebyshev iteration with a-priori bounds.  Same converged fields, about the same Krylov
+    iteration counts as the full cycle."""
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(64, 64)
+    res = {}
+    for ratio in (0.0, 4.0, 1.0e6):
+        ctx = context(mesh, dm)
+        attach_hierarchy(ctx, mesh, coarsest=4)
+        ctx.mg_set_truncation(ratio, 0.1)
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, *cavity_bc(dm, marks))
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-12
+        opts.momentum.precond = opts.poisson.precond = 1
+        its = 0
+        for step in range(3):
+            ctx.set_bdf(fo.bdf_alpha(step, 1.0), 2e-3)
+            info = ctx.step_ipcs(opts)
+            its += info.krylov_iterations_momentum
+            ctx.advance(0)
+        res[ratio] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), its)
+        ctx.close()
+    for ratio in (4.0, 1.0e6):
+        assert rel(res[ratio][0], res[0.0][0]) < 1e-9
+        assert rel(res[ratio][1], res[0.0][1]) < 1e-8
+    assert res[4.0][2] <= res[0.0][2] + 6
+    with pytest.raises(nat.NativeError):
+        context(mesh, dm).mg_set_truncation(-1.0, 0.1)

@@ -240,6 +240,7 @@ def cavity3d_bench(args):
     ctx.synchronize()
     if dist is not None:
         dist.barrier()
+    ctx.comm_stats(reset=True)
     t0 = time.perf_counter()
     newton = kry = poi = 0
     for i in range(args.warmup, args.warmup + args.steps):
@@ -251,6 +252,7 @@ def cavity3d_bench(args):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    comm_per_step = {k: v / args.steps for k, v in ctx.comm_stats().items()}
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -271,10 +273,10 @@ def cavity3d_bench(args):
                        "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
                        "newton_forcing": args.newton_forcing, "coarse_p1_levels": levels,
                        "parallelism": "1 GPU" if world == 1 else
-                       "%d slabs of %d cube layers, RCCL halo exchange + all-reduce" % (world, n),
+                       "%d slabs of %d cube layers, RCCL halo exchange (%s mode) + all-reduce" % (world, n, args.halo_mode),
                        "newton_its_per_step": newton / args.steps,
                        "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
-                       "host_setup_s": t_setup},
+                       "host_setup_s": t_setup, "comm_per_step_rank0": comm_per_step},
             "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<3,3,1,0> (velocity Jacobian, 3x3 block CSR)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -287,6 +289,7 @@ def cavity3d_bench(args):
 def _apply_truncation(ctx, args):
     parts = [float(v) for v in str(args.mg_truncation).split(",")]
     ctx.mg_set_truncation(parts[0], parts[1] if len(parts) > 1 else 0.1)
+    ctx.mg_set_halo_mode(args.halo_mode == "relaxed")
 
 
 def _serial_coarsest(n, dim=2):
@@ -318,6 +321,9 @@ def main():
                     help="velocity Jacobian in the step driver: 0 auto, 1 assembled, 2 matrix-free")
     ap.add_argument("--mass-solver", choices=("chebyshev", "cg"), default="chebyshev",
                     help="velocity-correction mass solve: Chebyshev with a-priori bounds (no dots) or Jacobi-CG")
+    ap.add_argument("--halo-mode", choices=("relaxed", "exact"), default="relaxed",
+                    help="N > 1: multigrid smoothing with one halo exchange per smoothing sequence "
+                         "(frozen ghosts in between) or per SpMV (the serial algorithm)")
     ap.add_argument("--mg-truncation", default="4,0.1",
                     help="R[,TOL]: truncate the velocity multigrid cycle at the first level with "
                          "c_v K_ii <= R alpha0/k M_ii, solved there by Chebyshev iteration to TOL (0: off)")
@@ -393,6 +399,7 @@ def main():
     ctx.synchronize()
     if dist is not None:
         dist.barrier()
+    ctx.comm_stats(reset=True)
     t0 = time.perf_counter()
     newton = kry = poi = 0
     for i in range(args.warmup, args.warmup + args.steps):
@@ -404,6 +411,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    comm_per_step = {k: v / args.steps for k, v in ctx.comm_stats().items()}
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -469,9 +477,10 @@ def main():
                    "preconditioner": "jacobi" if mg_levels is None else
                    "geometric multigrid, Chebyshev-Jacobi smoothing: V(0,3) momentum, V(2,2) Poisson; %d coarse P1 levels" % mg_levels,
                    "parallelism": "1 GPU" if world == 1 else
-                   "%d strips of 512 cell rows, RCCL halo exchange + all-reduce" % world,
+                   "%d strips of %d cell rows, RCCL halo exchange (%s mode) + all-reduce" % (world, n, args.halo_mode),
                    "newton_its_per_step": newton / args.steps,
-                   "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps},
+                   "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
+                   "comm_per_step_rank0": comm_per_step},
         "roofline": {"bound": "hbm",
                      "kernel": "k_spmv_stream<1,1,2,3>, finest multigrid level: Chebyshev-Jacobi smoothing step "
                                "y = x + c1 d + c2 dinv (b - L x) on the scalar P2 operator L (12.07 M nnz), "

@@ -253,6 +253,13 @@ int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* opts /* may be NULL *
  * Defaults: max_ratio = 4, coarse_tol = 0.1; max_ratio = 0 disables the truncation.  Re-evaluated whenever the step size or the
  * coefficients change. */
 int nsfem_mg_set_truncation(nsfem_ctx* ctx, double max_ratio, double coarse_tol);
+/* partitioned meshes: relaxed = 0 (default) exchanges the ghost values before every SpMV of the
+ * multigrid preconditioners, so the partitioned cycle IS the serial one; relaxed = 1 exchanges
+ * once per smoothing sequence and smooths with frozen ghost values in between (Chebyshev on the
+ * rank-local operator around the true residual: block-Jacobi across ranks, still a symmetric
+ * preconditioner) -- about a third fewer halo exchanges per step, iteration counts may differ
+ * slightly from the serial run.  Krylov operators, residuals and the mass solve stay exact. */
+int nsfem_mg_set_halo_mode(nsfem_ctx* ctx, int relaxed);
 
 /* ---- multi-GPU: one process per GPU, each owning a strip of the mesh (new; the reference
  * is serial).  The context is created on the LOCAL mesh (own cell rows + one ghost row);
@@ -272,6 +279,9 @@ int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int rank, int size
 int nsfem_comm_local_create(int size, void** group);
 void nsfem_comm_local_destroy(void* group);
 int nsfem_comm_attach_local(nsfem_ctx* ctx, void* group, int rank);
+/* communication of this rank since the last reset: out = {all-reduce calls, all-reduce payload
+ * bytes, halo exchanges, halo bytes sent}; zeros without a communicator */
+int nsfem_comm_stats(nsfem_ctx* ctx, int64_t out[4], int reset);
 
 /* ---- fused per-step drivers: replace _solve_time_step
  * (ns_ipcs_solver.py:198-208, ns_bdf_solver.py:102-106) ------------------------ */

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -160,6 +160,8 @@ def load_library(path=None):
         "nsfem_set_preconditioner_shift": (C.c_int, [vp, dbl]),
         "nsfem_p2_mass_bounds": (C.c_int, [C.c_int, pd, pd]),
         "nsfem_mg_set_truncation": (C.c_int, [vp, dbl, dbl]),
+        "nsfem_comm_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.c_int]),
+        "nsfem_mg_set_halo_mode": (C.c_int, [vp, C.c_int]),
         "nsfem_poisson_solve": (C.c_int, [vp, pd, i64, pi, pd, C.POINTER(KrylovOpts), C.POINTER(SolveInfo)]),
         "nsfem_profile_smoother": (C.c_int, [vp, C.c_int, pd, C.POINTER(i64), C.POINTER(i64)]),
         "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),
@@ -335,6 +337,15 @@ class NsfemContext:
         info = StepInfo()
         self._check(self._lib.nsfem_step_bdf(self._h, C.byref(o), C.byref(info)))
         return info
+
+    def comm_stats(self, reset=False):
+        """{allreduce_calls, allreduce_bytes, exchanges, exchange_bytes} of this rank"""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.nsfem_comm_stats(self._h, out, 1 if reset else 0))
+        return dict(zip(("allreduce_calls", "allreduce_bytes", "exchanges", "exchange_bytes"), [int(v) for v in out]))
+
+    def mg_set_halo_mode(self, relaxed):
+        self._check(self._lib.nsfem_mg_set_halo_mode(self._h, 1 if relaxed else 0))
 
     def mg_set_truncation(self, max_ratio, coarse_tol=0.1):
         self._check(self._lib.nsfem_mg_set_truncation(self._h, float(max_ratio), float(coarse_tol)))

@@ -1218,6 +1218,28 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
   API_END(ctx)
 }
 
+// communication counters of this rank since the last reset: {all-reduce calls, all-reduce payload
+// bytes, halo exchanges, halo bytes sent}
+extern "C" int nsfem_comm_stats(nsfem_ctx* ctx, int64_t out[4], int reset) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out, "null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (ctx->comm) {
+    out[0] = ctx->comm->n_allreduce; out[1] = ctx->comm->bytes_allreduce;
+    out[2] = ctx->comm->n_exchange; out[3] = ctx->comm->bytes_exchange;
+    if (reset) ctx->comm->n_allreduce = ctx->comm->bytes_allreduce = ctx->comm->n_exchange = ctx->comm->bytes_exchange = 0;
+  }
+  API_END(ctx)
+}
+
+extern "C" int nsfem_mg_set_halo_mode(nsfem_ctx* ctx, int relaxed) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  for (Multigrid* mg : {&ctx->mg_v, &ctx->mg_p, &ctx->mg_s, &ctx->mg_m}) mg->relaxed_halo = relaxed != 0;
+  ctx->graph_epoch++;
+  API_END(ctx)
+}
+
 extern "C" int nsfem_mg_set_truncation(nsfem_ctx* ctx, double max_ratio, double coarse_tol) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");

@@ -58,6 +58,7 @@ struct LocalComm : Comm {
   LocalGroup* g = nullptr;
   DevBuf<double> scratch;
   void reduce(hipStream_t s, double* dev, int64_t count, int op) {
+    count_allreduce(count);
     NSFEM_HIP(hipStreamSynchronize(s));
     g->ptr[rank] = dev;
     g->barrier();
@@ -74,6 +75,7 @@ struct LocalComm : Comm {
   void allreduce_sum(hipStream_t s, double* dev, int64_t count) override { reduce(s, dev, count, 0); }
   void allreduce_max(hipStream_t s, double* dev, int64_t count) override { reduce(s, dev, count, 1); }
   void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) override {
+    count_exchange(h, width);
     NSFEM_HIP(hipStreamSynchronize(s));
     g->ptr[rank] = vec;
     g->halo[rank] = h;
@@ -111,12 +113,15 @@ struct RcclComm : Comm {
     if (comm) (void)ncclCommDestroy(comm);
   }
   void allreduce_sum(hipStream_t s, double* dev, int64_t count) override {
+    count_allreduce(count);
     NSFEM_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, s));
   }
   void allreduce_max(hipStream_t s, double* dev, int64_t count) override {
+    count_allreduce(count);
     NSFEM_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclMax, comm, s));
   }
   void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) override {
+    count_exchange(h, width);
     const bool up = rank + 1 < size, down = rank > 0;
     NSFEM_NCCL(ncclGroupStart());
     if (up && h.send_up_cnt > 0)

@@ -42,6 +42,8 @@ struct SpmvArgs {
   double* d;
   double c1, c2;
   int nt;          // stream matrix values / column ids with non-temporal loads
+  int ghost;       // rows flagged 2 (ghosts of a partitioned mesh): 0 output 0, 1 carry x
+                   // (smoother step with frozen ghost values), 2 computed like free rows
 };
 
 template <int BR, int BC, int NV, int G, int EPI>
@@ -96,11 +98,16 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
     const size_t idx = (size_t)row * NO + lane;
     // mask values: 0 free, 1 Dirichlet (mode-dependent), 2 ghost of a partitioned mesh (the
     // owner computes the row: output 0, which also keeps ghosts out of the dot products)
-    const int mv = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    int mv = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    if (mv == 2 && a.ghost == 2) mv = 0;
     const bool m = mv != 0;
     if (mv == 2) {
-      if (EPI == EPI_CHEB) a.d[idx] = 0.0;
-      a.y[idx] = 0.0;
+      if (EPI == EPI_CHEB) {
+        a.d[idx] = 0.0;
+        a.y[idx] = a.ghost == 1 ? x[idx] : 0.0;
+      } else {
+        a.y[idx] = 0.0;
+      }
     } else if (EPI == EPI_RESID) {
       // identity rows: b - x ; zero rows: 0
       if (m)
@@ -234,11 +241,16 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
     for (; k < e; ++k) val += prod[k * NO + o];
     const size_t idx = (size_t)row * NO + o;
     const bool first = (EPI == EPI_CHEB || EPI == EPI_RESID) && t == (int)threadIdx.x;
-    const int mv = first ? pmv : ((a.maskmode != MASK_NONE) ? a.mask[idx] : 0);
+    int mv = first ? pmv : ((a.maskmode != MASK_NONE) ? a.mask[idx] : 0);
+    if (mv == 2 && a.ghost == 2) mv = 0;
     const bool m = mv != 0;
     if (mv == 2) {
-      if (EPI == EPI_CHEB) a.d[idx] = 0.0;
-      a.y[idx] = 0.0;
+      if (EPI == EPI_CHEB) {
+        a.d[idx] = 0.0;
+        a.y[idx] = a.ghost == 1 ? (first ? px : x[idx]) : 0.0;
+      } else {
+        a.y[idx] = 0.0;
+      }
     } else if (EPI == EPI_RESID) {
       const double bv = first ? pb : a.b[idx];
       if (m)
@@ -377,12 +389,15 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
     return e ? std::atoi(e) : 1;
   }();
   a.nt = nt;
+  a.ghost = 0;
   return a;
 }
 
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                 const uint8_t* rowmask, int maskmode) {
-  spmv_dispatch<EPI_STORE>(s, A, nv, make_args(x, nullptr, y, rowmask, maskmode));
+                 const uint8_t* rowmask, int maskmode, int ghost) {
+  SpmvArgs a = make_args(x, nullptr, y, rowmask, maskmode);
+  a.ghost = ghost;
+  spmv_dispatch<EPI_STORE>(s, A, nv, a);
 }
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                      double* y, const uint8_t* rowmask, int maskmode) {
@@ -406,9 +421,10 @@ void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, co
 }
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
-                      const uint8_t* rowmask) {
+                      const uint8_t* rowmask, int ghost) {
   SpmvArgs a = make_args(x, b, xout, rowmask, MASK_ZERO);
   a.dinv = dinv; a.d = d; a.c1 = c1; a.c2 = c2;
+  a.ghost = ghost;
   spmv_dispatch<EPI_CHEB>(s, A, nv, a);
 }
 

@@ -426,10 +426,12 @@ void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1
 // `steps` Chebyshev steps on A x = b.  x_in == nullptr: zero initial guess.  The result
 // is written to x_out (which may alias x_in only when steps >= 2).
 void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
-                       double* x_out, int steps) {
+                       double* x_out, int steps, bool ghosts_valid) {
   const int64_t n = (int64_t)L.n * nv;
   double rho = 0.0, c1, c2;
   const double* cur = x_in;
+  const bool relaxed = relaxed_halo && comm_active() && L.has_halo;
+  bool filled = ghosts_valid && relaxed;
   for (int k = 0; k < steps; ++k) {
     double rho_new;
     cheb_coeffs(L, k, rho, c1, c2, rho_new);
@@ -443,10 +445,13 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
                          L.d.p, out);
       NSFEM_HIP(hipGetLastError());
     } else {
-      halo_fill(s, L, cur);
+      if (!relaxed) halo_fill(s, L, cur);
+      else if (!filled && x_in != nullptr) halo_fill(s, L, cur);   // from zero: ghosts stay zero
+      filled = true;
       const bool timed = prof && &L == &lv[0] && prof_n + 2 <= prof_ev.size();
       if (timed) NSFEM_HIP(hipEventRecord(prof_ev[prof_n], s));
-      launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask);
+      launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask,
+                       relaxed && k + 1 < steps ? 1 : 0);
       if (timed) {
         NSFEM_HIP(hipEventRecord(prof_ev[prof_n + 1], s));
         prof_n += 2;
@@ -520,9 +525,12 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   }
   vcycle(s, l + 1, C.b.p, C.x.p);
   halo_fill(s, C, C.x.p);
+  const bool relaxed = relaxed_halo && comm_active() && L.has_halo;
   if (pre > 0) launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask);
-  else launch_spmv(s, *L.P, nv, C.x.p, x, L.mask, MASK_ZERO);      // x = P x_c (every row stored)
-  smooth(s, L, b, x, x, degree);
+  else launch_spmv(s, *L.P, nv, C.x.p, x, L.mask, MASK_ZERO, relaxed ? 2 : 0);   // x = P x_c (every row stored)
+  // relaxed mode without pre-smoothing: the ghost rows of x were interpolated from the (exchanged)
+  // coarse ghosts, exactly what the neighbour computes for them -> no exchange before smoothing
+  smooth(s, L, b, x, x, degree, relaxed && pre == 0);
   (void)n;
 }
 

@@ -128,8 +128,9 @@ enum MaskMode { MASK_NONE = 0, MASK_IDENTITY = 1, MASK_ZERO = 2 };
 // -------------------------- kernel launch wrappers ------------------------------
 // y = A x.  nv = number of interleaved right-hand sides the scalar blocks act on
 // (scalar P2 matrices applied to both velocity components use br=bc=1, nv=2).
+// ghost: treatment of rows flagged 2 (ghost rows of a partitioned mesh): 0 output 0, 2 computed
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                 const uint8_t* rowmask, int maskmode);
+                 const uint8_t* rowmask, int maskmode, int ghost = 0);
 // y = b - A x  (same arguments + b)
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
                      const double* b, double* y, const uint8_t* rowmask, int maskmode);
@@ -145,7 +146,7 @@ void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, co
                       double* y, const uint8_t* skipmask);
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
-                      const uint8_t* rowmask);
+                      const uint8_t* rowmask, int ghost = 0 /* 1: ghost rows keep x */);
 
 // element kernels
 struct MeshDev {
@@ -276,6 +277,13 @@ struct Comm {
   virtual void allreduce_max(hipStream_t s, double* dev, int64_t count) = 0;
   // fill the ghost ranges of `vec` (width entries per node) from the neighbouring ranks
   virtual void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) = 0;
+  // traffic counters (calls / payload bytes this rank sends), read through nsfem_comm_stats
+  int64_t n_allreduce = 0, n_exchange = 0, bytes_allreduce = 0, bytes_exchange = 0;
+  void count_allreduce(int64_t count) { ++n_allreduce; bytes_allreduce += 8 * count; }
+  void count_exchange(const HaloRange& h, int width) {
+    ++n_exchange;
+    bytes_exchange += 8 * (int64_t)width * ((rank + 1 < size ? h.send_up_cnt : 0) + (rank > 0 ? h.send_down_cnt : 0));
+  }
 };
 void launch_zero_ghost(hipStream_t s, int64_t n, const uint8_t* mask, double* x);  // x[mask==2]=0
 
@@ -358,6 +366,12 @@ struct Multigrid : Precond {
   size_t prof_n = 0;
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
   bool smoother_only = false;    // the last level is smoothed (coarse_steps), never solved globally
+  // partitioned meshes, relaxed mode: a smoothing sequence exchanges the ghost values ONCE (at
+  // its first step that reads them) and keeps them frozen afterwards -- Chebyshev iteration on
+  // the rank-local operator (block-Jacobi across ranks) around the true residual, still a
+  // symmetric preconditioner; prolongations compute the ghost rows themselves.  Default (false):
+  // one exchange per SpMV, the partitioned cycle IS the serial one.
+  bool relaxed_halo = false;
   // truncated cycle (mass-dominated operators): only the first `active` levels are used and the
   // last of them is SOLVED by `trunc_steps` Chebyshev steps over its whole spectrum
   // [trunc_lmin, lmax] -- no coarser level, no dense / global coarse solve, no all-reduce
@@ -372,7 +386,7 @@ struct Multigrid : Precond {
   void apply(hipStream_t s, const double* r, double* z) override;
   void vcycle(hipStream_t s, size_t l, const double* b, double* x);
   void smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
-              int steps);
+              int steps, bool ghosts_valid = false);
   void cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1, double& c2,
                    double& rho) const;
 };

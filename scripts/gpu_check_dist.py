@@ -13,6 +13,7 @@ use_mg = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 coarsest = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 part_coarsest = int(sys.argv[7]) if len(sys.argv) > 7 else coarsest     # partitioned levels stop here
 forcing = float(sys.argv[8]) if len(sys.argv) > 8 else 0.0
+relaxed = int(sys.argv[9]) if len(sys.argv) > 9 else 0
 
 def lid_bc(dm):
     """cavity BC on whatever boundary nodes of the unit square the (local) dof map holds"""
@@ -39,12 +40,16 @@ def run(ctx, out, key):
         opts.newton_forcing = forcing
         for o in (opts.momentum, opts.poisson, opts.correction):
             o.rtol = 1e-8
+        opts.correction.precond = 2
     infos = []
+    ctx.comm_stats(reset=True)
     for step in range(nsteps):
         ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
         infos.append(ctx.step_ipcs(opts))
         ctx.advance(0)
     out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
+    if key == 0:
+        print("comm per step (rank 0):", {k: v / nsteps for k, v in ctx.comm_stats().items()})
 
 # ---- single context reference
 mesh, dm, marks = box(n, n)
@@ -77,6 +82,7 @@ def worker(r):
         else:
             n2g, n1g = (2 * n + 1) ** 2, (n + 1) ** 2
             ctxs[r].set_partition(r, size, part.p2_ghost, part.p1_ghost, part.p2_halo, part.p1_halo, n2g, n1g)
+        ctxs[r].mg_set_halo_mode(relaxed)
         setup(ctxs[r], part.dofmap)
         run(ctxs[r], out, r)
     except Exception as e:

@@ -52,13 +52,18 @@ def _run(ctx, dm, nsteps, k, use_mg, out, key, cheb=False):
     out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
 
 
-@pytest.mark.parametrize("n,size,use_mg,tail,cheb", [(16, 2, False, False, False), (32, 4, True, False, False),
-                                                     (64, 2, True, False, False), (64, 2, True, True, False),
-                                                     (32, 2, True, False, True)])
-def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb):
+@pytest.mark.parametrize("n,size,use_mg,tail,cheb,relaxed", [
+    (16, 2, False, False, False, False), (32, 4, True, False, False, False),
+    (64, 2, True, False, False, False), (64, 2, True, True, False, False),
+    (32, 2, True, False, True, False), (64, 4, True, False, True, True), (64, 2, True, True, False, True)])
+def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, relaxed):
     """tail: the partitioned levels stop at 16 cells across and the rest of the hierarchy
     (16 -> 8 -> 4 -> 2) is the replicated global one -- still the serial algorithm.
-    cheb: the velocity correction uses the dot-product-free Chebyshev mass solve."""
+    cheb: the velocity correction uses the dot-product-free Chebyshev mass solve.
+    relaxed: nsfem_mg_set_halo_mode(1) -- frozen ghost values inside the smoothing sequences: a
+    different (block-Jacobi across ranks) but equally good preconditioner, so the converged fields
+    agree to solver tolerance, the iteration counts to within a few, and the number of halo
+    exchanges drops by about a third."""
     nsteps, k, coarsest = 3, 0.01, 2
     mesh, dm, _ = box(n, n)
     ref = {}
@@ -88,6 +93,7 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb):
             part = parts[r]
             if use_mg:
                 part.attach(ctxs[r])
+                ctxs[r].mg_set_halo_mode(relaxed)
             else:
                 ctxs[r].set_partition(r, size, part.p2_ghost, part.p1_ghost, part.p2_halo,
                                       part.p1_halo, (2 * n + 1) ** 2, (n + 1) ** 2)
@@ -110,12 +116,16 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb):
         p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
         for a, b in zip(infos, inf_ref):                 # the partitioned algorithm IS the serial one
             assert a.newton_iterations == b.newton_iterations
+            if relaxed:
+                assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= 3
+                assert abs(a.krylov_iterations_poisson - b.krylov_iterations_poisson) <= 3
+                continue
             assert a.krylov_iterations_momentum == b.krylov_iterations_momentum
             assert a.krylov_iterations_poisson == b.krylov_iterations_poisson
             if cheb:        # a-priori bounds: the step count is predicted, identical everywhere
                 assert a.krylov_iterations_correction == b.krylov_iterations_correction <= 60
-    assert rel(u, u_ref) < 1e-11
-    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-10
+    assert rel(u, u_ref) < (1e-9 if relaxed else 1e-11)
+    assert rel(p - p.mean(), p_ref - p_ref.mean()) < (1e-8 if relaxed else 1e-10)
     for r, part in enumerate(parts):                     # ghosts are copies of the owners' values
         ul, _, _ = out[r]
         assert np.abs(ul.reshape(-1, 2) - u.reshape(-1, 2)[part.p2_global]).max() < 1e-13

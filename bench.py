@@ -451,7 +451,7 @@ def main():
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9
     ms_jac, nbytes_jac = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_fetch_write_size.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_fetch_write_size.json")
     if world == 1 and n == 512 and mg_levels is not None and os.path.exists(pmc):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload:
         # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE;

@@ -86,6 +86,9 @@ class IPCSSolver(InstationarySolverBase):
             k.max_iter = self.krylov_max_iter
         if self._mg_levels is not None:
             o.momentum.precond = o.poisson.precond = 1
+        # velocity correction: Chebyshev iteration with a-priori element bounds (no dot products)
+        # unless the Jacobi-CG is asked for
+        o.correction.precond = 2 if getattr(self, "mass_solver", "chebyshev") == "chebyshev" else 0
         return o
 
     def _solve_time_step(self):
@@ -113,7 +116,8 @@ class IPCSSolver(InstationarySolverBase):
             raise RuntimeError("Newton solver did not converge")
         self.last_newton_residuals = residuals
         self._projection_solver.solve(**mg)
-        self._velocity_correction_solver.solve(**kw)
+        cheb = getattr(self, "mass_solver", "chebyshev") == "chebyshev"
+        self._velocity_correction_solver.solve(**dict(kw, precond=2 if cheb else 0))
 
     def set_initial_conditions(self, initial_conditions):
         super().set_initial_conditions(initial_conditions)

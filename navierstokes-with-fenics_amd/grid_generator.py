@@ -6,7 +6,8 @@ open_hyper_cube :211-353, HyperCubeBoundaryMarkers :36-46), producing the
 dolfin-free ``fem_mesh.Mesh`` / ``FacetMarkers`` pair.  hyper_cube / hyper_rectangle also build
 the 3D BoxMesh (Kuhn tetrahedra; the reference's 3D solver branches are "pragma: no cover",
 SURVEY.md D4, here they run).  mshr / gmsh are
-absent: spherical_shell (2D annulus) and the DFG channel are triangulated in-repo instead.
+absent: spherical_shell (2D annulus, 3D cubed-sphere shell of tetrahedra), the DFG channel and the
+backward-facing step are meshed in-repo instead.
 """
 from enum import Enum, auto
 
@@ -81,29 +82,67 @@ def hyper_rectangle(first_point, second_point, n_points=10):
 
 
 def open_hyper_cube(dim, n_points=10, openings=None):
-    """Unit square whose boundary carries ``opening`` markers on the given windows,
-    ``openings = ((position, center, width), ...)`` with position in
-    left/right/bottom/top."""
+    """Unit square / cube whose boundary carries ``opening`` markers on the given windows,
+    ``openings = ((position, center, width), ...)`` with position in left/right (x planes),
+    bottom/top (y planes), back/front (z planes, 3D); width is a float in 2D and a pair of floats
+    (the window's extent along the two in-plane axes, in axis order) in 3D
+    (reference: source/grid_generator.py:211-353)."""
     if openings is None:  # pragma: no cover
         return hyper_cube(dim, n_points)
     assert isinstance(openings, (tuple, list))
+    assert all(isinstance(o, (tuple, list)) for o in openings)
     mesh, markers = hyper_cube(dim, n_points)
     ids = HyperCubeBoundaryMarkers
     side = dict(left=(0, 0.0, ids.left), right=(0, 1.0, ids.right),
                 bottom=(1, 0.0, ids.bottom), top=(1, 1.0, ids.top))
+    if dim == 3:
+        side.update(back=(2, 0.0, ids.back), front=(2, 1.0, ids.front))
     for position, center, width in openings:
-        assert position in side, position
+        assert position in ("top", "bottom", "left", "right", "front", "back")
+        assert position in side, "front / back openings need dim == 3"
         assert isinstance(center, (tuple, list)) and len(center) == dim
-        assert isinstance(width, float) and width > 0.0
+        assert all(isinstance(x, float) for x in center)
+        if isinstance(width, float):
+            assert dim == 2
+            width = (width, )
+        else:
+            assert isinstance(width, (tuple, list)) and len(width) == dim - 1
+            assert all(isinstance(x, float) and x > 0.0 for x in width)
         axis, value, marker = side[position]
         assert abs(center[axis] - value) < 1.0e3 * 3.0e-16, "Center point is not on the boundary"
-        other = 1 - axis
-        c, half = center[other], 0.5 * width
+        others = [a for a in range(dim) if a != axis]
 
-        def window(X, a=axis, v=value, o=other, c=c, half=half):
-            return (np.abs(X[:, a] - v) < _NEAR) & (np.abs(X[:, o] - c) <= half)
+        def window(X, a=axis, v=value, others=others, center=center, width=width):
+            ok = np.abs(X[:, a] - v) < _NEAR
+            for o, w in zip(others, width):
+                ok &= np.abs(X[:, o] - center[o]) <= 0.5 * w
+            return ok
         markers.mark(window, ids.opening.value)
     return mesh, markers
+
+
+def _extract_facet_markers(geo_filename):
+    """{physical group name: id} of the ``Physical Curve`` / ``Physical Line`` statements of a
+    gmsh .geo file (reference: source/grid_generator.py:356-385)."""
+    import os
+    assert isinstance(geo_filename, str)
+    assert os.path.exists(geo_filename)
+    assert geo_filename.endswith(".geo")
+    facet_markers = dict()
+    with open(geo_filename, "r") as file:
+        for line in file:
+            if "Physical Curve" not in line and "Physical Line" not in line:
+                continue
+            inner = line[line.index("(") + 1: line.index(")")]
+            assert "," in inner
+            description, number = inner.split(",")
+            number = number.strip()
+            assert number.isnumeric()
+            description = description.strip().strip("'").strip('"')
+            assert description.replace(" ", "").isalpha()
+            assert description not in facet_markers
+            facet_markers[description] = int(number)
+    return facet_markers
 
 
 # ---------------------------------------------------------------------------------------------
@@ -212,14 +251,96 @@ def dfg_channel(m=4, n_refine=0, grading=1.3):
 # with projection of new boundary vertices onto the two circles, so it carries a multigrid
 # hierarchy.  ``n_points`` keeps mshr's meaning: about n_points cells across the diameter.
 # ---------------------------------------------------------------------------------------------
+def _spherical_shell_3d(ri, ro, n_points):
+    """Tetrahedral mesh of the shell ri <= |x| <= ro (the reference meshes it with mshr, which is
+    absent): a cubed sphere -- the six faces of a cube, each an m x m grid, projected radially and
+    extruded through n_r layers -- whose hexahedra are cut into 24 tetrahedra around their centre
+    and face centres, so neighbouring hexahedra (also across the patch seams) share the same face
+    triangulation.  Face centres on the two boundaries are projected onto the spheres."""
+    from fem_mesh import Mesh
+    h = 2.0 * ro / max(n_points, 1)
+    m = max(2, int(round(0.5 * np.pi * ro / h / 2.0)))         # cells along a patch edge
+    n_r = max(1, int(round((ro - ri) / h / 2.0)))
+    g = np.linspace(-1.0, 1.0, m + 1)
+    g = np.tan(0.25 * np.pi * g)                                # equi-angular cubed sphere
+    # surface lattice points of the cube [-1,1]^3, unique ids through the integer lattice key
+    key_to_id, dirs = {}, []
+
+    def surf_id(i, j, k):
+        key = (i, j, k)
+        if key not in key_to_id:
+            key_to_id[key] = len(dirs)
+            v = np.array([g[i], g[j], g[k]])
+            dirs.append(v / np.linalg.norm(v))
+        return key_to_id[key]
+
+    quads = []
+    for axis in range(3):
+        for side in (0, m):
+            for a in range(m):
+                for b in range(m):
+                    corner = []
+                    for da, db in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                        idx = [0, 0, 0]
+                        idx[axis] = side
+                        idx[(axis + 1) % 3] = a + da
+                        idx[(axis + 2) % 3] = b + db
+                        corner.append(surf_id(*idx))
+                    quads.append(corner)
+    dirs = np.array(dirs)
+    n_s = dirs.shape[0]
+    radii_l = np.linspace(ri, ro, n_r + 1)
+    coords = [r * dirs for r in radii_l]                        # layer l: ids l * n_s + surface id
+    coords = list(np.concatenate(coords, axis=0))
+    extra = {}
+
+    def centre(ids, radius=None):
+        key = tuple(sorted(ids))
+        if key not in extra:
+            c = np.mean([coords[i] for i in ids], axis=0)
+            if radius is not None:
+                c *= radius / np.linalg.norm(c)
+            extra[key] = len(coords)
+            coords.append(c)
+        return extra[key]
+
+    cells = []
+    for layer in range(n_r):
+        lo, hi = layer * n_s, (layer + 1) * n_s
+        for q in quads:
+            bot = [lo + v for v in q]
+            top = [hi + v for v in q]
+            hexa = bot + top
+            cc = centre(hexa)
+            faces = [(bot, ri if layer == 0 else None), (top, ro if layer == n_r - 1 else None)]
+            for e in range(4):
+                f = (e + 1) % 4
+                faces.append(([bot[e], bot[f], top[f], top[e]], None))
+            for quad, radius in faces:
+                fc = centre(quad, radius)
+                for e in range(4):
+                    cells.append((quad[e], quad[(e + 1) % 4], fc, cc))
+    mesh = Mesh(np.array(coords), np.array(cells, dtype=np.int32))
+    ids = SphericalAnnulusBoundaryMarkers
+    marks = FacetMarkers(mesh, 0)
+    rv = np.linalg.norm(mesh.coords, axis=1)
+    bf = np.nonzero(mesh.facet_on_boundary)[0]
+    inner = np.abs(rv[mesh.facets[bf, 0]] - ri) < 1e-9 * ro
+    marks.values[bf[inner]] = ids.interior_boundary.value
+    marks.values[bf[~inner]] = ids.exterior_boundary.value
+    return mesh, marks
+
+
 def spherical_shell(dim, radii, n_points=10):
     from fem_mesh import Mesh
     from multigrid import refinement_hierarchy
-    assert isinstance(dim, int) and dim == 2, "only the 2D annulus is built (SURVEY.md D4)"
+    assert isinstance(dim, int) and dim in (2, 3)
     assert isinstance(radii, (list, tuple)) and len(radii) == 2
     ri, ro = radii
     assert isinstance(ri, float) and ri > 0.0 and isinstance(ro, float) and ro > ri
     assert isinstance(n_points, int) and n_points >= 0
+    if dim == 3:
+        return _spherical_shell_3d(ri, ro, n_points)
     h = 2.0 * ro / max(n_points, 1)
     n_r = max(1, int(round((ro - ri) / h)))
     n_refine = 0

@@ -282,3 +282,47 @@ def test_p2_mass_element_bounds():
     lo, hi = C.c_double(), C.c_double()
     lib.nsfem_p2_mass_bounds(2, C.byref(lo), C.byref(hi))
     assert abs(ev[0] - lo.value) < 1e-10 and abs(ev[-1] - hi.value) < 1e-10
+
+
+def test_grid_generator_entry_points_of_the_reference_tests(tmp_path):
+    """tests/test_grid_generator.py:17-55 of the reference: every call it makes must construct a
+    mesh; plus the properties the solver relies on (conformity, marker ids, radii)."""
+    from grid_generator import (HyperCubeBoundaryMarkers as H, SphericalAnnulusBoundaryMarkers as S,
+                                _extract_facet_markers, hyper_cube, hyper_rectangle, open_hyper_cube,
+                                spherical_shell)
+    hyper_cube(2, 8), hyper_cube(3, 8)
+    hyper_rectangle((0.0, 0.0), (10.0, 1.0), 10), hyper_rectangle((0.0, 0.0), (10.0, 1.0), (50, 5))
+    hyper_rectangle((0.0, 0.0, 0.0), (10.0, 1.0, 2.0), 8)
+    hyper_rectangle((0.0, 0.0, 0.0), (10.0, 1.0, 2.0), (50, 5, 10))
+    openings = (("left", (0.0, 0.5), 0.1), ("right", (1.0, 0.7), 0.1), ("bottom", (0.7, 0.0), 0.05),
+                ("top", (0.5, 1.0), 0.8))
+    _, marks = open_hyper_cube(2, 8, openings)
+    assert H.opening.value in marks.ids()
+    openings = (("left", (0.0, 0.5, 0.5), (0.1, 0.2)), ("right", (1.0, 0.7, 0.3), (0.1, 0.1)),
+                ("bottom", (0.7, 0.0, 0.7), (0.05, 0.2)), ("top", (0.5, 1.0, 0.2), (0.8, 0.8)),
+                ("back", (0.7, 0.3, 0.0), (0.05, 0.1)), ("front", (0.5, 0.25, 1.0), (0.2, 0.3)))
+    mesh, marks = open_hyper_cube(3, 8, openings)
+    opening = marks.facets_with_id(H.opening.value)
+    # only the "top" window (0.8 x 0.8 around (0.5, ., 0.2), clipped by the cube) holds whole faces
+    mid = mesh.facet_midpoints()[opening]
+    assert opening.size == 48 and np.abs(mid[:, 1] - 1.0).max() < 1e-14
+    assert marks.ids() == {1, 2, 3, 4, 5, 6, 7}
+    with pytest.raises(AssertionError):
+        open_hyper_cube(2, 8, (("front", (0.5, 0.5), 0.1), ))
+    spherical_shell(2, (0.3, 1.0), 25)
+    mesh, marks = spherical_shell(3, (0.3, 1.0), 25)
+    # conforming: 4 faces per cell = 2 x interior faces + boundary faces
+    assert 4 * mesh.cells.shape[0] == 2 * (mesh.facets.shape[0] - mesh.facet_on_boundary.sum()) + \
+        mesh.facet_on_boundary.sum()
+    x = mesh.coords[mesh.cells]
+    vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / 6.0
+    assert vol.min() > 0.0 and abs(vol.sum() / (4.0 / 3.0 * np.pi * (1.0 - 0.3 ** 3)) - 1.0) < 0.01
+    for marker, radius in ((S.interior_boundary, 0.3), (S.exterior_boundary, 1.0)):
+        f = marks.facets_with_id(marker.value)
+        assert f.size > 0
+        assert np.abs(np.linalg.norm(mesh.coords[mesh.facets[f]], axis=2) - radius).max() < 1e-12
+    assert marks.ids() == {S.interior_boundary.value, S.exterior_boundary.value}
+    geo = tmp_path / "Example.geo"
+    geo.write_text('Point(1) = {0, 0, 0};\nPhysical Curve("inlet", 100) = {1};\n'
+                   "Physical Line('upper wall', 101) = {2, 3};\nPhysical Surface(\"fluid\", 5) = {1};\n")
+    assert _extract_facet_markers(str(geo)) == {"inlet": 100, "upper wall": 101}

@@ -396,16 +396,28 @@ def _locate_file(basename):
 
 
 def _read_external_mesh(basename):
-    """-> (mesh, facet markers, {physical name: id}) from ``<basename>.msh``."""
+    """-> (mesh, facet markers, {physical name: id}) from ``<basename>.msh`` or, when only the
+    reference's converted files are supplied, from the XDMF pair ``<basename>.xdmf`` /
+    ``<basename>_facet_markers.xdmf`` of ``grid_tools.generate_xdmf_mesh`` (the marker names
+    then come from the .geo file, as in the reference: source/grid_generator.py:406-437)."""
     from mesh_io import read_msh
     assert isinstance(basename, str) and basename.endswith(".geo")
     msh_file = _locate_file(basename.replace(".geo", ".msh"))
-    if msh_file is None:
+    if msh_file is not None:
+        mesh, markers, names, _ = read_msh(msh_file)
+        return mesh, markers, {name: tag for name, (dim, tag) in names.items() if dim == mesh._dim - 1}
+    xdmf_file = _locate_file(basename.replace(".geo", ".xdmf"))
+    facet_file = _locate_file(basename.replace(".geo", "_facet_markers.xdmf"))
+    if xdmf_file is None or facet_file is None:
         raise FileNotFoundError(
             "%s not found below the working directory: generate it with `gmsh -2 -format msh41 %s` "
             "(gmsh itself is not available in this environment)" % (basename.replace(".geo", ".msh"), basename))
-    mesh, markers, names, _ = read_msh(msh_file)
-    return mesh, markers, {name: tag for name, (dim, tag) in names.items() if dim == 1}
+    from grid_tools import read_xdmf_mesh
+    mesh, markers, _ = read_xdmf_mesh(xdmf_file, facet_file)
+    geo_file = _locate_file(basename)
+    names = _extract_facet_markers(geo_file) if geo_file is not None else \
+        {str(v): v for v in sorted(markers.ids(boundary_only=False)) if v != 0}
+    return mesh, markers, names
 
 
 class BackwardFacingStepMarkers(Enum):

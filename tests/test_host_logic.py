@@ -252,7 +252,8 @@ def test_reference_module_names_resolve():
                                                  "FunctionTime")),
                           ("grid_generator", ("hyper_cube", "hyper_rectangle", "open_hyper_cube",
                                               "spherical_shell", "channel_with_cylinder", "blasius_plate",
-                                              "backward_facing_step"))):
+                                              "backward_facing_step", "_extract_facet_markers")),
+                          ("grid_tools", ("generate_xdmf_mesh",))):
         mod = importlib.import_module(module)
         for name in names:
             assert hasattr(mod, name), (module, name)

@@ -226,3 +226,35 @@ def test_velocity_potential_post_processing():
     assert prob._get_boundary_conditions_map() == {VelocityBCType.no_slip: (M.bottom.value, ),
                                                    VelocityBCType.no_normal_flux: (M.left.value, )}
     ctx.close()
+
+
+def test_grid_tools_xdmf_mesh_conversion_and_ingest(tmp_path):
+    """grid_tools.generate_xdmf_mesh (reference source/grid_tools.py:70-121): .msh -> the XDMF
+    pair (cells + cell_markers, boundary facets + facet_markers, XML light data), read back by
+    read_xdmf_mesh; grid_generator picks the pair up when the .msh itself is not supplied and
+    takes the marker names from the .geo file."""
+    import grid_generator as gg
+    from grid_tools import generate_xdmf_mesh, read_xdmf_mesh
+    mesh, marks = gg.dfg_channel(2, 0)
+    os.makedirs("meshes")
+    geo = os.path.join("meshes", "DFGBenchmark.geo")
+    with open(geo, "w") as fh:
+        fh.write('Physical Curve("inlet", 1) = {1};\nPhysical Curve("outlet", 2) = {2};\n'
+                 'Physical Curve("bottom", 3) = {3};\nPhysical Curve("top", 4) = {4};\n'
+                 'Physical Curve("cylinder", 5) = {5, 6};\nPhysical Surface("fluid", 1) = {1};\n')
+    with pytest.raises(RuntimeError):                      # no gmsh here and no .msh yet
+        generate_xdmf_mesh(geo)
+    msh = os.path.join("meshes", "DFGBenchmark.msh")
+    write_msh(msh, mesh, marks, {"inlet": (1, 1), "cylinder": (1, 5), "fluid": (2, 1)})
+    xdmf_file, facet_file = generate_xdmf_mesh(geo)
+    assert xdmf_file.endswith("DFGBenchmark.xdmf") and facet_file.endswith("DFGBenchmark_facet_markers.xdmf")
+    assert 'Name="cell_markers"' in open(xdmf_file).read()
+    assert 'Name="facet_markers"' in open(facet_file).read() and "Polyline" in open(facet_file).read()
+    mesh2, marks2, cell_markers = read_xdmf_mesh(xdmf_file, facet_file)
+    assert np.array_equal(np.sort(mesh2.cells, axis=1), np.sort(mesh.cells, axis=1))      # (write_msh orients)
+    assert np.abs(mesh2.coords - mesh.coords).max() == 0.0
+    assert np.array_equal(marks2.values, marks.values) and (cell_markers == 1).all()
+    os.remove(msh)                                          # only the converted files are left
+    mesh3, marks3, names = gg.channel_with_cylinder()
+    assert names == {"inlet": 1, "outlet": 2, "bottom": 3, "top": 4, "cylinder": 5}
+    assert np.array_equal(marks3.values, marks.values) and mesh3.num_cells() == mesh.num_cells()

@@ -221,5 +221,14 @@ def evaluate(value, X):
     return np.tile(arr, (X.shape[0], 1))
 
 
+def __getattr__(name):
+    # dolfin.Function / FunctionSpace / project stand-ins live in fem_spaces (imported lazily:
+    # fem_spaces itself evaluates values through this module)
+    if name in ("Function", "FunctionSpace", "project"):
+        import fem_spaces
+        return getattr(fem_spaces, name)
+    raise AttributeError(name)
+
+
 def is_time_dependent(value):
     return hasattr(value, "_params") and any(k in value._params for k in ("t", "time"))

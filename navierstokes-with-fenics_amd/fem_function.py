@@ -42,23 +42,8 @@ class DeviceFunction:
 
     def __call__(self, point):
         """Point evaluation (host side, brute-force cell search; for tests/diagnostics)."""
-        dm = self._solver._dofmap
-        mesh = dm.mesh
-        dim = dm.dim
-        p = np.asarray(point, dtype=np.float64)[:dim]
-        x = mesh.coords[mesh.cells.astype(np.int64)]
-        J = np.transpose(x[:, 1:] - x[:, :1], (0, 2, 1))             # columns = edge vectors
-        ref = np.linalg.solve(J, (p[None, :] - x[:, 0])[:, :, None])[:, :, 0]
-        inside = np.nonzero((ref > -1e-12).all(axis=1) & (ref.sum(axis=1) < 1.0 + 1e-12))[0]
-        if inside.size == 0:
-            raise RuntimeError("point outside of the mesh")
-        c = int(inside[0])
-        l = np.concatenate([[1.0 - ref[c].sum()], ref[c]])
-        if self.field == "pressure":
-            return float(l @ self.vector()[dm.p1_dofmap[c]])
-        pairs = ((1, 2), (0, 2), (0, 1)) if dim == 2 else ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
-        N = np.array([li * (2 * li - 1) for li in l] + [4 * l[a] * l[b] for a, b in pairs])
-        return N @ self.nodal_values()[dm.p2_dofmap[c]]
+        from fem_spaces import evaluate_lagrange
+        return evaluate_lagrange(self._solver._dofmap, self.field, self.vector(), point)
 
 
 class MixedFunction:

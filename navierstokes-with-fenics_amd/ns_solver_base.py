@@ -226,7 +226,8 @@ class SolverBase:
         self._ctx = nat.NsfemContext(self._mesh.coords, self._mesh.cells, dm.p2_dofmap,
                                      dm.p1_dofmap, dm.n_p2, dm.n_p1, device=self._device)
         self._n_dofs = dm.n_dofs
-        self._Wh = dm
+        from fem_spaces import FunctionSpace
+        self._Wh = FunctionSpace(dm, "mixed")
         print("Number of cells {0}, number of DoFs: {1}".format(self._n_cells, self._n_dofs))
         # geometric multigrid hierarchy for the Krylov preconditioners (structured meshes
         # coarsen; any mesh gets at least the P2 -> P1 two-level hierarchy)
@@ -236,6 +237,70 @@ class SolverBase:
             # P2 -> P1 hierarchy is built)
             self._mg_levels = attach_hierarchy(self._ctx, None if periodic else self._mesh)
         self._push_coefficients()
+
+    # sub-space access and mixed <-> split assignment (reference :213-300, :424-476) -----------
+    def _get_subspaces(self):
+        """{"velocity": ..., "pressure": ...}: the collapsed sub-spaces of ``_Wh`` (created once)."""
+        assert hasattr(self, "_Wh")
+        if not hasattr(self, "_WhSub"):
+            self._WhSub = {key: self._Wh.sub(index).collapse()
+                           for key, index in self._field_association.items()}
+        return self._WhSub
+
+    def _get_subspace(self, field):
+        assert field in self._field_association
+        return self._get_subspaces()[field]
+
+    def _assign_function(self, receiving_functions, assigning_functions):
+        """Copy between a function on the joint space (or one of its ``split()`` parts) and
+        functions on the collapsed sub-spaces, in either direction; both arguments may be a
+        function or a ``{field: function}`` dictionary, exactly the combinations the reference
+        accepts (source/ns_solver_base.py:213-300)."""
+        assert hasattr(self, "_Wh")
+        spaces = self._get_subspaces()
+        is_function = lambda f: hasattr(f, "function_space") and hasattr(f, "vector")
+        assert is_function(receiving_functions) or isinstance(receiving_functions, dict)
+        assert is_function(assigning_functions) or isinstance(assigning_functions, dict)
+
+        def field_of(function):
+            for key, space in spaces.items():
+                if function in space:
+                    return key
+            return None
+
+        def joint_part(function, key):
+            """the storage of field ``key`` inside a function on Wh or on Wh.sub(index)"""
+            index = self._field_association[key]
+            if function in self._Wh:
+                return function.sub(index)
+            assert function in self._Wh.sub(index)
+            return function
+
+        if isinstance(receiving_functions, dict):
+            forward, pairs = True, receiving_functions
+        elif isinstance(assigning_functions, dict):
+            forward, pairs = False, assigning_functions
+        else:
+            key = field_of(receiving_functions)
+            forward = key is not None
+            if forward:
+                pairs = {key: receiving_functions}
+            else:
+                key = field_of(assigning_functions)
+                assert key is not None
+                pairs = {key: assigning_functions}
+        assert 1 <= len(pairs) <= 2
+        assert all(function in spaces[key] for key, function in pairs.items())
+        joint = assigning_functions if forward else receiving_functions
+        assert is_function(joint)
+        if len(pairs) == 2:
+            assert joint in self._Wh
+        for key, function in pairs.items():
+            part = joint_part(joint, key)
+            if forward:
+                function.assign(part)
+            else:
+                part.assign(function)
 
     def _push_coefficients(self):
         if hasattr(self, "_ctx") and hasattr(self, "_equation_coefficients"):

@@ -327,3 +327,72 @@ def test_grid_generator_entry_points_of_the_reference_tests(tmp_path):
     geo.write_text('Point(1) = {0, 0, 0};\nPhysical Curve("inlet", 100) = {1};\n'
                    "Physical Line('upper wall', 101) = {2, 3};\nPhysical Surface(\"fluid\", 5) = {1};\n")
     assert _extract_facet_markers(str(geo)) == {"inlet": 100, "upper wall": 101}
+
+
+def test_function_assigner_host_logic():
+    """The assertions of the reference's tests/test_function_assigner.py:26-72 (forward / backward
+    assignment between the joint Taylor-Hood space and its collapsed sub-spaces, with and without
+    dictionaries, point values of projected constants) on the host-side function spaces -- the
+    dof map stands in for the device context, which this logic never touches."""
+    import dlfn_compat as dlfn
+    from fem_mesh import TaylorHoodDofMap
+    from fem_spaces import FunctionSpace
+    from grid_generator import hyper_cube
+    from ns_solver_base import SolverBase
+    mesh, boundary_markers = hyper_cube(2, 5)
+    solver = SolverBase(mesh, boundary_markers)
+    solver._Wh = FunctionSpace(TaylorHoodDofMap(mesh), "mixed")
+    Wh = solver._Wh
+    WhSub = solver._get_subspaces()
+    assert solver._get_subspace("velocity") is WhSub["velocity"]
+    solution = dlfn.Function(Wh)
+    solution_dict = {"velocity": dlfn.Function(WhSub["velocity"]), "pressure": dlfn.Function(WhSub["pressure"])}
+    assert solution in Wh and solution_dict["velocity"] in WhSub["velocity"]
+    assert solution.split()[0] in Wh.sub(0) and solution.split()[0] not in WhSub["velocity"]
+    # forward assignment
+    dlfn.project(dlfn.Constant((1.0, 2.0, 3.0)), Wh, function=solution)
+    solver._assign_function(solution_dict, solution)
+    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([1.0, 2.0]))
+    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([3.0]))
+    # forward assignment split
+    dlfn.project(dlfn.Constant((10.0, 20.0, 30.0)), Wh, function=solution)
+    velocity, pressure = solution.split()
+    solver._assign_function({"velocity": solution_dict["velocity"]}, velocity)
+    solver._assign_function({"pressure": solution_dict["pressure"]}, pressure)
+    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([10.0, 20.0]))
+    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([30.0]))
+    # forward assignment split / no dict
+    dlfn.project(dlfn.Constant((100.0, 200.0, 300.0)), Wh, function=solution)
+    solver._assign_function(solution_dict["velocity"], velocity)
+    solver._assign_function(solution_dict["pressure"], pressure)
+    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([100.0, 200.0]))
+    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([300.0]))
+    # backward assignment
+    dlfn.project(dlfn.Constant((-1.0, -2.0)), WhSub["velocity"], function=solution_dict["velocity"])
+    dlfn.project(dlfn.Constant(-3.0), WhSub["pressure"], function=solution_dict["pressure"])
+    solver._assign_function(solution, solution_dict)
+    assert np.allclose(solution(0.1, 0.1), np.array([-1.0, -2.0, -3.0]))
+    # backward assignment split
+    dlfn.project(dlfn.Constant((-10.0, -20.0)), WhSub["velocity"], function=solution_dict["velocity"])
+    dlfn.project(dlfn.Constant(-30.0), WhSub["pressure"], function=solution_dict["pressure"])
+    velocity, pressure = solution.split()
+    solver._assign_function(velocity, {"velocity": solution_dict["velocity"]})
+    assert np.allclose(solution(0.1, 0.1), np.array([-10.0, -20.0, -3.0]))
+    solver._assign_function(pressure, {"pressure": solution_dict["pressure"]})
+    assert np.allclose(solution(0.1, 0.1), np.array([-10.0, -20.0, -30.0]))
+    # backward assignment split / no dict
+    dlfn.project(dlfn.Constant((-100.0, -200.0)), WhSub["velocity"], function=solution_dict["velocity"])
+    dlfn.project(dlfn.Constant(-300.0), WhSub["pressure"], function=solution_dict["pressure"])
+    solver._assign_function(velocity, solution_dict["velocity"])
+    assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -30.0]))
+    solver._assign_function(pressure, solution_dict["pressure"])
+    assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -300.0]))
+    # misuse is refused
+    with pytest.raises(AssertionError):
+        solver._assign_function(solution, solution)
+    with pytest.raises(AssertionError):
+        solver._assign_function({"velocity": solution_dict["pressure"]}, solution)
+    # non-constant data: a P2-representable field survives the round trip exactly
+    u = dlfn.project(dlfn.Expression(("x[0]*x[1]", "1.0 - x[1]*x[1]"), degree=2), WhSub["velocity"])
+    solver._assign_function(solution, {"velocity": u})
+    assert np.allclose(solution(0.3, 0.7)[:2], [0.21, 0.51])

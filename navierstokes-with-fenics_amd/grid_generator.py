@@ -36,6 +36,22 @@ class SphericalAnnulusBoundaryMarkers(Enum):
     exterior_boundary = auto()
 
 
+class GeometryType(Enum):
+    """geometry tags of the reference (source/grid_generator.py:11-15)"""
+    spherical_annulus = auto()
+    rectangle = auto()
+    square = auto()
+    other = auto()
+
+
+class SymmetricPipeBoundaryMarkers(Enum):
+    """physical ids of the gmsh pipe geometry (source/grid_generator.py:26-33)"""
+    wall = 100
+    symmetry = 101
+    inlet = 102
+    outlet = 103
+
+
 def _mark_box(mesh, lo, hi):
     markers = FacetMarkers(mesh, 0)
     ids = HyperCubeBoundaryMarkers

@@ -338,6 +338,19 @@ __global__ __launch_bounds__(256) void k3_conv_jac(int nc, const double* __restr
 #pragma unroll
             for (int b = 0; b < 3; ++b) acc[j][a * 3 + b] += wpi * pj * G[a][b];
         }
+      } else if (FORM == 1) {
+        // rotational: d/dv_(j,b) of [curl(u) x v + curl(v) x u]_a
+        //   = phi_j eps_(a c b) curl(u)_c  +  (u . g_j) d_ab - u_b g_j,a      (Picard: first term)
+        const double wu[3] = {G[2][1] - G[1][2], G[0][2] - G[2][0], G[1][0] - G[0][1]};
+        const double cx[3][3] = {{0.0, -wu[2], wu[1]}, {wu[2], 0.0, -wu[0]}, {-wu[1], wu[0], 0.0}};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            double t = pj * cx[a][b];
+            if (!PICARD) t += (a == b ? udg : 0.0) - uq[b] * gk[j][a];
+            acc[j][a * 3 + b] += wpi * t;
+          }
       } else if (FORM == 2) {
         const double hd = 0.5 * div * pj;
 #pragma unroll
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256) void k3_conv_jac(int nc, const double* __restr
 //   LIN = 0   r_(i,a) = int c(u)_a phi_i                          (residual)
 //   LIN = 1   r_(i,a) = int [d c(u)/du . v]_a phi_i               (Newton matrix times v)
 //   LIN = 2   Picard linearisation times v (source/ns_solver_base.py:478-499)
-// forms: 0 standard (grad u) u; 2 divergence + 1/2 div(u) u; 3 skew-symmetric
+// forms: 0 standard (grad u) u; 1 rotational curl(u) x u; 2 divergence + 1/2 div(u) u; 3 skew-symmetric
 //   1/2 [ (grad u) u . phi - ((grad phi) u) . u ]
 template <int FORM, int LIN>
 __global__ __launch_bounds__(256) void k3_conv_cell(int nc, const double* __restrict__ vx,
@@ -426,7 +439,9 @@ __global__ __launch_bounds__(256) void k3_conv_cell(int nc, const double* __rest
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double adv_u = Gu[a][0] * uq[0] + Gu[a][1] * uq[1] + Gu[a][2] * uq[2];     // (grad u) u
-      if (LIN == 0) {
+      if (FORM == 1) {
+        f[a] = 0.0;              // rotational form: set after the loop (needs all components)
+      } else if (LIN == 0) {
         f[a] = adv_u + (FORM == 2 ? 0.5 * divu * uq[a] : 0.0);
       } else {
         const double gv_u = Gv[a][0] * uq[0] + Gv[a][1] * uq[1] + Gv[a][2] * uq[2];    // (grad v) u
@@ -438,6 +453,21 @@ __global__ __launch_bounds__(256) void k3_conv_cell(int nc, const double* __rest
         }
       }
       if (FORM == 3) f[a] *= 0.5;
+    }
+    if (FORM == 1) {
+      // curl(u) x u ; Newton: curl(v) x u + curl(u) x v ; Picard: curl(u) x v
+      // (source/ns_solver_base.py:384, :492)
+      const double wu[3] = {Gu[2][1] - Gu[1][2], Gu[0][2] - Gu[2][0], Gu[1][0] - Gu[0][1]};
+      const double* z = LIN ? vq : uq;                       // curl(u) x z
+      f[0] = wu[1] * z[2] - wu[2] * z[1];
+      f[1] = wu[2] * z[0] - wu[0] * z[2];
+      f[2] = wu[0] * z[1] - wu[1] * z[0];
+      if (LIN == 1) {
+        const double wv[3] = {Gv[2][1] - Gv[1][2], Gv[0][2] - Gv[2][0], Gv[1][0] - Gv[0][1]};
+        f[0] += wv[1] * uq[2] - wv[2] * uq[1];
+        f[1] += wv[2] * uq[0] - wv[0] * uq[2];
+        f[2] += wv[0] * uq[1] - wv[1] * uq[0];
+      }
     }
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
@@ -562,12 +592,13 @@ void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22,
   switch (form * 2 + (picard ? 1 : 0)) {
     case 0: NSFEM_CJ3(0, false); break;
     case 1: NSFEM_CJ3(0, true); break;
+    case 2: NSFEM_CJ3(1, false); break;
+    case 3: NSFEM_CJ3(1, true); break;
     case 4: NSFEM_CJ3(2, false); break;
     case 5: NSFEM_CJ3(2, true); break;
     case 6: NSFEM_CJ3(3, false); break;
     case 7: NSFEM_CJ3(3, true); break;
-    default: throw Error(NSFEM_ERR_ARG, "convective form not available on tetrahedral meshes "
-                                        "(standard, divergence, skew_symmetric are)");
+    default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
   }
 #undef NSFEM_CJ3
   hipLaunchKernelGGL(k3_jac_gather, dim3(grid3((int64_t)p22.nnz * 9)), dim3(kBlock), 0, s, p22.nnz,
@@ -582,10 +613,10 @@ static void launch_conv_cell(hipStream_t s, const MeshDev& m, const double* u, c
   hipLaunchKernelGGL((k3_conv_cell<F, LIN>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, v, cc, m.rbuf.p)
   switch (form) {
     case 0: NSFEM_CC3(0); break;
+    case 1: NSFEM_CC3(1); break;
     case 2: NSFEM_CC3(2); break;
     case 3: NSFEM_CC3(3); break;
-    default: throw Error(NSFEM_ERR_ARG, "convective form not available on tetrahedral meshes "
-                                        "(standard, divergence, skew_symmetric are)");
+    default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
   }
 #undef NSFEM_CC3
   NSFEM_HIP(hipGetLastError());

@@ -99,6 +99,12 @@ def p2_basis(pts):
     return phi, dphi
 
 
+_LEVI_CIVITA = np.zeros((3, 3, 3))
+for _i, _j, _k in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+    _LEVI_CIVITA[_i, _j, _k] = 1.0
+    _LEVI_CIVITA[_i, _k, _j] = -1.0
+
+
 class Geometry:
     """Affine maps of all cells: detJ (absolute), J^{-T}."""
 
@@ -223,9 +229,13 @@ class Space:
         if form == "standard":
             f = adv
             be = np.einsum("cq,cqa,qi->cia", self.wdet, f, self.phi2)
+        elif form == "rotational" and self.dim == 3:
+            # cross(curl(u), u), source/ns_solver_base.py:384:  f_a = eps_acd curl_c u_d,
+            # curl_c = eps_cef d_e u_f  (gu[f, e] = d_e u_f)
+            curl = np.einsum("xef,cqfe->cqx", _LEVI_CIVITA, gu)
+            f = np.einsum("axd,cqx,cqd->cqa", _LEVI_CIVITA, curl, uq)
+            be = np.einsum("cq,cqa,qi->cia", self.wdet, f, self.phi2)
         elif form == "rotational":
-            if self.dim != 2:
-                raise NotImplementedError("rotational form: 2D only")
             curl = gu[:, :, 1, 0] - gu[:, :, 0, 1]
             f = np.stack([-curl * uq[:, :, 1], curl * uq[:, :, 0]], axis=2)
             be = np.einsum("cq,cqa,qi->cia", self.wdet, f, self.phi2)
@@ -267,6 +277,13 @@ class Space:
             udgi = np.einsum("cqb,cqib->cqi", uq, g)
             T6 = np.einsum("cq,cqi,qj,ab->ciajb", w, udgi, phi, d)
             Je = 0.5 * (T1 + T2) - 0.5 * (T5 + T6)
+        elif form == "rotational" and self.dim == 3:
+            E = _LEVI_CIVITA
+            curl = np.einsum("xef,cqfe->cqx", E, gu)
+            # d f_a / d u_(j,b) = eps_axb curl_x phi_j + eps_axd eps_xeb d_e phi_j u_d
+            Ta = np.einsum("cq,qi,axb,cqx,qj->ciajb", w, phi, E, curl, phi)
+            Tb = np.einsum("cq,qi,axd,xeb,cqje,cqd->ciajb", w, phi, E, E, g, uq)
+            Je = Ta + Tb
         elif form == "rotational":
             curl = gu[:, :, 1, 0] - gu[:, :, 0, 1]
             # f_a = eps_a * curl * u_{1-a}, eps = (-1, +1)
@@ -285,15 +302,34 @@ class Space:
         return self._coo(Je, rows, cols, (self.dim * self.n2, self.dim * self.n2))
 
     def picard_convection(self, u, form="standard"):
-        """(grad v) u . w  linearisation -- source/ns_solver_base.py:478-499 (standard only)."""
-        if form != "standard":
-            raise NotImplementedError(form)
-        uq, _ = self._u_at_q(u)
-        udg = np.einsum("cqb,cqjb->cqj", uq, self.g2)
-        T1 = np.einsum("cq,qi,cqj,ab->ciajb", self.wdet, self.phi2, udg, np.eye(self.dim))
+        """Picard linearisations of source/ns_solver_base.py:478-499 (trial v = phi_j e_b, test
+        w = phi_i e_a): standard (grad v) u . w; rotational cross(curl(u), v) . w; divergence
+        (grad v) u . w + 1/2 div(u) v . w; skew 1/2 [(grad v) u . w - (grad w) u . v]."""
+        uq, gu = self._u_at_q(u)
+        w, phi, g = self.wdet, self.phi2, self.g2
+        d = np.eye(self.dim)
+        udg = np.einsum("cqb,cqjb->cqj", uq, g)
+        T1 = np.einsum("cq,qi,cqj,ab->ciajb", w, phi, udg, d)
+        if form == "standard":
+            Je = T1
+        elif form == "rotational" and self.dim == 3:
+            curl = np.einsum("xef,cqfe->cqx", _LEVI_CIVITA, gu)
+            Je = np.einsum("cq,qi,axb,cqx,qj->ciajb", w, phi, _LEVI_CIVITA, curl, phi)
+        elif form == "rotational":
+            curl = gu[:, :, 1, 0] - gu[:, :, 0, 1]
+            rot = np.array([[0.0, -1.0], [1.0, 0.0]])                  # (-curl v_1, curl v_0)
+            Je = np.einsum("cq,qi,qj,cq,ab->ciajb", w, phi, phi, curl, rot)
+        elif form == "divergence":
+            div = np.einsum("cqaa->cq", gu)
+            Je = T1 + 0.5 * np.einsum("cq,qi,qj,cq,ab->ciajb", w, phi, phi, div, d)
+        elif form == "skew_symmetric":
+            udgi = np.einsum("cqb,cqib->cqi", uq, g)
+            Je = 0.5 * (T1 - np.einsum("cq,cqi,qj,ab->ciajb", w, udgi, phi, d))
+        else:
+            raise ValueError(form)
         rows = self.vdof[:, :, :, None, None]
         cols = self.vdof[:, None, None, :, :]
-        return self._coo(T1, rows, cols, (self.dim * self.n2, self.dim * self.n2))
+        return self._coo(Je, rows, cols, (self.dim * self.n2, self.dim * self.n2))
 
     # -- boundary integrals ---------------------------------------------------
     def traction_vector(self, facets, traction_nodal, length=None):

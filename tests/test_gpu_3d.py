@@ -64,7 +64,8 @@ def test_3d_constant_operators_and_spmv(setup3):
         assert rel(ctx.operator_apply(op, x), ref @ x) < 1e-13
 
 
-@pytest.mark.parametrize("form_id,form", [(0, "standard"), (2, "divergence"), (3, "skew_symmetric")])
+@pytest.mark.parametrize("form_id,form", [(0, "standard"), (1, "rotational"), (2, "divergence"),
+                                          (3, "skew_symmetric")])
 def test_3d_momentum_residual_jacobian_and_newton_update(setup3, form_id, form):
     _, dm, marks, ctx, s = setup3
     rng = np.random.default_rng(5)
@@ -95,11 +96,15 @@ def test_3d_momentum_residual_jacobian_and_newton_update(setup3, form_id, form):
     x = rng.standard_normal(dm.n_velocity)
     Jbc = fo.apply_dirichlet_rows(Jref, bd)
     assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Jbc @ x) < 1e-13
-    if form == "standard":
-        ctx.set_convective_form(form_id, picard=True)
-        Pbc = fo.apply_dirichlet_rows(L + s.picard_convection(u[3], form), bd)
-        assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Pbc @ x) < 1e-13
-        ctx.set_convective_form(form_id)
+    ctx.set_convective_form(form_id, picard=True)
+    Pref = L + s.picard_convection(u[3], form)
+    Pbc = fo.apply_dirichlet_rows(Pref, bd)
+    assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Pbc @ x) < 1e-13
+    ctx.assemble(nat.SYS_MOMENTUM)                         # assembled Picard matrix of the seam
+    P = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
+    assert abs(P - Pref).max() <= 1e-13 * abs(Pref).max()
+    ctx.set_convective_form(form_id)
+    ctx.assemble(nat.SYS_MOMENTUM)
     ctx.solve(nat.SYS_MOMENTUM, rtol=1e-13)
     dx = fo.spla.splu(fo.apply_dirichlet_rows(Jref, bd).tocsc()).solve(b)
     assert rel(ctx.get_state(nat.USTAR), u[3] - dx) < 1e-10
@@ -107,13 +112,10 @@ def test_3d_momentum_residual_jacobian_and_newton_update(setup3, form_id, form):
     ctx.set_convective_form(0)
 
 
-def test_3d_rotational_form_is_refused(setup3):
+def test_3d_unknown_convective_form_is_refused(setup3):
     _, dm, _, ctx, _ = setup3
-    ctx.set_convective_form(1)
-    ctx.set_bdf((1.0, -1.0, 0.0), 0.1)
     with pytest.raises(nat.NativeError):
-        ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
-    ctx.set_convective_form(0)
+        ctx.set_convective_form(7)
 
 
 def test_3d_ipcs_lid_driven_cavity_steps_match_oracle():

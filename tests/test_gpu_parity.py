@@ -523,8 +523,8 @@ def test_unstructured_mesh_ipcs_and_bdf_match_oracle():
                                           (3, "skew_symmetric")])
 def test_convective_forms_residual_jacobian_and_step(setup16, form_id, form):
     """All four weak forms of source/ns_solver_base.py:370-390: device residual and Newton
-    matrix vs the oracle's exact Gateaux derivative, Picard matrix (:478-499) for the standard
-    form, and IPCS steps with that form."""
+    matrix vs the oracle's exact Gateaux derivative, Picard matrix (:478-499), and IPCS steps with
+    that form."""
     mesh, dm, marks, ctx, s = setup16
     rng = np.random.default_rng(17 + form_id)
     u = rng.standard_normal(dm.n_velocity)
@@ -550,9 +550,8 @@ def test_convective_forms_residual_jacobian_and_step(setup16, form_id, form):
     ctx.assemble(nat.SYS_MOMENTUM)
     Jp = ctx.operator_csr(nat.OP_MOMENTUM_JAC)                 # device Picard matrix, any form
     assert rel(ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x), Jp @ x) < 1e-13
-    if form == "standard":
-        Jpref = L + 0.8 * s.picard_convection(u)
-        assert abs(Jp - Jpref).max() <= 1e-13 * abs(Jpref).max()
+    Jpref = L + 0.8 * s.picard_convection(u, form)            # (:478-499), every form
+    assert abs(Jp - Jpref).max() <= 1e-13 * abs(Jpref).max()
     ctx.set_convective_form(0)
     # two IPCS steps of the cavity with this form
     m2, dm2, marks2 = box(12, 12)

@@ -283,7 +283,7 @@ extern "C" int nsfem_set_viscous_form(nsfem_ctx* ctx, int traction_form) {
   NSFEM_REQUIRE(ctx, "null context");
   ctx->traction_form = traction_form ? 1 : 0;
   if (ctx->traction_form && !ctx->have_E) {
-    ctx->E.init(&ctx->p22, 2, 2, ctx->stream);
+    ctx->E.init(&ctx->p22, ctx->mesh.dim, ctx->mesh.dim, ctx->stream);
     launch_assemble_viscous_extra(ctx->stream, ctx->mesh, ctx->p22, ctx->E.vals.p);
     ctx->have_E = true;
   }
@@ -614,7 +614,7 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
     launch_convection_jacobian(s, c->mesh, c->p22, c->state[vel_slot].p, cc, c->L.vals.p, E,
                                c->coef[2], c->J.vals.p, c->conv_form, c->picard);
   else
-    if (c->mesh.dim == 3) jacobian_init_3d(s, c->p22.nnz, c->L.vals.p, c->J.vals.p);
+    if (c->mesh.dim == 3) jacobian_init_3d(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
     else launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
   const double g = coriolis_gamma(c);
   if (g != 0.0) launch_jac_add_skew(s, c->p22.nnz, g, c->M2.vals.p, c->J.vals.p);

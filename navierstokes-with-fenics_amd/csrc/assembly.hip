@@ -664,7 +664,7 @@ void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p1
 }
 void launch_assemble_viscous_extra(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                    double* extra) {
-  NSFEM_REQUIRE(m.dim == 2, "the traction form of the viscous term is built for 2D meshes only");
+  if (m.dim == 3) return assemble_viscous_extra_3d(s, m, p22, extra);
   DevBuf<double> tmp;
   tmp.alloc((size_t)m.n_cells * 144);
   hipLaunchKernelGGL(k_visc_extra, dim3(grid_for((int64_t)m.n_cells * 6)), dim3(kBlock), 0, s,
@@ -682,7 +682,7 @@ void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double*
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                 const double* u, double cc, const double* L, const double* E,
                                 double cvE, double* J, int form, bool picard) {
-  if (m.dim == 3) return convection_jacobian_3d(s, m, p22, u, cc, L, J, form, picard);
+  if (m.dim == 3) return convection_jacobian_3d(s, m, p22, u, cc, L, E, cvE, J, form, picard);
   const dim3 grid(grid_for((int64_t)m.n_cells * 6)), block(kBlock);
 #define NSFEM_CJ(F, P) \
   hipLaunchKernelGGL((k_conv_jac<F, P>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.ebuf.p)

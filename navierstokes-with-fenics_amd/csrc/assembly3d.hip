@@ -502,11 +502,13 @@ __global__ __launch_bounds__(256) void k3_jac_gather(int nnz, const int32_t* __r
                                                      const int32_t* __restrict__ cidx,
                                                      const double* __restrict__ ebuf,
                                                      const double* __restrict__ L,
+                                                     const double* __restrict__ E, double cvE,
                                                      double* __restrict__ J) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)nnz * 9) return;
   const int s = (int)(t / 9), e = (int)(t % 9);
   double acc = (e == 0 || e == 4 || e == 8) ? L[s] : 0.0;
+  if (E) acc += cvE * E[t];                      // traction-form block (3x3, same slot layout)
   if (ebuf)
     for (int k = cptr[s]; k < cptr[s + 1]; ++k) acc += ebuf[(size_t)cidx[k] * 9 + e];
   J[t] = acc;
@@ -579,13 +581,60 @@ void assemble_div_grad_3d(hipStream_t s, const MeshDev& m, const Pattern& p12, c
   gather_vals(s, p21, 3, t2, divT);
   NSFEM_HIP(hipStreamSynchronize(s));
 }
-void jacobian_init_3d(hipStream_t s, int nnz, const double* L, double* J) {
+void jacobian_init_3d(hipStream_t s, int nnz, const double* L, const double* E, double cvE,
+                      double* J) {
   hipLaunchKernelGGL(k3_jac_gather, dim3(grid3((int64_t)nnz * 9)), dim3(kBlock), 0, s, nnz, nullptr,
-                     nullptr, nullptr, L, J);
+                     nullptr, nullptr, L, E, cvE, J);
   NSFEM_HIP(hipGetLastError());
 }
+
+// traction-form extra block  E[(i,a),(j,b)] = int d_b phi_i d_a phi_j  (the grad(u)^T part of
+// inner(grad u + grad u^T, sym grad v), source/ns_solver_base.py:669-671), one thread per (cell, i)
+__global__ __launch_bounds__(256) void k3_visc_extra(int nc, const double* __restrict__ vx,
+                                                     double* __restrict__ E) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nc * 10) return;
+  const int i = (int)(t / nc), c = (int)(t % nc);
+  const CellGeo3 g = load_geo3(vx, nc, c);
+  double acc[10][9];
+#pragma unroll
+  for (int j = 0; j < 10; ++j)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) acc[j][e] = 0.0;
+  for (int q = 0; q < 15; ++q) {
+    const double w = c_q3.w[q] * g.adet;
+    double gi[3];
+    phys3(g, c_q3.dphi2[q][i], gi);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      double gj[3];
+      phys3(g, c_q3.dphi2[q][j], gj);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[j][a * 3 + b] += w * gi[b] * gj[a];
+    }
+  }
+  double* out = E + ((size_t)c * 100 + (size_t)i * 10) * 9;
+#pragma unroll
+  for (int j = 0; j < 10; ++j)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) out[j * 9 + e] = acc[j][e];
+}
+
+void assemble_viscous_extra_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, double* extra) {
+  DevBuf<double> tmp;
+  tmp.alloc((size_t)m.n_cells * 900);
+  hipLaunchKernelGGL(k3_visc_extra, dim3(grid3((int64_t)m.n_cells * 10)), dim3(kBlock), 0, s,
+                     m.n_cells, m.vx.p, tmp.p);
+  NSFEM_HIP(hipGetLastError());
+  gather_vals(s, p22, 9, tmp.p, extra);
+  NSFEM_HIP(hipStreamSynchronize(s));
+}
+
 void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, const double* u,
-                            double cc, const double* L, double* J, int form, bool picard) {
+                            double cc, const double* L, const double* E, double cvE, double* J,
+                            int form, bool picard) {
   const dim3 grid(grid3((int64_t)m.n_cells * 10)), block(kBlock);
 #define NSFEM_CJ3(F, P) \
   hipLaunchKernelGGL((k3_conv_jac<F, P>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, cc, m.ebuf.p)
@@ -602,7 +651,7 @@ void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22,
   }
 #undef NSFEM_CJ3
   hipLaunchKernelGGL(k3_jac_gather, dim3(grid3((int64_t)p22.nnz * 9)), dim3(kBlock), 0, s, p22.nnz,
-                     p22.cptr.p, p22.cidx.p, m.ebuf.p, L, J);
+                     p22.cptr.p, p22.cidx.p, m.ebuf.p, L, E, cvE, J);
   NSFEM_HIP(hipGetLastError());
 }
 template <int LIN>

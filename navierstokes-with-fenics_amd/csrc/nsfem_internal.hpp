@@ -183,9 +183,12 @@ void assemble_p1_scalar_3d(hipStream_t s, const MeshDev& m, const Pattern& p11, 
                            double* mass);
 void assemble_div_grad_3d(hipStream_t s, const MeshDev& m, const Pattern& p12, const Pattern& p21,
                           double* div, double* grad, double* divT);
-void jacobian_init_3d(hipStream_t s, int nnz, const double* L, double* J);
+void jacobian_init_3d(hipStream_t s, int nnz, const double* L, const double* E, double cvE,
+                      double* J);
+void assemble_viscous_extra_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, double* extra);
 void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22, const double* u,
-                            double cc, const double* L, double* J, int form, bool picard);
+                            double cc, const double* L, const double* E, double cvE, double* J,
+                            int form, bool picard);
 void convection_residual_3d(hipStream_t s, const MeshDev& m, const double* u, double cc, double* b,
                             int form);
 void convection_action_3d(hipStream_t s, const MeshDev& m, const double* u, const double* v,

@@ -262,3 +262,65 @@ def test_3d_spherical_shell_rotating_inner_sphere_matches_oracle():
     pg, po = ctx.get_state(nat.P_OLD), orc.p_old
     assert rel(pg - pg.mean(), po - po.mean()) < 1e-8
     ctx.close()
+
+
+def test_3d_traction_form_operator_and_open_boundary_steps_match_oracle():
+    """Traction form of the viscous term on tetrahedra (k3_visc_extra: E[(i,a),(j,b)] =
+    int d_b phi_i d_a phi_j, source/ns_solver_base.py:669-671) and boundary tractions
+    (source/ns_solver_base.py:121-155) on an open face: operator parity, then IPCS steps with a
+    body force and a traction on x = 1 (pressure prescribed there) against the LU oracle."""
+    import fem_host
+    mesh, dm, marks = box3((3, 3, 2), p1=(1.0, 0.9, 0.6))
+    ctx = context3(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    ctx.set_viscous_form(True)
+    E = ctx.operator_csr(nat.OP_VISCOUS_EXTRA)
+    K = fo.sp.kron(s.stiffness_p2(), fo.sp.identity(3))
+    ref = s.vector_stiffness(traction_form=True) - K
+    assert abs(E - ref).max() <= 1e-13 * abs(K).max()
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.05, body_force_term=1.0)
+    orc = fo.IPCSOracle(s, coef, traction_form=True, refactor_every_step=False)
+    X = dm.p2_coords
+    f = np.stack([np.sin(np.pi * X[:, 1]), -1.0 + X[:, 0], 0.5 * X[:, 2]], axis=1).ravel()
+    orc.body_force = f
+    facets = marks.facets_with_id(2)                                 # x = 1
+    traction = lambda Y: np.stack([0.3 * Y[:, 1], -0.1 + 0.0 * Y[:, 1], 0.2 * Y[:, 2]], axis=1)
+    orc.traction = fem_host.traction_vector(dm, facets, traction)
+    # the face load integrates the P2 interpolant exactly: total force = int t dA
+    tot = orc.traction.reshape(-1, 3).sum(axis=0)
+    assert np.abs(tot - [0.3 * 0.45 * 0.54, -0.1 * 0.54, 0.2 * 0.3 * 0.54]).max() < 1e-14
+    ctx.set_coeffs(1.0, 1.0, 0.05, 1.0)
+    ctx.set_state(nat.BODY_FORCE, f)
+    ctx.set_state(nat.TRACTION, orc.traction)
+    last = {}
+    for mid in (1, 3, 4, 5, 6):
+        nodes = np.unique(dm.facet_p2_nodes(marks.facets_with_id(mid)))
+        for a in range(3):
+            last.update(zip((3 * nodes + a).tolist(), [0.0] * nodes.size))
+    d = np.array(sorted(last), dtype=np.int64)
+    vbc = (d, np.zeros(d.size))
+    pn = np.unique(dm.facet_p1_nodes(facets))
+    pbc = (pn, 0.2 * np.ones(pn.size))
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, *pbc)
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-13
+    for step in range(2):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, 0.05)
+        info = ctx.step_ipcs(opts)
+        orc.step(alpha, 0.05, vbc, pbc)
+        assert info.newton_iterations == orc.newton_its[step]
+        ctx.advance(0)
+        orc.advance()
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    assert rel(ctx.get_state(nat.P_OLD), orc.p_old) < 1e-9
+    # assembled Jacobian of the seam with the traction block
+    u = ctx.get_state(nat.U1)
+    ctx.set_state(nat.USTAR, u)
+    ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+    J = ctx.operator_csr(nat.OP_MOMENTUM_JAC)
+    Jref = 1.5 / 0.05 * s.vector_mass() + 0.05 * s.vector_stiffness(True) + s.convection_jacobian(u)
+    assert abs(J - Jref).max() <= 1e-12 * abs(Jref).max()
+    ctx.close()

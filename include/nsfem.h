@@ -311,6 +311,9 @@ int nsfem_set_preconditioner_shift(nsfem_ctx* ctx, double shift);
  * residual/Jacobian and  c_euler omega_dot (e_z x x, w)  to its right-hand side
  * (reference source/ns_solver_base.py:173-211); call again when omega changes in time */
 int nsfem_set_angular_velocity(nsfem_ctx* ctx, double omega, double omega_dot);
+/* 3D meshes: angular velocity VECTOR and its time derivative, cross(Omega, u) / cross(dOmega/dt, x)
+ * (ns_solver_base.py:186-190, 207-209) */
+int nsfem_set_angular_velocity_3d(nsfem_ctx* ctx, const double omega[3], const double omega_dot[3]);
 /* CFL diagnostic of velocity slot `slot` for the step size k: max-norm of the cell-local P2
  * projection of  2 |u| k / h_circumdiameter  (reference source/ns_problem.py:554-587) */
 int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, double* cfl);

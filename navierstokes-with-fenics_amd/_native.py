@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -157,6 +157,7 @@ def load_library(path=None):
         "nsfem_shift_mean_pressure": (C.c_int, [vp, dbl, pd]),
         "nsfem_cfl_number": (C.c_int, [vp, C.c_int, dbl, pd]),
         "nsfem_set_angular_velocity": (C.c_int, [vp, dbl, dbl]),
+        "nsfem_set_angular_velocity_3d": (C.c_int, [vp, pd, pd]),
         "nsfem_set_preconditioner_shift": (C.c_int, [vp, dbl]),
         "nsfem_p2_mass_bounds": (C.c_int, [C.c_int, pd, pd]),
         "nsfem_mg_set_truncation": (C.c_int, [vp, dbl, dbl]),
@@ -477,6 +478,12 @@ class NsfemContext:
         self._check(self._lib.nsfem_set_preconditioner_shift(self._h, float(shift)))
 
     def set_angular_velocity(self, omega, omega_dot=0.0):
+        if np.ndim(omega) > 0:                       # 3D: vectors
+            w = np.ascontiguousarray(omega, dtype=np.float64)
+            wd = np.ascontiguousarray(omega_dot if np.ndim(omega_dot) > 0 else np.zeros(3), dtype=np.float64)
+            assert w.shape == (3, ) and wd.shape == (3, )
+            self._check(self._lib.nsfem_set_angular_velocity_3d(self._h, _dp(w), _dp(wd)))
+            return
         self._check(self._lib.nsfem_set_angular_velocity(self._h, float(omega), float(omega_dot)))
 
     def cfl_number(self, slot, step_size):

@@ -123,31 +123,38 @@ class FunctionTime:
 
 class AngularVelocityVector:
     """Angular velocity of the rotating frame of reference (reference:
-    source/auxiliary_classes.py:12-86).  ``value`` / ``derivative`` are plain floats here (the
-    reference wraps them in dolfin Constants that enter the forms); the solver pushes them to the
-    device before every solve (C ABI nsfem_set_angular_velocity).  2D only."""
+    source/auxiliary_classes.py:12-86).  ``value`` / ``derivative`` are plain numbers here (the
+    reference wraps them in dolfin Constants that enter the forms): a float about e_z in 2D, a
+    3-tuple in 3D; the solver pushes them to the device before every solve (C ABI
+    nsfem_set_angular_velocity / nsfem_set_angular_velocity_3d)."""
 
     def __init__(self, space_dim=2, function=None):
         assert isinstance(space_dim, int) and space_dim in (2, 3)
-        assert space_dim == 2, "3D rotating frames are not built (SURVEY.md D4)"
         self._space_dim = space_dim
         self._current_time = 0.0
-        self._value_size = 1
+        self._value_size = 1 if space_dim == 2 else 3
         if function is not None:
             self.set_angular_velocity_function(function)
 
+    def _convert(self, value):
+        if self._space_dim == 2:
+            return float(value)
+        value = tuple(float(v) for v in value)
+        assert len(value) == 3
+        return value
+
     def _modify_time(self):
-        self._omega = float(self._angular_velocity.value())
+        self._omega = self._convert(self._angular_velocity.value())
         if self._alpha is not None:
-            self._alpha = float(self._angular_velocity.derivative())
+            self._alpha = self._convert(self._angular_velocity.derivative())
 
     def set_angular_velocity_function(self, function):
         assert isinstance(function, FunctionTime)
         assert function.value_size == self._value_size
         self._angular_velocity = function
-        self._omega = float(function.value())
+        self._omega = self._convert(function.value())
         try:                                   # the derivative is optional (:37-50)
-            self._alpha = float(function.derivative())
+            self._alpha = self._convert(function.derivative())
         except (RuntimeError, NotImplementedError):
             self._alpha = None
 

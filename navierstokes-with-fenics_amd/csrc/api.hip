@@ -521,12 +521,28 @@ void nsfem_ctx::MomentumPrec::apply(hipStream_t s, const double* r, double* z) {
 
 constexpr int P10 = 10;      // partial-sum slots 10, 11 of the Krylov work space belong to the drivers
 static double cc_of(const nsfem_ctx* c) { return std::isfinite(c->coef[0]) ? c->coef[0] : 0.0; }
-// Coriolis factor 2 c_cor omega (source/ns_solver_base.py:173-191, 2D branch)
+// Coriolis factor 2 c_cor omega (source/ns_solver_base.py:173-191): a scalar about e_z in 2D, the
+// vector 2 c_cor Omega in 3D (coriolis_gamma3)
+static bool coriolis_active(const nsfem_ctx* c) {
+  if (c->mesh.dim == 2) return c->omega != 0.0;
+  return c->omega3[0] != 0.0 || c->omega3[1] != 0.0 || c->omega3[2] != 0.0;
+}
 static double coriolis_gamma(const nsfem_ctx* c) {
-  if (c->omega == 0.0) return 0.0;
-  if (c->mesh.dim != 2) throw Error(NSFEM_ERR_ARG, "rotating frames are built for 2D meshes only");
+  if (!coriolis_active(c)) return 0.0;
   if (!std::isfinite(c->coef[4])) throw Error(NSFEM_ERR_ARG, "angular velocity set but coriolis_term coefficient is None");
-  return 2.0 * c->coef[4] * c->omega;
+  return 2.0 * c->coef[4] * (c->mesh.dim == 2 ? c->omega : 1.0);
+}
+// y += (2 c_cor Omega x u, w): the mass matrix applied to the rotated field
+static void coriolis_apply(nsfem_ctx* c, double g, const double* u, double* y) {
+  hipStream_t s = c->stream;
+  if (!c->rot_tmp.p) c->rot_tmp.alloc((size_t)nvel(c));
+  if (c->mesh.dim == 2) {
+    launch_rot90(s, c->mesh.n_p2, g, u, c->rot_tmp.p);
+  } else {
+    const double gv[3] = {g * c->omega3[0], g * c->omega3[1], g * c->omega3[2]};
+    launch_cross3(s, c->mesh.n_p2, gv, u, c->rot_tmp.p);
+  }
+  launch_spmv_axpy(s, c->M2, c->mesh.dim, 1.0, c->rot_tmp.p, y, nullptr);
 }
 
 // time-step constant part of the momentum residual:
@@ -543,15 +559,24 @@ static void momentum_begin_step(nsfem_ctx* c, bool with_old_pressure = true) {
   } else {
     launch_axpby(s, nv, a1, c->state[NSFEM_U1].p, a2, c->state[NSFEM_U2].p, c->tmp_v.p);
   }
-  if (c->omega_dot != 0.0 && c->mesh.dim != 2)
-    throw Error(NSFEM_ERR_ARG, "rotating frames are built for 2D meshes only");
-  if (c->omega_dot != 0.0) {      // Euler acceleration  c_e (d omega/dt) e_z x x  (ns_solver_base.py:193-211)
+  const bool euler = c->mesh.dim == 2 ? c->omega_dot != 0.0
+                                      : (c->omega_dot3[0] != 0.0 || c->omega_dot3[1] != 0.0 || c->omega_dot3[2] != 0.0);
+  if (euler) {      // Euler acceleration  c_e (d Omega/dt) x x  (ns_solver_base.py:193-211)
     NSFEM_REQUIRE(std::isfinite(c->coef[5]), "angular acceleration set but euler_term coefficient is None");
     if (!c->rot_field.p) {
       c->rot_field.alloc((size_t)nv);
-      launch_rot_field(s, c->mesh, c->rot_field.p);
+      if (c->mesh.dim == 2) launch_rot_field(s, c->mesh, c->rot_field.p);       // e_z x x
+      else launch_coord_field_3d(s, c->mesh, c->rot_field.p);                    // x
     }
-    launch_axpby(s, nv, 1.0, c->tmp_v.p, c->coef[5] * c->omega_dot, c->rot_field.p, c->tmp_v.p);
+    if (c->mesh.dim == 2) {
+      launch_axpby(s, nv, 1.0, c->tmp_v.p, c->coef[5] * c->omega_dot, c->rot_field.p, c->tmp_v.p);
+    } else {
+      if (!c->rot_tmp.p) c->rot_tmp.alloc((size_t)nv);
+      const double a[3] = {c->coef[5] * c->omega_dot3[0], c->coef[5] * c->omega_dot3[1],
+                           c->coef[5] * c->omega_dot3[2]};
+      launch_cross3(s, c->mesh.n_p2, a, c->rot_field.p, c->rot_tmp.p);
+      launch_axpby(s, nv, 1.0, c->tmp_v.p, 1.0, c->rot_tmp.p, c->tmp_v.p);
+    }
   }
   launch_spmv(s, c->M2, c->mesh.dim, c->tmp_v.p, c->gconst.p, nullptr, MASK_NONE);
   if (with_old_pressure)   // IPCS: - c_p (p_old, div w); the monolithic scheme keeps p unknown
@@ -590,11 +615,7 @@ static void momentum_residual_raw(nsfem_ctx* c, const double* u, double* out) {
   const double cc = cc_of(c);
   if (cc != 0.0) launch_convection_residual(s, c->mesh, u, cc, out, c->conv_form);
   const double g = coriolis_gamma(c);
-  if (g != 0.0) {                 // 2 c_cor omega (e_z x u, w) = M applied to the rotated field
-    if (!c->rot_tmp.p) c->rot_tmp.alloc((size_t)nv);
-    launch_rot90(s, c->mesh.n_p2, g, u, c->rot_tmp.p);
-    launch_spmv_axpy(s, c->M2, 2, 1.0, c->rot_tmp.p, out, nullptr);
-  }
+  if (g != 0.0) coriolis_apply(c, g, u, out);
 }
 
 static double momentum_residual(nsfem_ctx* c) {
@@ -617,7 +638,14 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
     if (c->mesh.dim == 3) jacobian_init_3d(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
     else launch_jacobian_init(s, c->p22.nnz, c->L.vals.p, E, c->coef[2], c->J.vals.p);
   const double g = coriolis_gamma(c);
-  if (g != 0.0) launch_jac_add_skew(s, c->p22.nnz, g, c->M2.vals.p, c->J.vals.p);
+  if (g != 0.0) {
+    if (c->mesh.dim == 2) {
+      launch_jac_add_skew(s, c->p22.nnz, g, c->M2.vals.p, c->J.vals.p);
+    } else {
+      const double gv[3] = {g * c->omega3[0], g * c->omega3[1], g * c->omega3[2]};
+      launch_jac_add_skew3(s, c->p22.nnz, gv, c->M2.vals.p, c->J.vals.p);
+    }
+  }
   launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
 }
 
@@ -631,11 +659,7 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   if (cc != 0.0)
     launch_convection_action(s, c->mesh, c->state[vel_slot].p, x, cc, y, c->conv_form, c->picard);
   const double g = coriolis_gamma(c);
-  if (g != 0.0) {
-    if (!c->rot_tmp.p) c->rot_tmp.alloc((size_t)nv);
-    launch_rot90(s, c->mesh.n_p2, g, x, c->rot_tmp.p);
-    launch_spmv_axpy(s, c->M2, 2, 1.0, c->rot_tmp.p, y, nullptr);
-  }
+  if (g != 0.0) coriolis_apply(c, g, x, y);
   launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, x, y);                 // identity rows
   if (c->ghost_v.p) launch_zero_ghost(s, nv, c->mask_v.p, y);        // ghost rows: owner computes
 }
@@ -1619,9 +1643,23 @@ extern "C" int nsfem_set_preconditioner_shift(nsfem_ctx* ctx, double shift) {
 extern "C" int nsfem_set_angular_velocity(nsfem_ctx* ctx, double omega, double omega_dot) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
+  NSFEM_REQUIRE(ctx->mesh.dim == 2, "scalar angular velocity: 2D meshes (use nsfem_set_angular_velocity_3d)");
   NSFEM_REQUIRE(std::isfinite(omega) && std::isfinite(omega_dot), "non-finite angular velocity");
   ctx->omega = omega;
   ctx->omega_dot = omega_dot;
+  API_END(ctx)
+}
+
+// rotating frame (3D): angular velocity vector and its time derivative
+extern "C" int nsfem_set_angular_velocity_3d(nsfem_ctx* ctx, const double omega[3], const double omega_dot[3]) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && omega && omega_dot, "null argument");
+  NSFEM_REQUIRE(ctx->mesh.dim == 3, "vector angular velocity: 3D meshes only");
+  for (int a = 0; a < 3; ++a) {
+    NSFEM_REQUIRE(std::isfinite(omega[a]) && std::isfinite(omega_dot[a]), "non-finite angular velocity");
+    ctx->omega3[a] = omega[a];
+    ctx->omega_dot3[a] = omega_dot[a];
+  }
   API_END(ctx)
 }
 

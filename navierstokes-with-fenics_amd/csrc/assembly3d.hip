@@ -755,4 +755,31 @@ void launch_cfl_3d(hipStream_t s, const MeshDev& m, const double* u, double scal
   NSFEM_HIP(hipGetLastError());
 }
 
+// nodal coordinates of the P2 nodes (vertices and edge midpoints of the affine tetrahedra; every
+// cell sharing a node writes the same value) -- the field x of the Euler acceleration alpha x x
+__global__ __launch_bounds__(256) void k3_coord_field(int nc, const double* __restrict__ vx,
+                                                      const int32_t* __restrict__ p2,
+                                                      double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  double x[4][3];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[v][d] = vx[(size_t)(3 * v + d) * nc + c];
+  const int pr[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    double* o = out + 3 * (size_t)p2[(size_t)k * nc + c];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      o[d] = k < 4 ? x[k][d] : 0.5 * (x[pr[k - 4][0]][d] + x[pr[k - 4][1]][d]);
+  }
+}
+void launch_coord_field_3d(hipStream_t s, const MeshDev& m, double* out) {
+  hipLaunchKernelGGL(k3_coord_field, dim3(grid3(m.n_cells)), dim3(kBlock), 0, s, m.n_cells, m.vx.p,
+                     m.p2.p, out);
+  NSFEM_HIP(hipGetLastError());
+}
+
 }  // namespace nsfem

@@ -560,6 +560,32 @@ __global__ __launch_bounds__(256) void k_jac_add_skew(int64_t nnz, double g, con
     J[4 * s + 2] += m;
   }
 }
+// 3D: out = g x u per node ; J[s] += M[s] [g]_x  (Coriolis block with the vector g = 2 c_cor Omega)
+__global__ __launch_bounds__(256) void k_cross3(int64_t n_nodes, double gx, double gy, double gz,
+                                                const double* __restrict__ u, double* __restrict__ out) {
+  GRID_STRIDE(i, n_nodes) {
+    const double a = u[3 * i], b = u[3 * i + 1], c = u[3 * i + 2];
+    out[3 * i] = gy * c - gz * b;
+    out[3 * i + 1] = gz * a - gx * c;
+    out[3 * i + 2] = gx * b - gy * a;
+  }
+}
+__global__ __launch_bounds__(256) void k_jac_add_skew3(int64_t nnz, double gx, double gy, double gz,
+                                                       const double* __restrict__ M, double* __restrict__ J) {
+  GRID_STRIDE(s, nnz) {
+    const double m = M[s];
+    double* b = J + 9 * s;
+    b[1] -= m * gz; b[2] += m * gy;
+    b[3] += m * gz; b[5] -= m * gx;
+    b[6] -= m * gy; b[7] += m * gx;
+  }
+}
+void launch_cross3(hipStream_t s, int64_t n_nodes, const double g[3], const double* u, double* out) {
+  LAUNCH(k_cross3, vgrid(n_nodes), s, n_nodes, g[0], g[1], g[2], u, out);
+}
+void launch_jac_add_skew3(hipStream_t s, int64_t nnz, const double g[3], const double* M, double* J) {
+  LAUNCH(k_jac_add_skew3, vgrid(nnz), s, nnz, g[0], g[1], g[2], M, J);
+}
 void launch_rot90(hipStream_t s, int64_t n_nodes, double g, const double* u, double* out) {
   LAUNCH(k_rot90, vgrid(n_nodes), s, n_nodes, g, u, out);
 }

@@ -218,6 +218,9 @@ void launch_inv_diag(hipStream_t s, const BlockMat& A, int nv, const uint8_t* ro
 void launch_rot90(hipStream_t s, int64_t n_nodes, double g, const double* u, double* out);
 void launch_jac_add_skew(hipStream_t s, int64_t nnz, double g, const double* M, double* J);
 void launch_rot_field(hipStream_t s, const MeshDev& m, double* out);
+void launch_coord_field_3d(hipStream_t s, const MeshDev& m, double* out);
+void launch_cross3(hipStream_t s, int64_t n_nodes, const double g[3], const double* u, double* out);
+void launch_jac_add_skew3(hipStream_t s, int64_t nnz, const double g[3], const double* M, double* J);
 void launch_axpby(hipStream_t s, int64_t n, double a, const double* x, double b, const double* y,
                   double* z);                                     // z = a x + b y
 void launch_lincomb3(hipStream_t s, int64_t n, double a, const double* x, double b,
@@ -426,8 +429,10 @@ struct nsfem_ctx {
   int traction_form = 0;
   double coef[6] = {1.0, 1.0, 1.0, NAN, NAN, NAN};
   double alpha[3] = {1.0, -1.0, 0.0};
-  // rotating frame (2D): angular velocity and its time derivative; rot_field = nodal (-y, x)
+  // rotating frame: angular velocity and its time derivative (2D: scalars about e_z, rot_field =
+  // nodal (-y, x); 3D: vectors, rot_field = nodal coordinates x)
   double omega = 0.0, omega_dot = 0.0;
+  double omega3[3] = {0.0, 0.0, 0.0}, omega_dot3[3] = {0.0, 0.0, 0.0};
   nsfem::DevBuf<double> rot_field, rot_tmp;
   double k = 1.0;
   bool L_dirty = true;

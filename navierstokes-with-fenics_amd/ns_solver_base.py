@@ -135,7 +135,8 @@ class SolverBase:
     def _push_angular_velocity(self):
         if hasattr(self, "_angular_velocity") and hasattr(self, "_ctx"):
             av = self._angular_velocity
-            self._ctx.set_angular_velocity(av.value, 0.0 if av.derivative is None else av.derivative)
+            zero = 0.0 if av.space_dim == 2 else (0.0, 0.0, 0.0)
+            self._ctx.set_angular_velocity(av.value, zero if av.derivative is None else av.derivative)
 
     def set_periodic_boundary_conditions(self, constrained_domain, constrained_boundary_ids):
         assert isinstance(constrained_domain, dlfn.SubDomain)

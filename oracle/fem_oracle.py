@@ -628,13 +628,24 @@ class BDFOracle:
         if self.traction is not None:
             const += self.traction
         L = (a0 / k) * self.M + cv * self.K
-        if self.omega_dot:
-            X = s.p2_nodes()
-            rot = np.stack([-X[:, 1], X[:, 0]], axis=1).ravel()          # e_z x x, exact in P2
-            const += c["euler_term"] * self.omega_dot * (self.M @ rot)
-        if self.omega:
-            skew = sp.kron(s.mass_p2(), np.array([[0.0, -1.0], [1.0, 0.0]]), format="csr")
-            L = L + 2.0 * c["coriolis_term"] * self.omega * skew
+        if s.dim == 3:
+            # 3D: omega / omega_dot are vectors, cross(Omega, u) and cross(dOmega/dt, x)
+            # (source/ns_solver_base.py:186-190, 207-209)
+            if np.any(self.omega_dot):
+                rot = np.cross(np.asarray(self.omega_dot, dtype=float)[None, :], s.p2_nodes()).ravel()
+                const += c["euler_term"] * (self.M @ rot)
+            if np.any(self.omega):
+                wx, wy, wz = (float(v) for v in self.omega)
+                cross = np.array([[0.0, -wz, wy], [wz, 0.0, -wx], [-wy, wx, 0.0]])
+                L = L + 2.0 * c["coriolis_term"] * sp.kron(s.mass_p2(), cross, format="csr")
+        else:
+            if self.omega_dot:
+                X = s.p2_nodes()
+                rot = np.stack([-X[:, 1], X[:, 0]], axis=1).ravel()          # e_z x x, exact in P2
+                const += c["euler_term"] * self.omega_dot * (self.M @ rot)
+            if self.omega:
+                skew = sp.kron(s.mass_p2(), np.array([[0.0, -1.0], [1.0, 0.0]]), format="csr")
+                L = L + 2.0 * c["coriolis_term"] * self.omega * skew
         Bt = -cp * self.D.T
         B = -cp * self.D
         bd, bv = bc

@@ -324,3 +324,59 @@ def test_3d_traction_form_operator_and_open_boundary_steps_match_oracle():
     Jref = 1.5 / 0.05 * s.vector_mass() + 0.05 * s.vector_stiffness(True) + s.convection_jacobian(u)
     assert abs(J - Jref).max() <= 1e-12 * abs(Jref).max()
     ctx.close()
+
+
+def test_3d_rotating_frame_coriolis_and_euler_terms_match_oracle():
+    """3D branches of source/ns_solver_base.py:173-211 (the reference marks them no cover):
+    2 c_cor (Omega x u, w) in residual and Jacobian -- matrix-free and assembled -- and
+    c_e (dOmega/dt x x, w) on the right-hand side, with vector-valued Omega: two monolithic BDF
+    steps of the lid-driven cavity in a rotating frame against the LU oracle."""
+    from fem_mesh import box_mesh
+    from multigrid import attach_hierarchy
+    mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 4, 4, 4)
+    dm = TaylorHoodDofMap(mesh)
+    marks = FacetMarkers(mesh)
+    for axis in range(3):
+        marks.mark(lambda X, a=axis: np.abs(X[:, a]) < 1e-12, 2 * axis + 1)
+        marks.mark(lambda X, a=axis: np.abs(X[:, a] - 1.0) < 1e-12, 2 * axis + 2)
+    ctx = context3(mesh, dm)
+    attach_hierarchy(ctx, mesh, coarsest=2)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.05, body_force_term=None,
+                coriolis_term=1.5, euler_term=0.7)
+    ctx.set_coeffs(1.0, 1.0, 0.05, None, 1.5, 0.7)
+    bd, bv = lid_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.BDFOracle(s, coef, pin_pressure=True)
+    with pytest.raises(nat.NativeError):
+        ctx.set_angular_velocity(1.0, 0.0)                       # scalar form is the 2D one
+    for mode in (2, 1):                                          # matrix-free, assembled Jacobian
+        o = ctx.default_step_opts()
+        o.momentum.rtol, o.momentum.precond, o.matrix_free = 1e-13, 1, mode
+        for step, (omega, omega_dot) in enumerate([((0.3, -0.5, 0.8), (0.2, 0.1, -0.3)),
+                                                   ((0.4, -0.4, 1.1), (-0.1, 0.3, -0.4))]):
+            ctx.set_angular_velocity(omega, omega_dot)
+            alpha = fo.bdf_alpha(step, 1.0)
+            ctx.set_bdf(alpha, 0.05)
+            info = ctx.step_bdf(o)
+            ctx.advance(1)
+            if mode == 2:
+                orc.omega, orc.omega_dot = omega, omega_dot
+                orc.step(alpha, 0.05, (bd, bv))
+                orc.advance()
+                assert info.newton_iterations == orc.newton_its[-1]
+        nv = dm.n_velocity
+        if mode == 2:
+            u_mf, p_mf = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
+            assert rel(u_mf, orc.sol[1][:nv]) < 1e-9
+            po = orc.sol[1][nv:]
+            assert rel(p_mf - p_mf.mean(), po - po.mean()) < 1e-8
+            for slot in (nat.U0, nat.U1, nat.U2):
+                ctx.set_state(slot, np.zeros(nv))
+            for slot in (nat.P, nat.P_OLD):
+                ctx.set_state(slot, np.zeros(dm.n_p1))
+        else:
+            assert rel(ctx.get_state(nat.U1), u_mf) < 1e-10
+    ctx.close()

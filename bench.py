@@ -433,8 +433,9 @@ def main():
     ms_parity = 1e3 * (time.perf_counter() - t0) / n_par
     # dominant kernel of the timed steps: the Chebyshev-Jacobi smoothing step of the velocity
     # multigrid on its finest level (scalar P2 operator applied to both components, fused
-    # epilogue).  Its launches are timed IN SITU with one HIP-event pair each on the context's
-    # stream, over 5 further steps with the throughput settings (the event pairs stay out of the
+    # epilogue).  Its launches are timed IN SITU on the context's stream -- one HIP-event pair around
+    # every run of consecutive launches inside a smoothing sequence (a pair per launch would add
+    # ~4 us of event overhead to each 40 us kernel) -- over 5 further steps with the throughput settings (the event pairs stay out of the
     # timed region above).  Back-to-back repetitions of the same launch would be flattered by the
     # 256 MB Infinity Cache holding the 145 MB operator.
     if mg_levels is not None:
@@ -490,7 +491,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv,
                      "launches_timed": n_launches,
-                     "timing": "HIP-event pair around every finest-level launch during 5 solver steps"},
+                     "timing": "HIP-event pairs around the runs of consecutive finest-level launches (one pair per smoothing sequence) during 5 solver steps"},
         "jacobian_spmv": {"kernel": "k_spmv_stream<2,2,1,0> (assembled momentum Jacobian, 2x2 block CSR; "
                                     "used by the explicit assembly seam / matrix_free=1)",
                           "achieved": nbytes_jac / (ms_jac * 1e-3) / 1e9, "unit": "GB/s",

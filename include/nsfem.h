@@ -321,7 +321,8 @@ int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, double* cfl);
 /* ---- measurement hooks (bench.py): time `reps` launches of the dominant SpMV
  * with HIP events on the context's stream; ms per launch returned ------------- */
 /* in-situ HIP-event timing of the finest-level smoothing launches of the velocity multigrid
- * (the dominant kernel of a time step): enable != 0 starts sampling, enable == 0 stops and
+ * (the dominant kernel of a time step), one event pair around each run of consecutive launches
+ * of a smoothing sequence: enable != 0 starts sampling, enable == 0 stops and
  * reports average launch duration [ms], number of launches and algorithmic bytes per launch */
 int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* launches,
                            int64_t* algorithmic_bytes);

@@ -1795,6 +1795,7 @@ extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms
       for (hipEvent_t& e : mg.prof_ev) NSFEM_HIP(hipEventCreate(&e));
     }
     mg.prof_n = 0;
+    mg.prof_launches = 0;
     mg.prof = true;
     return NSFEM_OK;
   }
@@ -1806,7 +1807,7 @@ extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms
     NSFEM_HIP(hipEventElapsedTime(&t, mg.prof_ev[i], mg.prof_ev[i + 1]));
     total += t;
   }
-  const int64_t n_launch = (int64_t)(mg.prof_n / 2);
+  const int64_t n_launch = mg.prof_launches;
   if (avg_ms) *avg_ms = n_launch ? total / (double)n_launch : 0.0;
   if (launches) *launches = n_launch;
   if (algorithmic_bytes) {

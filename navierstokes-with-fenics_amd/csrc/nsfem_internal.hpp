@@ -370,6 +370,8 @@ struct Multigrid : Precond {
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
   size_t prof_n = 0;
+  bool prof_open = false;        // an event pair is open inside the current smooth() call
+  int64_t prof_launches = 0;     // launches covered by the recorded pairs
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
   bool smoother_only = false;    // the last level is smoothed (coarse_steps), never solved globally
   // partitioned meshes, relaxed mode: a smoothing sequence exchanges the ghost values ONCE (at

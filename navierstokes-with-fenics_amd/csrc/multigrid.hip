@@ -450,15 +450,22 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
       filled = true;
       // in-situ timing: ONE event pair around the run of consecutive finest-level smoothing
       // launches of this call (a pair per launch adds ~4 us of event overhead to a 40 us kernel)
-      const bool timed = prof && &L == &lv[0] && !(comm_active() && L.has_halo) &&
-                         prof_n + 2 <= prof_ev.size();
+      // (partitioned levels: halo exchanges sit between the launches -> one pair per launch)
+      const bool timed = prof && &L == &lv[0] && prof_n + 2 <= prof_ev.size();
       if (timed && !prof_open) {
         NSFEM_HIP(hipEventRecord(prof_ev[prof_n], s));
         prof_open = true;
       }
       launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask,
                        relaxed && k + 1 < steps ? 1 : 0);
-      if (prof_open) ++prof_launches;
+      if (prof_open) {
+        ++prof_launches;
+        if (comm_active() && L.has_halo) {
+          NSFEM_HIP(hipEventRecord(prof_ev[prof_n + 1], s));
+          prof_n += 2;
+          prof_open = false;
+        }
+      }
     }
     cur = out;
   }

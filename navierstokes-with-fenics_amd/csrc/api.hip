@@ -1050,8 +1050,15 @@ extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d
   for (int i = 0; i < n2; ++i)
     for (int a = 0; a < ctx->mesh.dim; ++a) gv[(size_t)ctx->mesh.dim * i + a] = d->p2_ghost[i] ? 2 : 0;
   for (int i = 0; i < n1; ++i) gp[i] = d->p1_ghost[i] ? 2 : 0;
-  ctx->ghost_v.upload(gv, s);
-  ctx->ghost_p.upload(gp, s);
+  // (a single-rank "partition" has no ghosts: keep the ghost arrays unallocated, so that none of
+  // the ghost-zeroing launches run)
+  bool any_ghost = false;
+  for (uint8_t g : gv) any_ghost |= g != 0;
+  for (uint8_t g : gp) any_ghost |= g != 0;
+  if (any_ghost) {
+    ctx->ghost_v.upload(gv, s);
+    ctx->ghost_p.upload(gp, s);
+  }
   ctx->halo_p2 = to_halo(d->p2_halo);
   ctx->mg_mv.lv.clear();            // rebuilt with the halo on the next Chebyshev mass solve
   ctx->halo_p1 = to_halo(d->p1_halo);

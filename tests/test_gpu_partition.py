@@ -50,6 +50,7 @@ def _run(ctx, dm, nsteps, k, use_mg, out, key, cheb=False):
         infos.append(ctx.step_ipcs(opts))
         ctx.advance(0)
     out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
+    out[("comm", key)] = ctx.comm_stats()
 
 
 @pytest.mark.parametrize("n,size,use_mg,tail,cheb,relaxed", [
@@ -129,6 +130,14 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, rel
     for r, part in enumerate(parts):                     # ghosts are copies of the owners' values
         ul, _, _ = out[r]
         assert np.abs(ul.reshape(-1, 2) - u.reshape(-1, 2)[part.p2_global]).max() < 1e-13
+    # communication counters (nsfem_comm_stats): none without a communicator; with one, every rank
+    # exchanged halos and all-reduced dot products, interior ranks send to two neighbours
+    assert ref[("comm", 0)] == dict(allreduce_calls=0, allreduce_bytes=0, exchanges=0, exchange_bytes=0)
+    st = [out[("comm", r)] for r in range(size)]
+    assert all(x["exchanges"] == st[0]["exchanges"] > 0 and x["allreduce_calls"] == st[0]["allreduce_calls"] > 0
+               for x in st)
+    if size > 2:
+        assert st[1]["exchange_bytes"] > st[0]["exchange_bytes"]
     for c in ctxs:
         c.close()
     nat.local_group_destroy(group)

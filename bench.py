@@ -173,6 +173,10 @@ def _init_dist(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and args.gpus != world:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (
+                             args.gpus, args.gpus, args.gpus))
     dist = None
     if world > 1 or os.environ.get("NSFEM_FORCE_COMM") is not None:
         import torch.distributed as dist

@@ -102,7 +102,7 @@ def dfg_bdf_bench(args):
     mesh, marks = gg.dfg_channel(4, args.dfg_refine)
     dm = TaylorHoodDofMap(mesh)
     ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
-    levels = attach_hierarchy(ctx, mesh)
+    levels = attach_hierarchy(ctx, mesh, args.mg_degree, args.mg_eig_ratio)
     ids = gg.DFGBoundaryMarkers
     last = {}
     for mid in (ids.inlet.value, ids.bottom.value, ids.top.value, ids.cylinder.value):
@@ -319,8 +319,10 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-multigrid", action="store_true")
-    ap.add_argument("--mg-degree", type=int, default=2, help="Chebyshev smoother degree")
-    ap.add_argument("--mg-eig-ratio", type=float, default=4.0)
+    ap.add_argument("--mg-degree", type=int, default=None,
+                    help="Chebyshev smoother degree (default: 2 on structured meshes, 3 on the DFG mesh)")
+    ap.add_argument("--mg-eig-ratio", type=float, default=None,
+                    help="smoothing interval [lmax / ratio, lmax] (default: 4 structured, 16 DFG)")
     ap.add_argument("--matrix-free", type=int, default=0, choices=(0, 1, 2),
                     help="velocity Jacobian in the step driver: 0 auto, 1 assembled, 2 matrix-free")
     ap.add_argument("--mass-solver", choices=("chebyshev", "cg"), default="chebyshev",

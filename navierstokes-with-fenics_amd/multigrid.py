@@ -102,12 +102,23 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200)
     return levels
 
 
-def attach_hierarchy(ctx, mesh, degree=2, eig_ratio=4.0, coarsest=None):
+def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None):
     """Build the hierarchy of a structured mesh (``mesh.structured`` = (p0, p1, nx, ny)) on the
     device context.  Returns the number of coarse P1 levels (0: mesh cannot be coarsened; the
-    two-level P2 -> P1 hierarchy is still built)."""
+    two-level P2 -> P1 hierarchy is still built).
+
+    Chebyshev smoother: ``degree`` steps over [lambda_max / eig_ratio, lambda_max].  Defaults
+    (None): 2 steps over a ratio of 4 on uniform structured meshes; 3 steps over a ratio of 16 on
+    refinement hierarchies of general (graded, curved) meshes, where the narrow interval leaves
+    too much of the spectrum to the Krylov method (DFG channel, BDF-2: 53.8 -> 35.3 ms/step,
+    29 -> 16 BiCGStab iterations per step)."""
     info = getattr(mesh, "structured", None) if mesh is not None else None
-    if mesh is not None and hasattr(mesh, "mg_levels"):
+    general = mesh is not None and hasattr(mesh, "mg_levels")
+    if degree is None:
+        degree = 3 if general else 2
+    if eig_ratio is None:
+        eig_ratio = 16.0 if general else 4.0
+    if general:
         levels = mesh.mg_levels                        # refinement hierarchy of a general mesh
     else:
         # coarsest None: down to the first level with <= 1200 nodes (512^2 -> 32^2 = 1089 nodes,

@@ -132,7 +132,7 @@ class StripPartition:
             self.global_tail = structured_hierarchy(self.p0, self.p1, last.nx, ly,
                                                     coarsest=global_coarsest)
 
-    def attach(self, ctx, degree=2, eig_ratio=4.0):
+    def attach(self, ctx, degree=None, eig_ratio=None):
         """Ship the partition, the local multigrid levels and the replicated global coarsest
         mesh to a device context created on ``self.mesh`` (a communicator must already be
         attached when size > 1)."""
@@ -148,7 +148,7 @@ class StripPartition:
         ctx.mg_set_global_coarse(cg.coords, cg.cells, self.coarse_global_offset)
         for mesh, (rowptr, col, val) in self.global_tail:
             ctx.mg_add_global_level(mesh.coords, mesh.cells, rowptr, col, val)
-        ctx.mg_finalize(degree, eig_ratio)
+        ctx.mg_finalize(2 if degree is None else degree, 4.0 if eig_ratio is None else eig_ratio)
         return len(self.levels)
 
 
@@ -252,7 +252,7 @@ class SlabPartition:
             self.global_tail = structured_hierarchy(self.p0, self.p1, last.nx, last.ny, lz,
                                                     coarsest=global_coarsest)
 
-    def attach(self, ctx, degree=2, eig_ratio=4.0):
+    def attach(self, ctx, degree=None, eig_ratio=None):
         from fem_mesh import box_mesh
         n2g, n1g = global_dof_counts(self.nx, self.ny, self.nz)
         ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, self.p2_halo,
@@ -264,5 +264,5 @@ class SlabPartition:
         ctx.mg_set_global_coarse(cg.coords, cg.cells, self.coarse_global_offset)
         for mesh, (rowptr, col, val) in self.global_tail:
             ctx.mg_add_global_level(mesh.coords, mesh.cells, rowptr, col, val)
-        ctx.mg_finalize(degree, eig_ratio)
+        ctx.mg_finalize(2 if degree is None else degree, 4.0 if eig_ratio is None else eig_ratio)
         return len(self.levels)

@@ -224,6 +224,11 @@ typedef struct {
   const double* p_val;
   const uint8_t* ghost;      /* [n_vertices] nonzero = ghost node; NULL on unpartitioned meshes */
   nsfem_halo halo;           /* used when ghost != NULL */
+  /* constrained (periodic) spaces: the P1 dof of every cell vertex, [n_cells * (dim + 1)], with
+   * n_dofs < n_vertices distinct ids (slaves share their master's dof); the geometry still comes
+   * from coords[cells].  NULL / 0: dof = vertex id.  P then has n_dofs columns. */
+  const int32_t* dofmap;
+  int32_t n_dofs;
 } nsfem_mg_level_desc;
 typedef struct {
   int32_t smoother_degree;   /* Chebyshev steps per pre/post smoothing (default 2) */

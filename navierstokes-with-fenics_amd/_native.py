@@ -91,7 +91,8 @@ class MgLevelDesc(C.Structure):
                 ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
                 ("n_fine", C.c_int32), ("p_rowptr", C.POINTER(C.c_int32)),
                 ("p_col", C.POINTER(C.c_int32)), ("p_val", C.POINTER(C.c_double)),
-                ("ghost", C.POINTER(C.c_uint8)), ("halo", Halo)]
+                ("ghost", C.POINTER(C.c_uint8)), ("halo", Halo),
+                ("dofmap", C.POINTER(C.c_int32)), ("n_dofs", C.c_int32)]
 
 
 class PartitionDesc(C.Structure):
@@ -380,7 +381,7 @@ class NsfemContext:
                                                   C.byref(info)))
         return x
 
-    def mg_add_level(self, coords, cells, p_rowptr, p_col, p_val, ghost=None, halo=None):
+    def mg_add_level(self, coords, cells, p_rowptr, p_col, p_val, ghost=None, halo=None, dofmap=None):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         rp = np.ascontiguousarray(p_rowptr, dtype=np.int32)
@@ -388,8 +389,11 @@ class NsfemContext:
         pv = np.ascontiguousarray(p_val, dtype=np.float64)
         g = None if ghost is None else np.ascontiguousarray(ghost, dtype=np.uint8)
         gp = g.ctypes.data_as(C.POINTER(C.c_uint8)) if g is not None else None
+        dm = None if dofmap is None else np.ascontiguousarray(dofmap, dtype=np.int32)
+        assert dm is None or dm.shape == cells.shape
         d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
-                        _ip(rp), _ip(pc), _dp(pv), gp, Halo.from_dict(halo))
+                        _ip(rp), _ip(pc), _dp(pv), gp, Halo.from_dict(halo),
+                        _ip(dm) if dm is not None else None, int(dm.max()) + 1 if dm is not None else 0)
         self._check(self._lib.nsfem_mg_add_level(self._h, C.byref(d)))
 
     def mg_set_schur_operator(self, level, csr, singular):
@@ -411,7 +415,7 @@ class NsfemContext:
         pc = np.ascontiguousarray(p_col, dtype=np.int32)
         pv = np.ascontiguousarray(p_val, dtype=np.float64)
         d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
-                        _ip(rp), _ip(pc), _dp(pv), None, Halo.from_dict(None))
+                        _ip(rp), _ip(pc), _dp(pv), None, Halo.from_dict(None), None, 0)
         self._check(self._lib.nsfem_mg_add_global_level(self._h, C.byref(d)))
 
     def mg_set_global_coarse(self, coords, cells, offset):

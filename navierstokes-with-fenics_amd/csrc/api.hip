@@ -908,26 +908,35 @@ extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* 
 // mesh arrays, pattern and the P1 stiffness / mass matrices of one coarse level (same space
 // dimension as the fine mesh)
 static void fill_p1_level(nsfem_ctx* ctx, nsfem_ctx::P1Level* lv, int n_vertices, int nc,
-                          const double* coords, const int32_t* cells) {
+                          const double* coords, const int32_t* cells,
+                          const int32_t* dofmap = nullptr, int n_dofs = 0) {
   hipStream_t s = ctx->stream;
   const int dim = ctx->mesh.dim, nl1 = dim + 1;
-  lv->n = n_vertices;
+  // numbering of the P1 space: vertex ids, or (periodic levels) the given cell dof map -- the
+  // geometry always comes from the vertex coordinates of the cells
+  const int32_t* dm = dofmap ? dofmap : cells;
+  const int n = dofmap ? n_dofs : n_vertices;
+  NSFEM_REQUIRE(n > 0 && n <= n_vertices, "bad number of coarse dofs");
+  lv->n = n;
   std::vector<double> vx((size_t)nl1 * dim * nc);
   std::vector<int32_t> p1((size_t)nl1 * nc);
   for (int c = 0; c < nc; ++c)
     for (int v = 0; v < nl1; ++v) {
       const int vid = cells[(size_t)c * nl1 + v];
       NSFEM_REQUIRE(vid >= 0 && vid < n_vertices, "coarse cell vertex id out of range");
-      p1[(size_t)v * nc + c] = vid;
+      const int dof = dm[(size_t)c * nl1 + v];
+      NSFEM_REQUIRE(dof >= 0 && dof < n, "coarse cell dof id out of range");
+      p1[(size_t)v * nc + c] = dof;
       for (int k = 0; k < dim; ++k) vx[(size_t)(dim * v + k) * nc + c] = coords[(size_t)vid * dim + k];
     }
   lv->mesh.dim = dim;
   lv->mesh.n_cells = nc;
-  lv->mesh.n_p1 = lv->mesh.n_vertices = n_vertices;
+  lv->mesh.n_p1 = n;
+  lv->mesh.n_vertices = n_vertices;
   lv->mesh.vx.upload(vx, s);
   lv->mesh.p1.upload(p1, s);
   HostPattern h;
-  build_pattern(n_vertices, n_vertices, nc, cells, nl1, cells, nl1, true, h);
+  build_pattern(n, n, nc, dm, nl1, dm, nl1, true, h);
   upload_pattern(s, h, lv->pat, true);
   lv->K.init(&lv->pat, 1, 1, s);
   lv->M.init(&lv->pat, 1, 1, s);
@@ -946,8 +955,9 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
   hipStream_t s = ctx->stream;
   nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
   ctx->coarse.push_back(lv);
-  fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells);
-  lv->to_finer.build(s, n_fine, d->n_vertices, d->p_rowptr, d->p_col, d->p_val);
+  NSFEM_REQUIRE(!(d->dofmap && d->ghost), "constrained (periodic) levels cannot be partitioned");
+  fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells, d->dofmap, d->n_dofs);
+  lv->to_finer.build(s, n_fine, lv->n, d->p_rowptr, d->p_col, d->p_val);
   if (d->ghost) {
     lv->h_ghost.assign(d->ghost, d->ghost + d->n_vertices);
     lv->halo = to_halo(d->halo);

@@ -102,7 +102,38 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200)
     return levels
 
 
-def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None):
+def periodic_levels(levels, fine_vertex_dof, domain):
+    """Turn the vertex-based levels of ``structured_hierarchy`` into levels of the PERIODIC P1
+    spaces (dolfin ``constrained_domain``; reference source/ns_solver_base.py:516-518): every
+    coarse mesh gets the dof of each vertex (slaves share their master's, as on the fine mesh:
+    ``TaylorHoodDofMap``), and the vertex prolongation P becomes  S_f P E_c  -- rows of one
+    representative vertex per finer dof, columns of all vertices of a coarse dof added up.
+    Returns [(mesh, (rowptr, col, val), cell dof map), ...] and is only valid for nested meshes
+    whose periodic images are lattice points on every level (structured meshes are)."""
+    import scipy.sparse as sp
+    from fem_mesh import _compact, periodic_entity_map
+    out = []
+    f_dof = np.asarray(fine_vertex_dof, dtype=np.int64)
+    for mesh, (rowptr, col, val) in levels:
+        nvc = mesh.num_vertices()
+        c_dof = _compact(np.arange(nvc, dtype=np.int64)[periodic_entity_map(mesh, domain)[1]])
+        n_f, n_c = int(f_dof.max()) + 1, int(c_dof.max()) + 1
+        P = sp.csr_matrix((val, col, rowptr), shape=(f_dof.size, nvc))
+        rep = np.full(n_f, -1, dtype=np.int64)                    # one vertex per finer dof
+        rep[f_dof[::-1]] = np.arange(f_dof.size - 1, -1, -1)
+        E = sp.csr_matrix((np.ones(nvc), (np.arange(nvc), c_dof)), shape=(nvc, n_c))
+        Pp = (P[rep] @ E).tocsr()
+        Pp.sum_duplicates()
+        Pp.sort_indices()
+        # all periodic images of a point interpolate alike: the representative's row is THE row
+        assert abs(Pp.sum(axis=1) - 1.0).max() < 1e-12
+        out.append((mesh, (Pp.indptr.astype(np.int32), Pp.indices.astype(np.int32), Pp.data.copy()),
+                    c_dof[mesh.cells.astype(np.int64)].astype(np.int32)))
+        f_dof = c_dof
+    return out
+
+
+def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None, periodic=None):
     """Build the hierarchy of a structured mesh (``mesh.structured`` = (p0, p1, nx, ny)) on the
     device context.  Returns the number of coarse P1 levels (0: mesh cannot be coarsened; the
     two-level P2 -> P1 hierarchy is still built).
@@ -125,6 +156,15 @@ def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None):
         # 64^3 -> 8^3 = 729), solved with a dense inverse on the device
         levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
     ctx.mg_prolongations = []                          # kept for attach_schur_laplacian
+    if periodic is not None:
+        # periodic = (constrained domain, P1 dof of every fine-mesh vertex): the coarse levels
+        # carry the periodic identification too; needs a coarsenable structured mesh
+        domain, fine_vertex_dof = periodic
+        for coarse_mesh, (rowptr, col, val), dofmap in periodic_levels(levels, fine_vertex_dof, domain):
+            ctx.mg_add_level(coarse_mesh.coords, coarse_mesh.cells, rowptr, col, val, dofmap=dofmap)
+            ctx.mg_prolongations.append((int(dofmap.max()) + 1, (rowptr, col, val)))
+        ctx.mg_finalize(degree, eig_ratio)
+        return len(levels)
     for coarse_mesh, (rowptr, col, val) in levels:
         ctx.mg_add_level(coarse_mesh.coords, coarse_mesh.cells, rowptr, col, val)
         ctx.mg_prolongations.append((coarse_mesh.coords.shape[0], (rowptr, col, val)))

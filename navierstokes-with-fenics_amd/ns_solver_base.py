@@ -234,9 +234,14 @@ class SolverBase:
         # coarsen; any mesh gets at least the P2 -> P1 two-level hierarchy)
         self._mg_levels = None
         if getattr(self, "use_multigrid", True):
-            # (periodic spaces: P1 nodes are not vertex ids, so only the two-level
+            # (periodic spaces on structured meshes: the coarse levels are periodic as well;
+            # on other meshes only the two-level
             # P2 -> P1 hierarchy is built)
-            self._mg_levels = attach_hierarchy(self._ctx, None if periodic else self._mesh)
+            if periodic and getattr(self._mesh, "structured", None) is not None:
+                self._mg_levels = attach_hierarchy(
+                    self._ctx, self._mesh, periodic=(self._constrained_domain, dm.p1_vertex_node))
+            else:
+                self._mg_levels = attach_hierarchy(self._ctx, None if periodic else self._mesh)
         self._push_coefficients()
 
     # sub-space access and mixed <-> split assignment (reference :213-300, :424-476) -----------

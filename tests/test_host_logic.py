@@ -396,3 +396,46 @@ def test_function_assigner_host_logic():
     u = dlfn.project(dlfn.Expression(("x[0]*x[1]", "1.0 - x[1]*x[1]"), degree=2), WhSub["velocity"])
     solver._assign_function(solution, {"velocity": u})
     assert np.allclose(solution(0.3, 0.7)[:2], [0.21, 0.51])
+
+
+def test_periodic_multigrid_levels():
+    """multigrid.periodic_levels: coarse levels of a periodic (constrained) P1 space -- slaves
+    share their master's dof on every level, the prolongation rows sum to one, every coarse dof
+    is injected from a finer dof, and smooth periodic functions interpolate with O(h^2) error."""
+    import dlfn_compat as dlfn
+    from fem_mesh import _compact, periodic_entity_map, rectangle_mesh
+    from multigrid import periodic_levels, structured_hierarchy
+
+    class Periodic(dlfn.SubDomain):
+        def inside(self, x, on_boundary):
+            return bool((dlfn.near(x[0], 0.0) or dlfn.near(x[1], 0.0)) and
+                        not (dlfn.near(x[0], 1.0) or dlfn.near(x[1], 1.0)) and on_boundary)
+
+        def map(self, x, y):
+            for a in range(2):
+                y[a] = x[a] - 1.0 if dlfn.near(x[a], 1.0) else x[a]
+
+    import scipy.sparse as sp
+    mesh = rectangle_mesh((0.0, 0.0), (1.0, 1.0), 16, 16)
+    dm = TaylorHoodDofMap(mesh, periodic_map=periodic_entity_map(mesh, Periodic()))
+    assert dm.n_p1 == 16 * 16
+    levels = periodic_levels(structured_hierarchy(*mesh.structured, coarsest=2), dm.p1_vertex_node, Periodic())
+    assert [int(d.max()) + 1 for _, _, d in levels] == [64, 16, 4]
+    fine_xy = dm.p1_coords
+    f = lambda X: np.sin(2 * np.pi * X[:, 0]) * np.cos(2 * np.pi * X[:, 1])
+    errs = []
+    for cmesh, (rowptr, col, val), dofmap in levels:
+        n_c = int(dofmap.max()) + 1
+        P = sp.csr_matrix((val, col, rowptr), shape=(fine_xy.shape[0], n_c))
+        assert abs(P.sum(axis=1) - 1.0).max() < 1e-14
+        single = np.diff(rowptr) == 1
+        assert np.array_equal(np.sort(col[rowptr[:-1][single]]), np.arange(n_c))      # injection
+        vm = periodic_entity_map(cmesh, Periodic())[1]
+        cdof = _compact(np.arange(cmesh.num_vertices())[vm])
+        assert np.array_equal(cdof[cmesh.cells], dofmap)
+        xy = np.zeros((n_c, 2))
+        masters = np.nonzero(vm == np.arange(cmesh.num_vertices()))[0]
+        xy[cdof[masters]] = cmesh.coords[masters]
+        errs.append(np.abs(P @ f(xy) - f(fine_xy)).max())
+        fine_xy = xy
+    assert errs[0] < 0.16 and errs[0] < errs[1]

@@ -1266,3 +1266,20 @@ def test_function_assigner_through_the_solver_as_in_the_reference():
     assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -30.0]))
     solver._assign_function(pressure, solution_dict["pressure"])
     assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -300.0]))
+
+
+def test_periodic_multigrid_keeps_krylov_counts_mesh_independent():
+    """Periodic spaces on structured meshes carry the periodic identification on every coarse
+    level (multigrid.periodic_levels, nsfem_mg_level_desc.dofmap): the Taylor-Green problem of the
+    reference's convergence study needs the same number of BiCGStab iterations on 64^2 and 128^2
+    cells (with the two-level P2 -> P1 fallback the count grows with the mesh)."""
+    counts = {}
+    for n in (64, 128):
+        problem = TaylorGreenVortex()
+        problem._n_points = n
+        problem._n_max_steps = 3
+        problem.solve_problem()
+        solver = problem._get_solver()
+        assert solver._mg_levels == {64: 1, 128: 2}[n]
+        counts[n] = solver.last_step_info.krylov_iterations_momentum
+    assert counts[128] <= 1.15 * counts[64] + 2

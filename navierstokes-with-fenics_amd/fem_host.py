@@ -41,22 +41,31 @@ def _p2_shape(pts):
                     + [4 * lam[:, a] * lam[:, b] for a, b in _EDGE_PAIRS[dim]], axis=1)
 
 
-def load_vector(mesh, cell_dofs, n_dofs, fun, degree=2, n_comp=1, quad_n=6):
+def load_vector(mesh, cell_dofs, n_dofs, fun, degree=2, n_comp=1, quad_n=None):
     """b_i = int f phi_i  for P1 (degree 1) or P2 (degree 2) scalar shape functions on
     triangles / tetrahedra; ``fun(X) -> [n] or [n, n_comp]``; vector results are
     node-interleaved."""
     dim = mesh.coords.shape[1]
+    if quad_n is None:          # conical Gauss rule: 36 points (degree 11) in 2D, 64 (degree 7) in 3D
+        quad_n = 6 if dim == 2 else 4
     pts, wt = conical_rule(quad_n, dim)
     N = _p2_shape(pts) if degree == 2 else _p1_shape(pts)
-    x = mesh.coords[mesh.cells.astype(np.int64)]                   # [c, dim+1, dim]
     lam = _p1_shape(pts)                                            # [q, dim+1]
-    X = np.einsum("qv,cvd->cqd", lam, x)                            # [c, q, dim]
-    det = np.abs(np.linalg.det(x[:, 1:] - x[:, :1]))
-    f = np.asarray(fun(X.reshape(-1, dim)), dtype=np.float64).reshape(X.shape[0], X.shape[1], -1)
-    be = np.einsum("c,q,qi,cqa->cia", det, wt, N, f)                # [c, nloc, n_comp]
+    wN = (wt[:, None] * N).T.copy()                                 # [nloc, q]
+    cells = mesh.cells.astype(np.int64)
     b = np.zeros(n_dofs * n_comp)
-    idx = n_comp * cell_dofs.astype(np.int64)[:, :, None] + np.arange(n_comp)[None, None, :]
-    np.add.at(b, idx.ravel(), be.ravel())
+    comp = np.arange(n_comp)[None, None, :]
+    chunk = max(1, 4_000_000 // pts.shape[0])                       # bounds the [cells, q, dim] temporaries
+    for c0 in range(0, cells.shape[0], chunk):
+        x = mesh.coords[cells[c0: c0 + chunk]]                      # [c, dim+1, dim]
+        nc = x.shape[0]
+        X = np.einsum("qv,cvd->qcd", lam, x)                        # [q, c, dim]
+        det = np.abs(np.linalg.det(x[:, 1:] - x[:, :1]))
+        f = np.asarray(fun(X.reshape(-1, dim)), dtype=np.float64).reshape(pts.shape[0], nc * n_comp)
+        # be[i, c, a] = det_c sum_q w_q N_qi f_qca : one GEMM per chunk
+        be = (wN @ f).reshape(N.shape[1], nc, n_comp) * det[None, :, None]
+        idx = n_comp * cell_dofs[c0: c0 + chunk].astype(np.int64).T[:, :, None] + comp     # [nloc, c, a]
+        b += np.bincount(idx.ravel(), weights=be.ravel(), minlength=b.size)
     return b
 
 

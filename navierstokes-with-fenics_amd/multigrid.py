@@ -181,9 +181,9 @@ def attach_schur_laplacian(ctx, velocity_bc_dofs):
     A_L is singular (constants) exactly when every velocity boundary dof is constrained."""
     import scipy.sparse as sp
     import _native as nat
-    D = ctx.operator_csr(nat.OP_DIV).tocsc()                        # n_p1 x 2 n_p2
+    D = ctx.operator_csr(nat.OP_DIV).tocsc()                        # n_p1 x (dim n_p2)
     m = ctx.operator_csr(nat.OP_MASS_P2).diagonal()
-    w = np.repeat(1.0 / m, 2)
+    w = np.repeat(1.0 / m, D.shape[1] // m.size)                    # node-interleaved components
     free = np.ones(D.shape[1], dtype=bool)
     free[np.asarray(velocity_bc_dofs, dtype=np.int64)] = False
     w[~free] = 0.0

@@ -1283,3 +1283,71 @@ def test_periodic_multigrid_keeps_krylov_counts_mesh_independent():
         assert solver._mg_levels == {64: 1, 128: 2}[n]
         counts[n] = solver.last_step_info.krylov_iterations_momentum
     assert counts[128] <= 1.15 * counts[64] + 2
+
+
+class ChannelFlow3D(InstationaryProblem):
+    """BASELINE.json configs[4] in small: 3D channel (2 : 1 : 1 box), parabolic-in-y,z inlet,
+    no-slip side walls, natural outflow; BDF-2 monolithic (open boundary: algebraic Schur
+    Laplacian) or IPCS with the pressure prescribed at the outlet -- the 3D counterpart of the
+    reference's tests/test_ipcs_solver.py / tests/test_transient_solvers.py channel problems."""
+
+    def __init__(self, n_points, solver_class):
+        super().__init__(None, start_time=0.0, end_time=1.0, desired_start_time_step=0.02, n_max_steps=4)
+        self._n_points = n_points
+        self._problem_name = "ChannelFlow3D"
+        self._output_frequency = 0
+        self._postprocessing_frequency = 0
+        self._pressure_outlet = solver_class is IPCSSolver
+        self.set_solver_class(solver_class)
+
+    def setup_mesh(self):
+        n = self._n_points
+        self._mesh, self._boundary_markers = hyper_rectangle((0.0, 0.0, 0.0), (2.0, 1.0, 1.0), (2 * n, n, n))
+
+    def set_equation_coefficients(self):
+        self._coefficient_handler = EquationCoefficientHandler(Re=20.0)
+
+    def set_initial_conditions(self):
+        self._initial_conditions = {"velocity": (0.0, 0.0, 0.0), "pressure": 0.0}
+
+    def set_boundary_conditions(self):
+        inlet = dlfn.Expression(("16.0*x[1]*(1.0-x[1])*x[2]*(1.0-x[2])", "0.0", "0.0"), degree=2)
+        M = HyperRectangleBoundaryMarkers
+        bcs = [(VelocityBCType.function, M.left.value, inlet)]
+        bcs += [(VelocityBCType.no_slip, m.value, None) for m in (M.bottom, M.top, M.back, M.front)]
+        if self._pressure_outlet:
+            bcs.insert(0, (PressureBCType.constant, M.right.value, 0.0))
+        self._bcs = tuple(bcs)
+
+
+@pytest.mark.parametrize("solver_class", [IPCSSolver, ImplicitBDFSolver])
+def test_3d_channel_flow_open_outlet_matches_oracle(solver_class):
+    problem = ChannelFlow3D(4, solver_class)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    assert problem._time_stepping.step_number == 4
+    dm = solver._dofmap
+    s = fo.Space(dm.mesh.coords, dm.mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    vd, vv = solver._velocity_dirichlet_arrays()
+    _, first = np.unique(vd[::-1], return_index=True)
+    keep = len(vd) - 1 - first
+    vbc = (vd[keep].astype(np.int64), vv[keep])
+    velocity, pressure = solver.solution.split()
+    u = velocity.nodal_values()
+    assert u[:, 0].max() > 0.5 and np.isfinite(u).all()          # the inflow has entered the channel
+    nv = dm.n_velocity
+    if solver_class is IPCSSolver:
+        orc = fo.IPCSOracle(s, solver._equation_coefficients, refactor_every_step=False)
+        pd, pv = solver._pressure_dirichlet_arrays()
+        for step in range(4):
+            orc.step(fo.bdf_alpha(step, 1.0), 0.02, vbc, (pd.astype(np.int64), pv))
+            orc.advance()
+        uo, po = orc.vel[1], orc.p_old
+    else:
+        orc = fo.BDFOracle(s, solver._equation_coefficients)
+        for step in range(4):
+            orc.step(fo.bdf_alpha(step, 1.0), 0.02, vbc)
+            orc.advance()
+        uo, po = orc.sol[1][:nv], orc.sol[1][nv:]
+    assert np.linalg.norm(velocity.vector() - uo) < 1e-6 * np.linalg.norm(uo)
+    assert np.linalg.norm(pressure.vector() - po) < 1e-6 * np.linalg.norm(po)

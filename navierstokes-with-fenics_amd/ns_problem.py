@@ -172,40 +172,44 @@ class ProblemBase:
         return os.path.join(self._results_dir, name)
 
     def _cell_gradients(self, nodal, dofmap, p2):
-        """physical gradients of a P1 / P2 field at the three vertices of every cell:
-        [nc, 3 vertices, components, 2]"""
+        """physical gradients of a P1 / P2 field at the vertices of every cell:
+        [nc, dim + 1 vertices, components, dim]"""
         mesh = self._mesh
+        dim = mesh._dim
         x = mesh.coords[mesh.cells.astype(np.int64)]
-        J = np.stack([x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]], axis=2)
+        J = np.stack([x[:, k + 1] - x[:, 0] for k in range(dim)], axis=2)
         JinvT = np.transpose(np.linalg.inv(J), (0, 2, 1))
-        dl = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
-        lam_at = np.eye(3)
+        dl = np.concatenate([-np.ones((1, dim)), np.eye(dim)], axis=0)        # grad lambda_i (reference)
+        lam_at = np.eye(dim + 1)
         vals = nodal[np.asarray(dofmap, dtype=np.int64)]
         if vals.ndim == 2:
             vals = vals[:, :, None]
         if not p2:
-            dphi = np.broadcast_to(dl, (3, 3, 2))
+            dphi = np.broadcast_to(dl, (dim + 1, dim + 1, dim))
         else:
-            dphi = np.zeros((3, 6, 2))
-            pairs = ((1, 2), (0, 2), (0, 1))
-            for v in range(3):
+            pairs = ((1, 2), (0, 2), (0, 1)) if dim == 2 else ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))
+            dphi = np.zeros((dim + 1, dim + 1 + len(pairs), dim))
+            for v in range(dim + 1):
                 l = lam_at[v]
-                for i in range(3):
+                for i in range(dim + 1):
                     dphi[v, i] = (4.0 * l[i] - 1.0) * dl[i]
                 for e, (a, b) in enumerate(pairs):
-                    dphi[v, 3 + e] = 4.0 * (l[a] * dl[b] + l[b] * dl[a])
+                    dphi[v, dim + 1 + e] = 4.0 * (l[a] * dl[b] + l[b] * dl[a])
         ref = np.einsum("vkd,cka->cvad", dphi, vals)               # reference gradients
         return np.einsum("cxd,cvad->cvax", JinvT, ref)
 
     def _compute_vorticity(self):
-        """curl of the P2 velocity; it lies in DG1, so the reference's L2 projection onto DG1
-        (:55-83) reproduces it exactly.  Stored per cell as the mean of its three vertex values."""
+        """curl of the P2 velocity (a scalar in 2D, a vector in 3D); it lies in DG1, so the
+        reference's L2 projection onto DG1 (:55-83) reproduces it exactly.  Stored per cell as the
+        mean of its vertex values (``vertex_values`` keeps the DG1 data)."""
         from fem_function import HostField
         dm = self._get_solver()._dofmap
-        if dm.dim != 2:
-            return None                     # 3D post-processing fields are not built
-        g = self._cell_gradients(self._get_velocity().nodal_values(), dm.p2_dofmap, True)
-        curl = g[:, :, 1, 0] - g[:, :, 0, 1]
+        g = self._cell_gradients(self._get_velocity().nodal_values(), dm.p2_dofmap, True)    # d_x u_a
+        if dm.dim == 2:
+            curl = g[:, :, 1, 0] - g[:, :, 0, 1]
+        else:
+            curl = np.stack([g[:, :, 2, 1] - g[:, :, 1, 2], g[:, :, 0, 2] - g[:, :, 2, 0],
+                             g[:, :, 1, 0] - g[:, :, 0, 1]], axis=2)
         field = HostField(self._mesh, "vorticity", "Cell", curl.mean(axis=1))
         field.vertex_values = curl
         return field
@@ -214,8 +218,6 @@ class ProblemBase:
         """grad of the P1 pressure: piecewise constant = its DG0 projection (:85-103)."""
         from fem_function import HostField
         dm = self._get_solver()._dofmap
-        if dm.dim != 2:
-            return None
         g = self._cell_gradients(self._get_pressure().nodal_values(), dm.p1_dofmap, False)
         return HostField(self._mesh, "pressure gradient", "Cell", g[:, 0, 0, :])
 

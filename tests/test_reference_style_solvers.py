@@ -1351,3 +1351,13 @@ def test_3d_channel_flow_open_outlet_matches_oracle(solver_class):
         uo, po = orc.sol[1][:nv], orc.sol[1][nv:]
     assert np.linalg.norm(velocity.vector() - uo) < 1e-6 * np.linalg.norm(uo)
     assert np.linalg.norm(pressure.vector() - po) < 1e-6 * np.linalg.norm(po)
+    # 3D post-processing fields (source/ns_problem.py:55-103): curl of a rigid rotation omega x x
+    # is 2 omega, the gradient of a linear pressure is its slope -- both exact in DG1 / DG0
+    import _native as nat
+    omega, slope = np.array([0.3, -0.5, 0.8]), np.array([1.5, -2.0, 0.25])
+    solver._ctx.set_state(nat.U0, np.cross(omega[None, :], dm.p2_coords).ravel())
+    solver._ctx.set_state(nat.P, dm.p1_coords @ slope)
+    w = problem._compute_vorticity()
+    assert w.values.shape == (dm.mesh.num_cells(), 3) and np.abs(w.values - 2.0 * omega).max() < 1e-12
+    g = problem._compute_pressure_gradient()
+    assert np.abs(g.values - slope).max() < 1e-12

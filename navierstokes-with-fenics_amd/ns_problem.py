@@ -14,6 +14,7 @@ computes every step through a DG LocalSolver (:554-603), is one device kernel.
 """
 import math
 import os
+import time
 
 import numpy as np
 
@@ -337,11 +338,14 @@ class InstationaryProblem(ProblemBase):
         assert hasattr(self, "_postprocessing_frequency")
         assert hasattr(self, "_output_frequency")
         ts = self._time_stepping
+        self.step_wall_times = []             # seconds per solver.solve() (diagnostic)
         while not ts.is_at_end() and ts.step_number < self._n_max_steps:
             self._set_next_step_size()
             ts.update_coefficients()
             print(ts)
+            t_wall = time.perf_counter()
             solver.solve()
+            self.step_wall_times.append(time.perf_counter() - t_wall)
             if self._postprocessing_frequency > 0 and \
                     ts.step_number % self._postprocessing_frequency == 0:
                 self.postprocess_solution()

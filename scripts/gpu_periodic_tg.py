@@ -18,9 +18,17 @@ if len(sys.argv) > 4 and sys.argv[4] == "twolevel":      # the old behaviour: P2
         orig()
         prob._mesh.structured = None
     prob.setup_mesh = setup
+if len(sys.argv) > 5 and sys.argv[5] == "ipcs":
+    prob.set_solver_class(T.IPCSSolver)
+if len(sys.argv) > 6:
+    prob._time_stepping_args = None
+    dt = float(sys.argv[6])
+    prob._start_time, prob._end_time = 0.0, dt * nsteps
+    prob._desired_start_time_step = dt
 t0 = time.time()
 prob.solve_problem()
 solver = prob._get_solver()
-print("dim %d n %d: levels %s dofs %d  last step info: newton %d kry %d  total %.1fs" % (
-    dim, n, solver._mg_levels, solver._n_dofs, solver.last_step_info.newton_iterations,
-    solver.last_step_info.krylov_iterations_momentum, time.time() - t0))
+i = solver.last_step_info
+print("dim %d n %d: levels %s dofs %d  last step info: newton %d kry %d poisson %d  total %.1fs  step times %s" % (
+    dim, n, solver._mg_levels, solver._n_dofs, i.newton_iterations, i.krylov_iterations_momentum,
+    i.krylov_iterations_poisson, time.time() - t0, getattr(prob, "step_wall_times", None)))

@@ -186,6 +186,104 @@ def _init_dist(args):
     return rank, world, local_rank, dist
 
 
+def tgv3d_bench(args):
+    """BASELINE.json configs[3] on ONE GPU: Taylor-Green vortex on the triple-periodic unit cube
+    (Kuhn tetrahedra instead of the hexahedra the config names -- the reference has simplices
+    only), Re = 100, IPCS, BDF-2, dt = 0.25 / n, periodic multigrid hierarchy, mean pressure
+    shifted to zero after every step (ns_solver_base.py:1190-1203).  The initial state is the
+    nodal interpolant of the analytic vortex (convergence_test/taylor_green_vortex.py:111-117)."""
+    import dlfn_compat as dlfn
+    from fem_mesh import TaylorHoodDofMap, box_mesh, periodic_entity_map
+    from multigrid import attach_hierarchy
+
+    class TriplePeriodic(dlfn.SubDomain):
+        def inside(self, x, on_boundary):
+            return bool(on_boundary and (dlfn.near(x[0], 0.0) or dlfn.near(x[1], 0.0) or dlfn.near(x[2], 0.0)))
+
+        def map(self, x_slave, x_master):
+            for a in range(3):
+                if dlfn.near(x_slave[a], 1.0):
+                    x_master[:] = x_slave
+                    x_master[a] -= 1.0
+                    return
+            x_master[:] = -10.0
+
+    n = args.n
+    t_setup = time.perf_counter()
+    mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
+    domain = TriplePeriodic()
+    dm = TaylorHoodDofMap(mesh, periodic_map=periodic_entity_map(mesh, domain))
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+    levels = attach_hierarchy(ctx, mesh, args.mg_degree, args.mg_eig_ratio,
+                              periodic=(domain, dm.p1_vertex_node))
+    _apply_truncation(ctx, args)
+    g = 2.0 * np.pi
+    X = dm.p2_coords
+    u0 = np.stack([np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]), -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1]),
+                   np.zeros(dm.n_p2)], axis=1).ravel()
+    Y = dm.p1_coords
+    p0 = -0.25 * (np.cos(2 * g * Y[:, 0]) + np.cos(2 * g * Y[:, 1]))
+    for slot in (nat.U0, nat.U1, nat.U2):
+        ctx.set_state(slot, u0)
+    for slot in (nat.P, nat.P_OLD):
+        ctx.set_state(slot, p0)
+    ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
+    ctx.set_dirichlet(nat.VELOCITY, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    t_setup = time.perf_counter() - t_setup
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = args.krylov_rtol
+    opts.momentum.precond = opts.poisson.precond = 1
+    opts.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
+    opts.newton_forcing = args.newton_forcing
+    dt = args.dt if args.dt != 1.0e-3 else 0.25 / n
+
+    def one_step(i):
+        ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), dt)
+        info = ctx.step_ipcs(opts)
+        ctx.shift_mean_pressure(0.0)
+        ctx.advance(0)
+        return info
+
+    for i in range(args.warmup):
+        one_step(i)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    newton = kry = poi = 0
+    for i in range(args.warmup, args.warmup + args.steps):
+        info = one_step(i)
+        newton += info.newton_iterations
+        kry += info.krylov_iterations_momentum
+        poi += info.krylov_iterations_poisson
+    ctx.synchronize()
+    sps = args.steps / (time.perf_counter() - t0)
+    # the vortex decays like exp(-2 g^2 t / Re): check the run against the analytic solution
+    t_end = dt * (args.warmup + args.steps)
+    u = ctx.get_state(nat.U1).reshape(-1, 3)
+    err = float(np.abs(u - np.exp(-2.0 * g * g * t_end / 100.0) * u0.reshape(-1, 3)).max())
+    ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 100)
+    achieved = nbytes / (ms_spmv * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "dof_updates_per_sec", "value": sps * dm.n_dofs, "unit": "DoF-updates/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "time_steps_per_sec": sps,
+        "config": {"workload": "3D Taylor-Green vortex, triple-periodic unit cube, %d^3 cubes x 6 Kuhn "
+                               "tetrahedra (%d dofs), Re=100, IPCS, BDF-2, dt=%g" % (n, dm.n_dofs, dt),
+                   "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "newton_forcing": args.newton_forcing, "coarse_p1_levels": levels,
+                   "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
+                   "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
+                   "max_abs_velocity_error_vs_analytic": err, "host_setup_s": t_setup},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<1,1,3,3> (finest-level Chebyshev smoothing step, "
+                                               "scalar P2 operator on 3 components; back-to-back launches)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv}}))
+    ctx.close()
+
+
 def cavity3d_bench(args):
     """3D lid-driven cavity on a Kuhn (BoxMesh) tetrahedral mesh, Re = 100, IPCS or monolithic
     BDF-2 -- the relative of BASELINE.json configs[3:5] (3D configurations beyond what the
@@ -334,10 +432,11 @@ def main():
                     help="R[,TOL]: truncate the velocity multigrid cycle at the first level with "
                          "c_v K_ii <= R alpha0/k M_ii, solved there by Chebyshev iteration to TOL (0: off)")
     ap.add_argument("--coarsest", type=int, default=0, help="cells across the coarsest multigrid mesh (0: default)")
-    ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf"),
+    ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf", "tgv3d-ipcs"),
                     default="cavity-ipcs",
                     help="cavity-ipcs = BASELINE configs[1] (headline); dfg-bdf = configs[2], 1 GPU; "
-                         "cavity3d-* = 3D tetrahedral cavity (--cells cubes per side), 1 GPU")
+                         "cavity3d-* = 3D tetrahedral cavity (--cells cubes per side); tgv3d-ipcs = configs[3] "
+                         "(triple-periodic Taylor-Green vortex) on 1 GPU")
     ap.add_argument("--dfg-refine", type=int, default=5)
     args = ap.parse_args()
     if args.workload == "dfg-bdf":
@@ -348,6 +447,12 @@ def main():
         if args.n == 512:
             args.n = 32
         return cavity3d_bench(args)
+    if args.workload == "tgv3d-ipcs":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("the tgv3d-ipcs workload is a single-GPU configuration (periodic meshes are not partitioned)")
+        if args.n == 512:
+            args.n = 32
+        return tgv3d_bench(args)
 
     rank, world, local_rank, dist = _init_dist(args)
 

@@ -250,6 +250,12 @@ int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cel
  * that mesh is too large for a dense solve every rank runs the remaining V-cycle redundantly on
  * the all-reduced right-hand side, so the small levels cost no halo exchange */
 int nsfem_mg_add_global_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* level);
+/* nsfem_mg_set_global_coarse for constrained (periodic) spaces: dofmap [n_cells * (dim + 1)] with
+ * n_dofs distinct P1 dofs; on periodic partitions the local coarsest level may wrap around the end
+ * of the global numbering (offset + local size > n_dofs) */
+int nsfem_mg_set_global_coarse_constrained(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cells,
+                                           const double* coords, const int32_t* cells,
+                                           const int32_t* dofmap, int32_t n_dofs, int64_t offset);
 int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* opts /* may be NULL */);
 /* truncated velocity cycle for mass-dominated operators (small time steps): the first P1 level
  * on which  c_v K_ii <= max_ratio * (alpha0/k) M_ii  for every node is solved by Chebyshev
@@ -277,6 +283,8 @@ typedef struct {
   const uint8_t* p1_ghost;   /* [n_p1] */
   nsfem_halo p2_halo, p1_halo;
   int64_t n_p2_global, n_p1_global;
+  int32_t periodic;          /* nonzero: the strips / slabs close periodically -- rank size-1 is
+                                the lower neighbour of rank 0, halo exchanges wrap around */
 } nsfem_partition_desc;
 int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* part);
 int nsfem_comm_unique_id(char* id128 /* 128 bytes out */);

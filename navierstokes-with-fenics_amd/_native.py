@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply",
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
-    "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse",
+    "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse", "nsfem_mg_set_global_coarse_constrained",
     "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
@@ -99,7 +99,7 @@ class PartitionDesc(C.Structure):
     _fields_ = [("rank", C.c_int32), ("size", C.c_int32),
                 ("p2_ghost", C.POINTER(C.c_uint8)), ("p1_ghost", C.POINTER(C.c_uint8)),
                 ("p2_halo", Halo), ("p1_halo", Halo),
-                ("n_p2_global", C.c_int64), ("n_p1_global", C.c_int64)]
+                ("n_p2_global", C.c_int64), ("n_p1_global", C.c_int64), ("periodic", C.c_int32)]
 
 
 class MgOpts(C.Structure):
@@ -175,6 +175,7 @@ def load_library(path=None):
                                                   C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                                   C.c_int]),
         "nsfem_mg_set_global_coarse": (C.c_int, [vp, i32, i32, pd, pi, i64]),
+        "nsfem_mg_set_global_coarse_constrained": (C.c_int, [vp, i32, i32, pd, pi, pi, i32, i64]),
         "nsfem_set_partition": (C.c_int, [vp, C.POINTER(PartitionDesc)]),
         "nsfem_comm_unique_id": (C.c_int, [C.c_char_p]),
         "nsfem_comm_attach_rccl": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
@@ -407,7 +408,7 @@ class NsfemContext:
                                                           _ip(rp), _ip(ci), _dp(cv),
                                                           1 if singular else 0))
 
-    def mg_add_global_level(self, coords, cells, p_rowptr, p_col, p_val):
+    def mg_add_global_level(self, coords, cells, p_rowptr, p_col, p_val, dofmap=None):
         """coarser level of the replicated hierarchy below the global coarsest mesh"""
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
@@ -416,23 +417,34 @@ class NsfemContext:
         pv = np.ascontiguousarray(p_val, dtype=np.float64)
         d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
                         _ip(rp), _ip(pc), _dp(pv), None, Halo.from_dict(None), None, 0)
+        if dofmap is not None:
+            dm = np.ascontiguousarray(dofmap, dtype=np.int32)
+            assert dm.shape == cells.shape
+            d.dofmap, d.n_dofs = _ip(dm), int(dm.max()) + 1
         self._check(self._lib.nsfem_mg_add_global_level(self._h, C.byref(d)))
 
-    def mg_set_global_coarse(self, coords, cells, offset):
+    def mg_set_global_coarse(self, coords, cells, offset, dofmap=None):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
+        if dofmap is not None:                     # constrained (periodic) global coarse space
+            dm = np.ascontiguousarray(dofmap, dtype=np.int32)
+            assert dm.shape == cells.shape
+            self._check(self._lib.nsfem_mg_set_global_coarse_constrained(
+                self._h, coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), _ip(dm),
+                int(dm.max()) + 1, int(offset)))
+            return
         self._check(self._lib.nsfem_mg_set_global_coarse(self._h, coords.shape[0], cells.shape[0],
                                                          _dp(coords), _ip(cells), int(offset)))
 
     # -- multi-GPU --------------------------------------------------------------------
     def set_partition(self, rank, size, p2_ghost, p1_ghost, p2_halo, p1_halo, n_p2_global,
-                      n_p1_global):
+                      n_p1_global, periodic=False):
         g2 = np.ascontiguousarray(p2_ghost, dtype=np.uint8)
         g1 = np.ascontiguousarray(p1_ghost, dtype=np.uint8)
         assert g2.size == self.n_p2 and g1.size == self.n_p1
         d = PartitionDesc(rank, size, g2.ctypes.data_as(C.POINTER(C.c_uint8)),
                           g1.ctypes.data_as(C.POINTER(C.c_uint8)), Halo.from_dict(p2_halo),
-                          Halo.from_dict(p1_halo), int(n_p2_global), int(n_p1_global))
+                          Halo.from_dict(p1_halo), int(n_p2_global), int(n_p1_global), 1 if periodic else 0)
         self._check(self._lib.nsfem_set_partition(self._h, C.byref(d)))
 
     def attach_local_comm(self, group, rank):

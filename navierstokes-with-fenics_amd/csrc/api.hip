@@ -955,11 +955,10 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
   hipStream_t s = ctx->stream;
   nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
   ctx->coarse.push_back(lv);
-  NSFEM_REQUIRE(!(d->dofmap && d->ghost), "constrained (periodic) levels cannot be partitioned");
   fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells, d->dofmap, d->n_dofs);
   lv->to_finer.build(s, n_fine, lv->n, d->p_rowptr, d->p_col, d->p_val);
-  if (d->ghost) {
-    lv->h_ghost.assign(d->ghost, d->ghost + d->n_vertices);
+  if (d->ghost) {                       // one flag per dof of the level (= per vertex without a dof map)
+    lv->h_ghost.assign(d->ghost, d->ghost + lv->n);
     lv->halo = to_halo(d->halo);
     lv->has_halo = true;
   }
@@ -1042,9 +1041,25 @@ extern "C" int nsfem_mg_add_global_level(nsfem_ctx* ctx, const nsfem_mg_level_de
   hipStream_t s = ctx->stream;
   nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
   ctx->global_tail.push_back(lv);
-  fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells);
-  lv->to_finer.build(s, n_fine, d->n_vertices, d->p_rowptr, d->p_col, d->p_val);
+  fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells, d->dofmap, d->n_dofs);
+  lv->to_finer.build(s, n_fine, lv->n, d->p_rowptr, d->p_col, d->p_val);
   NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+extern "C" int nsfem_mg_set_global_coarse_constrained(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cells,
+                                                      const double* coords, const int32_t* cells,
+                                                      const int32_t* dofmap, int32_t n_dofs,
+                                                      int64_t offset) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && coords && cells && dofmap && n_vertices > 0 && n_cells > 0 && n_dofs > 0, "bad argument");
+  NSFEM_REQUIRE(!ctx->mg_built, "hierarchy already finalized");
+  NSFEM_REQUIRE(!ctx->global_coarse, "global coarsest mesh already set");
+  NSFEM_REQUIRE(offset >= 0 && offset < n_dofs, "offset outside the global coarsest space");
+  nsfem_ctx::P1Level* lv = ctx->global_coarse = new nsfem_ctx::P1Level();
+  fill_p1_level(ctx, lv, n_vertices, n_cells, coords, cells, dofmap, n_dofs);
+  ctx->glob_off = offset;
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
   API_END(ctx)
 }
 
@@ -1074,6 +1089,8 @@ extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d
   ctx->halo_p1 = to_halo(d->p1_halo);
   ctx->n_p2_global = d->n_p2_global;
   ctx->n_p1_global = d->n_p1_global;
+  ctx->partition_periodic = d->periodic != 0;
+  if (ctx->comm) ctx->comm->periodic = ctx->partition_periodic;
   // masks carry the ghost flag from now on
   launch_overlay_ghost(s, nvel(ctx), ctx->ghost_v.p, ctx->mask_v.p);
   launch_overlay_ghost(s, n1, ctx->ghost_p.p, ctx->mask_p.p);
@@ -1088,6 +1105,7 @@ extern "C" int nsfem_comm_attach_local(nsfem_ctx* ctx, void* group, int rank) {
   delete ctx->comm;
   ctx->comm = nullptr;
   ctx->comm = make_local_comm(group, rank);
+  ctx->comm->periodic = ctx->partition_periodic;
   API_END(ctx)
 }
 
@@ -1098,6 +1116,7 @@ extern "C" int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int ran
   delete ctx->comm;
   ctx->comm = nullptr;
   ctx->comm = make_rccl_comm(id128, rank, size);
+  ctx->comm->periodic = ctx->partition_periodic;
   API_END(ctx)
 }
 
@@ -1142,7 +1161,8 @@ static void wire_partition(nsfem_ctx* ctx, Multigrid& mg, size_t first_p1, bool 
     t.setup_work(ctx->stream);
     mg.tail = &t;
   }
-  NSFEM_REQUIRE(mg.glob_off >= 0 && mg.glob_off + mg.lv.back().n <= mg.n_glob,
+  mg.glob_wrap = ctx->partition_periodic;
+  NSFEM_REQUIRE(mg.glob_off >= 0 && (mg.glob_wrap || mg.glob_off + mg.lv.back().n <= mg.n_glob),
                 "local coarsest level does not fit into the global coarsest mesh");
 }
 

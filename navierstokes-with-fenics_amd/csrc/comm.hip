@@ -80,18 +80,19 @@ struct LocalComm : Comm {
     g->ptr[rank] = vec;
     g->halo[rank] = h;
     g->barrier();
-    if (h.recv_above_cnt > 0 && rank + 1 < size) {
-      const HaloRange& o = g->halo[rank + 1];
+    const int above = up(), below = down();
+    if (h.recv_above_cnt > 0 && above >= 0) {
+      const HaloRange& o = g->halo[above];
       NSFEM_REQUIRE(o.send_down_cnt == h.recv_above_cnt, "halo size mismatch (above)");
       NSFEM_HIP(hipMemcpyAsync(vec + h.recv_above_off * width,
-                               g->ptr[rank + 1] + o.send_down_off * width,
+                               g->ptr[above] + o.send_down_off * width,
                                sizeof(double) * h.recv_above_cnt * width, hipMemcpyDeviceToDevice, s));
     }
-    if (h.recv_below_cnt > 0 && rank > 0) {
-      const HaloRange& o = g->halo[rank - 1];
+    if (h.recv_below_cnt > 0 && below >= 0) {
+      const HaloRange& o = g->halo[below];
       NSFEM_REQUIRE(o.send_up_cnt == h.recv_below_cnt, "halo size mismatch (below)");
       NSFEM_HIP(hipMemcpyAsync(vec + h.recv_below_off * width,
-                               g->ptr[rank - 1] + o.send_up_off * width,
+                               g->ptr[below] + o.send_up_off * width,
                                sizeof(double) * h.recv_below_cnt * width, hipMemcpyDeviceToDevice, s));
     }
     NSFEM_HIP(hipStreamSynchronize(s));
@@ -122,20 +123,24 @@ struct RcclComm : Comm {
   }
   void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) override {
     count_exchange(h, width);
-    const bool up = rank + 1 < size, down = rank > 0;
+    const int above = up(), below = down();
+    NSFEM_REQUIRE(!(periodic && size == 1), "a periodic partition needs at least two RCCL ranks");
+    // sends first (up, then down), receives in the order the peers send (from below = its
+    // send-up, then from above = its send-down): with two ranks of a periodic partition both
+    // neighbours are the SAME peer and RCCL matches the messages of a pair in issue order
     NSFEM_NCCL(ncclGroupStart());
-    if (up && h.send_up_cnt > 0)
+    if (above >= 0 && h.send_up_cnt > 0)
       NSFEM_NCCL(ncclSend(vec + h.send_up_off * width, (size_t)(h.send_up_cnt * width), ncclDouble,
-                          rank + 1, comm, s));
-    if (up && h.recv_above_cnt > 0)
-      NSFEM_NCCL(ncclRecv(vec + h.recv_above_off * width, (size_t)(h.recv_above_cnt * width),
-                          ncclDouble, rank + 1, comm, s));
-    if (down && h.send_down_cnt > 0)
+                          above, comm, s));
+    if (below >= 0 && h.send_down_cnt > 0)
       NSFEM_NCCL(ncclSend(vec + h.send_down_off * width, (size_t)(h.send_down_cnt * width),
-                          ncclDouble, rank - 1, comm, s));
-    if (down && h.recv_below_cnt > 0)
+                          ncclDouble, below, comm, s));
+    if (below >= 0 && h.recv_below_cnt > 0)
       NSFEM_NCCL(ncclRecv(vec + h.recv_below_off * width, (size_t)(h.recv_below_cnt * width),
-                          ncclDouble, rank - 1, comm, s));
+                          ncclDouble, below, comm, s));
+    if (above >= 0 && h.recv_above_cnt > 0)
+      NSFEM_NCCL(ncclRecv(vec + h.recv_above_off * width, (size_t)(h.recv_above_cnt * width),
+                          ncclDouble, above, comm, s));
     NSFEM_NCCL(ncclGroupEnd());
   }
 };

@@ -357,7 +357,7 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
   std::vector<double> gm((size_t)n * nv, 0.0);
   for (int i = 0; i < C.n; ++i)
     for (int v = 0; v < nv; ++v)
-      if (cur[(size_t)i * nv + v] == 1) gm[((size_t)glob_off + i) * nv + v] = 1.0;
+      if (cur[(size_t)i * nv + v] == 1) gm[(((size_t)glob_off + i) % (size_t)n) * nv + v] = 1.0;
   gb.alloc((size_t)n * nv);
   gx.alloc((size_t)n * nv);
   NSFEM_HIP(hipMemcpyAsync(gb.p, gm.data(), sizeof(double) * gm.size(), hipMemcpyHostToDevice, s));
@@ -494,9 +494,18 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
       // gather the owned right-hand sides into the global coarse vector (ghost entries are
       // zero, so overlapping lines add up correctly), solve redundantly, copy the local part
       gb.zero(s);
-      NSFEM_HIP(hipMemcpyAsync(gb.p + (size_t)glob_off * nv, b, sizeof(double) * n,
-                               hipMemcpyDeviceToDevice, s));
-      comm->allreduce_sum(s, gb.p, (int64_t)n_glob * nv);
+      // (periodic partitions: the local level may run past the end of the global numbering and
+      // continue at its start -- two segments)
+      const int64_t ntot = (int64_t)n_glob * nv, off = (int64_t)glob_off * nv;
+      // owned entries only (ghost entries of b are zero; on tiny periodic levels a ghost plane may
+      // even coincide with an owned plane of the same rank, so plain copies could overwrite data):
+      // segment-wise ADD into the zeroed global vector
+      for (int64_t pos = 0; pos < n;) {
+        const int64_t g = (off + pos) % ntot, len = std::min<int64_t>(n - pos, ntot - g);
+        launch_axpby(s, len, 1.0, gb.p + g, 1.0, b + pos, gb.p + g);
+        pos += len;
+      }
+      comm->allreduce_sum(s, gb.p, ntot);
       if (tail) {
         tail->vcycle(s, 0, gb.p, gx.p);
       } else {
@@ -505,8 +514,11 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
                            coarse_inv.p, gb.p, gx.p);
         NSFEM_HIP(hipGetLastError());
       }
-      NSFEM_HIP(hipMemcpyAsync(x, gx.p + (size_t)glob_off * nv, sizeof(double) * n,
-                               hipMemcpyDeviceToDevice, s));
+      for (int64_t pos = 0; pos < n;) {
+        const int64_t g = (off + pos) % ntot, len = std::min<int64_t>(n - pos, ntot - g);
+        NSFEM_HIP(hipMemcpyAsync(x + pos, gx.p + g, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
+        pos += len;
+      }
       return;
     }
     if (dense_coarse) {

@@ -277,6 +277,9 @@ struct HaloRange {
 };
 struct Comm {
   int rank = 0, size = 1;
+  bool periodic = false;     // the partition closes periodically: neighbours wrap around
+  int up() const { return rank + 1 < size ? rank + 1 : (periodic ? 0 : -1); }
+  int down() const { return rank > 0 ? rank - 1 : (periodic ? size - 1 : -1); }
   virtual ~Comm() {}
   // in-place sum over the ranks of `count` doubles in device memory, ordered on stream s
   virtual void allreduce_sum(hipStream_t s, double* dev, int64_t count) = 0;
@@ -288,7 +291,7 @@ struct Comm {
   void count_allreduce(int64_t count) { ++n_allreduce; bytes_allreduce += 8 * count; }
   void count_exchange(const HaloRange& h, int width) {
     ++n_exchange;
-    bytes_exchange += 8 * (int64_t)width * ((rank + 1 < size ? h.send_up_cnt : 0) + (rank > 0 ? h.send_down_cnt : 0));
+    bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.send_up_cnt : 0) + (down() >= 0 ? h.send_down_cnt : 0));
   }
 };
 void launch_zero_ghost(hipStream_t s, int64_t n, const uint8_t* mask, double* x);  // x[mask==2]=0
@@ -360,6 +363,7 @@ struct Multigrid : Precond {
   const BlockMat* globA = nullptr;
   int n_glob = 0;
   int64_t glob_off = 0;
+  bool glob_wrap = false;        // periodic partitions: the local coarsest level wraps around the global numbering
   DevBuf<double> gb, gx;
   // when the global coarsest mesh is too large for a dense solve it carries its own REPLICATED
   // hierarchy: a serial multigrid (no communicator) every rank runs redundantly on the
@@ -479,6 +483,7 @@ struct nsfem_ctx {
   double mg_trunc_ratio = 4.0;                 // > 0: truncate the velocity cycle where nu K_ii <= ratio * alpha M_ii
   double mg_trunc_tol = 0.1;
   int64_t glob_off = 0;
+  bool partition_periodic = false;
   // NSFEM_FORCE_COMM=1 routes a single-rank run through the communicator as well (lets a
   // one-GPU box exercise the RCCL all-reduce calls)
   bool distributed() const {

@@ -266,3 +266,166 @@ class SlabPartition:
             ctx.mg_add_global_level(mesh.coords, mesh.cells, rowptr, col, val)
         ctx.mg_finalize(2 if degree is None else degree, 4.0 if eig_ratio is None else eig_ratio)
         return len(self.levels)
+
+
+# ---------------------------------------------------------------------------------------------
+# triple-periodic boxes (BASELINE configs[3]: 3D Taylor-Green vortex across the GPUs of a node):
+# x and y are periodic INSIDE every slab (slave vertices / edges share their master's dof, as in
+# TaylorHoodDofMap's periodic maps), z is periodic ACROSS the ranks: the halo exchange wraps
+# around (rank size-1 <-> rank 0), every rank has a ghost plane below and a ghost layer above.
+# ---------------------------------------------------------------------------------------------
+def _xy_periodic_masters(mesh, p0, p1):
+    """(entity master [nv + ne], vertex master [nv]) identifying x = p1[0] with x = p0[0] and
+    y = p1[1] with y = p0[1] (z untouched), by lattice keys of vertices and edge midpoints."""
+    nv = mesh.num_vertices()
+    pts = np.concatenate([mesh.coords, mesh.edge_midpoints()], axis=0)
+    scale = 8.0 / max(mesh.hmin(), 1e-300)
+    L = np.array([p1[0] - p0[0], p1[1] - p0[1], 0.0])
+    wrapped = pts.copy()
+    for a in range(2):
+        on_far = np.abs(pts[:, a] - p1[a]) < 1e-9 * max(1.0, abs(L[a]))
+        wrapped[on_far, a] -= L[a]
+    key = lambda X: [tuple(r) for r in np.round((X - np.asarray(p0)) * scale).astype(np.int64)]
+    moved = np.nonzero(np.abs(wrapped - pts).sum(axis=1) > 0.0)[0]
+    master = np.arange(pts.shape[0], dtype=np.int64)
+    if moved.size:
+        kv = {k: i for i, k in enumerate(key(pts[:nv]))}
+        ke = {k: nv + i for i, k in enumerate(key(pts[nv:]))}
+        for i, k in zip(moved.tolist(), key(wrapped[moved])):
+            master[i] = (kv if i < nv else ke)[k]
+    return master, master[:nv].copy()
+
+
+class PeriodicSlabLevel(SlabLevel):
+    """P1 level of a triple-periodic slab: ghost plane below AND ghost layer above on every rank;
+    dof = (plane, iy mod ny, ix mod nx), so every lattice plane holds nx * ny dofs."""
+
+    def __init__(self, p0, p1, nx, ny, nz, layer0, own_layers):
+        super().__init__(p0, p1, nx, ny, nz + 1, layer0, own_layers, 1)     # (mesh may stick out by one layer)
+        # the box above was built on a domain one layer taller so that the last rank's ghost layer
+        # exists; restore the true spacing / coordinates
+        hz = (p1[2] - p0[2]) / nz
+        wv = (nx + 1) * (ny + 1)
+        self.mesh.coords[:, 2] = np.repeat(p0[2] + hz * (layer0 + np.arange(own_layers + 2)), wv)
+        self.has_below = self.has_above = True
+        ix, iy, iz = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(own_layers + 2), indexing="ij")
+        dof = (iz * ny + (iy % ny)) * nx + (ix % nx)
+        self.vertex_dof = dof.transpose(2, 1, 0).ravel().astype(np.int64)    # vertex id = (iz, iy, ix)
+        self.w1 = nx * ny
+        self.n_p1 = self.w1 * (own_layers + 2)
+        ghost = np.zeros(self.n_p1, dtype=np.uint8)
+        ghost[: self.w1] = GHOST
+        ghost[self.w1 * (own_layers + 1):] = GHOST
+        self.p1_ghost = ghost
+        w1 = self.w1
+        self.p1_halo = dict(send_up=(w1 * own_layers, w1), recv_above=(w1 * (own_layers + 1), w1),
+                            send_down=(w1, w1), recv_below=(0, w1))
+        self.dofmap = self.vertex_dof[self.mesh.cells.astype(np.int64)].astype(np.int32)
+
+
+class PeriodicSlabPartition:
+    """Rank ``rank`` of ``size`` of the triple-periodic (nx, ny, nz) Kuhn box: owns nz / size cube
+    layers (the dofs of its layers except the bottom lattice plane, which belongs to the rank
+    below -- for rank 0 that is rank size-1: the plane z = p0 IS the plane z = p1)."""
+
+    periodic = True
+
+    def __init__(self, p0, p1, nx, ny, nz, rank, size, coarsest=4, global_coarsest=None):
+        from multigrid import structured_prolongation_3d
+        import scipy.sparse as sp
+        assert nz % size == 0 and size >= 2, "needs at least two ranks (one rank: use a periodic dof map)"
+        own = nz // size
+        self.rank, self.size = rank, size
+        self.p0, self.p1, self.nx, self.ny, self.nz = tuple(p0), tuple(p1), nx, ny, nz
+        self.fine = PeriodicSlabLevel(p0, p1, nx, ny, nz, rank * own, own)
+        self.mesh = self.fine.mesh
+        self.dofmap = dm = TaylorHoodDofMap(self.mesh, periodic_map=_xy_periodic_masters(self.mesh, p0, (p1[0], p1[1], 0.0)))
+        assert np.array_equal(dm.p1_vertex_node, self.fine.vertex_dof)
+        w2 = 4 * nx * ny
+        self.w2 = w2
+        planes = 2 * (own + 1) + 1
+        assert dm.n_p2 == w2 * planes and dm.n_p1 == self.fine.n_p1
+        z2 = dm.p2_coords[:, 2]
+        assert np.all(np.diff(z2) >= -1e-12)                      # plane-contiguous numbering
+        ghost2 = np.zeros(dm.n_p2, dtype=np.uint8)
+        ghost2[:w2] = GHOST
+        ghost2[w2 * (2 * own + 1):] = GHOST
+        self.p2_ghost = ghost2
+        self.p2_halo = dict(send_up=(w2 * 2 * own, w2), recv_above=(w2 * (2 * own + 1), 2 * w2),
+                            send_down=(w2, 2 * w2), recv_below=(0, w2))
+        self.p1_ghost, self.p1_halo = self.fine.p1_ghost, self.fine.p1_halo
+        n2g, n1g = w2 * 2 * nz, nx * ny * nz
+        self.n_p2_global, self.n_p1_global = n2g, n1g
+        self.p2_global = (rank * own * 2 * w2 + np.arange(dm.n_p2)) % n2g
+        self.p1_global = (rank * own * self.fine.w1 + np.arange(dm.n_p1)) % n1g
+        self.p2_owned, self.p1_owned = ghost2 == 0, self.p1_ghost == 0
+        self.levels = []
+        lx, ly, lz, lown, fine_level = nx, ny, nz, own, self.fine
+        while lx % 2 == 0 and ly % 2 == 0 and lown % 2 == 0 and lown // 2 >= 1 \
+                and min(lx, ly, lz) // 2 >= coarsest:
+            cx, cy, cz, cown = lx // 2, ly // 2, lz // 2, lown // 2
+            lev = PeriodicSlabLevel(p0, p1, cx, cy, cz, rank * cown, cown)
+            # vertex prolongation from the coarse local box (cown + 1 layers) to its refinement
+            # (2 cown + 2 layers), cut to the vertex planes the finer local mesh has (lown + 2)
+            rowptr, col, val = structured_prolongation_3d(lx, ly, 2 * (cown + 1))
+            n_fine_v = (lx + 1) * (ly + 1) * (lown + 2)
+            P = sp.csr_matrix((val, col, rowptr))[:n_fine_v]
+            f_dof, c_dof = fine_level.vertex_dof, lev.vertex_dof
+            rep = np.full(int(f_dof.max()) + 1, -1, dtype=np.int64)
+            rep[f_dof[::-1]] = np.arange(f_dof.size - 1, -1, -1)
+            E = sp.csr_matrix((np.ones(c_dof.size), (np.arange(c_dof.size), c_dof)),
+                              shape=(c_dof.size, int(c_dof.max()) + 1))
+            Pp = (P[rep] @ E).tocsr()
+            Pp.sum_duplicates()
+            Pp.sort_indices()
+            self.levels.append((lev, (Pp.indptr.astype(np.int32), Pp.indices.astype(np.int32), Pp.data.copy())))
+            lx, ly, lz, lown, fine_level = cx, cy, cz, cown, lev
+        last = self.levels[-1][0] if self.levels else self.fine
+        self.coarse_global_shape = (last.nx, last.ny, lz)
+        self.coarse_global_offset = last.row0 * last.w1
+        self.global_coarsest = global_coarsest
+
+    def _global_periodic_levels(self):
+        """the replicated triple-periodic hierarchy below the partitioned levels: global coarse mesh
+        (+ coarser levels down to ``global_coarsest``) with their periodic dof maps"""
+        from fem_mesh import box_mesh
+        from multigrid import periodic_levels, structured_hierarchy
+        cx, cy, cz = self.coarse_global_shape
+        mesh = box_mesh(self.p0, self.p1, cx, cy, cz)
+        ix, iy, iz = np.meshgrid(np.arange(cx + 1), np.arange(cy + 1), np.arange(cz + 1), indexing="ij")
+        vdof = (((iz % cz) * cy + (iy % cy)) * cx + (ix % cx)).transpose(2, 1, 0).ravel().astype(np.int64)
+        tail = []
+        if self.global_coarsest is not None:
+            tail = structured_hierarchy(self.p0, self.p1, cx, cy, cz, coarsest=self.global_coarsest)
+        return mesh, vdof, tail
+
+    def attach(self, ctx, degree=None, eig_ratio=None):
+        import scipy.sparse as sp
+        ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, self.p2_halo,
+                          self.p1_halo, self.n_p2_global, self.n_p1_global, periodic=True)
+        for lev, (rowptr, col, val) in self.levels:
+            ctx.mg_add_level(lev.mesh.coords, lev.mesh.cells, rowptr, col, val,
+                             ghost=lev.p1_ghost, halo=lev.p1_halo, dofmap=lev.dofmap)
+        mesh, vdof, tail = self._global_periodic_levels()
+        ctx.mg_set_global_coarse(mesh.coords, mesh.cells, self.coarse_global_offset,
+                                 dofmap=vdof[mesh.cells.astype(np.int64)])
+        f_dof = vdof
+        for cmesh, (rowptr, col, val) in tail:            # replicated periodic levels below it
+            shape = cmesh.structured[2:]
+            ix, iy, iz = np.meshgrid(*[np.arange(k + 1) for k in shape], indexing="ij")
+            c_dof = (((iz % shape[2]) * shape[1] + (iy % shape[1])) * shape[0] + (ix % shape[0])) \
+                .transpose(2, 1, 0).ravel().astype(np.int64)
+            P = sp.csr_matrix((val, col, rowptr), shape=(f_dof.size, c_dof.size))
+            rep = np.full(int(f_dof.max()) + 1, -1, dtype=np.int64)
+            rep[f_dof[::-1]] = np.arange(f_dof.size - 1, -1, -1)
+            E = sp.csr_matrix((np.ones(c_dof.size), (np.arange(c_dof.size), c_dof)),
+                              shape=(c_dof.size, int(c_dof.max()) + 1))
+            Pp = (P[rep] @ E).tocsr()
+            Pp.sum_duplicates()
+            Pp.sort_indices()
+            ctx.mg_add_global_level(cmesh.coords, cmesh.cells, Pp.indptr.astype(np.int32),
+                                    Pp.indices.astype(np.int32), Pp.data.copy(),
+                                    dofmap=c_dof[cmesh.cells.astype(np.int64)])
+            f_dof = c_dof
+        ctx.mg_finalize(2 if degree is None else degree, 4.0 if eig_ratio is None else eig_ratio)
+        return len(self.levels)

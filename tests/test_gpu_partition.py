@@ -373,3 +373,120 @@ def test_chebyshev_mass_solve_matches_cg(dim):
     assert rel(res[True][0], res[False][0]) < 1e-10
     assert rel(res[True][1], res[False][1]) < 1e-8
     assert max(res[True][2]) <= (60 if dim == 2 else 130)
+
+
+@pytest.mark.parametrize("size,tail", [(2, False), (4, True)])
+def test_partitioned_triple_periodic_taylor_green_equals_single_context(size, tail):
+    """BASELINE configs[3] in small: Taylor-Green vortex on the triple-periodic cube, IPCS, slabs
+    along z whose halo exchange WRAPS AROUND (PeriodicSlabPartition: x, y periodic inside every
+    slab through the dof maps, z periodic across the ranks), periodic multigrid levels with the
+    replicated periodic global coarse problem -- in-process ranks against the single context with
+    the triple-periodic dof map."""
+    import dlfn_compat as dlfn
+    from fem_mesh import TaylorHoodDofMap, box_mesh, periodic_entity_map
+    from partition import PeriodicSlabPartition
+
+    class TriplePeriodic(dlfn.SubDomain):
+        def inside(self, x, on_boundary):
+            return bool(on_boundary and (dlfn.near(x[0], 0.0) or dlfn.near(x[1], 0.0) or dlfn.near(x[2], 0.0)))
+
+        def map(self, x_slave, x_master):
+            for a in range(3):
+                if dlfn.near(x_slave[a], 1.0):
+                    x_master[:] = x_slave
+                    x_master[a] -= 1.0
+                    return
+            x_master[:] = -10.0
+
+    n, nsteps, k, g = 8, 3, 0.02, 2.0 * np.pi
+
+    def fields(dmap):
+        X, Y = dmap.p2_coords, dmap.p1_coords
+        u = np.stack([np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]), -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1]),
+                      0.3 * np.sin(g * X[:, 2]) * np.cos(g * X[:, 0])], axis=1).ravel()
+        return u, -0.25 * (np.cos(2 * g * Y[:, 0]) + np.cos(2 * g * Y[:, 1]))
+
+    def run(ctx, dmap, out, key):
+        u0, p0 = fields(dmap)
+        for slot in (nat.U0, nat.U1, nat.U2):
+            ctx.set_state(slot, u0)
+        for slot in (nat.P, nat.P_OLD):
+            ctx.set_state(slot, p0)
+        ctx.set_coeffs(1.0, 1.0, 0.02)
+        ctx.set_dirichlet(nat.VELOCITY, np.zeros(0, np.int32), np.zeros(0))
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-12
+        opts.momentum.precond = opts.poisson.precond = 1
+        opts.correction.precond = 2
+        infos = []
+        for step in range(nsteps):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
+            infos.append(ctx.step_ipcs(opts))
+            ctx.advance(0)
+        out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
+
+    mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
+    domain = TriplePeriodic()
+    dm = TaylorHoodDofMap(mesh, periodic_map=periodic_entity_map(mesh, domain))
+    ref = {}
+    ctx0 = context(mesh, dm)
+    attach_hierarchy(ctx0, mesh, coarsest=2, periodic=(domain, dm.p1_vertex_node))
+    run(ctx0, dm, ref, 0)
+    u_ref, p_ref, inf_ref = ref[0]
+    ctx0.close()
+
+    group = nat.local_group_create(size)
+    parts = [PeriodicSlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n, r, size,
+                                   coarsest=4 if tail else 2, global_coarsest=2 if tail else None)
+             for r in range(size)]
+    ctxs = []
+    for r, part in enumerate(parts):
+        pdm = part.dofmap
+        c = nat.NsfemContext(part.mesh.coords, part.mesh.cells, pdm.p2_dofmap, pdm.p1_dofmap,
+                             pdm.n_p2, pdm.n_p1)
+        c.attach_local_comm(group, r)
+        ctxs.append(c)
+    out, errors = {}, []
+
+    def worker(r):
+        try:
+            parts[r].attach(ctxs[r])
+            run(ctxs[r], parts[r].dofmap, out, r)
+        except BaseException as exc:
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            errors.append((r, repr(exc)))
+            os._exit(17)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    # compare by coordinates (mod 1): key -> reference dof
+    key = lambda X: [tuple(r) for r in (np.round(X * 64).astype(np.int64) % 64)]
+    ref2 = {kk: i for i, kk in enumerate(key(dm.p2_coords))}
+    ref1 = {kk: i for i, kk in enumerate(key(dm.p1_coords))}
+    u = np.full_like(u_ref, np.nan)
+    p = np.full_like(p_ref, np.nan)
+    for r, part in enumerate(parts):
+        ul, pl, infos = out[r]
+        own2, own1 = np.nonzero(part.p2_owned)[0], np.nonzero(part.p1_owned)[0]
+        i2 = np.array([ref2[kk] for kk in key(part.dofmap.p2_coords[own2])])
+        i1 = np.array([ref1[kk] for kk in key(part.dofmap.p1_coords[own1])])
+        u.reshape(-1, 3)[i2] = ul.reshape(-1, 3)[own2]
+        p[i1] = pl[own1]
+        for a, b in zip(infos, inf_ref):
+            assert a.newton_iterations == b.newton_iterations
+            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= 1
+            assert abs(a.krylov_iterations_poisson - b.krylov_iterations_poisson) <= 1
+    assert np.isfinite(u).all() and np.isfinite(p).all()          # every dof is owned by exactly one rank
+    assert rel(u, u_ref) < 1e-9
+    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-8
+    for c in ctxs:
+        c.close()
+    nat.local_group_destroy(group)

@@ -439,3 +439,36 @@ def test_periodic_multigrid_levels():
         errs.append(np.abs(P @ f(xy) - f(fine_xy)).max())
         fine_xy = xy
     assert errs[0] < 0.16 and errs[0] < errs[1]
+
+
+def test_periodic_slab_partition_host_side():
+    """partition.PeriodicSlabPartition: every global dof of the triple-periodic box is owned by
+    exactly one rank, ghost copies sit at the owners' coordinates (mod the period), the halo
+    ranges are whole lattice planes, the periodic prolongations interpolate constants."""
+    import scipy.sparse as sp
+    from partition import PeriodicSlabPartition
+    size = 4
+    parts = [PeriodicSlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, 2.0), 4, 4, 8, r, size, coarsest=2,
+                                   global_coarsest=None) for r in range(size)]
+    p = parts[0]
+    assert p.n_p2_global == 4 * 16 * 16 and p.n_p1_global == 16 * 8
+    cov2, cov1 = np.zeros(p.n_p2_global, int), np.zeros(p.n_p1_global, int)
+    G2 = np.zeros((p.n_p2_global, 3))
+    for q in parts:
+        np.add.at(cov2, q.p2_global[q.p2_owned], 1)
+        np.add.at(cov1, q.p1_global[q.p1_owned], 1)
+        G2[q.p2_global[q.p2_owned]] = q.dofmap.p2_coords[q.p2_owned]
+    assert cov2.min() == cov2.max() == 1 and cov1.min() == cov1.max() == 1
+    for q in parts:
+        d = np.abs(G2[q.p2_global] - q.dofmap.p2_coords)
+        d[:, 2] = np.minimum(d[:, 2], np.abs(d[:, 2] - 2.0))              # z period 2
+        assert d.max() < 1e-14
+        w2, w1 = q.w2, q.fine.w1
+        assert q.p2_halo["send_up"] == (w2 * 4, w2) and q.p2_halo["recv_below"] == (0, w2)
+        assert q.p1_halo["recv_above"] == (w1 * 3, w1) and q.p1_halo["send_down"] == (w1, w1)
+        assert len(q.levels) == 1
+        lev, (rowptr, col, val) = q.levels[0]
+        P = sp.csr_matrix((val, col, rowptr))
+        assert P.shape == (q.dofmap.n_p1, lev.n_p1) and abs(P.sum(axis=1) - 1.0).max() < 1e-14
+        assert lev.dofmap.max() + 1 == lev.n_p1 == 2 * 2 * 3
+    assert p.coarse_global_shape == (2, 2, 4)

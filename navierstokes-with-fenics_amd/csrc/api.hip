@@ -1653,12 +1653,30 @@ extern "C" int nsfem_shift_mean_pressure(nsfem_ctx* ctx, double target, double* 
   NSFEM_REQUIRE(ctx, "null context");
   hipStream_t s = ctx->stream;
   const int64_t np = npre(ctx);
-  // int p dx = 1^T M_p p
-  launch_spmv(s, ctx->Mp, 1, ctx->state[NSFEM_P].p, ctx->tmp_p.p, nullptr, MASK_NONE);
+  // int p dx = 1^T M_p p ; partitioned meshes: owned rows only (ghost rows are the neighbours'),
+  // all-reduced, divided by the GLOBAL measure of the domain
+  ctx->kw.ensure(nvel(ctx));
+  double* parts = ctx->kw.parts.p + 5 * kParts;
+  const bool dist = ctx->distributed();
+  double area = ctx->area;
   launch_axpby(s, np, 0.0, ctx->tmp_p.p, 0.0, nullptr, ctx->rhs_p.p);
-  launch_add_scalar(s, np, 1.0, ctx->rhs_p.p);
-  launch_dot(s, np, ctx->tmp_p.p, ctx->rhs_p.p, ctx->kw.parts.p + 5 * kParts);
-  const double mean = host_sum_parts(s, ctx->kw, 5) / ctx->area;
+  launch_add_scalar(s, np, 1.0, ctx->rhs_p.p);                     // rhs_p = 1
+  if (dist) {
+    if (!(ctx->area_global > 0.0)) {
+      launch_spmv(s, ctx->Mp, 1, ctx->rhs_p.p, ctx->tmp_p.p, nullptr, MASK_NONE);
+      if (ctx->ghost_p.p) launch_zero_ghost(s, np, ctx->mask_p.p, ctx->tmp_p.p);
+      launch_dot(s, np, ctx->tmp_p.p, ctx->rhs_p.p, parts);
+      ctx->comm->allreduce_sum(s, parts, kParts);
+      ctx->area_global = host_sum_parts(s, ctx->kw, 5);
+    }
+    area = ctx->area_global;
+    ctx->comm->exchange(s, ctx->halo_p1, ctx->state[NSFEM_P].p, 1);
+  }
+  launch_spmv(s, ctx->Mp, 1, ctx->state[NSFEM_P].p, ctx->tmp_p.p, nullptr, MASK_NONE);
+  if (dist && ctx->ghost_p.p) launch_zero_ghost(s, np, ctx->mask_p.p, ctx->tmp_p.p);
+  launch_dot(s, np, ctx->tmp_p.p, ctx->rhs_p.p, parts);
+  if (dist) ctx->comm->allreduce_sum(s, parts, kParts);
+  const double mean = host_sum_parts(s, ctx->kw, 5) / area;
   if (mean_before) *mean_before = mean;
   launch_add_scalar(s, np, -(mean - target), ctx->state[NSFEM_P].p);
   NSFEM_HIP(hipStreamSynchronize(s));

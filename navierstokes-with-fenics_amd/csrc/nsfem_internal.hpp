@@ -484,6 +484,7 @@ struct nsfem_ctx {
   double mg_trunc_tol = 0.1;
   int64_t glob_off = 0;
   bool partition_periodic = false;
+  double area_global = 0.0;                    // measure of the whole (partitioned) domain, lazily all-reduced
   // NSFEM_FORCE_COMM=1 routes a single-rank run through the communicator as well (lets a
   // one-GPU box exercise the RCCL all-reduce calls)
   bool distributed() const {

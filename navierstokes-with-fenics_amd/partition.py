@@ -429,3 +429,116 @@ class PeriodicSlabPartition:
             f_dof = c_dof
         ctx.mg_finalize(2 if degree is None else degree, 4.0 if eig_ratio is None else eig_ratio)
         return len(self.levels)
+
+
+# ---------------------------------------------------------------------------------------------
+# doubly periodic rectangles (the reference's Taylor-Green convergence study in 2D): x periodic
+# inside every strip, y across the ranks -- the 2D counterpart of PeriodicSlabPartition
+# ---------------------------------------------------------------------------------------------
+class PeriodicStripLevel(StripLevel):
+    def __init__(self, p0, p1, nx, ny, row0, own_rows):
+        hy = (p1[1] - p0[1]) / ny
+        super().__init__(p0, (p1[0], p1[1] + hy), nx, ny + 1, row0, own_rows, 1)
+        self.mesh.coords[:, 1] = np.repeat(p0[1] + hy * (row0 + np.arange(own_rows + 2)), nx + 1)
+        self.has_below = self.has_above = True
+        ix, iy = np.meshgrid(np.arange(nx + 1), np.arange(own_rows + 2), indexing="xy")
+        self.vertex_dof = (iy * nx + (ix % nx)).ravel().astype(np.int64)          # vertex id = iy (nx+1) + ix
+        w1 = self.w1 = nx
+        self.n_p1 = w1 * (own_rows + 2)
+        ghost = np.zeros(self.n_p1, dtype=np.uint8)
+        ghost[:w1] = GHOST
+        ghost[w1 * (own_rows + 1):] = GHOST
+        self.p1_ghost = ghost
+        self.p1_halo = dict(send_up=(w1 * own_rows, w1), recv_above=(w1 * (own_rows + 1), w1),
+                            send_down=(w1, w1), recv_below=(0, w1))
+        self.dofmap = self.vertex_dof[self.mesh.cells.astype(np.int64)].astype(np.int32)
+
+
+class PeriodicStripPartition:
+    """Rank ``rank`` of ``size`` of the doubly periodic (nx, ny) right-diagonal rectangle mesh."""
+
+    periodic = True
+
+    def __init__(self, p0, p1, nx, ny, rank, size, coarsest=4, global_coarsest=None):
+        import scipy.sparse as sp
+        assert ny % size == 0 and size >= 2
+        own = ny // size
+        self.rank, self.size = rank, size
+        self.p0, self.p1, self.nx, self.ny = tuple(p0), tuple(p1), nx, ny
+        self.fine = PeriodicStripLevel(p0, p1, nx, ny, rank * own, own)
+        self.mesh = self.fine.mesh
+        masters = _xy_periodic_masters(self.mesh, (p0[0], p0[1]), (p1[0], np.inf))   # x only
+        self.dofmap = dm = TaylorHoodDofMap(self.mesh, periodic_map=masters)
+        assert np.array_equal(dm.p1_vertex_node, self.fine.vertex_dof)
+        w2 = self.w2 = 2 * nx
+        lines = 2 * (own + 1) + 1
+        assert dm.n_p2 == w2 * lines and np.all(np.diff(dm.p2_coords[:, 1]) >= -1e-12)
+        ghost2 = np.zeros(dm.n_p2, dtype=np.uint8)
+        ghost2[:w2] = GHOST
+        ghost2[w2 * (2 * own + 1):] = GHOST
+        self.p2_ghost = ghost2
+        self.p2_halo = dict(send_up=(w2 * 2 * own, w2), recv_above=(w2 * (2 * own + 1), 2 * w2),
+                            send_down=(w2, 2 * w2), recv_below=(0, w2))
+        self.p1_ghost, self.p1_halo = self.fine.p1_ghost, self.fine.p1_halo
+        self.n_p2_global, self.n_p1_global = w2 * 2 * ny, nx * ny
+        self.p2_global = (rank * own * 2 * w2 + np.arange(dm.n_p2)) % self.n_p2_global
+        self.p1_global = (rank * own * nx + np.arange(dm.n_p1)) % self.n_p1_global
+        self.p2_owned, self.p1_owned = ghost2 == 0, self.p1_ghost == 0
+        self.levels = []
+        lx, ly, lown, fine_level = nx, ny, own, self.fine
+        while lx % 2 == 0 and lown % 2 == 0 and lown // 2 >= 1 and min(lx, ly) // 2 >= coarsest:
+            cx, cy, cown = lx // 2, ly // 2, lown // 2
+            lev = PeriodicStripLevel(p0, p1, cx, cy, rank * cown, cown)
+            rowptr, col, val = structured_prolongation(lx, 2 * (cown + 1))
+            P = sp.csr_matrix((val, col, rowptr))[: (lx + 1) * (lown + 2)]
+            self.levels.append((lev, _constrain_prolongation(P, fine_level.vertex_dof, lev.vertex_dof)))
+            lx, ly, lown, fine_level = cx, cy, cown, lev
+        last = self.levels[-1][0] if self.levels else self.fine
+        self.coarse_global_shape = (last.nx, ly)
+        self.coarse_global_offset = last.row0 * last.w1
+        self.global_coarsest = global_coarsest
+
+    def attach(self, ctx, degree=None, eig_ratio=None):
+        from fem_mesh import rectangle_mesh
+        from multigrid import structured_hierarchy
+        ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, self.p2_halo,
+                          self.p1_halo, self.n_p2_global, self.n_p1_global, periodic=True)
+        for lev, (rowptr, col, val) in self.levels:
+            ctx.mg_add_level(lev.mesh.coords, lev.mesh.cells, rowptr, col, val,
+                             ghost=lev.p1_ghost, halo=lev.p1_halo, dofmap=lev.dofmap)
+        cx, cy = self.coarse_global_shape
+
+        def vdof_of(shape):
+            ix, iy = np.meshgrid(np.arange(shape[0] + 1), np.arange(shape[1] + 1), indexing="xy")
+            return ((iy % shape[1]) * shape[0] + (ix % shape[0])).ravel().astype(np.int64)
+
+        mesh = rectangle_mesh(self.p0, self.p1, cx, cy)
+        f_dof = vdof_of((cx, cy))
+        ctx.mg_set_global_coarse(mesh.coords, mesh.cells, self.coarse_global_offset,
+                                 dofmap=f_dof[mesh.cells.astype(np.int64)])
+        tail = [] if self.global_coarsest is None else \
+            structured_hierarchy(self.p0, self.p1, cx, cy, coarsest=self.global_coarsest)
+        import scipy.sparse as sp
+        for cmesh, (rowptr, col, val) in tail:
+            c_dof = vdof_of(cmesh.structured[2:])
+            P = sp.csr_matrix((val, col, rowptr), shape=(f_dof.size, c_dof.size))
+            rp, ci, cv = _constrain_prolongation(P, f_dof, c_dof)
+            ctx.mg_add_global_level(cmesh.coords, cmesh.cells, rp, ci, cv,
+                                    dofmap=c_dof[cmesh.cells.astype(np.int64)])
+            f_dof = c_dof
+        ctx.mg_finalize(2 if degree is None else degree, 4.0 if eig_ratio is None else eig_ratio)
+        return len(self.levels)
+
+
+def _constrain_prolongation(P, f_dof, c_dof):
+    """vertex prolongation P -> prolongation between constrained (periodic) dof sets: rows of one
+    representative vertex per finer dof, columns of all vertices of a coarse dof added up"""
+    import scipy.sparse as sp
+    rep = np.full(int(f_dof.max()) + 1, -1, dtype=np.int64)
+    rep[f_dof[::-1]] = np.arange(f_dof.size - 1, -1, -1)
+    E = sp.csr_matrix((np.ones(c_dof.size), (np.arange(c_dof.size), c_dof)),
+                      shape=(c_dof.size, int(c_dof.max()) + 1))
+    Pp = (P[rep] @ E).tocsr()
+    Pp.sum_duplicates()
+    Pp.sort_indices()
+    return Pp.indptr.astype(np.int32), Pp.indices.astype(np.int32), Pp.data.copy()

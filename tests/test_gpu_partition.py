@@ -375,36 +375,37 @@ def test_chebyshev_mass_solve_matches_cg(dim):
     assert max(res[True][2]) <= (60 if dim == 2 else 130)
 
 
-@pytest.mark.parametrize("size,tail", [(2, False), (4, True)])
-def test_partitioned_triple_periodic_taylor_green_equals_single_context(size, tail):
+@pytest.mark.parametrize("dim,size,tail", [(3, 2, False), (3, 4, True), (2, 2, False), (2, 4, True)])
+def test_partitioned_triple_periodic_taylor_green_equals_single_context(dim, size, tail):
     """BASELINE configs[3] in small: Taylor-Green vortex on the triple-periodic cube, IPCS, slabs
     along z whose halo exchange WRAPS AROUND (PeriodicSlabPartition: x, y periodic inside every
     slab through the dof maps, z periodic across the ranks), periodic multigrid levels with the
     replicated periodic global coarse problem -- in-process ranks against the single context with
     the triple-periodic dof map."""
     import dlfn_compat as dlfn
-    from fem_mesh import TaylorHoodDofMap, box_mesh, periodic_entity_map
-    from partition import PeriodicSlabPartition
+    from fem_mesh import TaylorHoodDofMap, box_mesh, periodic_entity_map, rectangle_mesh
+    from partition import PeriodicSlabPartition, PeriodicStripPartition
 
-    class TriplePeriodic(dlfn.SubDomain):
+    class TriplePeriodic(dlfn.SubDomain):          # (doubly periodic in 2D)
         def inside(self, x, on_boundary):
-            return bool(on_boundary and (dlfn.near(x[0], 0.0) or dlfn.near(x[1], 0.0) or dlfn.near(x[2], 0.0)))
+            return bool(on_boundary and any(dlfn.near(x[a], 0.0) for a in range(dim)))
 
         def map(self, x_slave, x_master):
-            for a in range(3):
+            for a in range(dim):
                 if dlfn.near(x_slave[a], 1.0):
                     x_master[:] = x_slave
                     x_master[a] -= 1.0
                     return
             x_master[:] = -10.0
 
-    n, nsteps, k, g = 8, 3, 0.02, 2.0 * np.pi
+    n, nsteps, k, g = (8 if dim == 3 else 16), 3, 0.02, 2.0 * np.pi
 
     def fields(dmap):
         X, Y = dmap.p2_coords, dmap.p1_coords
-        u = np.stack([np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]), -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1]),
-                      0.3 * np.sin(g * X[:, 2]) * np.cos(g * X[:, 0])], axis=1).ravel()
-        return u, -0.25 * (np.cos(2 * g * Y[:, 0]) + np.cos(2 * g * Y[:, 1]))
+        comps = [np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]), -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1])]
+        if dim == 3:
+            comps.append(0.3 * np.sin(g * X[:, 2]) * np.cos(g * X[:, 0]))
+        return np.stack(comps, axis=1).ravel(), -0.25 * (np.cos(2 * g * Y[:, 0]) + np.cos(2 * g * Y[:, 1]))
 
     def run(ctx, dmap, out, key):
         u0, p0 = fields(dmap)
@@ -430,7 +431,8 @@ def test_partitioned_triple_periodic_taylor_green_equals_single_context(size, ta
         out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos)
         out[("means", key)] = means
 
-    mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
+    lo, hi = (0.0, ) * dim, (1.0, ) * dim
+    mesh = box_mesh(lo, hi, n, n, n) if dim == 3 else rectangle_mesh(lo, hi, n, n)
     domain = TriplePeriodic()
     dm = TaylorHoodDofMap(mesh, periodic_map=periodic_entity_map(mesh, domain))
     ref = {}
@@ -441,9 +443,12 @@ def test_partitioned_triple_periodic_taylor_green_equals_single_context(size, ta
     ctx0.close()
 
     group = nat.local_group_create(size)
-    parts = [PeriodicSlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n, r, size,
-                                   coarsest=4 if tail else 2, global_coarsest=2 if tail else None)
-             for r in range(size)]
+    if dim == 3:
+        parts = [PeriodicSlabPartition(lo, hi, n, n, n, r, size, coarsest=4 if tail else 2,
+                                       global_coarsest=2 if tail else None) for r in range(size)]
+    else:
+        parts = [PeriodicStripPartition(lo, hi, n, n, r, size, coarsest=8 if tail else 4,
+                                        global_coarsest=2 if tail else None) for r in range(size)]
     ctxs = []
     for r, part in enumerate(parts):
         pdm = part.dofmap
@@ -481,7 +486,7 @@ def test_partitioned_triple_periodic_taylor_green_equals_single_context(size, ta
         own2, own1 = np.nonzero(part.p2_owned)[0], np.nonzero(part.p1_owned)[0]
         i2 = np.array([ref2[kk] for kk in key(part.dofmap.p2_coords[own2])])
         i1 = np.array([ref1[kk] for kk in key(part.dofmap.p1_coords[own1])])
-        u.reshape(-1, 3)[i2] = ul.reshape(-1, 3)[own2]
+        u.reshape(-1, dim)[i2] = ul.reshape(-1, dim)[own2]
         p[i1] = pl[own1]
         for a, b in zip(infos, inf_ref):
             assert a.newton_iterations == b.newton_iterations

@@ -375,8 +375,9 @@ def test_chebyshev_mass_solve_matches_cg(dim):
     assert max(res[True][2]) <= (60 if dim == 2 else 130)
 
 
-@pytest.mark.parametrize("dim,size,tail", [(3, 2, False), (3, 4, True), (2, 2, False), (2, 4, True)])
-def test_partitioned_triple_periodic_taylor_green_equals_single_context(dim, size, tail):
+@pytest.mark.parametrize("dim,size,tail,relaxed", [(3, 2, False, False), (3, 4, True, False), (2, 2, False, False),
+                                                   (2, 4, True, False), (3, 4, True, True), (2, 4, True, True)])
+def test_partitioned_triple_periodic_taylor_green_equals_single_context(dim, size, tail, relaxed):
     """BASELINE configs[3] in small: Taylor-Green vortex on the triple-periodic cube, IPCS, slabs
     along z whose halo exchange WRAPS AROUND (PeriodicSlabPartition: x, y periodic inside every
     slab through the dof maps, z periodic across the ranks), periodic multigrid levels with the
@@ -461,6 +462,7 @@ def test_partitioned_triple_periodic_taylor_green_equals_single_context(dim, siz
     def worker(r):
         try:
             parts[r].attach(ctxs[r])
+            ctxs[r].mg_set_halo_mode(relaxed)          # (bench.py's default on several GPUs)
             run(ctxs[r], parts[r].dofmap, out, r)
         except BaseException as exc:
             import traceback
@@ -490,13 +492,17 @@ def test_partitioned_triple_periodic_taylor_green_equals_single_context(dim, siz
         p[i1] = pl[own1]
         for a, b in zip(infos, inf_ref):
             assert a.newton_iterations == b.newton_iterations
-            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= 1
-            assert abs(a.krylov_iterations_poisson - b.krylov_iterations_poisson) <= 1
+            # (relaxed smoothing on slabs only two cube layers thick: a fifth more iterations at most)
+            slack = (lambda ref_its: max(3, 0.2 * ref_its)) if relaxed else (lambda ref_its: 1)
+            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= slack(b.krylov_iterations_momentum)
+            assert abs(a.krylov_iterations_poisson - b.krylov_iterations_poisson) <= slack(b.krylov_iterations_poisson)
     assert np.isfinite(u).all() and np.isfinite(p).all()          # every dof is owned by exactly one rank
     assert rel(u, u_ref) < 1e-9
     assert rel(p, p_ref) < 1e-8                                   # both shifted to zero mean
-    for r in range(size):
-        assert np.abs(np.array(out[("means", r)]) - np.array(ref[("means", 0)])).max() < 1e-10
+    for r in range(size):     # every rank computes the same GLOBAL mean (the level of the singular
+        assert np.abs(np.array(out[("means", r)]) - np.array(out[("means", 0)])).max() < 1e-13
+        if not relaxed:       # Poisson solution itself depends on the preconditioner: exact mode only)
+            assert np.abs(np.array(out[("means", r)]) - np.array(ref[("means", 0)])).max() < 1e-10
     for c in ctxs:
         c.close()
     nat.local_group_destroy(group)

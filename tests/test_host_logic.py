@@ -329,9 +329,51 @@ def test_grid_generator_entry_points_of_the_reference_tests(tmp_path):
     assert _extract_facet_markers(str(geo)) == {"inlet": 100, "upper wall": 101}
 
 
+def _check_joint_and_split_assignments(solver, dlfn, Wh, WhSub):
+    """Every variant of SolverBase._assign_function the reference's tests/test_function_assigner.py
+    exercises -- joint -> split and split -> joint, with a two-entry dictionary, with one-entry
+    dictionaries on the parts of ``joint.split()``, and with bare functions -- checked through
+    point values of projected constants at (0.1, 0.1)."""
+    point = (0.1, 0.1)
+    joint = dlfn.Function(Wh)
+    parts = {"velocity": dlfn.Function(WhSub["velocity"]), "pressure": dlfn.Function(WhSub["pressure"])}
+    index = {"velocity": 0, "pressure": 1}
+
+    def values_of_parts():
+        return np.concatenate([np.atleast_1d(parts["velocity"](*point)), np.atleast_1d(parts["pressure"](*point))])
+
+    for scale, style in ((1.0, "both"), (10.0, "single"), (100.0, "bare")):           # joint -> split
+        target = scale * np.array([1.0, 2.0, 3.0])
+        dlfn.project(dlfn.Constant(tuple(target)), Wh, function=joint)
+        views = joint.split()
+        if style == "both":
+            solver._assign_function(parts, joint)
+        for field in (() if style == "both" else ("velocity", "pressure")):
+            receiver = {field: parts[field]} if style == "single" else parts[field]
+            solver._assign_function(receiver, views[index[field]])
+        assert np.allclose(values_of_parts(), target)
+    expected = np.array(joint(*point))
+    for scale, style in ((1.0, "both"), (10.0, "single"), (100.0, "bare")):           # split -> joint
+        target = -scale * np.array([1.0, 2.0, 3.0])
+        dlfn.project(dlfn.Constant(tuple(target[:2])), WhSub["velocity"], function=parts["velocity"])
+        dlfn.project(dlfn.Constant(float(target[2])), WhSub["pressure"], function=parts["pressure"])
+        if style == "both":
+            solver._assign_function(joint, parts)
+            assert np.allclose(joint(*point), target)
+            expected = target.copy()
+            continue
+        views = joint.split()
+        for field, entries in (("velocity", slice(0, 2)), ("pressure", slice(2, 3))):
+            giver = {field: parts[field]} if style == "single" else parts[field]
+            solver._assign_function(views[index[field]], giver)
+            expected[entries] = target[entries]                  # the other field keeps its values
+            assert np.allclose(joint(*point), expected)
+    return joint, parts
+
+
 def test_function_assigner_host_logic():
-    """The assertions of the reference's tests/test_function_assigner.py:26-72 (forward / backward
-    assignment between the joint Taylor-Hood space and its collapsed sub-spaces, with and without
+    """The checks of the reference's tests/test_function_assigner.py (forward / backward assignment
+    between the joint Taylor-Hood space and its collapsed sub-spaces, with and without
     dictionaries, point values of projected constants) on the host-side function spaces -- the
     dof map stands in for the device context, which this logic never touches."""
     import dlfn_compat as dlfn
@@ -342,60 +384,21 @@ def test_function_assigner_host_logic():
     mesh, boundary_markers = hyper_cube(2, 5)
     solver = SolverBase(mesh, boundary_markers)
     solver._Wh = FunctionSpace(TaylorHoodDofMap(mesh), "mixed")
-    Wh = solver._Wh
-    WhSub = solver._get_subspaces()
+    Wh, WhSub = solver._Wh, solver._get_subspaces()
     assert solver._get_subspace("velocity") is WhSub["velocity"]
-    solution = dlfn.Function(Wh)
-    solution_dict = {"velocity": dlfn.Function(WhSub["velocity"]), "pressure": dlfn.Function(WhSub["pressure"])}
-    assert solution in Wh and solution_dict["velocity"] in WhSub["velocity"]
-    assert solution.split()[0] in Wh.sub(0) and solution.split()[0] not in WhSub["velocity"]
-    # forward assignment
-    dlfn.project(dlfn.Constant((1.0, 2.0, 3.0)), Wh, function=solution)
-    solver._assign_function(solution_dict, solution)
-    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([1.0, 2.0]))
-    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([3.0]))
-    # forward assignment split
-    dlfn.project(dlfn.Constant((10.0, 20.0, 30.0)), Wh, function=solution)
-    velocity, pressure = solution.split()
-    solver._assign_function({"velocity": solution_dict["velocity"]}, velocity)
-    solver._assign_function({"pressure": solution_dict["pressure"]}, pressure)
-    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([10.0, 20.0]))
-    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([30.0]))
-    # forward assignment split / no dict
-    dlfn.project(dlfn.Constant((100.0, 200.0, 300.0)), Wh, function=solution)
-    solver._assign_function(solution_dict["velocity"], velocity)
-    solver._assign_function(solution_dict["pressure"], pressure)
-    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([100.0, 200.0]))
-    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([300.0]))
-    # backward assignment
-    dlfn.project(dlfn.Constant((-1.0, -2.0)), WhSub["velocity"], function=solution_dict["velocity"])
-    dlfn.project(dlfn.Constant(-3.0), WhSub["pressure"], function=solution_dict["pressure"])
-    solver._assign_function(solution, solution_dict)
-    assert np.allclose(solution(0.1, 0.1), np.array([-1.0, -2.0, -3.0]))
-    # backward assignment split
-    dlfn.project(dlfn.Constant((-10.0, -20.0)), WhSub["velocity"], function=solution_dict["velocity"])
-    dlfn.project(dlfn.Constant(-30.0), WhSub["pressure"], function=solution_dict["pressure"])
-    velocity, pressure = solution.split()
-    solver._assign_function(velocity, {"velocity": solution_dict["velocity"]})
-    assert np.allclose(solution(0.1, 0.1), np.array([-10.0, -20.0, -3.0]))
-    solver._assign_function(pressure, {"pressure": solution_dict["pressure"]})
-    assert np.allclose(solution(0.1, 0.1), np.array([-10.0, -20.0, -30.0]))
-    # backward assignment split / no dict
-    dlfn.project(dlfn.Constant((-100.0, -200.0)), WhSub["velocity"], function=solution_dict["velocity"])
-    dlfn.project(dlfn.Constant(-300.0), WhSub["pressure"], function=solution_dict["pressure"])
-    solver._assign_function(velocity, solution_dict["velocity"])
-    assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -30.0]))
-    solver._assign_function(pressure, solution_dict["pressure"])
-    assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -300.0]))
+    joint, parts = _check_joint_and_split_assignments(solver, dlfn, Wh, WhSub)
+    assert joint in Wh and parts["velocity"] in WhSub["velocity"]
+    assert joint.split()[0] in Wh.sub(0) and joint.split()[0] not in WhSub["velocity"]
     # misuse is refused
     with pytest.raises(AssertionError):
-        solver._assign_function(solution, solution)
+        solver._assign_function(joint, joint)
     with pytest.raises(AssertionError):
-        solver._assign_function({"velocity": solution_dict["pressure"]}, solution)
+        solver._assign_function({"velocity": parts["pressure"]}, joint)
     # non-constant data: a P2-representable field survives the round trip exactly
     u = dlfn.project(dlfn.Expression(("x[0]*x[1]", "1.0 - x[1]*x[1]"), degree=2), WhSub["velocity"])
-    solver._assign_function(solution, {"velocity": u})
-    assert np.allclose(solution(0.3, 0.7)[:2], [0.21, 0.51])
+    solver._assign_function(joint, {"velocity": u})
+    assert np.allclose(joint(0.3, 0.7)[:2], [0.21, 0.51])
+
 
 
 def test_periodic_multigrid_levels():

@@ -1214,58 +1214,16 @@ def test_stationary_rotating_couette_flow_as_shipped():
 
 
 def test_function_assigner_through_the_solver_as_in_the_reference():
-    """tests/test_function_assigner.py of the reference, module-level set-up included:
+    """tests/test_function_assigner.py of the reference through the real solver object:
     ``SolverBase(mesh, markers)._setup_function_spaces()`` (creates the device context here),
     ``_get_subspaces``, projections of constants and every ``_assign_function`` variant."""
-    n_points = 5
-    mesh, boundary_markers = hyper_cube(2, n_points)
     from ns_solver_base import SolverBase
+    from test_host_logic import _check_joint_and_split_assignments
+    mesh, boundary_markers = hyper_cube(2, 5)
     solver = SolverBase(mesh, boundary_markers)
     solver._setup_function_spaces()
-    Wh = solver._Wh
-    WhSub = solver._get_subspaces()
-    solution = dlfn.Function(Wh)
-    solution_dict = dict()
-    solution_dict["velocity"] = dlfn.Function(WhSub["velocity"])
-    solution_dict["pressure"] = dlfn.Function(WhSub["pressure"])
-    # forward assignment
-    dlfn.project(dlfn.Constant((1.0, 2.0, 3.0)), Wh, function=solution)
-    solver._assign_function(solution_dict, solution)
-    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([1.0, 2.0]))
-    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([3.0]))
-    # forward assignment split
-    dlfn.project(dlfn.Constant((10.0, 20.0, 30.0)), Wh, function=solution)
-    velocity, pressure = solution.split()
-    solver._assign_function({"velocity": solution_dict["velocity"]}, velocity)
-    solver._assign_function({"pressure": solution_dict["pressure"]}, pressure)
-    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([10.0, 20.0]))
-    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([30.0]))
-    # forward assignment split / no dict
-    dlfn.project(dlfn.Constant((100.0, 200.0, 300.0)), Wh, function=solution)
-    solver._assign_function(solution_dict["velocity"], velocity)
-    solver._assign_function(solution_dict["pressure"], pressure)
-    assert np.allclose(solution_dict["velocity"](0.1, 0.1), np.array([100.0, 200.0]))
-    assert np.allclose(solution_dict["pressure"](0.1, 0.1), np.array([300.0]))
-    # backward assignment
-    dlfn.project(dlfn.Constant((-1.0, -2.0)), WhSub["velocity"], function=solution_dict["velocity"])
-    dlfn.project(dlfn.Constant(-3.0), WhSub["pressure"], function=solution_dict["pressure"])
-    solver._assign_function(solution, solution_dict)
-    assert np.allclose(solution(0.1, 0.1), np.array([-1.0, -2.0, -3.0]))
-    # backward assignment split
-    dlfn.project(dlfn.Constant((-10.0, -20.0)), WhSub["velocity"], function=solution_dict["velocity"])
-    dlfn.project(dlfn.Constant(-30.0), WhSub["pressure"], function=solution_dict["pressure"])
-    velocity, pressure = solution.split()
-    solver._assign_function(velocity, {"velocity": solution_dict["velocity"]})
-    assert np.allclose(solution(0.1, 0.1), np.array([-10.0, -20.0, -3.0]))
-    solver._assign_function(pressure, {"pressure": solution_dict["pressure"]})
-    assert np.allclose(solution(0.1, 0.1), np.array([-10.0, -20.0, -30.0]))
-    # backward assignment split / no dict
-    dlfn.project(dlfn.Constant((-100.0, -200.0)), WhSub["velocity"], function=solution_dict["velocity"])
-    dlfn.project(dlfn.Constant(-300.0), WhSub["pressure"], function=solution_dict["pressure"])
-    solver._assign_function(velocity, solution_dict["velocity"])
-    assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -30.0]))
-    solver._assign_function(pressure, solution_dict["pressure"])
-    assert np.allclose(solution(0.1, 0.1), np.array([-100.0, -200.0, -300.0]))
+    _check_joint_and_split_assignments(solver, dlfn, solver._Wh, solver._get_subspaces())
+
 
 
 def test_periodic_multigrid_keeps_krylov_counts_mesh_independent():

@@ -1319,3 +1319,27 @@ def test_3d_channel_flow_open_outlet_matches_oracle(solver_class):
     assert w.values.shape == (dm.mesh.num_cells(), 3) and np.abs(w.values - 2.0 * omega).max() < 1e-12
     g = problem._compute_pressure_gradient()
     assert np.abs(g.values - slope).max() < 1e-12
+
+
+def test_taylor_green_temporal_convergence_is_second_order():
+    """convergence_test/taylor_green_vortex.py of the reference (BDF-2 study against the exact
+    Taylor-Green vortex, :101-141) in small: three step sizes on 48 x 48 cells, nodal max error of
+    the velocity at t = 0.8 -- halving the step must divide the error by about four."""
+    g, Re, t_end = 2.0 * np.pi, 100.0, 0.8
+    errors = []
+    for dt in (0.2, 0.1, 0.05):
+        problem = TaylorGreenVortex()
+        problem._n_points = 48
+        problem._start_time, problem._end_time = 0.0, t_end
+        problem._desired_start_time_step = dt
+        problem._n_max_steps = 1000
+        problem.solve_problem()
+        assert abs(problem._time_stepping.current_time - t_end) < 1e-12
+        solver = problem._get_solver()
+        X = solver._dofmap.p2_coords
+        decay = np.exp(-2.0 * g * g * t_end / Re)
+        exact = decay * np.stack([np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]),
+                                  -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1])], axis=1)
+        errors.append(np.abs(solver.solution.split()[0].nodal_values() - exact).max())
+    assert errors[0] > errors[1] > errors[2]
+    assert 3.0 < errors[0] / errors[1] < 5.5 and 3.0 < errors[1] / errors[2] < 5.5

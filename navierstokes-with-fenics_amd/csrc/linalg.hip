@@ -404,8 +404,10 @@ void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x, 
   spmv_dispatch<EPI_RESID>(s, A, nv, make_args(x, b, y, rowmask, maskmode));
 }
 void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                            const uint8_t* rowmask) {
-  spmv_dispatch<EPI_ACCUM>(s, A, nv, make_args(x, nullptr, y, rowmask, MASK_ZERO));
+                            const uint8_t* rowmask, int ghost) {
+  SpmvArgs a = make_args(x, nullptr, y, rowmask, MASK_ZERO);
+  a.ghost = ghost;
+  spmv_dispatch<EPI_ACCUM>(s, A, nv, a);
 }
 void launch_spmv_scaled(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
                         double* y) {

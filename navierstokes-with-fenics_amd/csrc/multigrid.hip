@@ -553,11 +553,12 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   vcycle(s, l + 1, C.b.p, C.x.p);
   halo_fill(s, C, C.x.p);
   const bool relaxed = relaxed_halo && comm_active() && L.has_halo;
-  if (pre > 0) launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask);
+  // relaxed mode: the ghost rows of x take part in the prolongation -- interpolated from the
+  // (exchanged) coarse ghosts, added to ghost values that were valid before (filled for the
+  // residual), this is exactly what the owner computes for them -> no exchange before smoothing
+  if (pre > 0) launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask, relaxed ? 2 : 0);
   else launch_spmv(s, *L.P, nv, C.x.p, x, L.mask, MASK_ZERO, relaxed ? 2 : 0);   // x = P x_c (every row stored)
-  // relaxed mode without pre-smoothing: the ghost rows of x were interpolated from the (exchanged)
-  // coarse ghosts, exactly what the neighbour computes for them -> no exchange before smoothing
-  smooth(s, L, b, x, x, degree, relaxed && pre == 0);
+  smooth(s, L, b, x, x, degree, relaxed);
   (void)n;
 }
 

@@ -138,7 +138,7 @@ void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
 // y += A x (masked rows -> 0);  Chebyshev/Jacobi smoother step
 //   d = c1 d + c2 dinv (b - A x) ; xout = x + d   (masked rows -> 0)
 void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                            const uint8_t* rowmask);
+                            const uint8_t* rowmask, int ghost = 0 /* 2: ghost rows accumulate too */);
 // y = scale * A x ;  y += scale * A x on rows not flagged in skipmask (flagged rows untouched)
 void launch_spmv_scaled(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
                         double* y);

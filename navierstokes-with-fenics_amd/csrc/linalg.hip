@@ -919,12 +919,13 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     launch_residual(s, *op.A, op.nv, x, b, w.r.p, op.rowmask, op.maskmode);
   }
   LAUNCH(k_bicg_start, kParts, s, n, w.r.p, w.rhat.p, parts, scal);
-  reduce_slots(op, s, parts, P_RHO, 2);
-  // |b| for the relative criterion (read back together with |r0|: one round trip)
-  launch_dot(s, n, b, b, parts + P_PQ * kParts);
-  reduce_slots(op, s, parts, P_PQ, 1);
+  // |b| for the relative criterion goes into the slot next to (rho, |r0|^2): ONE all-reduce for
+  // the three start-up sums and one read-back for the two the host needs
+  static_assert(P_RR == P_RHO + 1 && P_TS == P_RHO + 2, "start-up slots must be adjacent");
+  launch_dot(s, n, b, b, parts + P_TS * kParts);
+  reduce_slots(op, s, parts, P_RHO, 3);
   double rr, bb;
-  host_sum_parts2(s, w, P_RR, P_PQ, rr, bb);
+  host_sum_parts2(s, w, P_RR, P_TS, rr, bb);
   const double r0 = std::sqrt(rr);
   const double bnorm = std::sqrt(bb);
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
@@ -1065,11 +1066,12 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   int cur = P_RZ0, nxt = P_RZ1;
   if (op.prec) op.prec->apply(s, w.r.p, w.p.p);
   LAUNCH(k_cg_start, kParts, s, n, w.r.p, op.prec ? nullptr : op.dinv, w.p.p, parts, cur);
-  reduce_slots(op, s, parts, cur, 2);
-  launch_dot(s, n, rhs, rhs, parts + P_TT * kParts);
-  reduce_slots(op, s, parts, P_TT, 1);
+  // |b| next to (r.z, |r0|^2) -- the first slot of the other (r.z, |r|^2) pair, rewritten by the
+  // first iteration: one all-reduce for the three start-up sums
+  launch_dot(s, n, rhs, rhs, parts + (cur + 2) * kParts);
+  reduce_slots(op, s, parts, cur, 3);
   double rr, bb;
-  host_sum_parts2(s, w, cur + 1, P_TT, rr, bb);
+  host_sum_parts2(s, w, cur + 1, cur + 2, rr, bb);
   const double r0 = std::sqrt(rr);
   const double bnorm = std::sqrt(bb);
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));

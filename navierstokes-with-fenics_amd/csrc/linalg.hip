@@ -1045,6 +1045,111 @@ __global__ __launch_bounds__(256) void k_cg_p(int64_t n, const double* __restric
   GRID_STRIDE(i, n) p[i] = z[i] + beta * p[i];
 }
 
+// ---- single-reduction (Chronopoulos-Gear) CG for operator-preconditioned solves: per iteration
+//   x += alpha p ; r -= alpha s ; u = M^-1 r ; w = A u ; (gamma, delta, |r|^2) = (r.u, w.u, r.r)
+//   beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)
+//   p = u + beta p ; s = w + beta s
+// ONE fused triple dot product (one all-reduce on partitioned meshes instead of two) and one fused
+// vector update per iteration.  gamma_old / alpha_old live in device scalars, double buffered.
+__global__ __launch_bounds__(256) void k_cgcg_dots(int64_t n, const double* __restrict__ r,
+                                                   const double* __restrict__ u,
+                                                   const double* __restrict__ wv,
+                                                   double* __restrict__ parts, int slot) {
+  __shared__ double sh[4];
+  double a = 0.0, b = 0.0, c = 0.0;
+  GRID_STRIDE(i, n) {
+    const double ri = r[i], ui = u[i];
+    a += ri * ui;
+    b += wv[i] * ui;
+    c += ri * ri;
+  }
+  a = block_sum(a, sh);
+  b = block_sum(b, sh);
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    parts[(slot + 0) * kParts + blockIdx.x] = a;
+    parts[(slot + 1) * kParts + blockIdx.x] = b;
+    parts[(slot + 2) * kParts + blockIdx.x] = c;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cgcg_update(int64_t n, int first, int parity,
+                                                     const double* __restrict__ u,
+                                                     const double* __restrict__ wv,
+                                                     double* __restrict__ p, double* __restrict__ sv,
+                                                     double* __restrict__ x, double* __restrict__ r,
+                                                     const double* __restrict__ parts, int slot,
+                                                     double* __restrict__ scal) {
+  __shared__ double sh[4];
+  const double gamma = sum_parts(parts + (slot + 0) * kParts, sh);
+  const double delta = sum_parts(parts + (slot + 1) * kParts, sh);
+  const double gamma_old = scal[8 + 2 * parity], alpha_old = scal[9 + 2 * parity];
+  const double beta = (first || gamma_old == 0.0) ? 0.0 : gamma / gamma_old;
+  double den = delta;
+  if (!first && alpha_old != 0.0) den -= beta * gamma / alpha_old;
+  const double alpha = (den != 0.0) ? gamma / den : 0.0;
+  GRID_STRIDE(i, n) {
+    const double pi = first ? u[i] : u[i] + beta * p[i];        // (first: p, s hold stale data)
+    const double si = first ? wv[i] : wv[i] + beta * sv[i];
+    p[i] = pi;
+    sv[i] = si;
+    x[i] += alpha * pi;
+    r[i] -= alpha * si;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[8 + 2 * (parity ^ 1)] = gamma;
+    scal[9 + 2 * (parity ^ 1)] = alpha;
+  }
+}
+
+static int pcg_single_reduction(hipStream_t s, KrylovWork& w, const LinOp& op, const double* rhs,
+                                double* x, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  const Pattern& pat = *op.A->pat;
+  const int64_t n = (int64_t)pat.n_rows * op.A->br * op.nv;
+  double* parts = w.parts.p;
+  double* scal = w.scal.p;
+  const int slot = P_RZ0;                       // gamma, delta, |r|^2 in slots 6, 7, 8 ; |b|^2 in 9
+  auto precond_and_dots = [&] {
+    op.prec->apply(s, w.r.p, w.z.p);                                    // u
+    fill_ghosts(op, s, w.z.p);
+    launch_spmv(s, *op.A, op.nv, w.z.p, w.q.p, op.rowmask, op.maskmode);   // w = A u
+    LAUNCH(k_cgcg_dots, kParts, s, n, w.r.p, w.z.p, w.q.p, parts, slot);
+  };
+  launch_residual(s, *op.A, op.nv, x, rhs, w.r.p, op.rowmask, op.maskmode);
+  precond_and_dots();
+  launch_dot(s, n, rhs, rhs, parts + (slot + 3) * kParts);
+  reduce_slots(op, s, parts, slot, 4);
+  double rr, bb;
+  host_sum_parts2(s, w, slot + 2, slot + 3, rr, bb);
+  const double r0 = std::sqrt(rr);
+  const double bnorm = std::sqrt(bb);
+  const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+  info.residual0 = info.residual = r0;
+  info.iterations = 0;
+  info.converged = (r0 <= target);
+  const int check = o.check_every > 0 ? o.check_every : 1;
+  int it = 0;
+  while (!info.converged && it < o.max_iter) {
+    LAUNCH(k_cgcg_update, kParts, s, n, it == 0 ? 1 : 0, it & 1, w.z.p, w.q.p, w.p.p, w.s.p, x,
+           w.r.p, parts, slot, scal);
+    precond_and_dots();
+    reduce_slots(op, s, parts, slot, 3);
+    ++it;
+    if ((it >= o.first_check && it % check == 0) || it == o.max_iter) {
+      rr = host_sum_parts(s, w, slot + 2);
+      if (!std::isfinite(rr)) {
+        info.iterations = it;
+        info.residual = rr;
+        return NSFEM_ERR_BREAKDOWN;
+      }
+      info.residual = std::sqrt(rr);
+      info.converged = info.residual <= target;
+    }
+  }
+  info.iterations = it;
+  return info.converged ? NSFEM_OK : NSFEM_ERR_NOT_CONVERGED;
+}
+
 int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
         const nsfem_krylov_opts& o, nsfem_solve_info& info, bool project_mean) {
   const Pattern& pat = *op.A->pat;
@@ -1062,6 +1167,8 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
     if (op.ghostmask) launch_zero_ghost(s, n, op.ghostmask, w.t.p);
     rhs = w.t.p;
   }
+  static const bool single_reduction = std::getenv("NSFEM_CG_TWO_REDUCTIONS") == nullptr;
+  if (op.prec && single_reduction) return pcg_single_reduction(s, w, op, rhs, x, o, info);
   launch_residual(s, *op.A, op.nv, x, rhs, w.r.p, op.rowmask, op.maskmode);
   int cur = P_RZ0, nxt = P_RZ1;
   if (op.prec) op.prec->apply(s, w.r.p, w.p.p);

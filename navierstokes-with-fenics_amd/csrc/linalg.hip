@@ -833,54 +833,66 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* __restr
   }
 }
 
-// parts[TS] = t.s ; parts[TT] = t.t
+// the five sums the second half of an iteration needs, in adjacent slots (ONE all-reduce):
+//   t.s, t.t (omega), rhat.s, rhat.t, s.s -- with r = s - omega t they give the new
+//   rho = rhat.r = rhat.s - omega rhat.t  and  |r|^2 = s.s - 2 omega t.s + omega^2 t.t
+// without a second reduction after the update
+enum { P_RHS = P_TT + 1, P_RHT = P_TT + 2, P_SS = P_TT + 3 };
 __global__ __launch_bounds__(256) void k_dot_ts_tt(int64_t n, const double* __restrict__ t,
                                                    const double* __restrict__ sv,
+                                                   const double* __restrict__ rhat,
                                                    double* __restrict__ parts) {
   __shared__ double sh[4];
-  double a = 0.0, b = 0.0;
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0;
   GRID_STRIDE(i, n) {
-    const double ti = t[i];
-    a += ti * sv[i];
+    const double ti = t[i], si = sv[i], hi = rhat[i];
+    a += ti * si;
     b += ti * ti;
+    c += hi * si;
+    d += hi * ti;
+    e += si * si;
   }
   a = block_sum(a, sh);
   b = block_sum(b, sh);
+  c = block_sum(c, sh);
+  d = block_sum(d, sh);
+  e = block_sum(e, sh);
   if (threadIdx.x == 0) {
     parts[P_TS * kParts + blockIdx.x] = a;
     parts[P_TT * kParts + blockIdx.x] = b;
+    parts[P_RHS * kParts + blockIdx.x] = c;
+    parts[P_RHT * kParts + blockIdx.x] = d;
+    parts[P_SS * kParts + blockIdx.x] = e;
   }
 }
 
-// omega = ts/tt ; x += alpha phat + omega shat ; r = s - omega t ; dots r.r, rhat.r
+// omega = ts/tt ; x += alpha phat + omega shat ; r = s - omega t ; rho and |r|^2 of the new
+// residual from the five (already global) sums: block 0 stores them as the only non-zero partial
 __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __restrict__ phat,
                                                  const double* __restrict__ shat,
                                                  const double* __restrict__ sv,
                                                  const double* __restrict__ t,
-                                                 const double* __restrict__ rhat,
                                                  double* __restrict__ x, double* __restrict__ r,
                                                  double* __restrict__ parts,
                                                  double* __restrict__ scal) {
   __shared__ double sh[4];
   const double ts = sum_parts(parts + P_TS * kParts, sh);
   const double tt = sum_parts(parts + P_TT * kParts, sh);
+  const double rhs = sum_parts(parts + P_RHS * kParts, sh);
+  const double rht = sum_parts(parts + P_RHT * kParts, sh);
+  const double ss = sum_parts(parts + P_SS * kParts, sh);
   const double omega = (tt > 0.0) ? ts / tt : 0.0;
   const double alpha = scal[S_ALPHA];
   const double rho = scal[S_RHO];
-  double rr = 0.0, rhr = 0.0;
   GRID_STRIDE(i, n) {
     x[i] += alpha * phat[i] + omega * shat[i];
-    const double ri = sv[i] - omega * t[i];
-    r[i] = ri;
-    rr += ri * ri;
-    rhr += rhat[i] * ri;
+    r[i] = sv[i] - omega * t[i];
   }
-  rr = block_sum(rr, sh);
-  rhr = block_sum(rhr, sh);
   __syncthreads();
   if (threadIdx.x == 0) {
-    parts[P_RR * kParts + blockIdx.x] = rr;
-    parts[P_RHO * kParts + blockIdx.x] = rhr;
+    const double rr = fmax(ss - 2.0 * omega * ts + omega * omega * tt, 0.0);
+    parts[P_RR * kParts + blockIdx.x] = blockIdx.x == 0 ? rr : 0.0;
+    parts[P_RHO * kParts + blockIdx.x] = blockIdx.x == 0 ? rhs - omega * rht : 0.0;
     if (blockIdx.x == 0) {
       scal[S_OMEGA] = omega;
       scal[S_RHO_OLD] = rho;
@@ -946,11 +958,9 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
            parts, scal);
     if (op.prec) op.prec->apply(s, w.s.p, w.shat.p);
     apply(w.shat.p, w.t.p);
-    LAUNCH(k_dot_ts_tt, kParts, s, n, w.t.p, w.s.p, parts);
-    reduce_slots(op, s, parts, P_TS, 2);
-    LAUNCH(k_bicg_xr, kParts, s, n, w.phat.p, w.shat.p, w.s.p, w.t.p, w.rhat.p, x, w.r.p, parts,
-           scal);
-    reduce_slots(op, s, parts, P_RHO, 2);
+    LAUNCH(k_dot_ts_tt, kParts, s, n, w.t.p, w.s.p, w.rhat.p, parts);
+    reduce_slots(op, s, parts, P_TS, 5);
+    LAUNCH(k_bicg_xr, kParts, s, n, w.phat.p, w.shat.p, w.s.p, w.t.p, x, w.r.p, parts, scal);
   };
   // iterations >= 1 replay one captured HIP graph (same kernels, same arguments): removes the
   // host launch cost of the ~100 small multigrid kernels per iteration

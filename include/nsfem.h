@@ -222,7 +222,8 @@ typedef struct {
   const int32_t* p_rowptr;   /* [n_fine + 1]     */
   const int32_t* p_col;
   const double* p_val;
-  const uint8_t* ghost;      /* [n_vertices] nonzero = ghost node; NULL on unpartitioned meshes */
+  const uint8_t* ghost;      /* one flag per P1 dof of the level ([n_vertices], or [n_dofs] with a
+                                dofmap): nonzero = ghost; NULL on unpartitioned meshes */
   nsfem_halo halo;           /* used when ghost != NULL */
   /* constrained (periodic) spaces: the P1 dof of every cell vertex, [n_cells * (dim + 1)], with
    * n_dofs < n_vertices distinct ids (slaves share their master's dof); the geometry still comes

@@ -143,8 +143,8 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, rel
     nat.local_group_destroy(group)
 
 
-@pytest.mark.parametrize("n,size,tail", [(32, 2, False), (64, 4, True)])
-def test_partitioned_monolithic_bdf_equals_single_context(n, size, tail):
+@pytest.mark.parametrize("n,size,tail,relaxed", [(32, 2, False, False), (64, 4, True, False), (64, 4, True, True)])
+def test_partitioned_monolithic_bdf_equals_single_context(n, size, tail, relaxed):
     """The monolithic BDF step on strips: halo-exchanged mixed operator (matrix-free velocity
     block), partitioned block preconditioner (Schur Laplacian and velocity V-cycles, pressure-mass
     smoother), all-reduced dots -- same Newton / BiCGStab counts and fields as one context."""
@@ -186,6 +186,7 @@ def test_partitioned_monolithic_bdf_equals_single_context(n, size, tail):
     def worker(r):
         try:
             parts[r].attach(ctxs[r])
+            ctxs[r].mg_set_halo_mode(relaxed)
             run(ctxs[r], parts[r].dofmap, out, r)
         except BaseException as exc:
             errors.append((r, repr(exc)))
@@ -205,9 +206,9 @@ def test_partitioned_monolithic_bdf_equals_single_context(n, size, tail):
         p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
         for a, b in zip(infos, inf_ref):
             assert a.newton_iterations == b.newton_iterations
-            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= 1
-    assert rel(u, u_ref) < 1e-10
-    assert rel(p - p.mean(), p_ref - p_ref.mean()) < 1e-9
+            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= (max(3, 0.2 * b.krylov_iterations_momentum) if relaxed else 1)
+    assert rel(u, u_ref) < (1e-8 if relaxed else 1e-10)
+    assert rel(p - p.mean(), p_ref - p_ref.mean()) < (1e-7 if relaxed else 1e-9)
     for c in ctxs:
         c.close()
     nat.local_group_destroy(group)

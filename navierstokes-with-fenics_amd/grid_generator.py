@@ -496,8 +496,44 @@ def backward_facing_step(m=2, n_refine=2):
         return mesh, markers, {marker.name: marker.value for marker in BackwardFacingStepMarkers}
 
 
-def blasius_plate():
-    return _read_external_mesh("BlasiusFlowProblem.geo")
+class BlasiusPlateMarkers(Enum):
+    """Physical groups the Blasius demo / test use (demo/blasius_flow.py:22-38): the plate is an
+    INTERNAL line (no-slip imposed through ``internal_constraints``)."""
+    inlet = auto()
+    outlet = auto()
+    bottom = auto()
+    top = auto()
+    plate = auto()
+
+
+def blasius_plate_mesh(n=16, length=2.0, height=1.0, plate=(0.5, 1.5)):
+    """In-repo stand-in for BlasiusFlowProblem.geo: the channel [0, length] x [0, height] with a
+    thin plate on the centre line y = height / 2 between x = plate[0] and plate[1], marked on
+    INTERIOR facets; right-diagonal triangles, ``n`` cells across the height (even, so that the
+    plate lies on a lattice line).  The structured mesh carries the multigrid hierarchy."""
+    assert n % 2 == 0
+    nx = int(round(n * length / height))
+    mesh = rectangle_mesh((0.0, 0.0), (length, height), nx, n)
+    marks = FacetMarkers(mesh, 0)
+    ids = BlasiusPlateMarkers
+    marks.mark(lambda X: np.abs(X[:, 0]) < 1e-12, ids.inlet.value)
+    marks.mark(lambda X: np.abs(X[:, 0] - length) < 1e-12, ids.outlet.value)
+    marks.mark(lambda X: np.abs(X[:, 1]) < 1e-12, ids.bottom.value)
+    marks.mark(lambda X: np.abs(X[:, 1] - height) < 1e-12, ids.top.value)
+    on_plate = lambda X: (np.abs(X[:, 1] - 0.5 * height) < 1e-12) & (X[:, 0] > plate[0] - 1e-12) & \
+        (X[:, 0] < plate[1] + 1e-12)
+    marks.mark(on_plate, ids.plate.value, boundary_only=False)
+    return mesh, marks
+
+
+def blasius_plate(n=16):
+    """BlasiusFlowProblem.msh when supplied, else the in-repo channel with an internal plate and
+    the marker map the .geo file defines."""
+    try:
+        return _read_external_mesh("BlasiusFlowProblem.geo")
+    except FileNotFoundError:
+        mesh, markers = blasius_plate_mesh(n)
+        return mesh, markers, {marker.name: marker.value for marker in BlasiusPlateMarkers}
 
 
 def channel_with_cylinder(m=4, n_refine=2):

@@ -148,8 +148,10 @@ def test_external_mesh_entry_points(tmp_path):
     import grid_generator as gg
     mesh, marks, names = gg.channel_with_cylinder(2, 0)
     assert names["cylinder"] == gg.DFGBoundaryMarkers.cylinder.value and mesh.num_cells() > 100
-    with pytest.raises(FileNotFoundError):
-        gg.blasius_plate()
+    mesh_b, marks_b, names_b = gg.blasius_plate(8)                  # in-repo stand-in: internal plate line
+    assert set(names_b) == {"inlet", "outlet", "bottom", "top", "plate"}
+    plate = marks_b.facets_with_id(names_b["plate"])
+    assert plate.size == 8 and not mesh_b.facet_on_boundary[plate].any()
     os.makedirs("meshes")
     write_msh(os.path.join("meshes", "DFGBenchmark.msh"), mesh, marks,
               {"inlet": (1, 1), "cylinder": (1, 5), "fluid": (2, 1)})

@@ -1032,12 +1032,11 @@ def test_stationary_couette_flow_periodic_with_traction():
 
 
 class FlatPlateProblem(StationaryProblem):
-    """Blasius-type flow over a flat plate embedded in a channel -- the reference's
-    BlasiusFlowProblem (tests/test_stationary_solvers.py:224-251, mesh from gmsh) on an in-repo
-    rectangle mesh: uniform inlet (1, 0), no normal flux on bottom / top, natural outlet, Re = 200
-    and the plate as an INTERNAL constraint (no-slip on marked interior facets)."""
-
-    PLATE = 7
+    """Blasius-type flow over a flat plate embedded in a channel -- demo/blasius_flow.py and the
+    reference's BlasiusFlowProblem (tests/test_stationary_solvers.py:224-251): uniform inlet (1, 0),
+    no normal flux on bottom / top, natural outlet, Re = 200 and the plate as an INTERNAL constraint
+    (no-slip on marked interior facets).  The gmsh file is not available: ``blasius_plate`` falls
+    back to the in-repo channel with an internal plate line and the same marker names."""
 
     def __init__(self, n_points):
         super().__init__(None)
@@ -1045,23 +1044,21 @@ class FlatPlateProblem(StationaryProblem):
         self._problem_name = "BlasiusFlow"
 
     def setup_mesh(self):
-        n = self._n_points
-        self._mesh, self._boundary_markers = hyper_rectangle((0.0, 0.0), (2.0, 1.0), (2 * n, n))
-        on_plate = lambda X: (np.abs(X[:, 1] - 0.5) < 1e-12) & (X[:, 0] > 0.5 - 1e-12) & (X[:, 0] < 1.5 + 1e-12)
-        self._boundary_markers.mark(on_plate, self.PLATE, boundary_only=False)
+        from grid_generator import blasius_plate
+        self._mesh, self._boundary_markers, self._boundary_marker_map = blasius_plate(self._n_points)
 
     def set_boundary_conditions(self):
-        ids = HyperRectangleBoundaryMarkers
+        names = self._boundary_marker_map
         inlet = dlfn.Expression(("1.0", "0.0"), degree=2)
-        self._bcs = ((VelocityBCType.function, ids.left.value, inlet),
-                     (VelocityBCType.no_normal_flux, ids.bottom.value, None),
-                     (VelocityBCType.no_normal_flux, ids.top.value, None))
+        self._bcs = ((VelocityBCType.function, names["inlet"], inlet),
+                     (VelocityBCType.no_normal_flux, names["bottom"], None),
+                     (VelocityBCType.no_normal_flux, names["top"], None))
 
     def set_equation_coefficients(self):
         self._coefficient_handler = EquationCoefficientHandler(Re=200.0)
 
     def set_internal_constraints(self):
-        self._internal_constraints = ((VelocityBCType.no_slip, self.PLATE, None), )
+        self._internal_constraints = ((VelocityBCType.no_slip, self._boundary_marker_map["plate"], None), )
 
     def postprocess_solution(self):
         self._add_to_field_output(self._compute_pressure_gradient())

@@ -65,8 +65,12 @@ class StationaryProblem(ProblemBase):
             self.postprocess_solution()
             self._write_xdmf_file()
             return
-        except (RuntimeError, AssertionError):
-            pass
+        except (RuntimeError, AssertionError) as err:
+            # only a failed nonlinear / linear iteration sends the problem into the Reynolds-number
+            # continuation; a missing device, a bad argument ... must stay loud
+            import _native as nat
+            if isinstance(err, nat.NativeError) and err.code not in (nat.ERR_NOT_CONVERGED, nat.ERR_BREAKDOWN):
+                raise
         # Reynolds continuation: logarithmic ramp from Re = 10 to the target
         Re_final = self._coefficient_handler.Re
         assert Re_final is not None and Re_final > 10.0, "nonlinear solve failed"

@@ -475,3 +475,37 @@ def test_periodic_slab_partition_host_side():
         assert P.shape == (q.dofmap.n_p1, lev.n_p1) and abs(P.sum(axis=1) - 1.0).max() < 1e-14
         assert lev.dofmap.max() + 1 == lev.n_p1 == 2 * 2 * 3
     assert p.coarse_global_shape == (2, 2, 4)
+
+
+def test_dolfin_shim_and_loud_failure_without_a_device():
+    """``import dolfin`` resolves to the dolfin-free stand-ins when this package is on the path
+    (the reference's demos run unchanged), and without a GPU the stationary driver reports the
+    missing device instead of wandering into the Reynolds-number continuation."""
+    import subprocess
+    import sys
+    code = (
+        "import dolfin as dlfn\n"
+        "from ns_problem import StationaryProblem, VelocityBCType\n"
+        "from grid_generator import hyper_cube, HyperCubeBoundaryMarkers as M\n"
+        "from auxiliary_classes import EquationCoefficientHandler\n"
+        "assert dlfn.near(1.0, 1.0 + 1e-16) and dlfn.DOLFIN_EPS < 1e-14 and abs(dlfn.pi - 3.14159265) < 1e-6\n"
+        "class P(StationaryProblem):\n"
+        "    def setup_mesh(self):\n"
+        "        self._mesh, self._boundary_markers = hyper_cube(2, 4)\n"
+        "    def set_boundary_conditions(self):\n"
+        "        lid = dlfn.Expression(('1.0', '0.0'), degree=2)\n"
+        "        self._bcs = tuple((VelocityBCType.no_slip, m.value, None) for m in (M.left, M.right, M.bottom)) + \\\n"
+        "            ((VelocityBCType.function, M.top.value, lid), )\n"
+        "    def set_equation_coefficients(self):\n"
+        "        self._coefficient_handler = EquationCoefficientHandler(Re=50.0)\n"
+        "dlfn.set_log_level(40)\n"
+        "P().solve_problem()\n")
+    import torch
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "navierstokes-with-fenics_amd"), NSFEM_NO_OUTPUT="1")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.getcwd())
+    if torch.cuda.is_available():
+        assert res.returncode == 0, res.stderr[-1500:]
+    else:
+        assert res.returncode != 0 and "no ROCm-capable device" in res.stderr and \
+            "nonlinear solve failed" not in res.stderr

@@ -543,4 +543,7 @@ def channel_with_cylinder(m=4, n_refine=2):
         return _read_external_mesh("DFGBenchmark.geo")
     except FileNotFoundError:
         mesh, markers = dfg_channel(m, n_refine)
-        return mesh, markers, {marker.name: marker.value for marker in DFGBoundaryMarkers}
+        names = {marker.name: marker.value for marker in DFGBoundaryMarkers}
+        # the physical group names of DFGBenchmark.geo as demo/dfg_benchmark.py uses them
+        names["lower wall"], names["upper wall"] = names["bottom"], names["top"]
+        return mesh, markers, names

@@ -75,9 +75,12 @@ class EquationCoefficientHandler:
     def __str__(self):
         lines = ["dimensionless numbers:"]
         lines += ["  {:4} = {:.3e}".format(k, v) for k, v in self._dimensionless_numbers.items()]
-        lines.append("equation coefficients:")
-        for k, v in self.equation_coefficients.items():
-            lines.append("  {:16} = {}".format(k, "None" if v is None else "{:.3e}".format(v)))
+        # (as in the reference, :190: only what has been computed so far is shown -- printing an
+        # empty handler must not raise)
+        if getattr(self, "_equation_coefficients", None):
+            lines.append("equation coefficients:")
+            for k, v in self._equation_coefficients.items():
+                lines.append("  {:16} = {}".format(k, "None" if v is None else "{:.3e}".format(v)))
         return "\n".join(lines)
 
 

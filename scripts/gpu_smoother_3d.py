@@ -1,4 +1,4 @@
-"""Scratch: finest-level smoother launch (back-to-back) on the 3D Kuhn mesh, non-periodic vs
+"""Scratch: finest-level smoother launch (timed between cache-flushing launches) on the 3D Kuhn mesh, non-periodic vs
 triple-periodic dof numbering."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

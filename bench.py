@@ -59,36 +59,55 @@ def cavity_dirichlet(dm, height):
     return dofs, vals
 
 
-def cpu_baseline(n_sample, k, steps):
+def cpu_baseline(sizes, k, workload_dofs):
     """Reference algorithm on the host CPU (1 process, as the reference runs): per Newton
     iteration full re-assembly + SuperLU; Poisson and mass matrices re-assembled and
-    re-factorised each step (dolfin LinearVariationalSolver behaviour)."""
+    re-factorised each step (dolfin LinearVariationalSolver behaviour).  Timed on a bounded
+    ladder of cavity sizes `sizes` = [(n, steps), ...]; the cost exponent (time per step ~
+    dofs^e) is fitted over the ladder and the rate at the workload size extrapolated with it
+    (the LU of the workload itself is out of reach: SURVEY.md section 8d)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fem_oracle as fo
     from fem_mesh import TaylorHoodDofMap
     from grid_generator import hyper_cube
-    mesh, _ = hyper_cube(2, n_sample)
-    dm = TaylorHoodDofMap(mesh)
-    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
-    bd, bv = cavity_dirichlet(dm, 1.0)
-    order = np.argsort(bd, kind="stable")
-    bd, bv = bd[order].astype(np.int64), bv[order]
-    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
-    orc = fo.IPCSOracle(s, coef, refactor_every_step=True)
-    orc.step(fo.bdf_alpha(0, 1.0), k, (bd, bv))     # warm-up (BDF-1 start step)
-    orc.advance()
-    t0 = time.perf_counter()
-    for step in range(1, steps + 1):
-        orc.step(fo.bdf_alpha(step, 1.0), k, (bd, bv))
+    samples = []
+    for n_sample, steps in sizes:
+        mesh, _ = hyper_cube(2, n_sample)
+        dm = TaylorHoodDofMap(mesh)
+        s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+        bd, bv = cavity_dirichlet(dm, 1.0)
+        order = np.argsort(bd, kind="stable")
+        bd, bv = bd[order].astype(np.int64), bv[order]
+        coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
+        orc = fo.IPCSOracle(s, coef, refactor_every_step=True)
+        orc.step(fo.bdf_alpha(0, 1.0), k, (bd, bv))     # warm-up (BDF-1 start step)
         orc.advance()
-    dt = time.perf_counter() - t0
-    sps = steps / dt
-    return {"value": sps * dm.n_dofs, "unit": "DoF-updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle IPCS (re-assembly + SuperLU per Newton iteration, Poisson/mass "
-                      "re-factorised per step) on the n=%d cavity (%d dofs), %d steps after 1 warm-up: "
-                      "%.3f steps/s x %d dofs (sparse LU scales super-linearly, so the rate at "
-                      "2.36 M dofs would be lower)" % (n_sample, dm.n_dofs, steps, sps, dm.n_dofs),
-            "sample_steps_per_s": sps, "sample_dofs": dm.n_dofs, "host_cpus": os.cpu_count()}
+        t0 = time.perf_counter()
+        for step in range(1, steps + 1):
+            orc.step(fo.bdf_alpha(step, 1.0), k, (bd, bv))
+            orc.advance()
+        dt = time.perf_counter() - t0
+        samples.append({"cells_per_side": n_sample, "dofs": dm.n_dofs, "steps": steps,
+                        "steps_per_s": steps / dt, "s_per_step": dt / steps})
+    big = samples[-1]
+    out = {"value": big["steps_per_s"] * big["dofs"], "unit": "DoF-updates/s", "cores": 1, "kind": "port",
+           "sample": "oracle IPCS (re-assembly + SuperLU per Newton iteration, Poisson/mass "
+                     "re-factorised per step) on the n=%d cavity (%d dofs), %d steps after 1 warm-up: "
+                     "%.3f steps/s x %d dofs; smaller sizes in `samples`" % (
+                         big["cells_per_side"], big["dofs"], big["steps"], big["steps_per_s"], big["dofs"]),
+           "sample_steps_per_s": big["steps_per_s"], "sample_dofs": big["dofs"],
+           "samples": samples, "host_cpus": os.cpu_count()}
+    if len(samples) >= 2:
+        x = np.log([v["dofs"] for v in samples])
+        y = np.log([v["s_per_step"] for v in samples])
+        e, c = np.polyfit(x, y, 1)
+        t_work = float(np.exp(c + e * np.log(workload_dofs)))
+        out["cost_exponent"] = float(e)
+        out["extrapolated_steps_per_s_at_workload"] = 1.0 / t_work
+        out["extrapolated_value_at_workload"] = workload_dofs / t_work
+        out["extrapolation"] = "s/step ~ dofs^%.2f fitted over `samples`, evaluated at %d dofs " \
+                               "(not measured: sparse LU fill at that size exceeds the host)" % (e, workload_dofs)
+    return out
 
 
 def dfg_bdf_bench(args):
@@ -143,6 +162,16 @@ def dfg_bdf_bench(args):
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     sps = args.steps / elapsed
+    # the physical output of the configuration (demo/dfg_benchmark.py:44-66): drag / lift coefficients
+    # from the surface traction on the cylinder, c = 2 F / (U_mean^2 D) with U_mean = D = 1.  The
+    # reference integrates  -p n + 1/Re sym(grad u) n  (its d lacks the factor 2 of the Newtonian
+    # stress); both variants are reported.  (The benchmark's published maxima, c_D ~ 3.23, c_L ~ 1.0,
+    # belong to the periodic vortex-shedding state at t > 30, far beyond these few steps.)
+    fc, fl = mesh.facet_cell_local(marks.facets_with_id(ids.cylinder.value))
+    f_ref, _, perimeter = ctx.boundary_force(fc, fl, 0.5 / 100.0, 1.0, nat.U0, nat.P)
+    f_std, _, _ = ctx.boundary_force(fc, fl, 1.0 / 100.0, 1.0, nat.U0, nat.P)
+    fc_all, fl_all = mesh.facet_cell_local(np.nonzero(mesh.facet_on_boundary)[0])
+    _, net_flux, _ = ctx.boundary_force(fc_all, fl_all, 0.0, 0.0, nat.U0, nat.P)
     ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9
     print(json.dumps({
@@ -157,7 +186,11 @@ def dfg_bdf_bench(args):
                    "preconditioner": "block-triangular (V-cycle velocity block, Cahouet-Chabard Schur "
                                      "with algebraic pressure Laplacian), %d coarse P1 levels" % levels,
                    "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
-                   "bicgstab_its_per_step": kry / args.steps, "host_setup_s": t_setup},
+                   "bicgstab_its_per_step": kry / args.steps, "host_setup_s": t_setup,
+                   "t_end": dt * (args.warmup + args.steps),
+                   "drag_lift_reference_formula": [-2.0 * f_ref[0], -2.0 * f_ref[1]],
+                   "drag_lift_newtonian_stress": [-2.0 * f_std[0], -2.0 * f_std[1]],
+                   "cylinder_perimeter_of_the_mesh": perimeter, "net_boundary_mass_flux": net_flux},
         "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<2,2,1,0> (velocity Jacobian block)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -223,8 +256,11 @@ def tgv3d_bench(args):
         # N > 1, weak scaling: every rank owns n cube layers of the n x n x (n N) box [0,1]^2 x [0,N],
         # periodic in all three directions (the planar vortex is z-invariant, so any z period fits);
         # z wraps around the ranks (PeriodicSlabPartition)
+        # (--scaling strong: ONE n^3 box cut into `world` periodic slabs of n / world cube layers)
         from partition import PeriodicSlabPartition
-        part = PeriodicSlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, float(world)), n, n, n * world, rank, world,
+        strong = args.scaling == "strong"
+        nz_global, zlen = (n, 1.0) if strong else (n * world, float(world))
+        part = PeriodicSlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, zlen), n, n, nz_global, rank, world,
                                      coarsest=args.coarsest if args.coarsest else 16, global_coarsest=4)
         mesh, dm = part.mesh, part.dofmap
         device = 0 if os.environ.get("NSFEM_SHARE_GPU") else local_rank
@@ -235,6 +271,7 @@ def tgv3d_bench(args):
         levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
         n_dofs = 3 * part.n_p2_global + part.n_p1_global
     _apply_truncation(ctx, args)
+    ctx.set_overlap(args.overlap == "on")
     g = 2.0 * np.pi
     X = dm.p2_coords
     u0 = np.stack([np.cos(g * X[:, 0]) * np.sin(g * X[:, 1]), -np.sin(g * X[:, 0]) * np.cos(g * X[:, 1]),
@@ -301,15 +338,16 @@ def tgv3d_bench(args):
     print(json.dumps({
         "metric": "dof_updates_per_sec", "value": sps * n_dofs, "unit": "DoF-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic", "time_steps_per_sec": sps,
         "config": {"workload": "3D Taylor-Green vortex, triple-periodic unit cube, %d^3 cubes x 6 Kuhn "
-                               "tetrahedra per GPU (%d dofs), Re=100, IPCS, BDF-2, dt=%g" % (n, n_dofs, dt),
+                               "tetrahedra %s (%d dofs), Re=100, IPCS, BDF-2, dt=%g" % (
+                                   n, "in total" if (world > 1 and args.scaling == "strong") else "per GPU", n_dofs, dt),
                    "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
                    "newton_forcing": args.newton_forcing, "coarse_p1_levels": levels,
                    "parallelism": "1 GPU" if world == 1 else
-                   "%d periodic slabs of %d cube layers, RCCL wrap-around halo exchange (%s mode) + all-reduce" % (
-                       world, n, args.halo_mode),
+                   "%d periodic slabs of %d cube layers, RCCL wrap-around halo exchange (%s mode, overlap %s) + all-reduce" % (
+                       world, n // world if args.scaling == "strong" else n, args.halo_mode, args.overlap),
                    "newton_its_per_step": newton / args.steps,
                    "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
                    "max_abs_velocity_error_vs_analytic": err, "host_setup_s": t_setup,
@@ -335,7 +373,9 @@ def cavity3d_bench(args):
     bdf = args.workload == "cavity3d-bdf"
     n = args.n
     t_setup = time.perf_counter()
-    part = SlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, float(world)), n, n, n * world, rank, world,
+    strong = args.scaling == "strong"
+    nz_global, zlen = (n, 1.0) if strong else (n * world, float(world))
+    part = SlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, zlen), n, n, nz_global, rank, world,
                          coarsest=args.coarsest if args.coarsest else (_serial_coarsest(n, 3) if world == 1 else 16),
                          global_coarsest=None if world == 1 else 4)
     mesh, dm = part.mesh, part.dofmap
@@ -347,11 +387,11 @@ def cavity3d_bench(args):
         ctx.attach_rccl_comm(ids[0], rank, world)
     levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
     X = dm.p2_coords
-    on = (np.abs(X[:, 2]) < 1e-12) | (np.abs(X[:, 2] - world) < 1e-12)
+    on = (np.abs(X[:, 2]) < 1e-12) | (np.abs(X[:, 2] - zlen) < 1e-12)
     for a in range(2):
         on |= (np.abs(X[:, a]) < 1e-12) | (np.abs(X[:, a] - 1.0) < 1e-12)
     nodes = np.nonzero(on)[0]
-    lid = np.abs(X[nodes, 2] - world) < 1e-12
+    lid = np.abs(X[nodes, 2] - zlen) < 1e-12
     dofs = np.concatenate([3 * nodes, 3 * nodes + 1, 3 * nodes + 2]).astype(np.int32)
     vals = np.concatenate([np.where(lid, 1.0, 0.0), np.zeros(2 * nodes.size)])
     ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
@@ -359,9 +399,10 @@ def cavity3d_bench(args):
     ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
     ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
     t_setup = time.perf_counter() - t_setup
-    n2g, n1g = global_dof_counts(n, n, n * world)
+    n2g, n1g = global_dof_counts(n, n, nz_global)
     n_dofs = 3 * n2g + n1g
     _apply_truncation(ctx, args)
+    ctx.set_overlap(args.overlap == "on")
     opts = ctx.default_step_opts()
     for o in (opts.momentum, opts.poisson, opts.correction):
         o.rtol = args.krylov_rtol
@@ -407,15 +448,16 @@ def cavity3d_bench(args):
         print(json.dumps({
             "metric": "dof_updates_per_sec", "value": sps * n_dofs, "unit": "DoF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "time_steps_per_sec": sps,
             "config": {"workload": "3D lid-driven cavity Re=100, %dx%dx%d cubes x 6 Kuhn tetrahedra "
-                                   "(%d dofs), %s, dt=%g" % (n, n, n * world, n_dofs,
+                                   "(%d dofs), %s, dt=%g" % (n, n, nz_global, n_dofs,
                                                              "BDF-2 monolithic" if bdf else "IPCS", dt),
                        "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
                        "newton_forcing": args.newton_forcing, "coarse_p1_levels": levels,
                        "parallelism": "1 GPU" if world == 1 else
-                       "%d slabs of %d cube layers, RCCL halo exchange (%s mode) + all-reduce" % (world, n, args.halo_mode),
+                       "%d slabs of %d cube layers, RCCL halo exchange (%s mode, overlap %s) + all-reduce" % (
+                           world, nz_global // world, args.halo_mode, args.overlap),
                        "newton_its_per_step": newton / args.steps,
                        "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
                        "host_setup_s": t_setup, "comm_per_step_rank0": comm_per_step},
@@ -426,6 +468,145 @@ def cavity3d_bench(args):
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def channel3d_bdf_bench(args):
+    """BASELINE.json configs[4] on ONE GPU: 3D channel, 2 : 1 : 1 box [0,2] x [0,1]^2 cut into
+    (2n, n, n) cubes x 6 Kuhn tetrahedra (the reference has simplices only), inlet
+    u_x = 16 y (1 - y) z (1 - z) at x = 0, no-slip side walls, natural outflow at x = 2,
+    Re = 1000 (--reynolds), fully implicit BDF-2 on the mixed P2^3 x P1 system
+    (source/ns_bdf_solver.py:36-106): Newton with the reference's criterion, BiCGStab on the mixed
+    operator (matrix-free velocity Jacobian), block-triangular preconditioner with the algebraic
+    Schur Laplacian of the open outlet.  Impulsive start from rest.  Checked invariants: Newton
+    converged in every step; discrete mass balance (flux in + out + walls = 0, the continuity
+    rows tested with the constant P1 function); inflow flux = integral of the interpolated inlet
+    profile (-4/9 + O(h^4))."""
+    import grid_generator as gg
+    from fem_mesh import TaylorHoodDofMap
+    from multigrid import attach_hierarchy, attach_schur_laplacian
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("channel3d-bdf is a single-GPU workload (the algebraic Schur Laplacian of the "
+                         "open outlet is assembled for one rank; see DESIGN.md)")
+    n = args.n
+    t_setup = time.perf_counter()
+    mesh, marks = gg.hyper_rectangle((0.0, 0.0, 0.0), (2.0, 1.0, 1.0), (2 * n, n, n))
+    dm = TaylorHoodDofMap(mesh)
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+    levels = attach_hierarchy(ctx, mesh, args.mg_degree, args.mg_eig_ratio)
+    M = gg.HyperRectangleBoundaryMarkers
+    inlet = np.unique(dm.facet_p2_nodes(marks.facets_with_id(M.left.value)))
+    walls = np.unique(np.concatenate([dm.facet_p2_nodes(marks.facets_with_id(m.value)).ravel()
+                                      for m in (M.bottom, M.top, M.back, M.front)]))
+    Xi = dm.p2_coords[inlet]
+    prof = 16.0 * Xi[:, 1] * (1.0 - Xi[:, 1]) * Xi[:, 2] * (1.0 - Xi[:, 2])
+    # list order of the reference's DirichletBC.apply: the inlet first, the walls win on shared edges
+    bd = np.concatenate([3 * inlet, 3 * inlet + 1, 3 * inlet + 2,
+                         3 * walls, 3 * walls + 1, 3 * walls + 2]).astype(np.int32)
+    bv = np.concatenate([prof, np.zeros(2 * inlet.size + 3 * walls.size)])
+    ctx.set_coeffs(1.0, 1.0, 1.0 / args.reynolds)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+    t_schur = time.perf_counter()
+    attach_schur_laplacian(ctx, np.unique(bd))
+    t_schur = time.perf_counter() - t_schur
+    t_setup = time.perf_counter() - t_setup
+    _apply_truncation(ctx, args)
+    opts = ctx.default_step_opts()
+    opts.momentum.rtol, opts.momentum.precond, opts.momentum.max_iter = args.krylov_rtol, 1, 500
+    opts.newton_forcing = args.newton_forcing
+    opts.matrix_free = args.matrix_free
+    dt = args.dt if args.dt != 1.0e-3 else 0.5 / n          # CFL ~ 1 for the unit peak inflow speed
+
+    def one_step(i):
+        ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), dt)
+        info = ctx.step_bdf(opts)
+        ctx.advance(1)
+        return info
+
+    for i in range(args.warmup):
+        one_step(i)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    newton = kry = 0
+    all_converged, worst = True, 0.0
+    for i in range(args.warmup, args.warmup + args.steps):
+        info = one_step(i)
+        newton += info.newton_iterations
+        kry += info.krylov_iterations_momentum
+        r = list(info.newton_residuals[: info.newton_iterations + 1])
+        all_converged &= bool(info.converged) and (r[-1] < 1e-10 or r[-1] / r[0] < 1e-9)
+        worst = max(worst, r[-1] / r[0])
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    sps = args.steps / elapsed
+    # ---- invariants of the computed state
+    nu = 1.0 / args.reynolds
+    flux = {}
+    for name, m in (("inlet", M.left), ("outlet", M.right), ("bottom", M.bottom), ("top", M.top),
+                    ("back", M.back), ("front", M.front)):
+        fc, fl = mesh.facet_cell_local(marks.facets_with_id(m.value))
+        _, flux[name], _ = ctx.boundary_force(fc, fl, nu, 0.0, nat.U0, nat.P)
+    balance = abs(sum(flux.values())) / abs(flux["inlet"])
+    # inflow: minus the integral of the P2 nodal interpolant of the inlet profile (face rule: area / 3
+    # x the three edge-midpoint values); it tends to the analytic -4/9 like h^4
+    fin = marks.facets_with_id(M.left.value)
+    mid = dm.facet_p2_nodes(fin)[:, 3:]
+    Xm = dm.p2_coords[mid]
+    pm = 16.0 * Xm[..., 1] * (1.0 - Xm[..., 1]) * Xm[..., 2] * (1.0 - Xm[..., 2])
+    tri = mesh.coords[mesh.facets[fin].astype(np.int64)]
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    inflow_expected = -float((area / 3.0 * pm.sum(axis=1)).sum())
+    inflow_err = abs(flux["inlet"] - inflow_expected)
+    u = ctx.get_state(nat.U0).reshape(-1, 3)
+    finite = bool(np.isfinite(u).all())
+    # ---- dominant kernel: finest-level Chebyshev smoothing step of the velocity multigrid inside the
+    # block preconditioner (scalar P2 operator on 3 interleaved components), in situ + cache-cold
+    ctx.profile_smoother(True)
+    ctx.profile_convection(True)
+    for i in range(args.warmup + args.steps, args.warmup + args.steps + 2):
+        one_step(i)
+    ms_sm, n_sm, nbytes = ctx.profile_smoother(False)
+    ms_conv, n_conv, nbytes_conv = ctx.profile_convection(False)
+    ms_cold, _ = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 50)
+    achieved = nbytes / (ms_sm * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "dof_updates_per_sec", "value": sps * dm.n_dofs, "unit": "DoF-updates/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "time_steps_per_sec": sps,
+        "config": {"workload": "3D channel flow Re=%g, 2:1:1 box, %dx%dx%d cubes x 6 Kuhn tetrahedra (%d cells, "
+                               "%d dofs), BDF-2 monolithic, parabolic inlet, natural outflow, dt=%g, "
+                               "impulsive start" % (args.reynolds, 2 * n, n, n, mesh.num_cells(), dm.n_dofs, dt),
+                   "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "newton_forcing": args.newton_forcing,
+                   "preconditioner": "block-triangular (V-cycle velocity block, Cahouet-Chabard Schur with "
+                                     "the algebraic pressure Laplacian D diag(M)^-1 D^T), %d coarse P1 levels" % levels,
+                   "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
+                   "bicgstab_its_per_step": kry / args.steps, "host_setup_s": t_setup,
+                   "host_schur_laplacian_s": t_schur,
+                   "invariants": {"newton_converged_every_step": all_converged,
+                                  "worst_newton_reduction": worst,
+                                  "flux": flux, "mass_balance_rel": balance,
+                                  "inflow_flux_error_vs_interpolated_profile": inflow_err,
+                                  "inflow_flux_minus_analytic_4_9": flux["inlet"] + 4.0 / 9.0,
+                                  "max_velocity": float(np.abs(u).max()), "finite": finite}},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<1,1,3,3> (finest-level Chebyshev smoothing step of the "
+                                               "velocity multigrid, scalar P2 operator on 3 interleaved components)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_sm,
+                     "launches_timed": n_sm, "timing": "in situ, HIP-event pairs around the smoothing sequences of 2 steps",
+                     "cold_cache": {"achieved": nbytes / (ms_cold * 1e-3) / 1e9,
+                                    "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_cold}},
+        "assembly": {"kernel": "k3_conv_cell<FORM,1> + node gather (matrix-free convection action)",
+                     "achieved": nbytes_conv / (ms_conv * 1e-3) / 1e9 if n_conv else None, "unit": "GB/s",
+                     "frac": nbytes_conv / (ms_conv * 1e-3) / 1e9 / HBM_PEAK_GBS if n_conv else None,
+                     "algorithmic_bytes_per_application": nbytes_conv, "ms_per_application": ms_conv,
+                     "applications_timed": n_conv}}))
+    ctx.close()
+    if not (all_converged and finite and balance < 1e-6 and inflow_err < 1e-10):
+        raise SystemExit("channel3d-bdf: invariant violated (converged %s, finite %s, mass balance %.2e, "
+                         "inflow error %.2e)" % (all_converged, finite, balance, inflow_err))
 
 
 def _apply_truncation(ctx, args):
@@ -442,19 +623,322 @@ def _serial_coarsest(n, dim=2):
     return n
 
 
+def _parse_cpu_samples(text):
+    """'24:4,32:4,48:3,64:3' -> [(24, 4), (32, 4), (48, 3), (64, 3)] (cells per side : timed steps)"""
+    out = []
+    for item in text.split(","):
+        n, _, k = item.partition(":")
+        out.append((int(n), int(k) if k else 3))
+    return sorted(out)
+
+
+def _owned_field_difference(ua, ub, owned, dim, dist):
+    """relative L2 and max-norm difference of two velocity fields over the OWNED nodes,
+    all-reduced over the ranks"""
+    m = np.repeat(owned, dim)
+    d = (ua - ub)[m]
+    sums = np.array([float(d @ d), float(ub[m] @ ub[m])])
+    mx = np.array([float(np.abs(d).max()) if d.size else 0.0, float(np.abs(ub[m]).max()) if d.size else 0.0])
+    if dist is not None:
+        import torch
+        t = torch.from_numpy(sums)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t2 = torch.from_numpy(mx)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+    return float(np.sqrt(sums[0] / max(sums[1], 1e-300))), float(mx[0] / max(mx[1], 1e-300))
+
+
+def _owned_pressure_difference(pa, pb, owned, dist):
+    """the same for the pressures, compared modulo a constant (enclosed flow)"""
+    a, b = pa[owned], pb[owned]
+    s = np.array([a.sum(), b.sum(), float(a.size)])
+    if dist is not None:
+        import torch
+        t = torch.from_numpy(s)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    a, b = a - s[0] / s[2], b - s[1] / s[2]
+    d = a - b
+    sums = np.array([float(d @ d), float(b @ b)])
+    if dist is not None:
+        import torch
+        t = torch.from_numpy(sums)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(np.sqrt(sums[0] / max(sums[1], 1e-300)))
+
+
+def cavity_ipcs_bench(args):
+    """headline workload: BASELINE.json configs[1] (see the module docstring)"""
+    rank, world, local_rank, dist = _init_dist(args)
+    strong = args.scaling == "strong"
+
+    # ---- local problem: strip `rank` of the global mesh (own rows + ghost row)
+    #   weak   : n x (n * world) cells on [0,1] x [0,world]   (fixed work per GPU)
+    #   strong : n x n cells on the unit square, cut into `world` strips (fixed total work)
+    from partition import StripPartition, global_dof_counts
+    n = args.n
+    ny_global, height = (n, 1.0) if strong else (n * world, float(world))
+    # one GPU: coarsest mesh <= 1200 nodes (dense solve, inverse computed on the device)
+    # partitioned: the distributed levels stop at 64 cells across (or where the strips cannot be
+    # halved any more); below that every rank runs the replicated global hierarchy without any
+    # halo exchange
+    part = StripPartition((0.0, 0.0), (1.0, height), n, ny_global, rank, world,
+                          coarsest=args.coarsest if args.coarsest else (_serial_coarsest(n) if world == 1 else 64),
+                          global_coarsest=None if world == 1 else 8)
+    dm = part.dofmap
+    device = local_rank
+    if os.environ.get("NSFEM_SHARE_GPU"):        # rehearsal of several ranks on a one-GPU box
+        device = 0
+    ctx = nat.NsfemContext(part.mesh.coords, part.mesh.cells, dm.p2_dofmap, dm.p1_dofmap,
+                           dm.n_p2, dm.n_p1, device)
+    if dist is not None:
+        ids = [nat.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.attach_rccl_comm(ids[0], rank, world)
+    mg_levels = None
+    n2g, n1g = global_dof_counts(n, ny_global)
+    if not args.no_multigrid:
+        mg_levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
+    else:
+        ctx.set_partition(rank, world, part.p2_ghost, part.p1_ghost, part.p2_halo, part.p1_halo,
+                          n2g, n1g)
+    ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
+    ctx.set_dirichlet(nat.VELOCITY, *cavity_dirichlet(dm, height))
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    n_dofs = 2 * n2g + n1g
+
+    _apply_truncation(ctx, args)
+    ctx.set_overlap(args.overlap == "on")
+
+    def throughput_opts():
+        o = ctx.default_step_opts()
+        for k in (o.momentum, o.poisson, o.correction):
+            k.rtol = args.krylov_rtol
+        if mg_levels is not None:
+            o.momentum.precond = o.poisson.precond = 1
+        o.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
+        o.newton_forcing = args.newton_forcing
+        o.matrix_free = args.matrix_free
+        return o
+
+    def exact_opts():
+        # direct-solver accuracy in every linear solve (rtol 1e-12 of SURVEY 8d's parity runs), exact
+        # Newton, Jacobi-CG mass solve, full (untruncated) velocity cycle
+        o = ctx.default_step_opts()
+        if mg_levels is not None:
+            o.momentum.precond = o.poisson.precond = 1
+        o.matrix_free = args.matrix_free
+        return o
+
+    zeros_v, zeros_p = np.zeros(ctx.n_velocity), np.zeros(ctx.n_p1)
+
+    def reset_state():
+        for slot in (nat.U0, nat.U1, nat.U2, nat.USTAR):
+            ctx.set_state(slot, zeros_v)
+        for slot in (nat.P, nat.P_OLD):
+            ctx.set_state(slot, zeros_p)
+
+    def one_step(i, opts):
+        ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), args.dt)
+        info = ctx.step_ipcs(opts)
+        ctx.advance(0)
+        return info
+
+    def timed_run(opts):
+        """W untimed + K timed steps from the zero state; (seconds, iteration sums)"""
+        reset_state()
+        for i in range(args.warmup):
+            one_step(i, opts)
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ctx.comm_stats(reset=True)
+        t0 = time.perf_counter()
+        its = np.zeros(3)
+        for i in range(args.warmup, args.warmup + args.steps):
+            info = one_step(i, opts)
+            its += (info.newton_iterations, info.krylov_iterations_momentum, info.krylov_iterations_poisson)
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        comm = {k: v / args.steps for k, v in ctx.comm_stats().items()}
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return elapsed, its / args.steps, comm
+
+    # ---- the timed region of the contract: W warm-up + K timed steps, throughput settings
+    opts = throughput_opts()
+    elapsed, its, comm_per_step = timed_run(opts)
+    steps_per_s = args.steps / elapsed
+    u_fast, p_fast = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
+
+    # ---- validation of what was timed: the SAME W + K steps from the same start with
+    # direct-solver accuracy (rtol 1e-12, exact Newton, Jacobi-CG mass solve, untruncated cycle);
+    # the fields of the timed run must agree to north_star's nonlinear tolerance 1e-6
+    ctx.mg_set_truncation(0.0, 0.1)
+    elapsed_exact, its_exact, _ = timed_run(exact_opts())
+    u_ref, p_ref = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
+    _apply_truncation(ctx, args)
+    du_l2, du_max = _owned_field_difference(u_fast, u_ref, part.p2_owned, 2, dist)
+    dp_l2 = _owned_pressure_difference(p_fast, p_ref, part.p1_owned, dist)
+    ms_parity = 1e3 * elapsed_exact / args.steps
+
+    # ---- dominant kernel of the timed steps: the Chebyshev-Jacobi smoothing step of the velocity
+    # multigrid on its finest level (scalar P2 operator applied to both components, fused
+    # epilogue).  Timed IN SITU on the context's stream -- one HIP-event pair around every run of
+    # consecutive launches inside a smoothing sequence -- over 5 further steps with the throughput
+    # settings (the event pairs stay out of the timed region above).  The launch's working set
+    # (252 MB at n = 512) fits the 256 MiB Infinity Cache, so the in-situ figure is cache assisted;
+    # `cold_cache` is the same launch timed between cache-flushing launches (HBM only).
+    i_next = args.warmup + args.steps
+    assembly = cold = None
+    if mg_levels is not None:
+        ctx.profile_smoother(True)
+        ctx.profile_convection(True)
+        for i in range(i_next, i_next + 5):
+            one_step(i, opts)
+        ms_spmv, n_launches, nbytes = ctx.profile_smoother(False)
+        ms_conv, n_conv, nbytes_conv = ctx.profile_convection(False)
+        if world == 1:
+            ms_cold, _ = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 100)
+            cold = {"achieved": nbytes / (ms_cold * 1e-3) / 1e9, "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "ms_per_launch": ms_cold,
+                    "timing": "100 launches, each preceded by a cache-flushing 2x2-block SpMV (%.2f GB streamed); "
+                              "flush time measured separately and subtracted (nsfem_time_spmv)" % (
+                                  ctx.time_spmv(nat.OP_MOMENTUM_JAC, 3)[1] / 1e9)}
+            ms_conv_cold, _ = ctx.time_spmv(nat.OP_CONVECTION_ACTION, 100)
+        else:
+            ms_conv_cold = None
+        if n_conv:
+            ach = nbytes_conv / (ms_conv * 1e-3) / 1e9
+            assembly = {"kernel": "k_conv_cell<FORM,1> + k_res_gather: matrix-free action of the convection "
+                                  "blocks of the velocity Jacobian (the per-Newton-iteration assembly of the "
+                                  "fused step; one thread per cell, element vectors gathered per node in fixed order)",
+                        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_application": nbytes_conv,
+                        "bytes_formula": "n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x) + n_dofs_velocity x 16 "
+                                         "(SURVEY.md 8d: vector assembly; the element buffer the two kernels hand "
+                                         "over, 2 x 96 B per cell, is implementation traffic and not counted)",
+                        "ms_per_application": ms_conv, "applications_timed": n_conv,
+                        "timing": "HIP-event pair around each application inside the BiCGStab solves of 5 solver steps"}
+            if ms_conv_cold is not None:
+                assembly["cold_cache"] = {"achieved": nbytes_conv / (ms_conv_cold * 1e-3) / 1e9,
+                                          "frac": nbytes_conv / (ms_conv_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "ms_per_application": ms_conv_cold}
+    else:
+        ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
+        n_launches = 200
+    achieved = nbytes / (ms_spmv * 1e-3) / 1e9
+    ms_jac, nbytes_jac = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
+    # HBM bytes per launch of the dominant kernel: NOT measurable inside this process (hardware
+    # counters need rocprofv3); the figure below is read from the committed PMC passes of this very
+    # command and labelled so (`traffic_source`), null when no such profile exists for the size
+    traffic = traffic_source = None
+    for tag in ("r02", "r01_h"):
+        pmc = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write_size.json" % tag)
+        if world == 1 and n == 512 and mg_levels is not None and os.path.exists(pmc):
+            # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE;
+            # the symbol is launched on every multigrid level, the finest-level launches are the maxima
+            c = json.load(open(pmc))
+            key = "void nsfem::k_spmv_stream<1, 1, 2, 3>"
+            if key in c["fetch"] and key in c["write"]:
+                traffic = (2.0 * c["fetch"][key]["max_KB"] + c["write"][key]["max_KB"]) * 1024.0
+                traffic_source = "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: " \
+                                 "profiles/%s_pmc_fetch_write_size.json (not measured by this run; counts " \
+                                 "Infinity-Cache hits as well)" % tag
+                break
+    tol_fields = 1.0e-6
+    out = {
+        "metric": "dof_updates_per_sec", "value": steps_per_s * n_dofs, "unit": "DoF-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "time_steps_per_sec": steps_per_s,
+        "config": {"workload": "2D lid-driven cavity Re=100, %dx%d right-diagonal Taylor-Hood P2/P1 "
+                               "(%d dofs), IPCS, BDF-2, dt=%g, zero initial state" % (
+                                   n, ny_global, n_dofs, args.dt),
+                   "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                   "newton_forcing": args.newton_forcing,
+                   "velocity_jacobian": {0: "matrix-free (default)", 1: "assembled block CSR",
+                                         2: "matrix-free"}[args.matrix_free],
+                   "ms_per_step_with_krylov_rtol_1e-12_exact_newton": ms_parity,
+                   "validation": {"what": "the %d timed + %d warm-up steps repeated from the same start with "
+                                          "Krylov rtol 1e-12, exact Newton, Jacobi-CG mass solve and the "
+                                          "untruncated velocity cycle; fields of the timed run vs those" % (
+                                              args.steps, args.warmup),
+                                  "max_rel_diff_velocity_vs_exact": du_l2,
+                                  "max_rel_diff_velocity_vs_exact_maxnorm": du_max,
+                                  "max_rel_diff_pressure_vs_exact": dp_l2,
+                                  "tolerance": tol_fields,
+                                  "newton_bicgstab_poisson_its_per_step_exact": [float(v) for v in its_exact]},
+                   "preconditioner": "jacobi" if mg_levels is None else
+                   "geometric multigrid, Chebyshev-Jacobi smoothing: V(0,3) momentum, V(2,2) Poisson; %d coarse P1 levels" % mg_levels,
+                   "parallelism": "1 GPU" if world == 1 else
+                   "%d strips of %d cell rows, RCCL halo exchange (%s mode, overlap %s) + all-reduce" % (
+                       world, ny_global // world, args.halo_mode, args.overlap),
+                   "newton_its_per_step": float(its[0]),
+                   "bicgstab_its_per_step": float(its[1]), "poisson_cg_its_per_step": float(its[2]),
+                   "comm_per_step_rank0": comm_per_step},
+        "roofline": {"bound": "hbm",
+                     "kernel": "k_spmv_stream<1,1,2,3>, finest multigrid level: Chebyshev-Jacobi smoothing step "
+                               "y = x + c1 d + c2 dinv (b - L x) on the scalar P2 operator L (%.2f M nnz), "
+                               "both velocity components" % (ctx.operator_nnz(nat.OP_MASS_P2) / 1e6) if mg_levels is not None else
+                               "k_spmv_stream<2,2,1,0> (momentum Jacobian)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv,
+                     "launches_timed": n_launches,
+                     "timing": "in situ: HIP-event pairs around the runs of consecutive finest-level launches (one pair "
+                               "per smoothing sequence) during 5 solver steps",
+                     "cache_note": "`achieved` / `frac` are in-situ figures; when the launch's working set "
+                                   "(algorithmic_bytes_per_launch) is below the 256 MiB Infinity Cache they are cache "
+                                   "assisted -- `cold_cache` is the HBM-only figure of the same launch",
+                     "cold_cache": cold},
+        "assembly": assembly,
+        "jacobian_spmv": {"kernel": "k_spmv_stream<2,2,1,0> (assembled momentum Jacobian, 2x2 block CSR; "
+                                    "used by the explicit assembly seam / matrix_free=1)",
+                          "achieved": nbytes_jac / (ms_jac * 1e-3) / 1e9, "unit": "GB/s",
+                          "frac": nbytes_jac / (ms_jac * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": nbytes_jac, "ms_per_launch": ms_jac},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(_parse_cpu_samples(args.cpu_samples), args.dt, n_dofs)
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if max(du_l2, dp_l2) > tol_fields:
+        raise SystemExit("bench: the timed fields differ from the exact-solver run by %.2e (velocity) / %.2e "
+                         "(pressure) > %.0e" % (du_l2, dp_l2, tol_fields))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cells", dest="n", type=int, default=512, help="cells per side and per rank (512 = BASELINE config 2)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cells", dest="n", type=int, default=None,
+                    help="cells per side (weak scaling: per rank; strong scaling: of the whole mesh); "
+                         "default 512 = BASELINE config 2 (strong scaling: 960, 8.3 M dofs)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="--gpus N > 1: weak = every rank a --cells x --cells strip (per-GPU work fixed); "
+                         "strong = ONE --cells x --cells mesh cut into N strips (total work fixed)")
+    ap.add_argument("--overlap", choices=("on", "off"), default="on",
+                    help="N > 1: halo exchange on a second stream under the interior rows of the SpMV")
     ap.add_argument("--dt", type=float, default=1.0e-3)
     ap.add_argument("--krylov-rtol", type=float, default=1.0e-8,
                     help="relative residual of the linear solves (Poisson, mass; Newton solves when exact)")
     ap.add_argument("--newton-forcing", type=float, default=1.0e-4,
                     help="inexact Newton: reduce each Newton linear residual only by this factor "
                          "(0 = exact Newton with --krylov-rtol)")
-    ap.add_argument("--cpu-sample-n", type=int, default=64)
+    ap.add_argument("--cpu-samples", default="24:4,32:4,48:3,64:3",
+                    help="CPU baseline ladder n:steps,... (cavity cells per side : timed steps); the default "
+                         "is ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-multigrid", action="store_true")
     ap.add_argument("--mg-degree", type=int, default=None,
@@ -472,188 +956,31 @@ def main():
                     help="R[,TOL]: truncate the velocity multigrid cycle at the first level with "
                          "c_v K_ii <= R alpha0/k M_ii, solved there by Chebyshev iteration to TOL (0: off)")
     ap.add_argument("--coarsest", type=int, default=0, help="cells across the coarsest multigrid mesh (0: default)")
-    ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf", "tgv3d-ipcs"),
+    ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf", "tgv3d-ipcs",
+                                           "channel3d-bdf"),
                     default="cavity-ipcs",
                     help="cavity-ipcs = BASELINE configs[1] (headline); dfg-bdf = configs[2], 1 GPU; "
                          "cavity3d-* = 3D tetrahedral cavity (--cells cubes per side); tgv3d-ipcs = configs[3] "
-                         "(triple-periodic Taylor-Green vortex) on 1 GPU")
+                         "(triple-periodic Taylor-Green vortex); channel3d-bdf = configs[4] (3D channel Re=1000, "
+                         "2:1:1 box, BDF-2 monolithic, open outlet)")
     ap.add_argument("--dfg-refine", type=int, default=5)
+    ap.add_argument("--reynolds", type=float, default=1000.0, help="channel3d-bdf: Reynolds number")
     args = ap.parse_args()
     if args.workload == "dfg-bdf":
         if int(os.environ.get("WORLD_SIZE", "1")) != 1:
             raise SystemExit("the dfg-bdf workload is a single-GPU configuration")
         return dfg_bdf_bench(args)
     if args.workload.startswith("cavity3d"):
-        if args.n == 512:
-            args.n = 32
+        args.n = args.n or 32
         return cavity3d_bench(args)
     if args.workload == "tgv3d-ipcs":
-        if args.n == 512:
-            args.n = 32
+        args.n = args.n or (64 if args.scaling == "strong" else 32)
         return tgv3d_bench(args)
-
-    rank, world, local_rank, dist = _init_dist(args)
-
-    # ---- local problem: strip `rank` of the 512 x (512 * world) mesh (own rows + ghost row)
-    from partition import StripPartition, global_dof_counts
-    n = args.n
-    # one GPU: coarsest mesh 32 cells across (1089-node dense solve, inverse computed on the device)
-    # partitioned: the distributed levels stop at 64 cells across; below that every rank runs the
-    # replicated global hierarchy (64 -> 8 cells across, dense solve at the bottom) without any
-    # halo exchange
-    part = StripPartition((0.0, 0.0), (1.0, float(world)), n, n * world, rank, world,
-                          coarsest=args.coarsest if args.coarsest else (_serial_coarsest(n) if world == 1 else 64),
-                          global_coarsest=None if world == 1 else 8)
-    dm = part.dofmap
-    device = local_rank
-    if os.environ.get("NSFEM_SHARE_GPU"):        # rehearsal of several ranks on a one-GPU box
-        device = 0
-    ctx = nat.NsfemContext(part.mesh.coords, part.mesh.cells, dm.p2_dofmap, dm.p1_dofmap,
-                           dm.n_p2, dm.n_p1, device)
-    if dist is not None:
-        ids = [nat.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.attach_rccl_comm(ids[0], rank, world)
-    mg_levels = None
-    if not args.no_multigrid:
-        mg_levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
-    else:
-        n2g, n1g = global_dof_counts(n, n * world)
-        ctx.set_partition(rank, world, part.p2_ghost, part.p1_ghost, part.p2_halo, part.p1_halo,
-                          n2g, n1g)
-    ctx.set_coeffs(1.0, 1.0, 1.0 / 100.0)
-    ctx.set_dirichlet(nat.VELOCITY, *cavity_dirichlet(dm, float(world)))
-    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
-    n2g, n1g = global_dof_counts(n, n * world)
-    n_dofs = 2 * n2g + n1g
-
-    _apply_truncation(ctx, args)
-    opts = ctx.default_step_opts()
-    for o in (opts.momentum, opts.poisson, opts.correction):
-        o.rtol = args.krylov_rtol
-    if mg_levels is not None:
-        opts.momentum.precond = opts.poisson.precond = 1
-    opts.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
-    opts.newton_forcing = args.newton_forcing
-    opts.matrix_free = args.matrix_free
-
-    def one_step(i):
-        ctx.set_bdf((1.0, -1.0, 0.0) if i == 0 else (1.5, -2.0, 0.5), args.dt)
-        info = ctx.step_ipcs(opts)
-        ctx.advance(0)
-        return info
-
-    for i in range(args.warmup):
-        one_step(i)
-    ctx.synchronize()
-    if dist is not None:
-        dist.barrier()
-    ctx.comm_stats(reset=True)
-    t0 = time.perf_counter()
-    newton = kry = poi = 0
-    for i in range(args.warmup, args.warmup + args.steps):
-        info = one_step(i)
-        newton += info.newton_iterations
-        kry += info.krylov_iterations_momentum
-        poi += info.krylov_iterations_poisson
-    ctx.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    comm_per_step = {k: v / args.steps for k, v in ctx.comm_stats().items()}
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-
-    steps_per_s = args.steps / elapsed
-    # the same steps with direct-solver accuracy in every linear solve (rtol 1e-12 of SURVEY 8d's
-    # parity runs, exact Newton): reported beside the headline, never as `value`
-    for o in (opts.momentum, opts.poisson, opts.correction):
-        o.rtol = 1.0e-12
-    opts.newton_forcing = 0.0
-    n_par = max(2, min(5, args.steps))
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup + args.steps, args.warmup + args.steps + n_par):
-        one_step(i)
-    ctx.synchronize()
-    ms_parity = 1e3 * (time.perf_counter() - t0) / n_par
-    # dominant kernel of the timed steps: the Chebyshev-Jacobi smoothing step of the velocity
-    # multigrid on its finest level (scalar P2 operator applied to both components, fused
-    # epilogue).  Its launches are timed IN SITU on the context's stream -- one HIP-event pair around
-    # every run of consecutive launches inside a smoothing sequence (a pair per launch would add
-    # ~4 us of event overhead to each 40 us kernel) -- over 5 further steps with the throughput settings (the event pairs stay out of the
-    # timed region above).  Back-to-back repetitions of the same launch would be flattered by the
-    # 256 MB Infinity Cache holding the 145 MB operator.
-    if mg_levels is not None:
-        for o in (opts.momentum, opts.poisson, opts.correction):
-            o.rtol = args.krylov_rtol
-        opts.newton_forcing = args.newton_forcing
-        ctx.profile_smoother(True)
-        for i in range(args.warmup + args.steps + n_par, args.warmup + args.steps + n_par + 5):
-            one_step(i)
-        ms_spmv, n_launches, nbytes = ctx.profile_smoother(False)
-    else:
-        ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
-        n_launches = 200
-    achieved = nbytes / (ms_spmv * 1e-3) / 1e9
-    ms_jac, nbytes_jac = ctx.time_spmv(nat.OP_MOMENTUM_JAC, 200)
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_fetch_write_size.json")
-    if world == 1 and n == 512 and mg_levels is not None and os.path.exists(pmc):
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload:
-        # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE;
-        # the symbol is launched on every multigrid level, the finest-level launches are the maxima
-        c = json.load(open(pmc))
-        key = "void nsfem::k_spmv_stream<1, 1, 2, 3>"
-        if key in c["fetch"] and key in c["write"]:
-            traffic = (2.0 * c["fetch"][key]["max_KB"] + c["write"][key]["max_KB"]) * 1024.0
-    out = {
-        "metric": "dof_updates_per_sec", "value": steps_per_s * n_dofs, "unit": "DoF-updates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "time_steps_per_sec": steps_per_s,
-        "config": {"workload": "2D lid-driven cavity Re=100, %dx%d right-diagonal Taylor-Hood P2/P1 "
-                               "(%d dofs), IPCS, BDF-2, dt=%g, zero initial state" % (
-                                   n, n * world, n_dofs, args.dt),
-                   "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
-                   "newton_forcing": args.newton_forcing,
-                   "velocity_jacobian": {0: "matrix-free (default)", 1: "assembled block CSR",
-                                         2: "matrix-free"}[args.matrix_free],
-                   "ms_per_step_with_krylov_rtol_1e-12_exact_newton": ms_parity,
-                   "preconditioner": "jacobi" if mg_levels is None else
-                   "geometric multigrid, Chebyshev-Jacobi smoothing: V(0,3) momentum, V(2,2) Poisson; %d coarse P1 levels" % mg_levels,
-                   "parallelism": "1 GPU" if world == 1 else
-                   "%d strips of %d cell rows, RCCL halo exchange (%s mode) + all-reduce" % (world, n, args.halo_mode),
-                   "newton_its_per_step": newton / args.steps,
-                   "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
-                   "comm_per_step_rank0": comm_per_step},
-        "roofline": {"bound": "hbm",
-                     "kernel": "k_spmv_stream<1,1,2,3>, finest multigrid level: Chebyshev-Jacobi smoothing step "
-                               "y = x + c1 d + c2 dinv (b - L x) on the scalar P2 operator L (12.07 M nnz), "
-                               "both velocity components" if mg_levels is not None else
-                               "k_spmv_stream<2,2,1,0> (momentum Jacobian)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv,
-                     "launches_timed": n_launches,
-                     "timing": "HIP-event pairs around the runs of consecutive finest-level launches (one pair per smoothing sequence) during 5 solver steps"},
-        "jacobian_spmv": {"kernel": "k_spmv_stream<2,2,1,0> (assembled momentum Jacobian, 2x2 block CSR; "
-                                    "used by the explicit assembly seam / matrix_free=1)",
-                          "achieved": nbytes_jac / (ms_jac * 1e-3) / 1e9, "unit": "GB/s",
-                          "frac": nbytes_jac / (ms_jac * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "algorithmic_bytes_per_launch": nbytes_jac, "ms_per_launch": ms_jac},
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.dt, 6)
-    if rank == 0:
-        print(json.dumps(out))
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if args.workload == "channel3d-bdf":
+        args.n = args.n or 32
+        return channel3d_bdf_bench(args)
+    args.n = args.n or (960 if args.scaling == "strong" else 512)
+    return cavity_ipcs_bench(args)
 
 
 if __name__ == "__main__":

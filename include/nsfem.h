@@ -88,8 +88,10 @@ enum nsfem_operator {
   NSFEM_OP_MOMENTUM_JAC = 7, /* IPCS/BDF velocity block of the Newton matrix  */
   NSFEM_OP_VISCOUS_EXTRA = 8, /* traction-form extra block (grad u^T : grad v) */
   NSFEM_OP_MOMENTUM_JAC_MF = 9, /* nsfem_operator_apply only: matrix-free velocity Jacobian */
-  NSFEM_OP_MOMENTUM_SMOOTHER = 10 /* nsfem_time_spmv only: finest-level Chebyshev step of the
+  NSFEM_OP_MOMENTUM_SMOOTHER = 10, /* nsfem_time_spmv only: finest-level Chebyshev step of the
                                      velocity multigrid (scalar P2 operator, fused epilogue) */
+  NSFEM_OP_CONVECTION_ACTION = 11 /* nsfem_time_spmv only: matrix-free convection action
+                                     (element kernel + node gather), cache-cold            */
 };
 
 enum nsfem_system {
@@ -272,6 +274,14 @@ int nsfem_mg_set_truncation(nsfem_ctx* ctx, double max_ratio, double coarse_tol)
  * preconditioner) -- about a third fewer halo exchanges per step, iteration counts may differ
  * slightly from the serial run.  Krylov operators, residuals and the mass solve stay exact. */
 int nsfem_mg_set_halo_mode(nsfem_ctx* ctx, int relaxed);
+/* partitioned meshes: enable != 0 runs the halo exchange of every Krylov operator application and
+ * smoothing step on the communicator's own HIP stream, concurrently with the row blocks of the
+ * product that reference no ghost column; the halo-adjacent row blocks follow after an event wait
+ * (SURVEY.md section 8e "overlapped with interior-row SpMV").  Results are bitwise those of the
+ * non-overlapped run.  Default: off. */
+int nsfem_set_overlap(nsfem_ctx* ctx, int enable);
+/* number of overlapped halo exchanges since the last reset */
+int nsfem_comm_overlapped(nsfem_ctx* ctx, int64_t* out, int reset);
 
 /* ---- multi-GPU: one process per GPU, each owning a strip of the mesh (new; the reference
  * is serial).  The context is created on the LOCAL mesh (own cell rows + one ghost row);
@@ -332,6 +342,18 @@ int nsfem_set_angular_velocity_3d(nsfem_ctx* ctx, const double omega[3], const d
  * projection of  2 |u| k / h_circumdiameter  (reference source/ns_problem.py:554-587) */
 int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, double* cfl);
 
+/* ---- boundary functionals of the solution: replaces dolfin.assemble(... * ds(subdomain_id)) in the
+ * reference's post-processing hooks (demo/dfg_benchmark.py:44-66: drag / lift from the traction
+ * -p n + 1/Re sym(grad u) n on the cylinder; demo/gravity_driven_flow.py:66-70: total mass flux).
+ * facet_cell[k] = cell adjacent to boundary facet k, facet_local[k] = local index of the vertex
+ * opposite to it in that cell (UFC local facet number).  out [dim + 2]:
+ *   out[0..dim-1] = int ( -p n + nu (grad u + sym grad u^T) n ) dS   (n = outward unit normal)
+ *   out[dim]      = int u . n dS ,   out[dim + 1] = int dS
+ * One thread per facet, exact facet quadrature, per-facet values summed in facet order. */
+int nsfem_boundary_force(nsfem_ctx* ctx, int velocity_slot, int pressure_slot, int32_t n_facets,
+                         const int32_t* facet_cell, const int32_t* facet_local, double nu,
+                         double sym, double* out);
+
 /* ---- measurement hooks (bench.py): time `reps` launches of the dominant SpMV
  * with HIP events on the context's stream; ms per launch returned ------------- */
 /* in-situ HIP-event timing of the finest-level smoothing launches of the velocity multigrid
@@ -342,6 +364,14 @@ int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* 
                            int64_t* algorithmic_bytes);
 int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                     int64_t* algorithmic_bytes);
+/* in-situ HIP-event timing of the matrix-free convection action of the velocity Jacobian inside
+ * the Newton-Krylov solves (element kernel k_conv_cell / k3_conv_cell + node gather = the
+ * per-iteration "assembly" of the fused step drivers; replaces the dolfin assemble(J) call of
+ * ns_ipcs_solver.py:136-147 / ns_bdf_solver.py:88-100): enable != 0 starts sampling, enable == 0
+ * stops and reports the average duration [ms] of one application, the number of applications and
+ * the algorithmic bytes of one application (SURVEY.md section 8d formula) */
+int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* applications,
+                             int64_t* algorithmic_bytes);
 /* extreme eigenvalues of diag(M_e)^-1 M_e of the P2 element mass matrix (host arithmetic only) */
 int nsfem_p2_mass_bounds(int dim, double* lmin, double* lmax);
 int nsfem_synchronize(nsfem_ctx* ctx);

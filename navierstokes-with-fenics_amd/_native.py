@@ -18,7 +18,8 @@ OK, ERR_ARG, ERR_HIP, ERR_BREAKDOWN, ERR_NOT_CONVERGED, ERR_COMM = 0, -1, -2, -3
 U0, U1, U2, USTAR, P, P_OLD, BODY_FORCE, TRACTION, P2_OLD = range(9)
 VELOCITY, PRESSURE, PRESSURE_PRECOND = 0, 1, 2
 (OP_MASS_P2, OP_STIFF_P2, OP_STIFF_P1, OP_MASS_P1, OP_DIV, OP_GRAD, OP_DIVT,
- OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA, OP_MOMENTUM_JAC_MF, OP_MOMENTUM_SMOOTHER) = range(11)
+ OP_MOMENTUM_JAC, OP_VISCOUS_EXTRA, OP_MOMENTUM_JAC_MF, OP_MOMENTUM_SMOOTHER,
+ OP_CONVECTION_ACTION) = range(12)
 SYS_MOMENTUM, SYS_POISSON, SYS_CORRECTION, SYS_MONOLITHIC = range(4)
 MAX_NEWTON = 64
 
@@ -32,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse", "nsfem_mg_set_global_coarse_constrained",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -164,8 +165,12 @@ def load_library(path=None):
         "nsfem_mg_set_truncation": (C.c_int, [vp, dbl, dbl]),
         "nsfem_comm_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.c_int]),
         "nsfem_mg_set_halo_mode": (C.c_int, [vp, C.c_int]),
+        "nsfem_set_overlap": (C.c_int, [vp, C.c_int]),
+        "nsfem_boundary_force": (C.c_int, [vp, C.c_int, C.c_int, i32, pi, pi, dbl, dbl, pd]),
+        "nsfem_comm_overlapped": (C.c_int, [vp, C.POINTER(C.c_int64), C.c_int]),
         "nsfem_poisson_solve": (C.c_int, [vp, pd, i64, pi, pd, C.POINTER(KrylovOpts), C.POINTER(SolveInfo)]),
         "nsfem_profile_smoother": (C.c_int, [vp, C.c_int, pd, C.POINTER(i64), C.POINTER(i64)]),
+        "nsfem_profile_convection": (C.c_int, [vp, C.c_int, pd, C.POINTER(i64), C.POINTER(i64)]),
         "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),
         "nsfem_synchronize": (C.c_int, [vp]),
         "nsfem_mg_add_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
@@ -347,6 +352,15 @@ class NsfemContext:
         self._check(self._lib.nsfem_comm_stats(self._h, out, 1 if reset else 0))
         return dict(zip(("allreduce_calls", "allreduce_bytes", "exchanges", "exchange_bytes"), [int(v) for v in out]))
 
+    def set_overlap(self, enable):
+        """halo exchanges on the communicator's stream under the interior rows of the products"""
+        self._check(self._lib.nsfem_set_overlap(self._h, 1 if enable else 0))
+
+    def comm_overlapped(self, reset=False):
+        out = C.c_int64()
+        self._check(self._lib.nsfem_comm_overlapped(self._h, C.byref(out), 1 if reset else 0))
+        return int(out.value)
+
     def mg_set_halo_mode(self, relaxed):
         self._check(self._lib.nsfem_mg_set_halo_mode(self._h, 1 if relaxed else 0))
 
@@ -474,6 +488,13 @@ class NsfemContext:
         self._check(self._lib.nsfem_operator_export(self._h, op, _ip(rowptr), _ip(col), _dp(val)))
         return sp.csr_matrix((val, col, rowptr), shape=(nr.value, ncol.value))
 
+    def operator_nnz(self, op):
+        """block-nonzeros x block size of a device operator"""
+        nr, ncol, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.nsfem_operator_shape(self._h, op, C.byref(nr), C.byref(ncol),
+                                                   C.byref(nnz)))
+        return nnz.value
+
     def operator_apply(self, op, x):
         if op == OP_MOMENTUM_JAC_MF:                 # matrix-free Jacobian at u = USTAR
             x = np.ascontiguousarray(x, dtype=np.float64)
@@ -502,6 +523,19 @@ class NsfemContext:
             return
         self._check(self._lib.nsfem_set_angular_velocity(self._h, float(omega), float(omega_dot)))
 
+    def boundary_force(self, facet_cell, facet_local, nu, symmetric=1.0, velocity_slot=U0,
+                       pressure_slot=P):
+        """(force [dim], flux, measure) over the given boundary facets:
+        force = int (-p n + nu (grad u + symmetric grad u^T) n) dS, flux = int u.n dS"""
+        fc = np.ascontiguousarray(facet_cell, dtype=np.int32)
+        fl = np.ascontiguousarray(facet_local, dtype=np.int32)
+        assert fc.shape == fl.shape and fc.ndim == 1
+        out = np.zeros(self.dim + 2)
+        self._check(self._lib.nsfem_boundary_force(self._h, int(velocity_slot), int(pressure_slot),
+                                                   fc.size, _ip(fc), _ip(fl), float(nu),
+                                                   float(symmetric), _dp(out)))
+        return out[:self.dim].copy(), float(out[self.dim]), float(out[self.dim + 1])
+
     def cfl_number(self, slot, step_size):
         out = C.c_double()
         self._check(self._lib.nsfem_cfl_number(self._h, int(slot), float(step_size), C.byref(out)))
@@ -513,6 +547,14 @@ class NsfemContext:
         ms, n, nbytes = C.c_double(), C.c_int64(), C.c_int64()
         self._check(self._lib.nsfem_profile_smoother(self._h, 1 if enable else 0, C.byref(ms),
                                                      C.byref(n), C.byref(nbytes)))
+        return None if enable else (ms.value, n.value, nbytes.value)
+
+    def profile_convection(self, enable):
+        """start (True) / stop (False -> (avg ms per application, applications, algorithmic bytes))
+        the in-situ timing of the matrix-free convection action (element kernel + node gather)"""
+        ms, n, nbytes = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self._lib.nsfem_profile_convection(self._h, 1 if enable else 0, C.byref(ms),
+                                                       C.byref(n), C.byref(nbytes)))
         return None if enable else (ms.value, n.value, nbytes.value)
 
     def time_spmv(self, op, reps=50):

@@ -652,12 +652,22 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
 void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   const int64_t nv = nvel(c);
   const int dim = c->mesh.dim;
-  if (c->distributed()) c->comm->exchange(s, c->halo_p2, const_cast<double*>(x), dim);
-  launch_spmv(s, c->L, dim, x, y, nullptr, MASK_NONE);
+  // (partitioned: the halo exchange of x runs under the interior rows of the L product; the
+  // element kernel of the convection action below reads the ghost nodes and comes after it)
+  product_with_halo(c->distributed() ? c->comm : nullptr, &c->halo_p2, dim, s, x, c->L.pat,
+                    [&](int phase) { launch_spmv(s, c->L, dim, x, y, nullptr, MASK_NONE, 0, phase); });
   if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, nullptr);
   const double cc = cc_of(c);
-  if (cc != 0.0)
+  if (cc != 0.0) {
+    nsfem_ctx::Probe& pr = c->conv_probe;
+    const bool timed = pr.on && pr.n + 2 <= pr.ev.size();
+    if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
     launch_convection_action(s, c->mesh, c->state[vel_slot].p, x, cc, y, c->conv_form, c->picard);
+    if (timed) {
+      NSFEM_HIP(hipEventRecord(pr.ev[pr.n + 1], s));
+      pr.n += 2;
+    }
+  }
   const double g = coriolis_gamma(c);
   if (g != 0.0) coriolis_apply(c, g, x, y);
   launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, x, y);                 // identity rows
@@ -961,6 +971,7 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
     lv->h_ghost.assign(d->ghost, d->ghost + lv->n);
     lv->halo = to_halo(d->halo);
     lv->has_halo = true;
+    mark_interior_blocks(lv->pat, lv->h_ghost);
   }
   NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
@@ -1085,6 +1096,8 @@ extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d
     ctx->ghost_p.upload(gp, s);
   }
   ctx->halo_p2 = to_halo(d->p2_halo);
+  mark_interior_blocks(ctx->p22, ctx->h_ghost_p2);   // row blocks that can run under the halo exchange
+  mark_interior_blocks(ctx->p11, ctx->h_ghost_p1);
   ctx->mg_mv.lv.clear();            // rebuilt with the halo on the next Chebyshev mass solve
   ctx->halo_p1 = to_halo(d->p1_halo);
   ctx->n_p2_global = d->n_p2_global;
@@ -1106,6 +1119,7 @@ extern "C" int nsfem_comm_attach_local(nsfem_ctx* ctx, void* group, int rank) {
   ctx->comm = nullptr;
   ctx->comm = make_local_comm(group, rank);
   ctx->comm->periodic = ctx->partition_periodic;
+  ctx->comm->overlap = ctx->overlap;
   API_END(ctx)
 }
 
@@ -1117,6 +1131,7 @@ extern "C" int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int ran
   ctx->comm = nullptr;
   ctx->comm = make_rccl_comm(id128, rank, size);
   ctx->comm->periodic = ctx->partition_periodic;
+  ctx->comm->overlap = ctx->overlap;
   API_END(ctx)
 }
 
@@ -1290,6 +1305,27 @@ extern "C" int nsfem_comm_stats(nsfem_ctx* ctx, int64_t out[4], int reset) {
     out[2] = ctx->comm->n_exchange; out[3] = ctx->comm->bytes_exchange;
     if (reset) ctx->comm->n_allreduce = ctx->comm->bytes_allreduce = ctx->comm->n_exchange = ctx->comm->bytes_exchange = 0;
   }
+  API_END(ctx)
+}
+
+// number of halo exchanges since the last reset that ran on the communicator's stream under the
+// interior rows of the product consuming them (nsfem_set_overlap)
+extern "C" int nsfem_comm_overlapped(nsfem_ctx* ctx, int64_t* out, int reset) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out, "null argument");
+  *out = ctx->comm ? ctx->comm->n_overlapped : 0;
+  if (reset && ctx->comm) ctx->comm->n_overlapped = 0;
+  API_END(ctx)
+}
+
+// partitioned meshes: run the halo exchanges of the Krylov operators and of the smoothing steps on
+// the communicator's own stream, concurrently with the row blocks that reference no ghost column
+extern "C" int nsfem_set_overlap(nsfem_ctx* ctx, int enable) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  if (ctx->comm) ctx->comm->overlap = enable != 0;
+  ctx->overlap = enable != 0;
+  ctx->graph_epoch++;
   API_END(ctx)
 }
 
@@ -1741,6 +1777,40 @@ extern "C" int nsfem_cfl_number(nsfem_ctx* ctx, int slot, double step_size, doub
   API_END(ctx)
 }
 
+// Surface force, mass flux and measure of a set of boundary facets (csrc/boundary.hip): one thread
+// per facet, per-facet values summed here in facet order.
+extern "C" int nsfem_boundary_force(nsfem_ctx* ctx, int velocity_slot, int pressure_slot,
+                                    int32_t n_facets, const int32_t* facet_cell,
+                                    const int32_t* facet_local, double nu, double sym, double* out) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out && (n_facets == 0 || (facet_cell && facet_local)), "null argument");
+  NSFEM_REQUIRE(velocity_slot >= 0 && velocity_slot < NSFEM_N_SLOTS && slot_size(ctx, velocity_slot) == nvel(ctx),
+                "not a velocity slot");
+  NSFEM_REQUIRE(pressure_slot >= 0 && pressure_slot < NSFEM_N_SLOTS && slot_size(ctx, pressure_slot) == npre(ctx),
+                "not a pressure slot");
+  const int dim = ctx->mesh.dim, w = dim + 2;
+  for (int k = 0; k < w; ++k) out[k] = 0.0;
+  if (n_facets == 0) return NSFEM_OK;
+  for (int32_t f = 0; f < n_facets; ++f) {
+    NSFEM_REQUIRE(facet_cell[f] >= 0 && facet_cell[f] < ctx->mesh.n_cells, "facet cell out of range");
+    NSFEM_REQUIRE(facet_local[f] >= 0 && facet_local[f] <= dim, "local facet index out of range");
+  }
+  hipStream_t s = ctx->stream;
+  DevBuf<int32_t> dc, dl;
+  DevBuf<double> dout;
+  dc.upload(facet_cell, (size_t)n_facets, s);
+  dl.upload(facet_local, (size_t)n_facets, s);
+  dout.alloc((size_t)n_facets * w);
+  launch_boundary_force(s, ctx->mesh, n_facets, dc.p, dl.p, ctx->state[velocity_slot].p,
+                        ctx->state[pressure_slot].p, nu, sym, dout.p);
+  std::vector<double> h((size_t)n_facets * w);
+  NSFEM_HIP(hipMemcpyAsync(h.data(), dout.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  for (int32_t f = 0; f < n_facets; ++f)
+    for (int k = 0; k < w; ++k) out[k] += h[(size_t)f * w + k];
+  API_END(ctx)
+}
+
 // ----------------------------------------------------------- operator access
 static const BlockMat* get_op(nsfem_ctx* c, int op, int* nv_apply) {
   *nv_apply = 1;
@@ -1873,10 +1943,86 @@ extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms
   API_END(ctx)
 }
 
+// Algorithmic bytes of one matrix-free convection action  y += c_c [d conv(u)/du] x  (SURVEY.md
+// section 8d, "assembly of a vector"): per cell the vertex coordinates, the P2 dof ids and the
+// nodal values of u and x gathered through them; the output vector read-modify-written once.
+static int64_t convection_action_bytes(const nsfem_ctx* c) {
+  const int64_t dim = c->mesh.dim, nl1 = dim + 1, nl2 = dim == 2 ? 6 : 10;
+  return (int64_t)c->mesh.n_cells * (nl1 * dim * 8 + nl2 * 4 + 2 * nl2 * dim * 8) +
+         (int64_t)c->mesh.n_p2 * dim * 16;
+}
+
+// In-situ timing of the matrix-free convection action inside the Newton-Krylov solves (one HIP-event
+// pair around every k_conv_cell<FORM,LIN> + k_res_gather pair on the context's stream).
+extern "C" int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_ms,
+                                        int64_t* applications, int64_t* algorithmic_bytes) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null context");
+  nsfem_ctx::Probe& pr = ctx->conv_probe;
+  if (enable) {
+    if (pr.ev.empty()) {
+      pr.ev.resize(4096);
+      for (hipEvent_t& e : pr.ev) NSFEM_HIP(hipEventCreate(&e));
+    }
+    pr.n = 0;
+    pr.on = true;
+    return NSFEM_OK;
+  }
+  pr.on = false;
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < pr.n; i += 2) {
+    float t = 0.f;
+    NSFEM_HIP(hipEventElapsedTime(&t, pr.ev[i], pr.ev[i + 1]));
+    total += t;
+  }
+  const int64_t n = (int64_t)(pr.n / 2);
+  if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
+  if (applications) *applications = n;
+  if (algorithmic_bytes) *algorithmic_bytes = convection_action_bytes(ctx);
+  API_END(ctx)
+}
+
 extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                                int64_t* algorithmic_bytes) {
   API_BEGIN
   NSFEM_REQUIRE(ctx && reps > 0 && ms_per_launch, "bad argument");
+  if (op == NSFEM_OP_CONVECTION_ACTION) {
+    // matrix-free convection action at u = U1 in the direction x = U0, each repetition preceded by
+    // a cache-flushing product with the block Jacobian array (timed separately and subtracted)
+    hipStream_t s = ctx->stream;
+    const double cc = cc_of(ctx) != 0.0 ? cc_of(ctx) : 1.0;
+    DevBuf<double> fx, fy, y;
+    fx.alloc((size_t)nvel(ctx));
+    fy.alloc((size_t)nvel(ctx));
+    y.alloc((size_t)nvel(ctx));
+    fx.zero(s);
+    y.zero(s);
+    auto flush = [&] { launch_spmv(s, ctx->J, 1, fx.p, fy.p, nullptr, MASK_NONE); };
+    auto step = [&] {
+      launch_convection_action(s, ctx->mesh, ctx->state[NSFEM_U1].p, ctx->state[NSFEM_U0].p, cc, y.p,
+                               ctx->conv_form, false);
+    };
+    hipEvent_t e0, e1;
+    NSFEM_HIP(hipEventCreate(&e0));
+    NSFEM_HIP(hipEventCreate(&e1));
+    auto timed = [&](bool with_step) {
+      for (int i = 0; i < 3; ++i) { flush(); if (with_step) step(); }
+      NSFEM_HIP(hipEventRecord(e0, s));
+      for (int i = 0; i < reps; ++i) { flush(); if (with_step) step(); }
+      NSFEM_HIP(hipEventRecord(e1, s));
+      NSFEM_HIP(hipEventSynchronize(e1));
+      float t = 0.f;
+      NSFEM_HIP(hipEventElapsedTime(&t, e0, e1));
+      return (double)t;
+    };
+    const double t_both = timed(true), t_flush = timed(false);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (t_both - t_flush) / reps;
+    if (algorithmic_bytes) *algorithmic_bytes = convection_action_bytes(ctx);
+    return NSFEM_OK;
+  }
   if (op == NSFEM_OP_MOMENTUM_SMOOTHER) {
     // one Chebyshev-Jacobi smoothing step of the velocity multigrid on its finest level: the
     // scalar P2 operator L applied to the interleaved components with the fused epilogue

@@ -44,6 +44,8 @@ struct SpmvArgs {
   int nt;          // stream matrix values / column ids with non-temporal loads
   int ghost;       // rows flagged 2 (ghosts of a partitioned mesh): 0 output 0, 1 carry x
                    // (smoother step with frozen ghost values), 2 computed like free rows
+  int skip0, skipn; // stream kernel: logical row blocks >= skip0 are shifted by skipn
+  int phase;       // 0 all row blocks, 1 interior blocks only, 2 halo-adjacent blocks only
 };
 
 template <int BR, int BC, int NV, int G, int EPI>
@@ -157,8 +159,9 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
   constexpr int NO = BR * NV;
   __shared__ double prod[kStreamNnz * NO];
   const int per = gridDim.x >> 3;
-  const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (lb >= n_rblk) return;
+  if (lb >= a.skip0) lb += a.skipn;     // halo-adjacent launch: jump over the interior row blocks
   const int r0 = rblk[lb], r1 = rblk[lb + 1];
   const int s0 = rowptr[r0], s1 = rowptr[r1];
   const double* __restrict__ x = a.x;
@@ -295,10 +298,30 @@ void build_rowblocks(Pattern& p, hipStream_t s) {
   blk.push_back(p.n_rows);
   p.n_rblk = (int)blk.size() - 1;
   p.rblk.upload(blk, s);
+  p.h_rblk.swap(blk);
+  p.int_b0 = p.int_b1 = 0;
+}
+
+void mark_interior_blocks(Pattern& p, const std::vector<uint8_t>& ghost_cols) {
+  p.int_b0 = p.int_b1 = 0;
+  if (p.n_rblk == 0 || (int)ghost_cols.size() != p.n_cols) return;
+  int best0 = 0, best1 = 0, run0 = 0;
+  for (int b = 0; b <= p.n_rblk; ++b) {
+    bool dirty = b == p.n_rblk;
+    if (!dirty)
+      for (int k = p.h_rowptr[p.h_rblk[b]]; k < p.h_rowptr[p.h_rblk[b + 1]] && !dirty; ++k)
+        dirty = ghost_cols[p.h_col[k]] != 0;
+    if (dirty) {
+      if (b - run0 > best1 - best0) { best0 = run0; best1 = b; }
+      run0 = b + 1;
+    }
+  }
+  p.int_b0 = best0;
+  p.int_b1 = best1;
 }
 
 template <int EPI>
-static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvArgs& a) {
+static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvArgs& a_in) {
   const Pattern& p = *A.pat;
   static const int use_stream = [] {
     const char* e = std::getenv("NSFEM_SPMV_STREAM");
@@ -311,10 +334,26 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
   const bool stream = p.n_rblk > 0 &&
                       (use_stream == 1 || (use_stream == -1 && kStreamDefault(shape22) && long_rows));
   if (stream) {
-    const int grid = (p.n_rblk + 7) & ~7;
+    // interior / halo-adjacent split of a partitioned product (see product_with_halo)
+    SpmvArgs a = a_in;
+    int nb = p.n_rblk;
+    const int32_t* rb = p.rblk.p;
+    a.skip0 = nb;
+    a.skipn = 0;
+    if (a.phase == 1) {
+      nb = p.int_b1 - p.int_b0;
+      rb += p.int_b0;
+      a.skip0 = nb;
+    } else if (a.phase == 2) {
+      nb = p.n_rblk - (p.int_b1 - p.int_b0);
+      a.skip0 = p.int_b0;
+      a.skipn = p.int_b1 - p.int_b0;
+    }
+    if (nb <= 0) return;
+    const int grid = (nb + 7) & ~7;
 #define NSFEM_STREAM(BR, BC, NV)                                                              \
-  hipLaunchKernelGGL((k_spmv_stream<BR, BC, NV, EPI>), dim3(grid), dim3(256), 0, s, p.n_rblk, \
-                     p.rblk.p, p.rowptr.p, p.col.p, A.vals.p, a)
+  hipLaunchKernelGGL((k_spmv_stream<BR, BC, NV, EPI>), dim3(grid), dim3(256), 0, s, nb,        \
+                     rb, p.rowptr.p, p.col.p, A.vals.p, a)
     if (A.br == 2 && A.bc == 2 && nv == 1) NSFEM_STREAM(2, 2, 1);
     else if (A.br == 1 && A.bc == 1 && nv == 2) NSFEM_STREAM(1, 1, 2);
     else if (A.br == 1 && A.bc == 1 && nv == 1) NSFEM_STREAM(1, 1, 1);
@@ -329,6 +368,10 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     NSFEM_HIP(hipGetLastError());
     return;
   }
+  // (the lane-group kernel has no row-block split: the interior phase is empty, the halo-adjacent
+  // phase computes every row)
+  if (a_in.phase == 1) return;
+  const SpmvArgs& a = a_in;
   // lanes per block row: 4 for short rows (P1 7-point, P2 x P1), 8 otherwise; the
   // NSFEM_SPMV_G environment variable overrides it (tuning experiments only)
   static const int forced = [] {
@@ -390,13 +433,17 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
   }();
   a.nt = nt;
   a.ghost = 0;
+  a.skip0 = 0x7fffffff;
+  a.skipn = 0;
+  a.phase = 0;
   return a;
 }
 
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                 const uint8_t* rowmask, int maskmode, int ghost) {
+                 const uint8_t* rowmask, int maskmode, int ghost, int phase) {
   SpmvArgs a = make_args(x, nullptr, y, rowmask, maskmode);
   a.ghost = ghost;
+  a.phase = phase;
   spmv_dispatch<EPI_STORE>(s, A, nv, a);
 }
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
@@ -423,10 +470,11 @@ void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, co
 }
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
-                      const uint8_t* rowmask, int ghost) {
+                      const uint8_t* rowmask, int ghost, int phase) {
   SpmvArgs a = make_args(x, b, xout, rowmask, MASK_ZERO);
   a.dinv = dinv; a.d = d; a.c1 = c1; a.c2 = c2;
   a.ghost = ghost;
+  a.phase = phase;
   spmv_dispatch<EPI_CHEB>(s, A, nv, a);
 }
 
@@ -904,10 +952,6 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __rest
 static inline void reduce_slots(const LinOp& op, hipStream_t s, double* parts, int slot, int nslots) {
   if (op.comm) op.comm->allreduce_sum(s, parts + (size_t)slot * kParts, (int64_t)nslots * kParts);
 }
-// fill the ghost entries of an SpMV input from their owners
-static inline void fill_ghosts(const LinOp& op, hipStream_t s, const double* v) {
-  if (op.comm && op.halo) op.comm->exchange(s, *op.halo, const_cast<double*>(v), op.halo_width);
-}
 
 int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
              const nsfem_krylov_opts& o, nsfem_solve_info& info) {
@@ -920,8 +964,9 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     if (op.custom) {
       op.custom->apply(s, in, out);          // custom operators exchange their own inputs
     } else {
-      fill_ghosts(op, s, in);
-      launch_spmv(s, *op.A, op.nv, in, out, op.rowmask, op.maskmode);
+      product_with_halo(op.comm, op.halo, op.halo_width, s, in, op.A->pat, [&](int phase) {
+        launch_spmv(s, *op.A, op.nv, in, out, op.rowmask, op.maskmode, 0, phase);
+      });
     }
   };
   if (op.custom) {
@@ -1121,8 +1166,9 @@ static int pcg_single_reduction(hipStream_t s, KrylovWork& w, const LinOp& op, c
   const int slot = P_RZ0;                       // gamma, delta, |r|^2 in slots 6, 7, 8 ; |b|^2 in 9
   auto precond_and_dots = [&] {
     op.prec->apply(s, w.r.p, w.z.p);                                    // u
-    fill_ghosts(op, s, w.z.p);
-    launch_spmv(s, *op.A, op.nv, w.z.p, w.q.p, op.rowmask, op.maskmode);   // w = A u
+    product_with_halo(op.comm, op.halo, op.halo_width, s, w.z.p, op.A->pat, [&](int phase) {
+      launch_spmv(s, *op.A, op.nv, w.z.p, w.q.p, op.rowmask, op.maskmode, 0, phase);   // w = A u
+    });
     LAUNCH(k_cgcg_dots, kParts, s, n, w.r.p, w.z.p, w.q.p, parts, slot);
   };
   launch_residual(s, *op.A, op.nv, x, rhs, w.r.p, op.rowmask, op.maskmode);
@@ -1199,8 +1245,9 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   const int check = o.check_every > 0 ? o.check_every : 1;
   int it = 0;
   auto body = [&](int cur_, int nxt_) {
-    fill_ghosts(op, s, w.p.p);
-    launch_spmv(s, *op.A, op.nv, w.p.p, w.q.p, op.rowmask, op.maskmode);
+    product_with_halo(op.comm, op.halo, op.halo_width, s, w.p.p, op.A->pat, [&](int phase) {
+      launch_spmv(s, *op.A, op.nv, w.p.p, w.q.p, op.rowmask, op.maskmode, 0, phase);
+    });
     launch_dot(s, n, w.p.p, w.q.p, parts + P_PQ * kParts);
     reduce_slots(op, s, parts, P_PQ, 1);
     LAUNCH(k_cg_update, kParts, s, n, w.p.p, w.q.p, op.prec ? nullptr : op.dinv, x, w.r.p, w.z.p,

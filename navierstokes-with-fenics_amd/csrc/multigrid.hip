@@ -445,8 +445,7 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
                          L.d.p, out);
       NSFEM_HIP(hipGetLastError());
     } else {
-      if (!relaxed) halo_fill(s, L, cur);
-      else if (!filled && x_in != nullptr) halo_fill(s, L, cur);   // from zero: ghosts stay zero
+      const bool need_fill = !relaxed || (!filled && x_in != nullptr);   // from zero: ghosts stay zero
       filled = true;
       // in-situ timing: ONE event pair around the run of consecutive finest-level smoothing
       // launches of this call (a pair per launch adds ~4 us of event overhead to a 40 us kernel)
@@ -456,8 +455,11 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
         NSFEM_HIP(hipEventRecord(prof_ev[prof_n], s));
         prof_open = true;
       }
-      launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask,
-                       relaxed && k + 1 < steps ? 1 : 0);
+      const int gmode = relaxed && k + 1 < steps ? 1 : 0;
+      product_with_halo(need_fill && comm_active() && L.has_halo ? comm : nullptr, &L.halo, nv, s, cur,
+                        L.A->pat, [&](int phase) {
+        launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask, gmode, phase);
+      });
       if (prof_open) {
         ++prof_launches;
         if (comm_active() && L.has_halo) {

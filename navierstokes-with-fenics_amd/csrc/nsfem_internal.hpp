@@ -85,9 +85,15 @@ struct Pattern {
   DevBuf<int32_t> cptr, cidx;             // per slot: sources (cell * nr*nc + i * nc + j)
   DevBuf<int32_t> rblk;                   // row blocks of the CSR-stream SpMV (n_rblk + 1)
   int n_rblk = 0;
+  std::vector<int32_t> h_rblk;            // host copy (interior / halo-adjacent split)
+  // partitioned meshes: the row blocks [int_b0, int_b1) reference no ghost column -- they can run
+  // while the halo exchange of the input vector is still in flight (mark_interior_blocks)
+  int int_b0 = 0, int_b1 = 0;
   std::vector<int32_t> h_rowptr, h_col;   // kept for export
 };
 void build_rowblocks(Pattern& p, hipStream_t s);
+// longest run of row blocks none of whose columns is flagged in `ghost_cols` ([n_cols] flags)
+void mark_interior_blocks(Pattern& p, const std::vector<uint8_t>& ghost_cols);
 void build_inverse_index(int n_targets, int64_t n_sources,
                          const std::function<int32_t(int64_t)>& target_of,
                          std::vector<int32_t>& ptr, std::vector<int32_t>& idx);
@@ -129,8 +135,10 @@ enum MaskMode { MASK_NONE = 0, MASK_IDENTITY = 1, MASK_ZERO = 2 };
 // y = A x.  nv = number of interleaved right-hand sides the scalar blocks act on
 // (scalar P2 matrices applied to both velocity components use br=bc=1, nv=2).
 // ghost: treatment of rows flagged 2 (ghost rows of a partitioned mesh): 0 output 0, 2 computed
+// phase (partitioned meshes, halo exchange overlapped with the product): 0 all rows, 1 only the
+// row blocks that touch no ghost column (Pattern::int_b0..int_b1), 2 the remaining row blocks
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                 const uint8_t* rowmask, int maskmode, int ghost = 0);
+                 const uint8_t* rowmask, int maskmode, int ghost = 0, int phase = 0);
 // y = b - A x  (same arguments + b)
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
                      const double* b, double* y, const uint8_t* rowmask, int maskmode);
@@ -146,7 +154,7 @@ void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, co
                       double* y, const uint8_t* skipmask);
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
-                      const uint8_t* rowmask, int ghost = 0 /* 1: ghost rows keep x */);
+                      const uint8_t* rowmask, int ghost = 0 /* 1: ghost rows keep x */, int phase = 0);
 
 // element kernels
 struct MeshDev {
@@ -210,6 +218,10 @@ void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, 
                               double cc, double* y, int form, bool picard);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b, int form);
+// per-facet surface force / flux / measure (boundary.hip): out[nf][dim + 2]
+void launch_boundary_force(hipStream_t s, const MeshDev& m, int nf, const int32_t* fcell,
+                           const int32_t* flocal, const double* u, const double* p, double nu,
+                           double sym, double* out);
 // diag extraction: d[(i,a)] = 1 / A_ii[a][a]  (mask rows -> 1)
 void launch_inv_diag(hipStream_t s, const BlockMat& A, int nv, const uint8_t* rowmask,
                      double* dinv);
@@ -286,6 +298,33 @@ struct Comm {
   virtual void allreduce_max(hipStream_t s, double* dev, int64_t count) = 0;
   // fill the ghost ranges of `vec` (width entries per node) from the neighbouring ranks
   virtual void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) = 0;
+  // ---- overlap of the exchange with the interior rows of the product that consumes `vec`:
+  // exchange_begin orders the exchange after everything queued on `s` so far and runs it on the
+  // communicator's own stream; exchange_end makes `s` wait for its completion.  Between the two
+  // calls the caller launches (on `s`) only work that neither reads the ghost ranges nor writes
+  // the send ranges of `vec`.
+  bool overlap = false;
+  hipStream_t cs = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr;
+  int64_t n_overlapped = 0;
+  void exchange_begin(hipStream_t s, const HaloRange& h, double* vec, int width) {
+    if (!cs) {
+      NSFEM_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      NSFEM_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      NSFEM_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    }
+    NSFEM_HIP(hipEventRecord(ev_in, s));
+    NSFEM_HIP(hipStreamWaitEvent(cs, ev_in, 0));
+    exchange(cs, h, vec, width);
+    NSFEM_HIP(hipEventRecord(ev_done, cs));
+    ++n_overlapped;
+  }
+  void exchange_end(hipStream_t s) { NSFEM_HIP(hipStreamWaitEvent(s, ev_done, 0)); }
+  void release_streams() {
+    if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
+    if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
+    if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+  }
   // traffic counters (calls / payload bytes this rank sends), read through nsfem_comm_stats
   int64_t n_allreduce = 0, n_exchange = 0, bytes_allreduce = 0, bytes_exchange = 0;
   void count_allreduce(int64_t count) { ++n_allreduce; bytes_allreduce += 8 * count; }
@@ -295,6 +334,25 @@ struct Comm {
   }
 };
 void launch_zero_ghost(hipStream_t s, int64_t n, const uint8_t* mask, double* x);  // x[mask==2]=0
+
+// product with a halo-dependent input: exchange, then launch(0) -- or, when the communicator
+// overlaps and the pattern has interior row blocks, exchange on the communicator's stream under
+// launch(1) (interior blocks), then launch(2) (halo-adjacent blocks) after the event wait
+template <class F>
+inline void product_with_halo(Comm* comm, const HaloRange* halo, int width, hipStream_t s,
+                              const double* v, const Pattern* pat, F&& launch) {
+  if (!comm || !halo) { launch(0); return; }
+  double* vec = const_cast<double*>(v);
+  if (!comm->overlap || !pat || pat->n_rblk == 0 || pat->int_b1 <= pat->int_b0) {
+    comm->exchange(s, *halo, vec, width);
+    launch(0);
+    return;
+  }
+  comm->exchange_begin(s, *halo, vec, width);
+  launch(1);
+  comm->exchange_end(s);
+  launch(2);
+}
 
 // abstract operator (block systems): y = A x on vectors of length n
 struct Operator {
@@ -484,6 +542,7 @@ struct nsfem_ctx {
   double mg_trunc_tol = 0.1;
   int64_t glob_off = 0;
   bool partition_periodic = false;
+  bool overlap = false;                        // halo exchanges under the interior rows (nsfem_set_overlap)
   double area_global = 0.0;                    // measure of the whole (partitioned) domain, lazily all-reduced
   // NSFEM_FORCE_COMM=1 routes a single-rank run through the communicator as well (lets a
   // one-GPU box exercise the RCCL all-reduce calls)
@@ -526,6 +585,14 @@ struct nsfem_ctx {
   double prec_shift = 0.0;          // mass shift of the velocity / Schur preconditioners
   nsfem::BlockMat Lprec;            // (alpha0/k + shift) M + c_v K when shift != 0
   int hint_mom[4] = {0, 0, 0, 0}, hint_poi = 0, hint_cor = 0;   // Krylov iteration counts of the last step
+  // in-situ timing of the matrix-free convection action (k_conv_cell + k_res_gather): one HIP-event
+  // pair per application while enabled (nsfem_profile_convection; bench.py's assembly roofline)
+  struct Probe {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    size_t n = 0;
+    ~Probe() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+  } conv_probe;
   bool mf_active = false;           // the running step driver applies the Jacobian matrix-free
   struct MixedOp : nsfem::Operator {
     nsfem_ctx* c = nullptr;
@@ -536,6 +603,7 @@ struct nsfem_ctx {
     void apply(hipStream_t s, const double* r, double* z) override;
   } block_prec;
   ~nsfem_ctx() {
+    if (comm) comm->release_streams();
     for (P1Level* p : coarse) delete p;
     for (CsrOp* p : schur_ops) delete p;
     for (P1Level* p : global_tail) delete p;

@@ -132,6 +132,15 @@ class Mesh:
         n[flip] *= -1.0
         return n
 
+    def facet_cell_local(self, facet_ids):
+        """(adjacent cell, UFC local facet number = index of the opposite vertex) of the given
+        facets -- the arrays nsfem_boundary_force takes (include/nsfem.h)"""
+        facet_ids = np.asarray(facet_ids, dtype=np.int64)
+        cells = self.facet_cell[facet_ids].astype(np.int64)
+        local = np.argmax(self.cell_facets[cells] == facet_ids[:, None], axis=1)
+        assert np.all(self.cell_facets[cells, local] == facet_ids)
+        return cells.astype(np.int32), local.astype(np.int32)
+
     def hmin(self):
         e = self.coords[self.edges[:, 1]] - self.coords[self.edges[:, 0]]
         return float(np.sqrt((e * e).sum(axis=1)).min())

@@ -351,6 +351,58 @@ class Space:
         return b
 
 
+def boundary_functionals(space, facet_vertices, facet_cell, u, p, nu, sym):
+    """dolfin.assemble(f * ds(subdomain)) of the reference's post-processing hooks restated
+    (demo/dfg_benchmark.py:44-66, demo/gravity_driven_flow.py:66-70; FacetNormal = outward unit
+    normal):  (int (-p n + nu (grad u + sym grad u^T) n) dS [dim],  int u.n dS,  int dS)
+    over the facets given by their vertex ids ``facet_vertices`` [nf, dim] and adjacent cells.
+    Route deliberately different from the device kernel: Gauss points on the PHYSICAL facet
+    (4-point Gauss on edges, 3 x 3 collapsed Gauss on triangles), pulled back to the cell's
+    reference coordinates through J^-1; normal from the facet's own geometry, oriented away from
+    the cell centroid."""
+    dim = space.dim
+    fv = np.asarray(facet_vertices, dtype=np.int64)
+    fc = np.asarray(facet_cell, dtype=np.int64)
+    X = space.coords[fv]                                       # [nf, dim, dim]
+    if dim == 2:
+        t = X[:, 1] - X[:, 0]
+        meas = np.linalg.norm(t, axis=1)
+        nrm = np.stack([t[:, 1], -t[:, 0]], axis=1) / meas[:, None]
+        g, w = np.polynomial.legendre.leggauss(4)
+        lam = np.stack([0.5 * (1.0 - g), 0.5 * (1.0 + g)], axis=1)       # [q, 2]
+        wq = 0.5 * w
+    else:
+        cr = np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0])
+        meas = 0.5 * np.linalg.norm(cr, axis=1)
+        nrm = cr / np.linalg.norm(cr, axis=1)[:, None]
+        pts, wt = collapsed_gauss_rule(3, 2)
+        lam = np.concatenate([(1.0 - pts.sum(axis=1))[:, None], pts], axis=1)   # [q, 3]
+        wq = 2.0 * wt
+    xc = space.geo.x[fc]                                       # [nf, dim+1, dim]
+    centroid = xc.mean(axis=1)
+    flip = ((centroid - X.mean(axis=1)) * nrm).sum(axis=1) > 0.0
+    nrm[flip] *= -1.0
+    xq = np.einsum("qv,fvd->fqd", lam, X)                      # physical points [nf, q, dim]
+    Jinv = np.transpose(space.geo.JinvT[fc], (0, 2, 1))        # [nf, dim, dim]
+    ref = np.einsum("fab,fqb->fqa", Jinv, xq - xc[:, None, 0, :])
+    force = np.zeros(dim)
+    flux = 0.0
+    ue = u[space.vdof[fc]]                                     # [nf, n2loc, dim]
+    pe = p[space.p1[fc]]
+    for f in range(fv.shape[0]):
+        phi2, dphi2 = p2_basis(ref[f])
+        phi1, _ = p1_basis(ref[f])
+        g2 = np.einsum("ab,qnb->qna", space.geo.JinvT[fc[f]], dphi2)     # physical gradients
+        uq = phi2 @ ue[f]                                      # [q, dim]
+        G = np.einsum("qkb,ka->qab", g2, ue[f])                # d_b u_a
+        pq = phi1 @ pe[f]
+        n = nrm[f]
+        tr = -pq[:, None] * n[None, :] + nu * np.einsum("qab,b->qa", G + sym * np.transpose(G, (0, 2, 1)), n)
+        force += meas[f] * (wq @ tr)
+        flux += meas[f] * (wq @ (uq @ n))
+    return force, float(flux), float(meas.sum())
+
+
 # --------------------------------------------------------------------------
 # Dirichlet handling (dolfin DirichletBC.apply semantics, third party)
 # --------------------------------------------------------------------------

@@ -1,30 +1,26 @@
 """Scratch: periodic Taylor-Green vortex (2D / 3D) through the solver classes -- Krylov iteration
-counts per step with the periodic multigrid hierarchy."""
+counts per step with the periodic multigrid hierarchy.
+usage: gpu_periodic_tg.py DIM N STEPS [mg|twolevel] [bdf|ipcs] [DT]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "navierstokes-with-fenics_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 os.chdir("/tmp")
-import numpy as np
-import test_reference_style_solvers as T
+from problem_specs import build_problem
+from test_solver_classes_gpu import CASES
 dim, n, nsteps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-cls = T.TaylorGreenVortex if dim == 2 else T.TaylorGreenVortex3D
-prob = cls.__new__(cls)
-cls.__init__(prob)
-prob._n_points = n
-if hasattr(prob, "_n_max_steps"): prob._n_max_steps = nsteps
+scheme = sys.argv[5] if len(sys.argv) > 5 else "bdf"
+dt = float(sys.argv[6]) if len(sys.argv) > 6 else 0.1
+if dim == 2:
+    spec = CASES["taylor_green"](n=n, dt=dt, steps=nsteps, t1=max(1.0, dt * nsteps), scheme=scheme)
+else:
+    spec = CASES["taylor_green_3d"](n=n, dt=dt, steps=nsteps, scheme=scheme)
+prob = build_problem(spec)
 if len(sys.argv) > 4 and sys.argv[4] == "twolevel":      # the old behaviour: P2 -> P1 only
     orig = prob.setup_mesh
     def setup():
         orig()
         prob._mesh.structured = None
     prob.setup_mesh = setup
-if len(sys.argv) > 5 and sys.argv[5] == "ipcs":
-    prob.set_solver_class(T.IPCSSolver)
-if len(sys.argv) > 6:
-    prob._time_stepping_args = None
-    dt = float(sys.argv[6])
-    prob._start_time, prob._end_time = 0.0, dt * nsteps
-    prob._desired_start_time_step = dt
 t0 = time.time()
 prob.solve_problem()
 solver = prob._get_solver()

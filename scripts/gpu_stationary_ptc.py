@@ -8,19 +8,17 @@ os.chdir("/tmp")
 import numpy as np
 import dlfn_compat as dlfn
 dlfn.set_log_level(20)
-import test_reference_style_solvers as T
+from problem_specs import build_problem
+from test_solver_classes_gpu import CASES
 
 what, n, Re = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
 t0 = time.time()
 if what == "couette":
-    problem = T.RotatingCouetteFlow(n, (0.25, 1.0), Re=Re)
+    problem = build_problem(CASES["rotating_couette"](n=n, Re=Re))
 elif what == "step":
-    problem = T.BackwardFacingStepProblem()
+    problem = build_problem(CASES["backward_step"]())
 else:
-    class Cav(T.StationaryCavityProblem):
-        def set_equation_coefficients(self):
-            self._coefficient_handler = T.EquationCoefficientHandler(Re=Re)
-    problem = Cav(n)
+    problem = build_problem(CASES["stationary_cavity"](n=n, Re=Re))
 problem.solve_problem()
 solver = problem._get_solver()
 i = solver.newton_info

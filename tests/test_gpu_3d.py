@@ -380,3 +380,91 @@ def test_3d_rotating_frame_coriolis_and_euler_terms_match_oracle():
         else:
             assert rel(ctx.get_state(nat.U1), u_mf) < 1e-10
     ctx.close()
+
+
+def test_3d_boundary_force_and_flux_match_oracle(setup3):
+    """nsfem_boundary_force on tetrahedra (edge-midpoint rule on the boundary faces) against the
+    oracle's facet integral (3 x 3 collapsed Gauss on the physical face) for random nodal fields:
+    per marked side and over the whole boundary; Gauss' theorem against the divergence rows."""
+    mesh, dm, marks, ctx, s = setup3
+    rng = np.random.default_rng(17)
+    u, p = rng.standard_normal(dm.n_velocity), rng.standard_normal(dm.n_p1)
+    ctx.set_state(nat.U0, u)
+    ctx.set_state(nat.P, p)
+    sets = [marks.facets_with_id(m) for m in (1, 2, 6)] + [np.nonzero(mesh.facet_on_boundary)[0]]
+    for facets in sets:
+        fc, fl = mesh.facet_cell_local(facets)
+        for nu, sym in ((0.01, 1.0), (0.3, 0.0)):
+            force, flux, meas = ctx.boundary_force(fc, fl, nu, sym)
+            f_o, flux_o, meas_o = fo.boundary_functionals(s, mesh.facets[facets], mesh.facet_cell[facets],
+                                                          u, p, nu, sym)
+            assert np.abs(force - f_o).max() < 1e-12 * max(1.0, np.abs(f_o).max())
+            assert abs(flux - flux_o) < 1e-12 * max(1.0, abs(flux_o))
+            assert abs(meas - meas_o) < 1e-13 * meas_o
+    assert abs(meas - 2.0 * (1.0 * 0.8 + 1.0 * 0.6 + 0.8 * 0.6)) < 1e-12
+    assert abs(flux - ctx.operator_apply(nat.OP_DIV, u).sum()) < 1e-11
+
+
+def test_3d_channel_re1000_bdf2_open_outlet_matches_oracle():
+    """BASELINE configs[4] in small, at its Reynolds number: 2 : 1 : 1 channel, (8, 4, 4) cubes,
+    inlet 16 y (1 - y) z (1 - z), no-slip side walls, natural outflow, Re = 1000, fully implicit
+    BDF-2 on the mixed system (source/ns_bdf_solver.py:36-106) with the algebraic Schur Laplacian
+    of the open outlet -- against the LU oracle: same Newton counts, fields to 1e-8; then the
+    invariants bench.py --workload channel3d-bdf checks (mass balance from nsfem_boundary_force,
+    inflow flux -4/9)."""
+    from multigrid import attach_hierarchy, attach_schur_laplacian
+    n = 4
+    mesh, dm, marks = box3((2 * n, n, n), p1=(2.0, 1.0, 1.0))
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    inlet = np.unique(dm.facet_p2_nodes(marks.facets_with_id(1)))
+    walls = np.unique(np.concatenate([dm.facet_p2_nodes(marks.facets_with_id(m)).ravel() for m in (3, 4, 5, 6)]))
+    Xi = dm.p2_coords[inlet]
+    prof = 16.0 * Xi[:, 1] * (1.0 - Xi[:, 1]) * Xi[:, 2] * (1.0 - Xi[:, 2])
+    last = dict(zip((3 * inlet).tolist(), prof.tolist()))
+    for a in (1, 2):
+        last.update(zip((3 * inlet + a).tolist(), [0.0] * inlet.size))
+    for a in range(3):
+        last.update(zip((3 * walls + a).tolist(), [0.0] * walls.size))
+    d = np.array(sorted(last), dtype=np.int64)
+    vbc = (d, np.array([last[i] for i in d.tolist()]))
+    nu = 1.0e-3
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=nu, body_force_term=None)
+    ctx = context3(mesh, dm)
+    attach_hierarchy(ctx, mesh, coarsest=1)
+    ctx.set_coeffs(1.0, 1.0, nu)
+    ctx.set_dirichlet(nat.VELOCITY, *vbc)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+    assert attach_schur_laplacian(ctx, d) is False            # open outlet: non-singular
+    orc = fo.BDFOracle(s, coef)
+    opts = ctx.default_step_opts()
+    opts.momentum.rtol, opts.momentum.precond, opts.momentum.max_iter = 1e-13, 1, 500
+    k = 0.5 / n
+    for step in range(3):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, k)
+        info = ctx.step_bdf(opts)
+        orc.step(alpha, k, vbc)
+        assert info.converged and info.newton_iterations == orc.newton_its[step]
+        assert info.krylov_iterations_momentum <= 60 * info.newton_iterations
+        ctx.advance(1)
+        orc.advance()
+    nv = dm.n_velocity
+    assert rel(ctx.get_state(nat.U1), orc.sol[1][:nv]) < 1e-8
+    assert rel(ctx.get_state(nat.P_OLD), orc.sol[1][nv:]) < 1e-8
+    flux = {}
+    for m in range(1, 7):
+        fc, fl = mesh.facet_cell_local(marks.facets_with_id(m))
+        flux[m] = ctx.boundary_force(fc, fl, nu, 0.0, nat.U0, nat.P)[1]
+    # inflow = integral of the P2 interpolant of the (biquadratic) inlet profile: area / 3 x the
+    # edge-midpoint values of every inlet face; -4/9 up to O(h^4)
+    fin = marks.facets_with_id(1)
+    Xm = dm.p2_coords[dm.facet_p2_nodes(fin)[:, 3:]]
+    pm = 16.0 * Xm[..., 1] * (1.0 - Xm[..., 1]) * Xm[..., 2] * (1.0 - Xm[..., 2])
+    tri = mesh.coords[mesh.facets[fin].astype(np.int64)]
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    assert abs(flux[1] + (area / 3.0 * pm.sum(axis=1)).sum()) < 1e-13
+    assert abs(flux[1] + 4.0 / 9.0) < 1e-3
+    assert abs(sum(flux.values())) < 1e-9 and flux[2] > 0.4   # what enters leaves through x = 2
+    assert max(abs(flux[m]) for m in (3, 4, 5, 6)) < 1e-14
+    ctx.close()

@@ -693,3 +693,102 @@ def test_truncated_velocity_cycle_is_only_a_preconditioner_change():
     assert res[4.0][2] <= res[0.0][2] + 6
     with pytest.raises(nat.NativeError):
         context(mesh, dm).mg_set_truncation(-1.0, 0.1)
+
+
+# ------------------------------------------------ boundary functionals (drag / lift / flux)
+def _random_state(dm, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal(dm.n_velocity), rng.standard_normal(dm.n_p1)
+
+
+@pytest.mark.parametrize("nu,sym", [(0.5 / 100.0, 1.0), (0.013, 0.0)])
+def test_boundary_force_matches_oracle_on_the_dfg_cylinder(nu, sym):
+    """nsfem_boundary_force (one thread per facet, 2-point Gauss on the edge) against the oracle's
+    facet integral (4-point Gauss on the physical edge, pulled back through J^-1) on the curved
+    cylinder boundary of the small DFG channel mesh -- the drag / lift functional of the
+    reference's demo/dfg_benchmark.py:44-66 -- and on the whole boundary (mass flux of
+    demo/gravity_driven_flow.py:66-70); random nodal fields, so nothing cancels."""
+    import grid_generator as gg
+    mesh, marks = gg.dfg_channel(2, 1)
+    dm = TaylorHoodDofMapOf(mesh)
+    ctx = context(mesh, dm)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    u, p = _random_state(dm, 3)
+    ctx.set_state(nat.U0, u)
+    ctx.set_state(nat.P, p)
+    for facets in (marks.facets_with_id(gg.DFGBoundaryMarkers.cylinder.value),
+                   np.nonzero(mesh.facet_on_boundary)[0]):
+        fc, fl = mesh.facet_cell_local(facets)
+        force, flux, meas = ctx.boundary_force(fc, fl, nu, sym)
+        f_o, flux_o, meas_o = fo.boundary_functionals(s, mesh.facets[facets], mesh.facet_cell[facets], u, p, nu, sym)
+        assert np.abs(force - f_o).max() < 1e-12 * max(1.0, np.abs(f_o).max())
+        assert abs(flux - flux_o) < 1e-12 * max(1.0, abs(flux_o))
+        assert abs(meas - meas_o) < 1e-13 * meas_o
+    # Gauss' theorem on the discrete field: total boundary flux = sum of the divergence rows
+    # tested with the constant pressure function
+    assert abs(flux - ctx.operator_apply(nat.OP_DIV, u).sum()) < 1e-10
+    # the polygonal cylinder of this mesh has the perimeter of its chords
+    fcyl = marks.facets_with_id(gg.DFGBoundaryMarkers.cylinder.value)
+    fc, fl = mesh.facet_cell_local(fcyl)
+    _, _, perim = ctx.boundary_force(fc, fl, 0.0, 0.0)
+    assert 0.95 * np.pi < perim < np.pi
+    ctx.close()
+
+
+def TaylorHoodDofMapOf(mesh):
+    from fem_mesh import TaylorHoodDofMap
+    return TaylorHoodDofMap(mesh)
+
+
+def test_n512_production_solver_options_match_the_exact_solver_run():
+    """What bench.py times, at the size it times it (BASELINE configs[1], 2,364,419 dofs):
+    geometric multigrid (V(0,3) momentum / V(2,2) Poisson), truncated velocity cycle (4, 0.1),
+    Chebyshev mass solve, inexact Newton (forcing 1e-4), Krylov rtol 1e-8, iteration hints --
+    against the same mesh and steps with direct-solver accuracy (Krylov rtol 1e-12, exact Newton,
+    Jacobi-CG mass solve, untruncated cycle).  Fields must agree to north_star's nonlinear
+    tolerance 1e-6 (pressure modulo a constant: enclosed flow)."""
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(512, 512)
+    ctx = context(mesh, dm)
+    assert attach_hierarchy(ctx, mesh) == 4
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    bd, bv = cavity_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    n_steps, k = 6, 1.0e-3
+
+    def run(production):
+        for slot in (nat.U0, nat.U1, nat.U2, nat.USTAR):
+            ctx.set_state(slot, np.zeros(dm.n_velocity))
+        for slot in (nat.P, nat.P_OLD):
+            ctx.set_state(slot, np.zeros(dm.n_p1))
+        opts = ctx.default_step_opts()
+        opts.momentum.precond = opts.poisson.precond = 1
+        if production:
+            ctx.mg_set_truncation(4.0, 0.1)
+            for o in (opts.momentum, opts.poisson, opts.correction):
+                o.rtol = 1.0e-8
+            opts.correction.precond = 2
+            opts.newton_forcing = 1.0e-4
+        else:
+            ctx.mg_set_truncation(0.0, 0.1)
+        its = []
+        for step in range(n_steps):
+            ctx.set_bdf(fo.bdf_alpha(step, 1.0), k)
+            info = ctx.step_ipcs(opts)
+            assert info.converged
+            r = info.newton_residuals
+            assert r[info.newton_iterations] < max(1e-10, 1e-9 * r[0])      # the reference's criterion
+            its.append((info.newton_iterations, info.krylov_iterations_momentum,
+                        info.krylov_iterations_poisson, info.krylov_iterations_correction))
+            ctx.advance(0)
+        return ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), its
+
+    u_fast, p_fast, its_fast = run(True)
+    u_ref, p_ref, its_ref = run(False)
+    assert np.abs(u_fast[bd] - bv).max() == 0.0
+    assert rel(u_fast, u_ref) < 1e-6
+    assert rel(p_fast - p_fast.mean(), p_ref - p_ref.mean()) < 1e-6
+    # the production settings are the cheaper ones: fewer Krylov iterations in total
+    assert sum(i[1] for i in its_fast) < sum(i[1] for i in its_ref)
+    ctx.close()

@@ -53,18 +53,24 @@ def _run(ctx, dm, nsteps, k, use_mg, out, key, cheb=False):
     out[("comm", key)] = ctx.comm_stats()
 
 
-@pytest.mark.parametrize("n,size,use_mg,tail,cheb,relaxed", [
-    (16, 2, False, False, False, False), (32, 4, True, False, False, False),
-    (64, 2, True, False, False, False), (64, 2, True, True, False, False),
-    (32, 2, True, False, True, False), (64, 4, True, False, True, True), (64, 2, True, True, False, True)])
-def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, relaxed):
+@pytest.mark.parametrize("n,size,use_mg,tail,cheb,relaxed,overlap", [
+    (16, 2, False, False, False, False, False), (32, 4, True, False, False, False, False),
+    (64, 2, True, False, False, False, False), (64, 2, True, True, False, False, False),
+    (32, 2, True, False, True, False, False), (64, 4, True, False, True, True, False),
+    (64, 2, True, True, False, True, False),
+    (64, 2, False, False, False, False, True), (64, 2, True, False, True, False, True),
+    (64, 4, True, True, True, True, True)])
+def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, relaxed, overlap):
     """tail: the partitioned levels stop at 16 cells across and the rest of the hierarchy
     (16 -> 8 -> 4 -> 2) is the replicated global one -- still the serial algorithm.
     cheb: the velocity correction uses the dot-product-free Chebyshev mass solve.
     relaxed: nsfem_mg_set_halo_mode(1) -- frozen ghost values inside the smoothing sequences: a
     different (block-Jacobi across ranks) but equally good preconditioner, so the converged fields
     agree to solver tolerance, the iteration counts to within a few, and the number of halo
-    exchanges drops by about a third."""
+    exchanges drops by about a third.
+    overlap: nsfem_set_overlap(1) -- the halo exchanges of the Krylov operators and smoothing steps
+    run on the communicator's own stream under the row blocks that touch no ghost column, the
+    halo-adjacent row blocks follow after an event wait: same arithmetic, same results."""
     nsteps, k, coarsest = 3, 0.01, 2
     mesh, dm, _ = box(n, n)
     ref = {}
@@ -86,6 +92,7 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, rel
         c = nat.NsfemContext(part.mesh.coords, part.mesh.cells, pdm.p2_dofmap, pdm.p1_dofmap,
                              pdm.n_p2, pdm.n_p1)
         c.attach_local_comm(group, r)
+        c.set_overlap(overlap)
         ctxs.append(c)
     out, errors = {}, []
 
@@ -99,6 +106,7 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, rel
                 ctxs[r].set_partition(r, size, part.p2_ghost, part.p1_ghost, part.p2_halo,
                                       part.p1_halo, (2 * n + 1) ** 2, (n + 1) ** 2)
             _run(ctxs[r], part.dofmap, nsteps, k, use_mg, out, r, cheb)
+            out[("overlapped", r)] = ctxs[r].comm_overlapped()
         except BaseException as exc:                     # a dead rank would deadlock the others
             errors.append((r, repr(exc)))
             os._exit(17)
@@ -138,6 +146,13 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, rel
                for x in st)
     if size > 2:
         assert st[1]["exchange_bytes"] > st[0]["exchange_bytes"]
+    # overlapped exchanges: none unless enabled; when enabled, the bulk of them (every Krylov
+    # operator application and smoothing step of a level that has interior row blocks)
+    for r in range(size):
+        if overlap:
+            assert 0.3 * st[r]["exchanges"] < out[("overlapped", r)] <= st[r]["exchanges"]
+        else:
+            assert out[("overlapped", r)] == 0
     for c in ctxs:
         c.close()
     nat.local_group_destroy(group)

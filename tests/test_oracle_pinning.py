@@ -336,3 +336,44 @@ def test_cfl_number_closed_form_3d_and_keast_rule():
     assert np.abs(fo.circumdiameter(s.geo.x) - h).max() < 1e-14
     u = np.tile([2.0, -1.0, 2.0], dm.n_p2)
     assert abs(fo.cfl_number(s, u, 0.05) - 2.0 * 3.0 * 0.05 / h) < 1e-13
+
+
+def test_boundary_functionals_closed_forms():
+    """oracle restatement of assemble(f * ds) (demo/dfg_benchmark.py:44-66): polynomial fields
+    on the unit square / cube, checked against Gauss' theorem evaluated by hand --
+    int -p n = -int grad p,  int nu (grad u + grad u^T) n = nu int (lap u + grad div u),
+    int u.n = int div u; Poiseuille wall drag 6 nu L per unit height-1 channel wall."""
+    from fem_mesh import TaylorHoodDofMap
+    from grid_generator import hyper_cube, hyper_rectangle
+    for dim, n in ((2, 3), (3, 2)):
+        mesh, marks = hyper_cube(dim, n)
+        dm = TaylorHoodDofMap(mesh)
+        s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+        X, Y = dm.p2_coords, dm.p1_coords
+        if dim == 2:
+            u = np.stack([X[:, 0] ** 2 + X[:, 1], X[:, 0] * X[:, 1]], axis=1).ravel()
+            expect_force = np.array([-2.0, 1.0]) + 0.3 * np.array([5.0, 0.0])
+            expect_flux = 1.5
+        else:
+            u = np.stack([X[:, 0] ** 2 + X[:, 1], X[:, 0] * X[:, 2], X[:, 2] ** 2 - X[:, 1]], axis=1).ravel()
+            # lap u = (2, 0, 2), div u = 2x + 2z -> grad div = (2, 0, 2)
+            expect_force = np.array([-2.0, 1.0, 0.0]) + 0.3 * np.array([4.0, 0.0, 4.0])
+            expect_flux = 2.0
+        p = 1.0 + 2.0 * Y[:, 0] - Y[:, 1]
+        bf = np.nonzero(mesh.facet_on_boundary)[0]
+        force, flux, meas = fo.boundary_functionals(s, mesh.facets[bf], mesh.facet_cell[bf], u, p, 0.3, 1.0)
+        assert np.abs(force - expect_force).max() < 1e-13
+        assert abs(flux - expect_flux) < 1e-13 and abs(meas - 2.0 * dim) < 1e-13
+    # Poiseuille channel (tests/test_ipcs_solver.py:37-43 inputs): wall shear on the bottom wall
+    L, nu = 3.0, 0.1
+    mesh, marks = hyper_rectangle((0.0, 0.0), (L, 1.0), (6, 4))
+    dm = TaylorHoodDofMap(mesh)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    X, Y = dm.p2_coords, dm.p1_coords
+    u = np.stack([6.0 * X[:, 1] * (1.0 - X[:, 1]), 0.0 * X[:, 1]], axis=1).ravel()
+    p = 12.0 * nu * (L - Y[:, 0])
+    wall = marks.facets_with_id(3)                      # bottom, outward normal (0, -1)
+    force, flux, meas = fo.boundary_functionals(s, mesh.facets[wall], mesh.facet_cell[wall], u, p, nu, 1.0)
+    # traction on the fluid: -p n + nu (du_x/dy) n_y e_x = (-6 nu, p) -> integrated: (-6 nu L, 6 nu L^2)
+    assert abs(force[0] + 6.0 * nu * L) < 1e-13 and abs(force[1] - 6.0 * nu * L * L) < 1e-12
+    assert abs(flux) < 1e-14 and abs(meas - L) < 1e-14

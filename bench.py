@@ -247,7 +247,8 @@ def tgv3d_bench(args):
     if world == 1:
         mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
         domain = TriplePeriodic()
-        dm = TaylorHoodDofMap(mesh, periodic_map=periodic_entity_map(mesh, domain))
+        from fem_mesh import preferred_p2_order
+        dm = TaylorHoodDofMap(mesh, reorder=preferred_p2_order(3), periodic_map=periodic_entity_map(mesh, domain))
         ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
         levels = attach_hierarchy(ctx, mesh, args.mg_degree, args.mg_eig_ratio,
                                   periodic=(domain, dm.p1_vertex_node))
@@ -490,7 +491,8 @@ def channel3d_bdf_bench(args):
     n = args.n
     t_setup = time.perf_counter()
     mesh, marks = gg.hyper_rectangle((0.0, 0.0, 0.0), (2.0, 1.0, 1.0), (2 * n, n, n))
-    dm = TaylorHoodDofMap(mesh)
+    from fem_mesh import preferred_p2_order
+    dm = TaylorHoodDofMap(mesh, reorder=preferred_p2_order(3))
     ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
     levels = attach_hierarchy(ctx, mesh, args.mg_degree, args.mg_eig_ratio)
     M = gg.HyperRectangleBoundaryMarkers

@@ -158,7 +158,12 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
       build_inverse_index(m->n_p2, (int64_t)nc * nl2,
                           [&](int64_t src) { return m->p2_dofmap[src]; }, ptr, idx);
       fresh->mesh.nptr.upload(ptr, s);
-      fresh->mesh.nidx.upload(idx, s);
+      std::vector<int32_t> dst(idx.size());
+      for (size_t pos = 0; pos < idx.size(); ++pos) {
+        const int64_t src = idx[pos];
+        dst[(size_t)(src % nl2) * nc + (size_t)(src / nl2)] = (int32_t)pos;
+      }
+      fresh->mesh.ndst.upload(dst, s);
       fresh->mesh.ebuf.alloc((size_t)nc * nl2 * nl2 * dim * dim);
       fresh->mesh.rbuf.alloc((size_t)nc * nl2 * dim);
     }
@@ -187,6 +192,7 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   launch_assemble_p1_scalar(s, fresh->mesh, fresh->p11, fresh->Ap.vals.p, fresh->Mp.vals.p);
   launch_assemble_div_grad(s, fresh->mesh, fresh->p12, fresh->p21, fresh->Dv.vals.p,
                            fresh->Gr.vals.p, fresh->DT.vals.p);
+  for (BlockMat* A : {&fresh->M2, &fresh->K2, &fresh->Ap, &fresh->Mp}) A->sell_update(s);
   // ---- state + work vectors
   for (int i = 0; i < NSFEM_N_SLOTS; ++i) {
     fresh->state[i].alloc((size_t)slot_size(fresh, i));
@@ -432,6 +438,7 @@ static void ensure_L(nsfem_ctx* c) {
   // L = alpha0/k M + c_viscous K   (scalar P2; acts on all velocity components)
   const double a = c->alpha[0] / c->k, b = c->coef[2];
   launch_scale_combine(c->stream, c->p22.nnz, a, c->M2.vals.p, b, c->K2.vals.p, c->L.vals.p);
+  c->L.sell_update(c->stream);
   // preconditioner version: (alpha0/k + shift) M + c_viscous K -- the multigrid hierarchy of the
   // velocity block is built on it.  shift = 0 (all transient problems): the operator itself.
   // shift = 1/tau > 0 (stationary problems at high cell Peclet numbers): the V-cycle then
@@ -441,17 +448,24 @@ static void ensure_L(nsfem_ctx* c) {
   if (c->prec_shift != 0.0) {
     if (!c->Lprec.vals.p) c->Lprec.init(&c->p22, 1, 1, c->stream);
     launch_scale_combine(c->stream, c->p22.nnz, ap, c->M2.vals.p, b, c->K2.vals.p, c->Lprec.vals.p);
+    c->Lprec.sell_update(c->stream);
   }
   if (c->mg_built) {
     c->mg_v.lv[0].A = c->prec_shift != 0.0 ? &c->Lprec : &c->L;
     launch_scale_combine(c->stream, c->p11.nnz, ap, c->Mp.vals.p, b, c->Ap.vals.p, c->Lc0.vals.p);
-    for (nsfem_ctx::P1Level* lv : c->coarse)
+    c->Lc0.sell_update(c->stream);
+    for (nsfem_ctx::P1Level* lv : c->coarse) {
       launch_scale_combine(c->stream, lv->pat.nnz, ap, lv->M.vals.p, b, lv->K.vals.p, lv->Lc.vals.p);
+      lv->Lc.sell_update(c->stream);
+    }
     if (c->global_coarse) {
       nsfem_ctx::P1Level* g = c->global_coarse;
       launch_scale_combine(c->stream, g->pat.nnz, ap, g->M.vals.p, b, g->K.vals.p, g->Lc.vals.p);
-      for (nsfem_ctx::P1Level* t : c->global_tail)
+      g->Lc.sell_update(c->stream);
+      for (nsfem_ctx::P1Level* t : c->global_tail) {
         launch_scale_combine(c->stream, t->pat.nnz, ap, t->M.vals.p, b, t->K.vals.p, t->Lc.vals.p);
+        t->Lc.sell_update(c->stream);
+      }
     }
     select_velocity_cycle_depth(c, ap, b);
     c->mg_v_dirty = true;
@@ -514,9 +528,9 @@ static void mg_refresh(nsfem_ctx* c, bool momentum) {
 }
 
 void nsfem_ctx::MomentumPrec::apply(hipStream_t s, const double* r, double* z) {
+  // Newton rows of Dirichlet dofs are identity rows: the preconditioner must be too -- the last
+  // finest-level smoothing step of the cycle writes z = r on them (Multigrid::identity_rows)
   c->mg_v.apply(s, r, z);
-  // Newton rows of Dirichlet dofs are identity rows: the preconditioner must be too
-  launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, r, z);
 }
 
 constexpr int P10 = 10;      // partial-sum slots 10, 11 of the Krylov work space belong to the drivers
@@ -533,7 +547,8 @@ static double coriolis_gamma(const nsfem_ctx* c) {
   return 2.0 * c->coef[4] * (c->mesh.dim == 2 ? c->omega : 1.0);
 }
 // y += (2 c_cor Omega x u, w): the mass matrix applied to the rotated field
-static void coriolis_apply(nsfem_ctx* c, double g, const double* u, double* y) {
+static void coriolis_apply(nsfem_ctx* c, double g, const double* u, double* y,
+                           const uint8_t* skipmask = nullptr) {
   hipStream_t s = c->stream;
   if (!c->rot_tmp.p) c->rot_tmp.alloc((size_t)nvel(c));
   if (c->mesh.dim == 2) {
@@ -542,7 +557,7 @@ static void coriolis_apply(nsfem_ctx* c, double g, const double* u, double* y) {
     const double gv[3] = {g * c->omega3[0], g * c->omega3[1], g * c->omega3[2]};
     launch_cross3(s, c->mesh.n_p2, gv, u, c->rot_tmp.p);
   }
-  launch_spmv_axpy(s, c->M2, c->mesh.dim, 1.0, c->rot_tmp.p, y, nullptr);
+  launch_spmv_axpy(s, c->M2, c->mesh.dim, 1.0, c->rot_tmp.p, y, skipmask);
 }
 
 // time-step constant part of the momentum residual:
@@ -654,24 +669,26 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   const int dim = c->mesh.dim;
   // (partitioned: the halo exchange of x runs under the interior rows of the L product; the
   // element kernel of the convection action below reads the ghost nodes and comes after it)
+  // identity rows on the Dirichlet dofs and zero ghost rows come out of the L product itself
+  // (row mask, MASK_IDENTITY); every later contribution leaves the flagged rows untouched
+  (void)nv;
   product_with_halo(c->distributed() ? c->comm : nullptr, &c->halo_p2, dim, s, x, c->L.pat,
-                    [&](int phase) { launch_spmv(s, c->L, dim, x, y, nullptr, MASK_NONE, 0, phase); });
-  if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, nullptr);
+                    [&](int phase) { launch_spmv(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, 0, phase); });
+  if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, c->mask_v.p);
   const double cc = cc_of(c);
   if (cc != 0.0) {
     nsfem_ctx::Probe& pr = c->conv_probe;
     const bool timed = pr.on && pr.n + 2 <= pr.ev.size();
     if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
-    launch_convection_action(s, c->mesh, c->state[vel_slot].p, x, cc, y, c->conv_form, c->picard);
+    launch_convection_action(s, c->mesh, c->state[vel_slot].p, x, cc, y, c->conv_form, c->picard,
+                             c->mask_v.p);
     if (timed) {
       NSFEM_HIP(hipEventRecord(pr.ev[pr.n + 1], s));
       pr.n += 2;
     }
   }
   const double g = coriolis_gamma(c);
-  if (g != 0.0) coriolis_apply(c, g, x, y);
-  launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, x, y);                 // identity rows
-  if (c->ghost_v.p) launch_zero_ghost(s, nv, c->mask_v.p, y);        // ghost rows: owner computes
+  if (g != 0.0) coriolis_apply(c, g, x, y, c->mask_v.p);
 }
 
 // 0 = auto = matrix-free: inside the fused step drivers the velocity Jacobian is applied as
@@ -952,6 +969,8 @@ static void fill_p1_level(nsfem_ctx* ctx, nsfem_ctx::P1Level* lv, int n_vertices
   lv->M.init(&lv->pat, 1, 1, s);
   lv->Lc.init(&lv->pat, 1, 1, s);
   launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+  lv->K.sell_update(s);
+  lv->M.sell_update(s);
 }
 
 extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) {
@@ -1015,6 +1034,7 @@ extern "C" int nsfem_mg_set_schur_operator(nsfem_ctx* ctx, int level, int32_t n,
   op->mat.pat = &p;
   op->mat.br = op->mat.bc = 1;
   op->mat.vals.upload(val, (size_t)p.nnz, s);
+  op->mat.sell_update(s);
   NSFEM_HIP(hipStreamSynchronize(s));
   ctx->mg_s.lv[level].A = &op->mat;
   ctx->mg_s_dirty = true;
@@ -1242,6 +1262,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
     // cycle; measured 6 % faster steps than V(2,2) at equal iteration counts)
     mg.pre_degree = 0;
     mg.degree = degree + 1;
+    mg.identity_rows = true;     // z = r on Dirichlet rows, written by the last smoothing step
     if (const char* e = std::getenv("NSFEM_MGV_PRE")) mg.pre_degree = std::atoi(e);
     if (const char* e = std::getenv("NSFEM_MGV_POST")) mg.degree = std::atoi(e);
     mg.lv.clear();
@@ -1498,8 +1519,7 @@ void nsfem_ctx::BlockPrec::apply(hipStream_t s, const double* r, double* z) {
   NSFEM_HIP(hipMemcpyAsync(c->tmp_v.p, r, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
   launch_spmv_axpy(s, c->DT, 1, cp, zp, c->tmp_v.p, c->mask_v.p);
   if (c->ghost_p.p) launch_zero_ghost(s, np, c->mask_p.p, zp);      // keep ghost entries out of the dots
-  c->mg_v.apply(s, c->tmp_v.p, z);
-  launch_copy_at(s, c->nbc_v, c->bc_v_dofs.p, c->tmp_v.p, z);
+  c->mg_v.apply(s, c->tmp_v.p, z);        // (identity rows on the Dirichlet dofs: Multigrid::identity_rows)
 }
 
 // F_u = L u + g + c_c conv(u) - c_p D^T p ; F_p = -c_p D u ; Dirichlet rows x_i - g_i

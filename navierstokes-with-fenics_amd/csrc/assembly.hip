@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256) void k_conv_cell(int nc, const double* __restr
                                                    const int32_t* __restrict__ p2,
                                                    const double* __restrict__ u,
                                                    const double* __restrict__ v, double cc,
+                                                   const int32_t* __restrict__ ndst,
                                                    double* __restrict__ rbuf) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
@@ -562,36 +563,44 @@ __global__ __launch_bounds__(256) void k_conv_cell(int nc, const double* __restr
       }
     }
   }
-  double2* out = reinterpret_cast<double2*>(rbuf) + (size_t)c * 6;
+  // node-sorted element buffer: entry (c, i) lands inside the contiguous run of its node
+  double2* out = reinterpret_cast<double2*>(rbuf);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) out[i] = make_double2(rx[i], ry[i]);
+  for (int i = 0; i < 6; ++i) out[ndst[(size_t)i * nc + c]] = make_double2(rx[i], ry[i]);
 }
 
-// b[(node, a)] += sum of the element vectors of the cells around the node (fixed order)
+// b[(node, a)] += sum of the element vectors of the cells around the node: the contiguous run
+// nptr[n] .. nptr[n + 1] of the node-sorted buffer, summed in ascending (cell) order
 __global__ __launch_bounds__(256) void k_res_gather(int n_nodes, const int32_t* __restrict__ nptr,
-                                                    const int32_t* __restrict__ nidx,
                                                     const double* __restrict__ rbuf,
+                                                    const uint8_t* __restrict__ skip,
                                                     double* __restrict__ b) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= n_nodes) return;
+  bool sx = false, sy = false;          // flagged entries (Dirichlet / ghost rows) stay untouched
+  if (skip) {
+    sx = skip[2 * (size_t)n] != 0;
+    sy = skip[2 * (size_t)n + 1] != 0;
+    if (sx && sy) return;
+  }
   const double2* __restrict__ rb = reinterpret_cast<const double2*>(rbuf);
   double2 acc = reinterpret_cast<double2*>(b)[n];
   int k = nptr[n];
   const int e = nptr[n + 1];
-  // four independent loads in flight per lane, summed in ascending source order (deterministic)
-  for (; k + 4 <= e; k += 4) {
-    const int i0 = nidx[k], i1 = nidx[k + 1], i2 = nidx[k + 2], i3 = nidx[k + 3];
-    const double2 v0 = rb[i0], v1 = rb[i1], v2 = rb[i2], v3 = rb[i3];
+  for (; k + 4 <= e; k += 4) {          // four independent loads in flight per lane
+    const double2 v0 = rb[k], v1 = rb[k + 1], v2 = rb[k + 2], v3 = rb[k + 3];
     acc.x += v0.x; acc.y += v0.y;
     acc.x += v1.x; acc.y += v1.y;
     acc.x += v2.x; acc.y += v2.y;
     acc.x += v3.x; acc.y += v3.y;
   }
   for (; k < e; ++k) {
-    const double2 v = rb[nidx[k]];
+    const double2 v = rb[k];
     acc.x += v.x;
     acc.y += v.y;
   }
+  if (sx) acc.x = reinterpret_cast<double2*>(b)[n].x;
+  if (sy) acc.y = reinterpret_cast<double2*>(b)[n].y;
   reinterpret_cast<double2*>(b)[n] = acc;
 }
 
@@ -707,7 +716,7 @@ static void launch_conv_cell(hipStream_t s, const MeshDev& m, const double* u, c
                              double cc, int form) {
   const dim3 grid(grid_for(m.n_cells)), block(kBlock);
 #define NSFEM_CC(F) \
-  hipLaunchKernelGGL((k_conv_cell<F, LIN>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, v, cc, m.rbuf.p)
+  hipLaunchKernelGGL((k_conv_cell<F, LIN>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, v, cc, m.ndst.p, m.rbuf.p)
   switch (form) {
     case 0: NSFEM_CC(0); break;
     case 1: NSFEM_CC(1); break;
@@ -724,19 +733,19 @@ void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u
   if (m.dim == 3) return convection_residual_3d(s, m, u, cc, b, form);
   launch_conv_cell<0>(s, m, u, nullptr, cc, form);
   hipLaunchKernelGGL(k_res_gather, dim3(grid_for(m.n_p2)), dim3(kBlock), 0, s, m.n_p2, m.nptr.p,
-                     m.nidx.p, m.rbuf.p, b);
+                     m.rbuf.p, (const uint8_t*)nullptr, b);
   NSFEM_HIP(hipGetLastError());
 }
 
 // y += c_c [d conv(u)/du] v (Newton) or its Picard linearisation: matrix-free action of the
 // convection blocks of the velocity Jacobian
 void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, const double* v,
-                              double cc, double* y, int form, bool picard) {
-  if (m.dim == 3) return convection_action_3d(s, m, u, v, cc, y, form, picard);
+                              double cc, double* y, int form, bool picard, const uint8_t* skipmask) {
+  if (m.dim == 3) return convection_action_3d(s, m, u, v, cc, y, form, picard, skipmask);
   if (picard) launch_conv_cell<2>(s, m, u, v, cc, form);
   else launch_conv_cell<1>(s, m, u, v, cc, form);
   hipLaunchKernelGGL(k_res_gather, dim3(grid_for(m.n_p2)), dim3(kBlock), 0, s, m.n_p2, m.nptr.p,
-                     m.nidx.p, m.rbuf.p, y);
+                     m.rbuf.p, skipmask, y);
   NSFEM_HIP(hipGetLastError());
 }
 

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void k3_conv_cell(int nc, const double* __rest
                                                     const int32_t* __restrict__ p2,
                                                     const double* __restrict__ u,
                                                     const double* __restrict__ v, double cc,
+                                                    const int32_t* __restrict__ ndst,
                                                     double* __restrict__ rbuf) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
@@ -488,12 +489,13 @@ __global__ __launch_bounds__(256) void k3_conv_cell(int nc, const double* __rest
       }
     }
   }
-  double* out = rbuf + (size_t)c * 30;
+  // node-sorted element buffer: entry (c, i) lands inside the contiguous run of its node
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    out[i * 3] = r[i][0];
-    out[i * 3 + 1] = r[i][1];
-    out[i * 3 + 2] = r[i][2];
+    double* out = rbuf + (size_t)ndst[(size_t)i * nc + c] * 3;
+    out[0] = r[i][0];
+    out[1] = r[i][1];
+    out[2] = r[i][2];
   }
 }
 
@@ -515,25 +517,27 @@ __global__ __launch_bounds__(256) void k3_jac_gather(int nnz, const int32_t* __r
 }
 
 __global__ __launch_bounds__(256) void k3_res_gather(int n_nodes, const int32_t* __restrict__ nptr,
-                                                     const int32_t* __restrict__ nidx,
                                                      const double* __restrict__ rbuf,
+                                                     const uint8_t* __restrict__ skip,
                                                      double* __restrict__ b) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)n_nodes * 3) return;
+  if (skip && skip[t] != 0) return;     // flagged entries (Dirichlet / ghost rows) stay untouched
   const int n = (int)(t / 3), a = (int)(t % 3);
   double acc = b[t];
   int k = nptr[n];
   const int e = nptr[n + 1];
-  // four independent loads in flight per lane, summed in ascending source order (deterministic)
+  // the node's contributions are the contiguous run nptr[n] .. nptr[n+1] of the node-sorted
+  // buffer; four independent loads in flight per lane, summed in ascending (cell) order
   for (; k + 4 <= e; k += 4) {
-    const double v0 = rbuf[(size_t)nidx[k] * 3 + a], v1 = rbuf[(size_t)nidx[k + 1] * 3 + a];
-    const double v2 = rbuf[(size_t)nidx[k + 2] * 3 + a], v3 = rbuf[(size_t)nidx[k + 3] * 3 + a];
+    const double v0 = rbuf[(size_t)k * 3 + a], v1 = rbuf[(size_t)(k + 1) * 3 + a];
+    const double v2 = rbuf[(size_t)(k + 2) * 3 + a], v3 = rbuf[(size_t)(k + 3) * 3 + a];
     acc += v0;
     acc += v1;
     acc += v2;
     acc += v3;
   }
-  for (; k < e; ++k) acc += rbuf[(size_t)nidx[k] * 3 + a];
+  for (; k < e; ++k) acc += rbuf[(size_t)k * 3 + a];
   b[t] = acc;
 }
 
@@ -659,7 +663,7 @@ static void launch_conv_cell(hipStream_t s, const MeshDev& m, const double* u, c
                              double cc, int form) {
   const dim3 grid(grid3(m.n_cells)), block(kBlock);
 #define NSFEM_CC3(F) \
-  hipLaunchKernelGGL((k3_conv_cell<F, LIN>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, v, cc, m.rbuf.p)
+  hipLaunchKernelGGL((k3_conv_cell<F, LIN>), grid, block, 0, s, m.n_cells, m.vx.p, m.p2.p, u, v, cc, m.ndst.p, m.rbuf.p)
   switch (form) {
     case 0: NSFEM_CC3(0); break;
     case 1: NSFEM_CC3(1); break;
@@ -675,18 +679,18 @@ void convection_residual_3d(hipStream_t s, const MeshDev& m, const double* u, do
                             int form) {
   launch_conv_cell<0>(s, m, u, nullptr, cc, form);
   hipLaunchKernelGGL(k3_res_gather, dim3(grid3((int64_t)m.n_p2 * 3)), dim3(kBlock), 0, s, m.n_p2,
-                     m.nptr.p, m.nidx.p, m.rbuf.p, b);
+                     m.nptr.p, m.rbuf.p, (const uint8_t*)nullptr, b);
   NSFEM_HIP(hipGetLastError());
 }
 
 // y += c_c [d conv(u)/du] v  (Newton) or its Picard linearisation: the matrix-free action of the
 // convection blocks of the velocity Jacobian
 void convection_action_3d(hipStream_t s, const MeshDev& m, const double* u, const double* v,
-                          double cc, double* y, int form, bool picard) {
+                          double cc, double* y, int form, bool picard, const uint8_t* skipmask) {
   if (picard) launch_conv_cell<2>(s, m, u, v, cc, form);
   else launch_conv_cell<1>(s, m, u, v, cc, form);
   hipLaunchKernelGGL(k3_res_gather, dim3(grid3((int64_t)m.n_p2 * 3)), dim3(kBlock), 0, s, m.n_p2,
-                     m.nptr.p, m.nidx.p, m.rbuf.p, y);
+                     m.nptr.p, m.rbuf.p, skipmask, y);
   NSFEM_HIP(hipGetLastError());
 }
 

@@ -46,7 +46,12 @@ struct SpmvArgs {
                    // (smoother step with frozen ghost values), 2 computed like free rows
   int skip0, skipn; // stream kernel: logical row blocks >= skip0 are shifted by skipn
   int phase;       // 0 all row blocks, 1 interior blocks only, 2 halo-adjacent blocks only
+  int ident;       // smoother step: rows flagged 1 take y = b (identity rows of a preconditioner for a
+                   // Newton matrix with dolfin-style Dirichlet rows) instead of 0
+  int dbg;         // NSFEM_SPMV_DEBUG (measurement experiments only; wrong results): 1 = gather from
+                   // the chunk's own rows (perfectly local x), 2 = skip the x gather altogether
 };
+struct XcdSplit { int s[9]; };   // SELL kernel: workgroup range [s[x], s[x+1]) of XCD x (s[8] = 0: round robin)
 
 template <int BR, int BC, int NV, int G, int EPI>
 __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restrict__ rowptr,
@@ -127,6 +132,8 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
         dn = a.c2 * a.dinv[idx] * (a.b[idx] - val);
         if (a.c1 != 0.0) dn += a.c1 * a.d[idx];
         xn = x[idx] + dn;
+      } else if (a.ident) {
+        xn = a.b[idx];
       }
       a.d[idx] = dn;
       a.y[idx] = xn;
@@ -151,8 +158,9 @@ constexpr int kStreamNnz = NSFEM_STREAM_NNZ;
 // measured sweep, see profiles/)
 static inline bool kStreamDefault(bool shape22) { (void)shape22; return true; }
 
+// version 1 (round 1) of the kernel: the default (NSFEM_STREAM_V=2 selects the wide-load variant below)
 template <int BR, int BC, int NV, int EPI>
-__global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* __restrict__ rblk,
+__global__ __launch_bounds__(256) void k_spmv_stream_v1(int n_rblk, const int32_t* __restrict__ rblk,
                                                      const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col,
                                                      const double* __restrict__ vals, SpmvArgs a) {
@@ -270,6 +278,8 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
         dn = a.c2 * (first ? pdinv : a.dinv[idx]) * ((first ? pb : a.b[idx]) - val);
         if (a.c1 != 0.0) dn += a.c1 * (first ? pd : a.d[idx]);
         xn = (first ? px : x[idx]) + dn;
+      } else if (a.ident) {
+        xn = first ? pb : a.b[idx];
       }
       a.d[idx] = dn;
       a.y[idx] = xn;
@@ -281,25 +291,414 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int32_t* 
   }
 }
 
+// Version 2 of the streaming phase (round 2): the kernel was bound by the length of its dependent
+// load chain times the workgroups a CU can hold, not by HBM (scripts/micro/readbw.hip: 6.2 TB/s
+// read-only, 5.2 TB/s 3 reads + 1 write on the same box against 3.7-4.7 TB/s here):
+//   * every lane owns FOUR CONSECUTIVE nonzeros of a 16-byte aligned window over the chunk: one
+//     16-byte column load and two 16-byte value loads per lane (scalar blocks) instead of eight
+//     4 / 8-byte loads -- the chunk limit is 1020 nonzeros so that the aligned window fits;
+//   * one 16-byte record {r0, r1, s0, s1} per chunk instead of two dependent index loads;
+//   * the row pointers of the chunk's rows are fetched at the start (latency hidden behind the
+//     streaming phase) and parked in LDS for the reduction phase.
+template <int BR, int BC, int NV, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int4* __restrict__ rbinfo,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const double* __restrict__ vals, SpmvArgs a) {
+  constexpr int NO = BR * NV;
+  constexpr int BS = BR * BC;
+  // dynamic LDS: the products of the chunk, then its row pointers (sized for the pattern's
+  // longest chunk: the 3-component kernel must stay below 160 KB / 6 per workgroup)
+  extern __shared__ double smem[];
+  double* prod = smem;
+  int32_t* rp = reinterpret_cast<int32_t*>(smem + kStreamNnz * NO);
+  const int per = gridDim.x >> 3;
+  int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (lb >= n_rblk) return;
+  if (lb >= a.skip0) lb += a.skipn;     // halo-adjacent launch: jump over the interior row blocks
+  const int4 info = rbinfo[lb];
+  const int r0 = info.x, r1 = info.y, s0 = info.z, s1 = info.w;
+  const double* __restrict__ x = a.x;
+  const int tid = threadIdx.x;
+  // row pointers of the chunk (relative to s0) -> LDS, needed after the barrier only
+  const int nrows = r1 - r0;
+  for (int t = tid; t <= nrows; t += 256) rp[t] = rowptr[r0 + t] - s0;
+  // epilogue operands of this thread's first output entry: issued before the streaming phase so
+  // that their latency hides behind it (the smoother epilogue reads b, dinv, d, x and the mask)
+  const int nout = nrows * NO;
+  const bool pre = tid < nout;
+  const size_t pidx = (size_t)r0 * NO + tid;
+  int pmv = 0;
+  double pb = 0.0, pdinv = 0.0, pd = 0.0, px = 0.0;
+  if (pre && (EPI == EPI_CHEB || EPI == EPI_RESID)) {
+    pmv = (a.maskmode != MASK_NONE) ? a.mask[pidx] : 0;
+    pb = a.b[pidx];
+    if (EPI == EPI_CHEB) {
+      pdinv = a.dinv[pidx];
+      if (a.c1 != 0.0) pd = a.d[pidx];
+      px = x[pidx];
+    }
+  }
+  // streaming phase: lane `tid` owns the nonzeros a0 + 4 tid .. a0 + 4 tid + 3 of the aligned
+  // window starting at a0 = s0 rounded down to a multiple of 4 (s1 - a0 <= 1023 by construction)
+  const int a0 = s0 & ~3;
+  const int k0 = a0 + 4 * tid;
+  int cc_[4];
+  double av[4][BS];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) cc_[u] = -1;
+  if (k0 < s1) {
+    // (k0 is a multiple of 4: 16-byte aligned column quad, 32-byte aligned value quad; every device
+    // buffer carries 64 bytes of slack (DevBuf::alloc), entries outside [s0, s1) are discarded)
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v4i* cq4 = reinterpret_cast<const v4i*>(col + k0);
+    const v4i c4 = a.nt ? __builtin_nontemporal_load(cq4) : *cq4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cc_[u] = (k0 + u >= s0 && k0 + u < s1) ? c4[u] : -1;
+    if (BS == 1) {
+      const v2d* vq = reinterpret_cast<const v2d*>(vals + k0);
+      const v2d v01 = a.nt ? __builtin_nontemporal_load(vq) : vq[0];
+      const v2d v23 = a.nt ? __builtin_nontemporal_load(vq + 1) : vq[1];
+      av[0][0] = v01[0]; av[1][0] = v01[1]; av[2][0] = v23[0]; av[3][0] = v23[1];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (cc_[u] >= 0) {
+#pragma unroll
+          for (int t = 0; t < BS; ++t)
+            av[u][t] = a.nt ? __builtin_nontemporal_load(vals + (size_t)(k0 + u) * BS + t)
+                            : vals[(size_t)(k0 + u) * BS + t];
+        }
+    }
+  }
+  if (a.dbg == 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (cc_[u] >= 0) cc_[u] = r0 + (4 * tid + u) % nrows;
+  }
+  double xv[4][BC * NV];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (cc_[u] >= 0) {
+#pragma unroll
+      for (int t = 0; t < BC * NV; ++t)
+        xv[u][t] = a.dbg == 2 ? (double)cc_[u] : x[(size_t)cc_[u] * (BC * NV) + t];
+    }
+  // products -> LDS.  Nonzero q = 4 tid + u of the aligned window is parked at slot u * 256 + tid:
+  // consecutive lanes write consecutive slots (the natural slot q would put the lanes 4 NO doubles
+  // apart: a 16-way bank conflict)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (cc_[u] >= 0) {
+      const int slot = u * 256 + tid;
+#pragma unroll
+      for (int r = 0; r < BR; ++r)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double acc = 0.0;
+#pragma unroll
+          for (int cc = 0; cc < BC; ++cc) acc += av[u][r * BC + cc] * xv[u][cc * NV + v];
+          prod[slot * NO + r * NV + v] = acc;
+        }
+    }
+  __syncthreads();
+  // one thread per output entry (row, o); window position q of the row's k-th nonzero is
+  // k + (s0 - a0), its slot (q & 3) * 256 + (q >> 2)
+  const int shift = s0 - a0;
+  for (int t = tid; t < nout; t += 256) {
+    const int lrow = t / NO, o = t % NO;
+    const int row = r0 + lrow;
+    double val = 0.0;
+    int q = rp[lrow] + shift;
+    const int e = rp[lrow + 1] + shift;
+    for (; q + 4 <= e; q += 4) {          // 4 LDS reads in flight, summed in ascending order
+      const double v0 = prod[(((q)&3) * 256 + ((q) >> 2)) * NO + o];
+      const double v1 = prod[(((q + 1) & 3) * 256 + ((q + 1) >> 2)) * NO + o];
+      const double v2 = prod[(((q + 2) & 3) * 256 + ((q + 2) >> 2)) * NO + o];
+      const double v3 = prod[(((q + 3) & 3) * 256 + ((q + 3) >> 2)) * NO + o];
+      val += v0;
+      val += v1;
+      val += v2;
+      val += v3;
+    }
+    for (; q < e; ++q) val += prod[((q & 3) * 256 + (q >> 2)) * NO + o];
+    const size_t idx = (size_t)row * NO + o;
+    const bool first = (EPI == EPI_CHEB || EPI == EPI_RESID) && t == tid;
+    int mv = first ? pmv : ((a.maskmode != MASK_NONE) ? a.mask[idx] : 0);
+    if (mv == 2 && a.ghost == 2) mv = 0;
+    const bool m = mv != 0;
+    if (mv == 2) {
+      if (EPI == EPI_CHEB) {
+        a.d[idx] = 0.0;
+        a.y[idx] = a.ghost == 1 ? (first ? px : x[idx]) : 0.0;
+      } else {
+        a.y[idx] = 0.0;
+      }
+    } else if (EPI == EPI_RESID) {
+      const double bv = first ? pb : a.b[idx];
+      if (m)
+        val = (a.maskmode == MASK_IDENTITY) ? bv - x[idx] : 0.0;
+      else
+        val = bv - val;
+      a.y[idx] = val;
+    } else if (EPI == EPI_ACCUM) {
+      if (!m) a.y[idx] += a.c2 * val;
+      else if (a.maskmode == MASK_ZERO) a.y[idx] = 0.0;
+    } else if (EPI == EPI_CHEB) {
+      double dn = 0.0, xn = 0.0;
+      if (!m) {
+        dn = a.c2 * (first ? pdinv : a.dinv[idx]) * ((first ? pb : a.b[idx]) - val);
+        if (a.c1 != 0.0) dn += a.c1 * (first ? pd : a.d[idx]);
+        xn = (first ? px : x[idx]) + dn;
+      } else if (a.ident) {
+        xn = first ? pb : a.b[idx];
+      }
+      a.d[idx] = dn;
+      a.y[idx] = xn;
+    } else {
+      if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
+      else val *= a.c2;
+      a.y[idx] = val;
+    }
+  }
+}
+
+// --- SELL-64 variant: one wavefront per slice of 64 rows, lane r walks row r through the
+// column-major slice (coalesced column / value loads, one entry of 64 different rows per pass).
+// On the parity-class numberings of the structured meshes the 64 column ids of a pass are
+// consecutive, so the x gather of the wave is ONE contiguous run (64 NV doubles) instead of the
+// ~50 scattered cache lines a CSR pass over 64 consecutive nonzeros of 2-3 rows touches.  No LDS,
+// no cross-lane reduction; the epilogues are those of the other kernels.  Same ascending order of
+// a row's entries as the CSR kernels.
+template <int NV, int EPI, int U, int PIPE>
+__global__ __launch_bounds__(256) void k_spmv_sell(int n_rows, int n_slices, int n_wg,
+                                                   const int32_t* __restrict__ sptr,
+                                                   const int32_t* __restrict__ scol,
+                                                   const double* __restrict__ sval, SpmvArgs a,
+                                                   XcdSplit xs) {
+  // workgroups b, b + 8, ... run on the same XCD (round-robin dispatch): XCD x walks its own
+  // contiguous, nonzero-balanced range of workgroups, so its L2 sees one spatial slab of x
+  int wg;
+  if (xs.s[8] > 0) {
+    const int xcd = blockIdx.x & 7;
+    wg = xs.s[xcd] + (int)(blockIdx.x >> 3);
+    if (wg >= xs.s[xcd + 1]) return;
+  } else {
+    wg = blockIdx.x;
+    if (wg >= n_wg) return;
+    if (wg >= a.skip0) wg += a.skipn;
+  }
+  const int slice = wg * 4 + ((int)threadIdx.x >> 6);
+  if (slice >= n_slices) return;
+  const int lane = threadIdx.x & 63;
+  const int row = slice * 64 + lane;
+  const bool live = row < n_rows;
+  const int base = sptr[slice];
+  const int w = (sptr[slice + 1] - base) >> 6;           // wave-uniform
+  const double* __restrict__ x = a.x;
+  double acc[NV];
+#pragma unroll
+  for (int o = 0; o < NV; ++o) acc[o] = 0.0;
+  const int32_t* __restrict__ cp = scol + (size_t)base + lane;
+  const double* __restrict__ vp = sval + (size_t)base + lane;
+  // groups of U entries per lane: U column ids + U values (coalesced, non-temporal), then the U x
+  // gathers, all independent -> U (1 + NV) loads in flight per lane.  PIPE: the column ids / values
+  // of the next group are requested before the gathers of the current one are consumed.
+  // branch-free: entries past the slice width re-read its last entry with a zero weight (the
+  // select is wave-uniform); vmcnt retires loads in issue order, so the next group's column /
+  // value loads are issued AFTER the gathers of the current group and stay in flight while the
+  // gathers are consumed
+  int c[U], cn[U];
+  double v[U], vn[U];
+  auto fetch = [&](int k0, int* cc, double* vv) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k0 + u < w ? k0 + u : w - 1;
+      cc[u] = __builtin_nontemporal_load(cp + (size_t)kk * 64);
+      const double t = __builtin_nontemporal_load(vp + (size_t)kk * 64);
+      vv[u] = k0 + u < w ? t : 0.0;
+    }
+  };
+  if (w > 0) {
+    fetch(0, c, v);
+    for (int k = 0; k < w; k += U) {
+      double xv[U][NV];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < NV; ++t) xv[u][t] = x[(size_t)c[u] * NV + t];
+      if (PIPE && k + U < w) fetch(k + U, cn, vn);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < NV; ++t) acc[t] += v[u] * xv[u][t];
+      if (PIPE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { c[u] = cn[u]; v[u] = vn[u]; }
+      } else if (k + U < w) {
+        fetch(k + U, c, v);
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int o = 0; o < NV; ++o) {
+    const size_t idx = (size_t)row * NV + o;
+    double val = acc[o];
+    int m_ = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    if (m_ == 2 && a.ghost == 2) m_ = 0;
+    const bool m = m_ != 0;
+    if (m_ == 2) {
+      if (EPI == EPI_CHEB) {
+        a.d[idx] = 0.0;
+        a.y[idx] = a.ghost == 1 ? x[idx] : 0.0;
+      } else {
+        a.y[idx] = 0.0;
+      }
+    } else if (EPI == EPI_RESID) {
+      if (m) val = (a.maskmode == MASK_IDENTITY) ? a.b[idx] - x[idx] : 0.0;
+      else val = a.b[idx] - val;
+      a.y[idx] = val;
+    } else if (EPI == EPI_ACCUM) {
+      if (!m) a.y[idx] += a.c2 * val;
+      else if (a.maskmode == MASK_ZERO) a.y[idx] = 0.0;
+    } else if (EPI == EPI_CHEB) {
+      double dn = 0.0, xn = 0.0;
+      if (!m) {
+        dn = a.c2 * a.dinv[idx] * (a.b[idx] - val);
+        if (a.c1 != 0.0) dn += a.c1 * a.d[idx];
+        xn = x[idx] + dn;
+      } else if (a.ident) {
+        xn = a.b[idx];
+      }
+      a.d[idx] = dn;
+      a.y[idx] = xn;
+    } else {
+      if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
+      else val *= a.c2;
+      a.y[idx] = val;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sell_fill(int64_t len, const int32_t* __restrict__ src,
+                                                   const double* __restrict__ csr,
+                                                   double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int sidx = src[i];
+    out[i] = sidx >= 0 ? csr[sidx] : 0.0;
+  }
+}
+
+// SELL-64 layout of a pattern (host, once): kept only when the zero padding stays below 10 % of
+// the nonzeros, i.e. when consecutive rows have (nearly) equal length -- the parity-class
+// numberings of structured meshes and every P1 lattice operator
+void build_sell(Pattern& p, hipStream_t s) {
+  p.n_slices = 0;
+  p.sell_len = 0;
+  static const int enabled = [] {
+    // measured (round 2, MI355X): on the parity-class numbering SELL-64 beats the CSR-stream kernel
+    // by 6 % in 3D (261 vs 278 us in situ at n = 64: the whole step 26.4 vs 28.3 ms) and loses 15 %
+    // in 2D (68 vs 59 us cache-cold at n = 512).  Default (1): patterns with >= 20 entries per row
+    // on average, i.e. the tetrahedral P2 operators; 2: every pattern that qualifies; 0: never
+    const char* e = std::getenv("NSFEM_SELL");
+    return e ? std::atoi(e) : 1;
+  }();
+  if (!enabled || p.n_rows < 2048 || p.h_rowptr.empty()) return;
+  if (enabled == 1 && (double)p.nnz < 20.0 * p.n_rows) return;
+  const int ns = (p.n_rows + 63) / 64;
+  std::vector<int32_t> ptr((size_t)ns + 1, 0);
+  int64_t total = 0;
+  for (int sl = 0; sl < ns; ++sl) {
+    int w = 0;
+    for (int r = sl * 64; r < std::min(p.n_rows, sl * 64 + 64); ++r)
+      w = std::max(w, p.h_rowptr[r + 1] - p.h_rowptr[r]);
+    total += (int64_t)w * 64;
+    if (total > 0x7fffff00LL) return;                       // 32-bit entry offsets
+    ptr[sl + 1] = (int32_t)total;
+  }
+  if ((double)total > 1.10 * (double)p.nnz) return;
+  std::vector<int32_t> col((size_t)total), src((size_t)total);
+  for (int sl = 0; sl < ns; ++sl) {
+    const int w = (ptr[sl + 1] - ptr[sl]) / 64;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int r = sl * 64 + lane;
+      const int s0 = r < p.n_rows ? p.h_rowptr[r] : 0, len = r < p.n_rows ? p.h_rowptr[r + 1] - s0 : 0;
+      // padding entries reference a column the row (or, past the end, the last row) reads anyway
+      const int safe = r < p.n_rows ? (len > 0 ? p.h_col[s0] : 0) : 0;
+      for (int k = 0; k < w; ++k) {
+        const size_t pos = (size_t)ptr[sl] + (size_t)k * 64 + lane;
+        col[pos] = k < len ? p.h_col[s0 + k] : safe;
+        src[pos] = k < len ? s0 + k : -1;
+      }
+    }
+  }
+  p.sell_ptr.upload(ptr, s);
+  p.sell_col.upload(col, s);
+  p.sell_src.upload(src, s);
+  p.n_slices = ns;
+  p.sell_len = total;
+  p.sell_w0 = p.sell_w1 = 0;
+  // nonzero-balanced contiguous workgroup ranges for the 8 XCDs
+  const int nwg = (ns + 3) / 4;
+  p.sell_xcd[0] = 0;
+  int wgi = 0;
+  for (int x = 1; x <= 8; ++x) {
+    const int64_t target = total * x / 8;
+    while (wgi < nwg && (int64_t)ptr[std::min(ns, (wgi + 1) * 4)] <= target) ++wgi;
+    p.sell_xcd[x] = x == 8 ? nwg : wgi;
+  }
+}
+
+void BlockMat::sell_update(hipStream_t s) {
+  sell_ready = false;
+  if (!pat || pat->n_slices == 0 || br != 1 || bc != 1) return;
+  if (sell_vals.n != (size_t)pat->sell_len) sell_vals.alloc((size_t)pat->sell_len);
+  const int grid = (int)std::min<int64_t>((pat->sell_len + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_sell_fill, dim3(grid), dim3(256), 0, s, pat->sell_len, pat->sell_src.p, vals.p,
+                     sell_vals.p);
+  NSFEM_HIP(hipGetLastError());
+  sell_ready = true;
+}
+
 // greedy row blocks with <= kStreamNnz nonzeros (host, once per pattern); patterns with a
 // longer row keep n_rblk = 0 and use the lane-group kernel
 void build_rowblocks(Pattern& p, hipStream_t s) {
+  // (1020 = 1024 - 4: the kernel reads a 16-byte aligned window of 256 column quads over the chunk)
+  constexpr int kLimit = kStreamNnz - 4;
   std::vector<int32_t> blk;
   blk.push_back(0);
   int start = 0;
-  for (int r = 0; r < p.n_rows; ++r) {
+  p.n_rblk = 0;
+  bool ok = true;
+  for (int r = 0; r < p.n_rows && ok; ++r) {
     const int len = p.h_rowptr[r + 1] - p.h_rowptr[r];
-    if (len > kStreamNnz) { p.n_rblk = 0; return; }
-    if (p.h_rowptr[r + 1] - p.h_rowptr[start] > kStreamNnz) {
+    if (len > kLimit) ok = false;
+    if (p.h_rowptr[r + 1] - p.h_rowptr[start] > kLimit) {
       blk.push_back(r);
       start = r;
     }
   }
-  blk.push_back(p.n_rows);
-  p.n_rblk = (int)blk.size() - 1;
-  p.rblk.upload(blk, s);
-  p.h_rblk.swap(blk);
+  if (ok) {
+    blk.push_back(p.n_rows);
+    p.n_rblk = (int)blk.size() - 1;
+    std::vector<int32_t> info((size_t)p.n_rblk * 4);
+    for (int b = 0; b < p.n_rblk; ++b) {
+      info[4 * b] = blk[b];
+      info[4 * b + 1] = blk[b + 1];
+      info[4 * b + 2] = p.h_rowptr[blk[b]];
+      info[4 * b + 3] = p.h_rowptr[blk[b + 1]];
+    }
+    p.rblk.upload(info, s);
+    p.rblk1.upload(blk, s);
+    p.max_chunk_rows = 0;
+    for (int b = 0; b < p.n_rblk; ++b) p.max_chunk_rows = std::max(p.max_chunk_rows, blk[b + 1] - blk[b]);
+    p.h_rblk.swap(blk);
+  }
   p.int_b0 = p.int_b1 = 0;
+  build_sell(p, s);
 }
 
 void mark_interior_blocks(Pattern& p, const std::vector<uint8_t>& ghost_cols) {
@@ -318,6 +717,24 @@ void mark_interior_blocks(Pattern& p, const std::vector<uint8_t>& ghost_cols) {
   }
   p.int_b0 = best0;
   p.int_b1 = best1;
+  // the same for the SELL workgroups (4 slices = 256 rows each)
+  p.sell_w0 = p.sell_w1 = 0;
+  if (p.n_slices > 0) {
+    const int nwg = (p.n_slices + 3) / 4;
+    int b0 = 0, b1 = 0, r0 = 0;
+    for (int b = 0; b <= nwg; ++b) {
+      bool dirty = b == nwg;
+      if (!dirty)
+        for (int k = p.h_rowptr[std::min(p.n_rows, b * 256)]; k < p.h_rowptr[std::min(p.n_rows, b * 256 + 256)] && !dirty; ++k)
+          dirty = ghost_cols[p.h_col[k]] != 0;
+      if (dirty) {
+        if (b - r0 > b1 - b0) { b0 = r0; b1 = b; }
+        r0 = b + 1;
+      }
+    }
+    p.sell_w0 = b0;
+    p.sell_w1 = b1;
+  }
 }
 
 template <int EPI>
@@ -327,6 +744,60 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     const char* e = std::getenv("NSFEM_SPMV_STREAM");
     return e ? std::atoi(e) : -1;          // -1: per-shape default
   }();
+  if (A.sell_ready && p.n_slices > 0 && A.br == 1 && A.bc == 1 && nv >= 1 && nv <= 3) {
+    SpmvArgs a = a_in;
+    const int nwg_all = (p.n_slices + 3) / 4;
+    int nwg = nwg_all;
+    a.skip0 = nwg_all;
+    a.skipn = 0;
+    if (a.phase == 1) {                    // interior workgroups only: shift the logical index
+      nwg = p.sell_w1 - p.sell_w0;
+      a.skip0 = 0;
+      a.skipn = p.sell_w0;
+    } else if (a.phase == 2) {
+      nwg = nwg_all - (p.sell_w1 - p.sell_w0);
+      a.skip0 = p.sell_w0;
+      a.skipn = p.sell_w1 - p.sell_w0;
+    }
+    if (nwg <= 0) return;
+    XcdSplit xs;
+    for (int x = 0; x < 9; ++x) xs.s[x] = 0;
+    int grid = (nwg + 7) & ~7;
+    static const int balance = [] {
+      const char* e = std::getenv("NSFEM_SELL_BALANCE");
+      return e ? std::atoi(e) : 1;
+    }();
+    if (a.phase == 0 && balance) {          // whole operator: balanced contiguous XCD ranges
+      int most = 0;
+      for (int x = 0; x < 9; ++x) xs.s[x] = p.sell_xcd[x];
+      for (int x = 0; x < 8; ++x) most = std::max(most, xs.s[x + 1] - xs.s[x]);
+      grid = 8 * most;
+    }
+#define NSFEM_SELL_LAUNCH(NV, U, PIPE)                                                               \
+  hipLaunchKernelGGL((k_spmv_sell<NV, EPI, U, PIPE>), dim3(grid), dim3(256), 0, s, p.n_rows,         \
+                     p.n_slices, nwg, p.sell_ptr.p, p.sell_col.p, A.sell_vals.p, a, xs)
+    // tuning switch (smoother epilogue only): NSFEM_SELL_VARIANT = 0 (U 4), 1 (U 8), 2 (U 8 pipelined,
+    // default), 3 (U 12 pipelined / U 10 for 3 components)
+    static const int variant = [] {
+      const char* e = std::getenv("NSFEM_SELL_VARIANT");
+      return e ? std::atoi(e) : 2;
+    }();
+    const int var = EPI == EPI_CHEB ? variant : 2;
+#define NSFEM_SELL_NV(NV, UBIG)                        \
+  do {                                                 \
+    if (var == 0) NSFEM_SELL_LAUNCH(NV, 4, 0);         \
+    else if (var == 1) NSFEM_SELL_LAUNCH(NV, 8, 0);    \
+    else if (var == 3) NSFEM_SELL_LAUNCH(NV, UBIG, 1); \
+    else NSFEM_SELL_LAUNCH(NV, 8, 1);                  \
+  } while (0)
+    if (nv == 1) NSFEM_SELL_NV(1, 12);
+    else if (nv == 2) NSFEM_SELL_NV(2, 12);
+    else NSFEM_SELL_NV(3, 10);
+#undef NSFEM_SELL_NV
+#undef NSFEM_SELL_LAUNCH
+    NSFEM_HIP(hipGetLastError());
+    return;
+  }
   const bool shape22 = A.br == 2 && A.bc == 2;
   // measured (n = 512): the stream kernel wins on every operator except the short-row P2 x P1
   // gradient (4.6 entries per row), which keeps the lane-group kernel
@@ -337,7 +808,7 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     // interior / halo-adjacent split of a partitioned product (see product_with_halo)
     SpmvArgs a = a_in;
     int nb = p.n_rblk;
-    const int32_t* rb = p.rblk.p;
+    const int4* rb = reinterpret_cast<const int4*>(p.rblk.p);
     a.skip0 = nb;
     a.skipn = 0;
     if (a.phase == 1) {
@@ -351,9 +822,23 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     }
     if (nb <= 0) return;
     const int grid = (nb + 7) & ~7;
+    static const int version = [] {
+      // measured in situ (round 2): v1 44-46 us / 278 us (2D n = 512 / 3D n = 64 finest-level smoothing
+      // launch), v2 45-47 us / 303 us -- v2 only wins cache-cold in 2D (49-52 vs 54-58 us)
+      const char* e = std::getenv("NSFEM_STREAM_V");
+      return e ? std::atoi(e) : 1;
+    }();
+    const int32_t* rb1 = p.rblk1.p + (a.phase == 1 ? p.int_b0 : 0);
 #define NSFEM_STREAM(BR, BC, NV)                                                              \
-  hipLaunchKernelGGL((k_spmv_stream<BR, BC, NV, EPI>), dim3(grid), dim3(256), 0, s, nb,        \
-                     rb, p.rowptr.p, p.col.p, A.vals.p, a)
+  do {                                                                                        \
+    if (version == 1)                                                                         \
+      hipLaunchKernelGGL((k_spmv_stream_v1<BR, BC, NV, EPI>), dim3(grid), dim3(256), 0, s, nb, \
+                         rb1, p.rowptr.p, p.col.p, A.vals.p, a);                              \
+    else                                                                                      \
+      hipLaunchKernelGGL((k_spmv_stream<BR, BC, NV, EPI>), dim3(grid), dim3(256),              \
+                         (size_t)kStreamNnz * (BR * NV) * 8 + (size_t)(p.max_chunk_rows + 2) * 4, s, \
+                         nb, rb, p.rowptr.p, p.col.p, A.vals.p, a);                           \
+  } while (0)
     if (A.br == 2 && A.bc == 2 && nv == 1) NSFEM_STREAM(2, 2, 1);
     else if (A.br == 1 && A.bc == 1 && nv == 2) NSFEM_STREAM(1, 1, 2);
     else if (A.br == 1 && A.bc == 1 && nv == 1) NSFEM_STREAM(1, 1, 1);
@@ -436,6 +921,12 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
   a.skip0 = 0x7fffffff;
   a.skipn = 0;
   a.phase = 0;
+  a.ident = 0;
+  static const int dbg = [] {
+    const char* e = std::getenv("NSFEM_SPMV_DEBUG");
+    return e ? std::atoi(e) : 0;
+  }();
+  a.dbg = dbg;
   return a;
 }
 
@@ -470,11 +961,12 @@ void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, co
 }
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
-                      const uint8_t* rowmask, int ghost, int phase) {
+                      const uint8_t* rowmask, int ghost, int phase, int ident) {
   SpmvArgs a = make_args(x, b, xout, rowmask, MASK_ZERO);
   a.dinv = dinv; a.d = d; a.c1 = c1; a.c2 = c2;
   a.ghost = ghost;
   a.phase = phase;
+  a.ident = ident;
   spmv_dispatch<EPI_CHEB>(s, A, nv, a);
 }
 

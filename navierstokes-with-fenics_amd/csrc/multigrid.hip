@@ -426,7 +426,7 @@ void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1
 // `steps` Chebyshev steps on A x = b.  x_in == nullptr: zero initial guess.  The result
 // is written to x_out (which may alias x_in only when steps >= 2).
 void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
-                       double* x_out, int steps, bool ghosts_valid) {
+                       double* x_out, int steps, bool ghosts_valid, bool ident_last) {
   const int64_t n = (int64_t)L.n * nv;
   double rho = 0.0, c1, c2;
   const double* cur = x_in;
@@ -458,7 +458,8 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
       const int gmode = relaxed && k + 1 < steps ? 1 : 0;
       product_with_halo(need_fill && comm_active() && L.has_halo ? comm : nullptr, &L.halo, nv, s, cur,
                         L.A->pat, [&](int phase) {
-        launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask, gmode, phase);
+        launch_cheb_step(s, *L.A, nv, cur, b, L.dinv.p, L.d.p, c1, c2, out, L.mask, gmode, phase,
+                         ident_last && k == steps - 1 ? 1 : 0);
       });
       if (prof_open) {
         ++prof_launches;
@@ -488,7 +489,7 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
   if (truncated() && l + 1 == active) {
-    smooth(s, L, b, nullptr, x, trunc_steps);
+    smooth(s, L, b, nullptr, x, trunc_steps, false, identity_rows && l == 0 && trunc_steps >= 2);
     return;
   }
   if (l + 1 == lv.size()) {
@@ -560,7 +561,7 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
   // residual), this is exactly what the owner computes for them -> no exchange before smoothing
   if (pre > 0) launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask, relaxed ? 2 : 0);
   else launch_spmv(s, *L.P, nv, C.x.p, x, L.mask, MASK_ZERO, relaxed ? 2 : 0);   // x = P x_c (every row stored)
-  smooth(s, L, b, x, x, degree, relaxed);
+  smooth(s, L, b, x, x, degree, relaxed, identity_rows && l == 0);
   (void)n;
 }
 

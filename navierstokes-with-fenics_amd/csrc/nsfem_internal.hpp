@@ -55,7 +55,9 @@ struct DevBuf {
   void alloc(size_t count) {
     release();
     n = count;
-    if (count) NSFEM_HIP(hipMalloc(&p, count * sizeof(T)));
+    // (+64 bytes of slack: the SpMV kernels read 16-byte aligned quads that may end past the last
+    // entry of a column / value array)
+    if (count) NSFEM_HIP(hipMalloc(&p, count * sizeof(T) + 64));
   }
   void upload(const T* host, size_t count, hipStream_t s) {
     if (count != n) alloc(count);
@@ -83,15 +85,34 @@ struct Pattern {
   int n_rows = 0, n_cols = 0, nnz = 0, nr = 0, nc = 0;
   DevBuf<int32_t> rowptr, col, diag, slot;
   DevBuf<int32_t> cptr, cidx;             // per slot: sources (cell * nr*nc + i * nc + j)
-  DevBuf<int32_t> rblk;                   // row blocks of the CSR-stream SpMV (n_rblk + 1)
+  DevBuf<int32_t> rblk;                   // chunks of the CSR-stream SpMV: n_rblk records {r0, r1, s0, s1}
+  DevBuf<int32_t> rblk1;                  // the same chunks as a plain row-start table (v1 kernel)
   int n_rblk = 0;
+  int max_chunk_rows = 0;                 // rows of the longest chunk (LDS row-pointer table)
   std::vector<int32_t> h_rblk;            // host copy (interior / halo-adjacent split)
   // partitioned meshes: the row blocks [int_b0, int_b1) reference no ghost column -- they can run
   // while the halo exchange of the input vector is still in flight (mark_interior_blocks)
   int int_b0 = 0, int_b1 = 0;
+  // SELL-64 layout (sliced ELLPACK, slices of 64 rows = one wavefront, entries of a slice stored
+  // column-major: lane r of a wave walks row r) for patterns whose consecutive rows have (nearly)
+  // equal length -- structured numberings that group the P2 nodes by lattice-parity class.  The
+  // k-th entries of 64 consecutive rows then sit at consecutive column ids: the x gather of a wave
+  // is one contiguous run instead of ~50 scattered cache lines.  Built by build_sell when the
+  // padding stays below a few per cent; n_slices = 0 otherwise (CSR-stream kernel).
+  DevBuf<int32_t> sell_ptr;               // [n_slices + 1] entry offsets (multiples of 64)
+  DevBuf<int32_t> sell_col;               // column ids, padding entries point at the row itself
+  DevBuf<int32_t> sell_src;               // CSR slot of every entry, -1 = padding
+  int n_slices = 0;
+  int64_t sell_len = 0;
+  int sell_w0 = 0, sell_w1 = 0;           // interior workgroups (4 slices each), see int_b0/int_b1
+  // contiguous workgroup ranges of the 8 XCDs, balanced by (padded) nonzeros: the parity-class
+  // numberings group rows of very different length (3D vertex rows 65, edge rows 14-32 entries),
+  // an equal-count split would leave one XCD with 2-3 times the work of the others
+  int sell_xcd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<int32_t> h_rowptr, h_col;   // kept for export
 };
 void build_rowblocks(Pattern& p, hipStream_t s);
+void build_sell(Pattern& p, hipStream_t s);
 // longest run of row blocks none of whose columns is flagged in `ghost_cols` ([n_cols] flags)
 void mark_interior_blocks(Pattern& p, const std::vector<uint8_t>& ghost_cols);
 void build_inverse_index(int n_targets, int64_t n_sources,
@@ -103,11 +124,18 @@ struct BlockMat {
   const Pattern* pat = nullptr;
   int br = 1, bc = 1;
   DevBuf<double> vals;
+  // copy of the values in the pattern's SELL-64 order (scalar matrices on patterns that have one);
+  // refreshed by sell_update() after every change of `vals` -- the SpMV kernels use it only while
+  // sell_ready is set
+  DevBuf<double> sell_vals;
+  bool sell_ready = false;
   void init(const Pattern* p, int br_, int bc_, hipStream_t s) {
     pat = p; br = br_; bc = bc_;
     vals.alloc((size_t)p->nnz * br * bc);
     vals.zero(s);
+    sell_ready = false;
   }
+  void sell_update(hipStream_t s);        // linalg.hip
 };
 
 // reference-element tables (7-point degree-5 rule)
@@ -154,7 +182,8 @@ void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, co
                       double* y, const uint8_t* skipmask);
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
-                      const uint8_t* rowmask, int ghost = 0 /* 1: ghost rows keep x */, int phase = 0);
+                      const uint8_t* rowmask, int ghost = 0 /* 1: ghost rows keep x */, int phase = 0,
+                      int ident = 0 /* 1: rows flagged 1 take xout = b (identity rows) */);
 
 // element kernels
 struct MeshDev {
@@ -163,7 +192,11 @@ struct MeshDev {
   DevBuf<double> vx;        // SoA vertex coords per cell: [6][n_cells] (x0,y0,x1,y1,x2,y2)
   DevBuf<int32_t> p2;       // SoA [6][n_cells]
   DevBuf<int32_t> p1;       // SoA [3][n_cells]
-  DevBuf<int32_t> nptr, nidx;   // per P2 node: sources (cell * 6 + i) of vector assembly
+  // vector assembly without atomics: the element vectors are stored NODE-SORTED -- entry (cell, i)
+  // goes to position ndst[i][cell] (SoA [6 | 10][n_cells]) of rbuf, the contributions of node n are
+  // the contiguous run nptr[n] .. nptr[n + 1] (ascending cell order: deterministic sums, and the
+  // gather kernel streams the buffer instead of chasing 16 / 24-byte pieces through it)
+  DevBuf<int32_t> nptr, ndst;
   DevBuf<double> ebuf;      // element Jacobian blocks [cell][6][6][4] (plain stores)
   DevBuf<double> rbuf;      // element residual [cell][6][2]
 };
@@ -200,7 +233,7 @@ void convection_jacobian_3d(hipStream_t s, const MeshDev& m, const Pattern& p22,
 void convection_residual_3d(hipStream_t s, const MeshDev& m, const double* u, double cc, double* b,
                             int form);
 void convection_action_3d(hipStream_t s, const MeshDev& m, const double* u, const double* v,
-                          double cc, double* y, int form, bool picard);
+                          double cc, double* y, int form, bool picard, const uint8_t* skipmask = nullptr);
 void launch_assemble_p1_scalar(hipStream_t s, const MeshDev& m, const Pattern& p11,
                                double* stiff, double* mass);
 void launch_assemble_div_grad(hipStream_t s, const MeshDev& m, const Pattern& p12,
@@ -214,8 +247,10 @@ void launch_jacobian_init(hipStream_t s, int nnz, const double* L, const double*
 void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                 const double* u, double cc, const double* L, const double* E,
                                 double cvE, double* J, int form, bool picard);
+// skipmask != nullptr: vector entries with a nonzero flag are left untouched by the node gather
 void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, const double* v,
-                              double cc, double* y, int form, bool picard);
+                              double cc, double* y, int form, bool picard,
+                              const uint8_t* skipmask = nullptr);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b, int form);
 // per-facet surface force / flux / measure (boundary.hip): out[nf][dim + 2]
@@ -436,6 +471,10 @@ struct Multigrid : Precond {
   int64_t prof_launches = 0;     // launches covered by the recorded pairs
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
   bool smoother_only = false;    // the last level is smoothed (coarse_steps), never solved globally
+  // preconditioner of a Newton matrix with dolfin-style Dirichlet rows: the result carries z = r on
+  // the rows flagged 1 of level 0 -- written by the epilogue of the last finest-level smoothing step
+  // instead of a separate copy kernel
+  bool identity_rows = false;
   // partitioned meshes, relaxed mode: a smoothing sequence exchanges the ghost values ONCE (at
   // its first step that reads them) and keeps them frozen afterwards -- Chebyshev iteration on
   // the rank-local operator (block-Jacobi across ranks) around the true residual, still a
@@ -456,7 +495,7 @@ struct Multigrid : Precond {
   void apply(hipStream_t s, const double* r, double* z) override;
   void vcycle(hipStream_t s, size_t l, const double* b, double* x);
   void smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
-              int steps, bool ghosts_valid = false);
+              int steps, bool ghosts_valid = false, bool ident_last = false);
   void cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1, double& c2,
                    double& rho) const;
 };

@@ -197,12 +197,37 @@ class TaylorHoodDofMap:
     """
 
     def __init__(self, mesh, reorder=True, periodic_map=None):
+        """reorder: True / "lex" lexicographic lattice order (strip / slab partitions rely on it:
+        halos are contiguous ranges); "parity" = structured meshes only (``mesh.structured``):
+        nodes grouped by the parity class of their half-lattice index (vertices, then the edge
+        types), lexicographic inside a class -- consecutive rows of every P2 operator then have
+        equal length and their k-th columns are consecutive ids, which is what the SELL-64 SpMV
+        kernel (csrc/linalg.hip: k_spmv_sell) needs for a fully coalesced x gather; falls back to
+        "lex" on general meshes; False keeps the entity order."""
         self.mesh = mesh
         nv, ne = mesh.num_vertices(), mesh.num_edges()
         xy = np.concatenate([mesh.coords, mesh.edge_midpoints()], axis=0)      # entity order
         n_ent = nv + ne
         dim = self.dim = mesh._dim
-        if reorder:
+        lattice = getattr(mesh, "structured", None) if reorder == "parity" else None
+        self.ordering = "parity" if lattice is not None else ("lex" if reorder else "entity")
+        if lattice is not None:
+            lo = np.asarray(lattice[0], dtype=np.float64)
+            hi = np.asarray(lattice[1], dtype=np.float64)
+            cells = np.asarray(lattice[2:], dtype=np.float64)
+            q = np.round((xy - lo) * (2.0 * cells / (hi - lo))).astype(np.int64)   # half-lattice index
+            cls = np.zeros(n_ent, dtype=np.int64)
+            for a in range(dim):
+                cls |= (q[:, a] & 1) << a
+            # slabs of `block` half-lattice planes along the slowest axis, the classes inside a slab:
+            # a contiguous row range is a spatial slab again (each XCD's L2 then holds the few
+            # planes of x its rows touch), yet 64 consecutive rows still belong to one class
+            block = self.parity_block = int(getattr(mesh, "parity_block", 4 if dim == 3 else 16))
+            slab = q[:, dim - 1] // block
+            order = np.lexsort(tuple(q[:, k] for k in range(dim)) + (cls, slab))   # slab slowest, x fastest
+            ent_to_node = np.empty(n_ent, dtype=np.int64)
+            ent_to_node[order] = np.arange(n_ent)
+        elif reorder:
             scale = 1.0 / max(mesh.hmin(), 1e-300)
             q = np.round(xy * (4.0 * scale)).astype(np.int64)      # robust lexicographic key
             order = np.lexsort(tuple(q[:, k] for k in range(dim)))   # x fastest, last axis slowest
@@ -255,6 +280,16 @@ class TaylorHoodDofMap:
     def facet_p1_nodes(self, facet_ids):
         f = self.mesh.facets[facet_ids].astype(np.int64)
         return self.p1_vertex_node[f]
+
+
+def preferred_p2_order(dim):
+    """numbering of the scalar P2 nodes on structured single-GPU meshes: lexicographic in 2D,
+    parity classes in 3D (pairs with the SELL-64 SpMV kernel: measured 6 % faster smoothing
+    launches and 7 % faster time steps than lexicographic + CSR-stream on tetrahedra, 15 % slower
+    on triangles); the environment variable NSFEM_P2_ORDER = lex | parity overrides it"""
+    import os
+    choice = os.environ.get("NSFEM_P2_ORDER", "parity" if dim == 3 else "lex")
+    return "parity" if choice == "parity" else True
 
 
 def _compact(ids):

@@ -222,7 +222,8 @@ class SolverBase:
             # periodic constraint: slave entities share the dofs of their masters (dolfin
             # FunctionSpace(..., constrained_domain=...), reference :516-518)
             periodic = periodic_entity_map(self._mesh, self._constrained_domain)
-        self._dofmap = TaylorHoodDofMap(self._mesh, periodic_map=periodic)
+        from fem_mesh import preferred_p2_order
+        self._dofmap = TaylorHoodDofMap(self._mesh, reorder=preferred_p2_order(self._mesh.geometry().dim()), periodic_map=periodic)
         dm = self._dofmap
         self._ctx = nat.NsfemContext(self._mesh.coords, self._mesh.cells, dm.p2_dofmap,
                                      dm.p1_dofmap, dm.n_p2, dm.n_p1, device=self._device)

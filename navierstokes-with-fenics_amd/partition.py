@@ -80,7 +80,10 @@ class StripPartition:
         g = 1 if rank < size - 1 else 0
         self.fine = StripLevel(p0, p1, nx, ny, rank * own, own, g)
         self.mesh = self.fine.mesh
-        self.dofmap = TaylorHoodDofMap(self.mesh)
+        if size == 1:      # no halos to keep contiguous: the numbering is free (NSFEM_P2_ORDER)
+            from fem_mesh import preferred_p2_order
+            self.mesh.structured = (tuple(p0), tuple(p1), nx, ny)
+        self.dofmap = TaylorHoodDofMap(self.mesh, reorder=preferred_p2_order(2) if size == 1 else True)
         dm = self.dofmap
         # P2 lattice lines: 2*rows + 1 lines of w2 nodes, lexicographic (dof map reorders so)
         w2 = 2 * nx + 1
@@ -210,7 +213,10 @@ class SlabPartition:
         g = 1 if rank < size - 1 else 0
         self.fine = SlabLevel(p0, p1, nx, ny, nz, rank * own, own, g)
         self.mesh = self.fine.mesh
-        self.dofmap = dm = TaylorHoodDofMap(self.mesh)
+        if size == 1:      # no halos to keep contiguous: the numbering is free (NSFEM_P2_ORDER)
+            from fem_mesh import preferred_p2_order
+            self.mesh.structured = (tuple(p0), tuple(p1), nx, ny, nz)
+        self.dofmap = dm = TaylorHoodDofMap(self.mesh, reorder=preferred_p2_order(3) if size == 1 else True)
         w2 = (2 * nx + 1) * (2 * ny + 1)
         self.w2 = w2
         planes = 2 * self.fine.rows + 1

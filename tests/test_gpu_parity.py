@@ -792,3 +792,69 @@ def test_n512_production_solver_options_match_the_exact_solver_run():
     # the production settings are the cheaper ones: fewer Krylov iterations in total
     assert sum(i[1] for i in its_fast) < sum(i[1] for i in its_ref)
     ctx.close()
+
+
+@pytest.mark.parametrize("dim,n", [(2, 96), (3, 16)])
+def test_sell_kernel_on_parity_numbering_equals_csr_kernel_on_lattice_numbering(dim, n):
+    """NSFEM_SELL=2 (read when the first pattern is built -- this test runs in a child process; the
+    default, 1, uses the kernel for tetrahedral P2 operators only): with the parity-class numbering
+    of structured meshes
+    (TaylorHoodDofMap(reorder="parity")) the scalar P2 / P1 operators use the SELL-64 SpMV kernel
+    (k_spmv_sell: one wavefront per 64 rows, coalesced x gather); the lexicographic numbering keeps
+    the CSR-stream kernel.  Same mesh, same problem, both numberings: products against the exported
+    CSR matrices, then multigrid-preconditioned IPCS steps (every epilogue of the kernel: store,
+    residual, Chebyshev smoothing step, masked rows) -- the fields agree node by node to solver
+    tolerance."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NSFEM_SELL") != "2":            # 2: SELL on every qualifying pattern (2D too)
+        env = dict(os.environ, NSFEM_SELL="2")
+        here = os.path.abspath(__file__)
+        node = "%s::test_sell_kernel_on_parity_numbering_equals_csr_kernel_on_lattice_numbering[%d-%d]" % (here, dim, n)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", node],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "1 passed" in r.stdout
+        return
+    from fem_mesh import TaylorHoodDofMap, box_mesh, rectangle_mesh
+    from multigrid import attach_hierarchy
+    mesh = rectangle_mesh((0.0, 0.0), (1.0, 1.0), n, n) if dim == 2 else box_mesh((0, 0, 0), (1, 1, 1), n, n, n)
+    rng = np.random.default_rng(7)
+    out = {}
+    for mode in ("parity", True):
+        dm = TaylorHoodDofMap(mesh, reorder=mode)
+        ctx = context(mesh, dm)
+        for op in (nat.OP_MASS_P2, nat.OP_STIFF_P2, nat.OP_STIFF_P1):
+            A = ctx.operator_csr(op)
+            x = rng.standard_normal(A.shape[1])
+            assert rel(ctx.operator_apply(op, x), A @ x) < 1e-13
+        attach_hierarchy(ctx, mesh, coarsest=4 if dim == 2 else 2)
+        X = dm.p2_coords
+        on = np.zeros(dm.n_p2, bool)
+        for a in range(dim):
+            on |= (np.abs(X[:, a]) < 1e-12) | (np.abs(X[:, a] - 1.0) < 1e-12)
+        nodes = np.nonzero(on)[0]
+        lid = np.abs(X[nodes, dim - 1] - 1.0) < 1e-12
+        dofs = np.concatenate([dim * nodes + a for a in range(dim)]).astype(np.int32)
+        vals = np.concatenate([np.where(lid, 1.0, 0.0)] + [np.zeros(nodes.size)] * (dim - 1))
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, dofs, vals)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        opts.momentum.precond = opts.poisson.precond = 1
+        opts.correction.precond = 2
+        its = []
+        for step in range(3):
+            ctx.set_bdf(fo.bdf_alpha(step, 1.0), 0.5 / n)
+            info = ctx.step_ipcs(opts)
+            its.append((info.newton_iterations, info.krylov_iterations_momentum, info.krylov_iterations_poisson))
+            ctx.advance(0)
+        # node-by-node comparison through the coordinates (the numberings differ)
+        key = np.lexsort(tuple(np.round(X[:, a] * 4 * n).astype(np.int64) for a in range(dim)))
+        out[mode] = (ctx.get_state(nat.U1).reshape(-1, dim)[key], ctx.get_state(nat.P_OLD), its)
+        ctx.close()
+    (ua, pa, ia), (ub, pb, ib) = out["parity"], out[True]
+    assert rel(ua, ub) < 1e-9 and rel(pa - pa.mean(), pb - pb.mean()) < 1e-8
+    for a, b in zip(ia, ib):
+        assert a[0] == b[0] and abs(a[1] - b[1]) <= 1 and abs(a[2] - b[2]) <= 1

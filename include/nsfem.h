@@ -16,8 +16,9 @@
  *   - one context per process x device, one HIP stream per context; calls on a
  *     context are not re-entrant (the reference is single threaded).
  *   - all floating point data is fp64, all indices int32.
- *   - velocity vectors are node-interleaved: index = 2 * p2_node + component;
- *     "mixed" vectors are [velocity (2*n_p2) | pressure (n_p1)].
+ *   - dim = 2 (triangles) or 3 (tetrahedra); velocity vectors are node-interleaved:
+ *     index = dim * p2_node + component; "mixed" vectors are
+ *     [velocity (dim * n_p2) | pressure (n_p1)].
  */
 #ifndef NSFEM_H
 #define NSFEM_H
@@ -40,29 +41,32 @@ enum nsfem_status {
 };
 
 /* Mesh + dof maps: what dolfin.Mesh / FunctionSpace(mesh, P2^d x P1) hold in the
- * reference (source/ns_solver_base.py:501-524).  Triangles only (dim = 2). */
+ * reference (source/ns_solver_base.py:501-524).  Affine simplices: triangles (dim = 2) or
+ * tetrahedra (dim = 3); local P2 order = vertices, then the edge midpoints in UFC edge order
+ * (triangle: e(v1v2), e(v0v2), e(v0v1); tetrahedron: e(v2v3), e(v1v3), e(v1v2), e(v0v3), e(v0v2),
+ * e(v0v1)). */
 typedef struct {
-  int32_t dim;               /* 2                                             */
+  int32_t dim;               /* 2 or 3                                        */
   int32_t n_cells;
   int32_t n_vertices;
   int32_t n_p2;              /* scalar P2 nodes                               */
   int32_t n_p1;              /* P1 nodes                                      */
   const double* coords;      /* [n_vertices * dim]                            */
-  const int32_t* cells;      /* [n_cells * 3] vertex ids                      */
-  const int32_t* p2_dofmap;  /* [n_cells * 6] (v0,v1,v2,e12,e02,e01)          */
-  const int32_t* p1_dofmap;  /* [n_cells * 3]                                 */
+  const int32_t* cells;      /* [n_cells * (dim + 1)] vertex ids              */
+  const int32_t* p2_dofmap;  /* [n_cells * 6 | 10]                            */
+  const int32_t* p1_dofmap;  /* [n_cells * (dim + 1)]                         */
 } nsfem_mesh_desc;
 
 /* state slots (device-resident vectors) */
 enum nsfem_slot {
-  NSFEM_U0 = 0,      /* velocity at t_{n+1}   (IPCS _velocities[0])   [2*n_p2] */
+  NSFEM_U0 = 0,      /* velocity at t_{n+1}   (IPCS _velocities[0]) [dim*n_p2] */
   NSFEM_U1 = 1,      /* velocity at t_n                                       */
   NSFEM_U2 = 2,      /* velocity at t_{n-1}                                   */
   NSFEM_USTAR = 3,   /* IPCS _intermediate_velocity                           */
   NSFEM_P = 4,       /* pressure                                    [n_p1]    */
   NSFEM_P_OLD = 5,   /* IPCS _old_pressure / BDF pressure at t_n              */
-  NSFEM_BODY_FORCE = 6, /* nodal P2 interpolant of f               [2*n_p2]   */
-  NSFEM_TRACTION = 7,   /* assembled boundary traction vector      [2*n_p2]   */
+  NSFEM_BODY_FORCE = 6, /* nodal P2 interpolant of f             [dim*n_p2]   */
+  NSFEM_TRACTION = 7,   /* assembled boundary traction vector    [dim*n_p2]   */
   NSFEM_P2_OLD = 8,  /* BDF: pressure at t_{n-1} (keeps _solutions[2] whole)  */
   NSFEM_N_SLOTS = 9
 };
@@ -82,9 +86,9 @@ enum nsfem_operator {
   NSFEM_OP_STIFF_P2 = 1,     /* scalar P2 stiffness                           */
   NSFEM_OP_STIFF_P1 = 2,     /* (grad p, grad q)  ns_ipcs_solver.py:160       */
   NSFEM_OP_MASS_P1 = 3,
-  NSFEM_OP_DIV = 4,          /* (div u, q)       n_p1 x 2 n_p2                */
-  NSFEM_OP_GRAD = 5,         /* (grad p, w)      2 n_p2 x n_p1                */
-  NSFEM_OP_DIVT = 6,         /* (p, div w)       2 n_p2 x n_p1                */
+  NSFEM_OP_DIV = 4,          /* (div u, q)       n_p1 x dim n_p2              */
+  NSFEM_OP_GRAD = 5,         /* (grad p, w)      dim n_p2 x n_p1              */
+  NSFEM_OP_DIVT = 6,         /* (p, div w)       dim n_p2 x n_p1              */
   NSFEM_OP_MOMENTUM_JAC = 7, /* IPCS/BDF velocity block of the Newton matrix  */
   NSFEM_OP_VISCOUS_EXTRA = 8, /* traction-form extra block (grad u^T : grad v) */
   NSFEM_OP_MOMENTUM_JAC_MF = 9, /* nsfem_operator_apply only: matrix-free velocity Jacobian */
@@ -211,15 +215,15 @@ int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y);
  * library integrates the coarse operators on the device, adds the P2 <- P1 transfer of
  * the fine mesh itself and builds two V-cycle preconditioners: pressure Poisson and
  * alpha0/k M + c_v K.  Selected per solve with nsfem_krylov_opts.precond = 1. */
-/* contiguous halo ranges of a strip partition, in node units (offset, count) */
+/* contiguous halo ranges of a strip (2D) / slab (3D) partition, in node units (offset, count) */
 typedef struct {
   int64_t send_up_off, send_up_cnt, recv_above_off, recv_above_cnt;
   int64_t send_down_off, send_down_cnt, recv_below_off, recv_below_cnt;
 } nsfem_halo;
 typedef struct {
   int32_t n_vertices, n_cells;
-  const double* coords;      /* [n_vertices * 2] */
-  const int32_t* cells;      /* [n_cells * 3]    */
+  const double* coords;      /* [n_vertices * dim]     */
+  const int32_t* cells;      /* [n_cells * (dim + 1)]  */
   int32_t n_fine;
   const int32_t* p_rowptr;   /* [n_fine + 1]     */
   const int32_t* p_col;

@@ -169,7 +169,7 @@ void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, doub
                  const uint8_t* rowmask, int maskmode, int ghost = 0, int phase = 0);
 // y = b - A x  (same arguments + b)
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
-                     const double* b, double* y, const uint8_t* rowmask, int maskmode);
+                     const double* b, double* y, const uint8_t* rowmask, int maskmode, int phase = 0);
 
 // y += A x (masked rows -> 0);  Chebyshev/Jacobi smoother step
 //   d = c1 d + c2 dinv (b - A x) ; xout = x + d   (masked rows -> 0)

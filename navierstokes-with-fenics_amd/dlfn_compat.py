@@ -11,6 +11,9 @@ import math
 
 import numpy as np
 
+from form_language import (FacetNormal, Measure, Operand, assemble, dot, ds, dx, grad, inner,  # noqa: F401
+                           sqrt)
+
 pi = math.pi
 DOLFIN_EPS = 3.0e-16
 _LOG_LEVEL = [20]
@@ -29,7 +32,7 @@ def near(a, b, eps=DOLFIN_EPS):
     return np.abs(np.asarray(a) - b) < eps
 
 
-class Constant:
+class Constant(Operand):
     def __init__(self, value, name=None):
         self._v = np.atleast_1d(np.asarray(value, dtype=np.float64)).copy()
         self._scalar = np.ndim(value) == 0
@@ -69,64 +72,131 @@ _NAMESPACE = dict(where=np.where, sin=np.sin, cos=np.cos, tan=np.tan, exp=np.exp
                   DOLFIN_EPS=DOLFIN_EPS)
 
 
+_NAMESPACE.update(logical_and=np.logical_and, logical_or=np.logical_or, logical_not=np.logical_not)
+
+
+def _c_int_div(a, b):
+    """C++ division of two integer operands truncates toward zero"""
+    return int(a / b) if isinstance(a, (int, np.integer)) and isinstance(b, (int, np.integer)) else a / b
+
+
+_NAMESPACE["c_int_div"] = _c_int_div
+
+_BINARY = {"||": 1, "&&": 2, "==": 3, "!=": 3, "<": 4, ">": 4, "<=": 4, ">=": 4, "+": 5, "-": 5,
+           "*": 6, "/": 6, "%": 6}
+
+
+def _tokenize(code):
+    import re
+    token = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+|\d+)"
+                       r"|([A-Za-z_][A-Za-z_0-9]*(?:::[A-Za-z_][A-Za-z_0-9]*)*)|(\|\||&&|==|!=|<=|>=|[-+*/%<>!?:(),\[\]]))")
+    pos, out = 0, []
+    code = code.strip()
+    while pos < len(code):
+        m = token.match(code, pos)
+        if not m or m.end() == pos:
+            raise SyntaxError("cannot parse the expression at: %r" % code[pos:pos + 20])
+        num, name, op = m.groups()
+        out.append(("num", num) if num else ("name", name.split("::")[-1]) if name else ("op", op))
+        pos = m.end()
+    return out
+
+
 def _cpp_to_python(code):
-    """C++ expression -> numpy-evaluable Python: ``std::`` dropped, ``&&``/``||``/``!`` mapped to
-    elementwise logic, and the conditional operator ``c ? a : b`` (right-associative, lowest
-    precedence) rewritten as ``where(c, a, b)`` inside every parenthesis level."""
-    code = code.replace("std::", "").replace("&&", " & ").replace("||", " | ")
+    """C++ expression string -> numpy-evaluable Python source.  A small precedence parser (instead
+    of textual replacement): ``a && b`` / ``a || b`` / ``!a`` become logical_and / logical_or /
+    logical_not CALLS (Python's ``&`` / ``|`` bind tighter than comparisons), the conditional
+    operator ``c ? a : b`` (right-associative, lowest precedence) becomes ``where(c, a, b)``, a
+    quotient of two integer-valued operands truncates like C++ (``1/2*x[0]`` is 0), ``std::`` is
+    dropped."""
+    toks = _tokenize(code)
+    pos = [0]
 
-    def ternary(expr):
-        depth, q = 0, -1
-        for i, ch in enumerate(expr):
-            depth += ch in "([" 
-            depth -= ch in ")]"
-            if ch == "?" and depth == 0:
-                q = i
-                break
-        if q < 0:
-            return expr
-        depth, nested = 0, 0
-        for j in range(q + 1, len(expr)):
-            ch = expr[j]
-            depth += ch in "(["
-            depth -= ch in ")]"
-            if depth == 0 and ch == "?":
-                nested += 1
-            elif depth == 0 and ch == ":":
-                if nested == 0:
-                    return "where(%s, %s, %s)" % (expr[:q], ternary(expr[q + 1:j]), ternary(expr[j + 1:]))
-                nested -= 1
-        raise SyntaxError("unbalanced conditional operator in expression: " + expr)
+    def peek():
+        return toks[pos[0]] if pos[0] < len(toks) else ("end", "")
 
-    def walk(expr):                      # rewrite innermost parentheses first
-        out, i = "", 0
-        while i < len(expr):
-            if expr[i] == "(":
-                depth, j = 1, i + 1
-                while depth:
-                    depth += expr[j] == "("
-                    depth -= expr[j] == ")"
-                    j += 1
-                inner = expr[i + 1:j - 1]
-                parts, d, start = [], 0, 0          # split arguments at top-level commas
-                for k, ch in enumerate(inner):
-                    d += ch in "(["
-                    d -= ch in ")]"
-                    if ch == "," and d == 0:
-                        parts.append(inner[start:k])
-                        start = k + 1
-                parts.append(inner[start:])
-                out += "(" + ",".join(ternary(walk(a)) for a in parts) + ")"
-                i = j
+    def take(kind=None, value=None):
+        t = peek()
+        if (kind and t[0] != kind) or (value and t[1] != value):
+            raise SyntaxError("unexpected %r in expression %r" % (t[1], code))
+        pos[0] += 1
+        return t
+
+    def primary():                               # -> (source, is_integer)
+        kind, val = peek()
+        if kind == "num":
+            take()
+            return val, val.isdigit()
+        if kind == "name":
+            take()
+            src = val
+            while peek() == ("op", "(") or peek() == ("op", "["):
+                if peek()[1] == "(":
+                    take()
+                    args = []
+                    if peek() != ("op", ")"):
+                        args.append(ternary()[0])
+                        while peek() == ("op", ","):
+                            take()
+                            args.append(ternary()[0])
+                    take("op", ")")
+                    src = "%s(%s)" % (src, ", ".join(args))
+                else:
+                    take()
+                    idx = ternary()[0]
+                    take("op", "]")
+                    src = "%s[%s]" % (src, idx)
+            return src, False
+        if (kind, val) == ("op", "("):
+            take()
+            inner, is_int = ternary()
+            take("op", ")")
+            return "(%s)" % inner, is_int
+        raise SyntaxError("unexpected %r in expression %r" % (val, code))
+
+    def unary():
+        kind, val = peek()
+        if kind == "op" and val in "+-":
+            take()
+            operand, is_int = unary()
+            return "(%s%s)" % (val, operand), is_int
+        if (kind, val) == ("op", "!"):
+            take()
+            return "logical_not(%s)" % unary()[0], False
+        return primary()
+
+    def binary(min_prec):
+        left, lint = unary()
+        while peek()[0] == "op" and peek()[1] in _BINARY and _BINARY[peek()[1]] >= min_prec:
+            op = take()[1]
+            right, rint = binary(_BINARY[op] + 1)
+            if op == "&&":
+                left, lint = "logical_and(%s, %s)" % (left, right), False
+            elif op == "||":
+                left, lint = "logical_or(%s, %s)" % (left, right), False
+            elif op == "/" and lint and rint:
+                left, lint = "c_int_div(%s, %s)" % (left, right), True
             else:
-                out += expr[i]
-                i += 1
-        return out
+                left, lint = "(%s %s %s)" % (left, op, right), lint and rint and op in "+-*%"
+        return left, lint
 
-    return ternary(walk(code)).strip()
+    def ternary():
+        cond, cint = binary(1)
+        if peek() == ("op", "?"):
+            take()
+            a, _ = ternary()
+            take("op", ":")
+            b, _ = ternary()
+            return "where(%s, %s, %s)" % (cond, a, b), False
+        return cond, cint
+
+    src, _ = ternary()
+    if pos[0] != len(toks):
+        raise SyntaxError("unexpected %r in expression %r" % (peek()[1], code))
+    return src
 
 
-class Expression:
+class Expression(Operand):
     """``Expression("cpp string" | (strings...), degree=k, **parameters)``.
 
     Parameters become attributes and may be re-assigned (``expr.t = 0.3``), which is
@@ -153,6 +223,11 @@ class Expression:
         else:
             object.__setattr__(self, key, value)
 
+    @property
+    def T(self):                         # a parameter called T wins over the transpose of the mix-in
+        params = object.__getattribute__(self, "_params")
+        return params["T"] if "T" in params else Operand.T.fget(self)
+
     def value_rank(self):
         return 0 if self._scalar else 1
 
@@ -172,7 +247,7 @@ class Expression:
         return cols[0].copy() if self._scalar else np.stack(cols, axis=1)
 
 
-class UserExpression:
+class UserExpression(Operand):
     """Python-callable expression: subclass and implement ``eval(values, x)`` and
     ``value_shape()`` as in dolfin."""
 
@@ -221,12 +296,34 @@ def evaluate(value, X):
     return np.tile(arr, (X.shape[0], 1))
 
 
+def FunctionSpace(*args, **kwargs):
+    """``FunctionSpace(dofmap, kind)`` of fem_spaces, or dolfin's ``FunctionSpace(mesh, "CG", k)``
+    (target of ``project`` in the reference's post-processing hooks)"""
+    import fem_spaces
+    import form_language
+    if len(args) >= 2 and isinstance(args[1], str) and hasattr(args[0], "num_cells"):
+        return form_language.LagrangeSpaceRequest(args[0], args[1], args[2] if len(args) > 2 else kwargs.get("degree", 1))
+    return fem_spaces.FunctionSpace(*args, **kwargs)
+
+
+def project(value, space, function=None):
+    """``dolfin.project``: onto the solver's spaces (fem_spaces.project: constants and functions the
+    space reproduces) or, for a form expression and ``FunctionSpace(mesh, "CG", 1)``, the L2
+    projection with the mass solve on the device"""
+    import fem_spaces
+    import form_language
+    if isinstance(space, form_language.LagrangeSpaceRequest):
+        assert function is None
+        return form_language.project_expression(value, space)
+    return fem_spaces.project(value, space, function)
+
+
 def __getattr__(name):
-    # dolfin.Function / FunctionSpace / project stand-ins live in fem_spaces (imported lazily:
-    # fem_spaces itself evaluates values through this module)
-    if name in ("Function", "FunctionSpace", "project"):
+    # the dolfin.Function stand-in lives in fem_spaces (imported lazily: fem_spaces itself evaluates
+    # values through this module)
+    if name == "Function":
         import fem_spaces
-        return getattr(fem_spaces, name)
+        return fem_spaces.Function
     raise AttributeError(name)
 
 

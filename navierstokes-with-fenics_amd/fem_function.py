@@ -7,8 +7,10 @@ source/ns_ipcs_solver.py:241-247).  Here the values live in HBM inside the
 """
 import numpy as np
 
+from form_language import Operand
 
-class DeviceFunction:
+
+class DeviceFunction(Operand):
     """One field (velocity: node-interleaved P2^2, or pressure: P1) in one state slot."""
 
     def __init__(self, solver, field, slot, name=None):

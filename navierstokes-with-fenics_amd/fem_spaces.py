@@ -16,6 +16,8 @@ on plain numpy storage:
 """
 import numpy as np
 
+from form_language import Operand
+
 _KINDS = ("mixed", "velocity", "pressure")
 
 
@@ -81,7 +83,7 @@ class FunctionSpace:
         return space is not None and space() is self
 
 
-class Function:
+class Function(Operand):
     def __init__(self, space, values=None, name=None):
         assert isinstance(space, FunctionSpace)
         self._space = space

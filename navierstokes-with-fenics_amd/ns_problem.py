@@ -105,6 +105,22 @@ class ProblemBase:
                 bc_map[bc[0]] = tuple(sorted(set(bc_map.get(bc[0], ())) | {bc[1]}))
         return bc_map
 
+    def _compute_boundary_force(self, boundary_id, symmetric_gradient_factor=0.5):
+        """Surface force  int ( -p n + c_v f (grad u + grad u^T) n ) dS  over the boundary part
+        ``boundary_id`` (n = outward normal of the fluid domain, c_v = viscous coefficient, f =
+        ``symmetric_gradient_factor``: 1/2 reproduces the traction of the reference's
+        demo/dfg_benchmark.py:54-61, 1 the Newtonian stress) -- one device kernel
+        (nsfem_boundary_force) instead of a dolfin ``assemble(... * ds(id))``.  New helper; the
+        reference's callers spell this out in UFL, which ``dlfn.assemble`` evaluates as well."""
+        import _native as nat
+        solver = self._get_solver()
+        facets = self._boundary_markers.facets_with_id(boundary_id)
+        facets = facets[self._mesh.facet_on_boundary[facets]]
+        cells, local = self._mesh.facet_cell_local(facets)
+        nu = float(solver._equation_coefficients["viscous_term"]) * float(symmetric_gradient_factor)
+        force, _, _ = solver._ctx.boundary_force(cells, local, nu, 1.0, nat.U0, nat.P)
+        return tuple(float(v) for v in force)
+
     def _compute_stream_potential(self):
         """Velocity potential phi (the reference's "stream potential", :105-176): P1 solution of
         (grad phi, grad psi) = (div u, psi) - sum over the remaining boundaries of (n . u, psi),

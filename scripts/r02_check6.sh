@@ -1,0 +1,10 @@
+#!/bin/bash
+set -o pipefail
+O=$(pwd)/gpurun_out/r02n
+mkdir -p $O
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?" | tee -a $O/summary.txt
+tail -3 $O/gpu_tests.log
+timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" | tee -a $O/summary.txt
+timeout -k 10 300 python bench.py --workload tgv3d-ipcs --cells 64 --steps 10 --warmup 3 > $O/tgv64.json 2> $O/tgv64.err; echo "tgv rc=$?" | tee -a $O/summary.txt
+timeout -k 10 300 python bench.py --workload dfg-bdf --steps 10 --warmup 3 > $O/dfg.json 2> $O/dfg.err; echo "dfg rc=$?" | tee -a $O/summary.txt
+python scripts/show_bench.py $O/*.json

@@ -25,7 +25,8 @@ Spec keys (all optional except ``mesh`` and ``bcs``):
   clock          dict(t0, t1, dt, steps)
   scheme         "ipcs" | "bdf"
   convection     weak form of the convective term
-  output, postprocessing   frequencies; ``fields``: derived fields added in postprocess_solution
+  output, postprocessing   frequencies; ``fields``: derived fields added in postprocess_solution;
+                 ``hook``: callable(problem) run at the end of postprocess_solution
 An expr is ``(strings, params, degree)`` -- C++ expression strings as dolfin.Expression takes them.
 """
 import numpy as np
@@ -201,10 +202,12 @@ def build_problem(spec):
         def set_internal_constraints(self):
             self._internal_constraints = _bc_rows(spec["internal"], self._sides)
         TableProblem.set_internal_constraints = set_internal_constraints
-    if spec.get("fields"):
+    if spec.get("fields") or spec.get("hook"):
         def postprocess_solution(self):
-            for name in spec["fields"]:
+            for name in spec.get("fields", ()):
                 self._add_to_field_output(getattr(self, "_compute_" + name)())
+            if spec.get("hook"):
+                spec["hook"](self)
         TableProblem.postprocess_solution = postprocess_solution
     return TableProblem()
 

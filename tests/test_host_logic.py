@@ -509,3 +509,70 @@ def test_dolfin_shim_and_loud_failure_without_a_device():
     else:
         assert res.returncode != 0 and "no ROCm-capable device" in res.stderr and \
             "nonlinear solve failed" not in res.stderr
+
+
+def test_cpp_expression_strings_follow_cpp_semantics():
+    """dolfin compiles Expression strings as C++: ``&&`` / ``||`` / ``!`` are logical operators with
+    lower precedence than comparisons, ``c ? a : b`` nests to the right, and a quotient of two
+    integer literals truncates (``1/2*x[0]`` is zero)."""
+    import dlfn_compat as dlfn
+    X = np.array([[0.2, 0.3], [0.7, 0.2], [0.9, 0.9]])
+    cases = {
+        "x[0] > 0.5 && x[1] < 0.5 ? 1 : 0": [0.0, 1.0, 0.0],
+        "!(x[0] > 0.5) ? 2.0 : -1.0": [2.0, -1.0, -1.0],
+        "x[0] < 0.3 || x[1] > 0.8 ? 1.0 : (x[0] > 0.6 ? 2.0 : 3.0)": [1.0, 2.0, 1.0],
+        "1/2*x[0]": [0.0, 0.0, 0.0],
+        "7 / 2 * x[0]": [0.6, 2.1, 2.7],
+        "1.0/2*x[0]": [0.1, 0.35, 0.45],
+        "std::pow(x[0], 2) + fabs(-x[1])": [0.34, 0.69, 1.71],
+        "x[1]*omega* ( (t >= t_acc) ? 1.0: t / t_acc)": [0.075, 0.05, 0.225],
+        "-1.0/4.0 * x[0]": [-0.05, -0.175, -0.225],
+        "1e-3*x[0] + 2.5E2": [250.0002, 250.0007, 250.0009],
+    }
+    for code, expect in cases.items():
+        e = dlfn.Expression(code, degree=2, omega=1.0, t_acc=1.0, t=0.25)
+        assert np.allclose(e.eval_at(X), expect, rtol=0, atol=1e-14), code
+    e = dlfn.Expression(("x[0] >= 0.5 && x[1] >= 0.5 ? 1.0 : 0.0", "0.0"), degree=1)
+    assert e.eval_at(X).tolist() == [[0.0, 0.0], [0.0, 0.0], [1.0, 0.0]]
+    with pytest.raises(SyntaxError):
+        dlfn.Expression("x[0] +* 2", degree=1)
+    with pytest.raises(SyntaxError):
+        dlfn.Expression("x[0] ? 1.0", degree=1)
+
+
+def test_form_language_functionals_on_host_functions():
+    """The slice of dolfin's form language the reference's post-processing hooks use (FacetNormal,
+    Measure / ds / dx, grad, .T, dot, indexing, assemble) on host Functions of the solver spaces:
+    polynomial fields on the unit square / cube against values integrated by hand (Gauss' theorem)."""
+    import dlfn_compat as dlfn
+    import fem_spaces
+    from fem_mesh import TaylorHoodDofMap
+    from grid_generator import hyper_cube
+    for dim, n in ((2, 3), (3, 2)):
+        mesh, marks = hyper_cube(dim, n)
+        dm = TaylorHoodDofMap(mesh)
+        w = fem_spaces.Function(fem_spaces.FunctionSpace(dm, "mixed"))
+        X, Y = dm.p2_coords, dm.p1_coords
+        if dim == 2:
+            u = np.stack([X[:, 0] ** 2 + X[:, 1], X[:, 0] * X[:, 1]], axis=1)
+            force, flux, kinetic = [-0.5, 1.0], 1.5, 0.5 * (1 / 5 + 1 / 3 + 1 / 3 + 1 / 9)
+        else:
+            u = np.stack([X[:, 0] ** 2 + X[:, 1], X[:, 0] * X[:, 2], X[:, 2] ** 2 - X[:, 1]], axis=1)
+            force, flux, kinetic = [-0.8, 1.0, 1.2], 2.0, None
+        w.vector()[: dm.n_velocity] = u.ravel()
+        w.vector()[dm.n_velocity:] = 1.0 + 2.0 * Y[:, 0] - Y[:, 1]
+        vel, p = w.split()
+        nrm = dlfn.FacetNormal(mesh)
+        dA = dlfn.Measure("ds", domain=mesh, subdomain_data=marks)
+        assert abs(dlfn.assemble(dlfn.dot(nrm, vel) * dA) - flux) < 1e-13
+        d = dlfn.Constant(0.5) * (dlfn.grad(vel) + dlfn.grad(vel).T)
+        traction = -p * nrm + 0.6 * dlfn.dot(d, nrm)
+        assert np.allclose([dlfn.assemble(traction[i] * dA) for i in range(dim)], force, atol=1e-13)
+        assert abs(dlfn.assemble(dlfn.Constant(1.0) * dA(1)) - 1.0) < 1e-14          # one side of the box
+        assert abs(dlfn.assemble(dlfn.Constant(1.0) * dlfn.ds(domain=mesh)) - 2.0 * dim) < 1e-13
+        if kinetic is not None:
+            assert abs(dlfn.assemble(dlfn.Constant(0.5) * dlfn.dot(vel, vel) * dlfn.dx(domain=mesh)) - kinetic) < 1e-14
+        # position-dependent coefficients and powers: int x_0^2 p dx
+        xe = dlfn.Expression("x[0]", degree=1)
+        val = dlfn.assemble(xe ** 2 * p * dlfn.dx(domain=mesh))
+        assert abs(val - (1 / 3 + 2 / 4 - 0.5 / 3)) < 1e-14

@@ -557,6 +557,85 @@ def test_open_outlet_schur_laplacian_algebraic_vs_geometric():
         assert close(a, b, 1e-7)
 
 
+def test_dfg_drag_and_lift_through_the_form_language():
+    """What the reference's demo/dfg_benchmark.py computes in its post-processing hook -- traction
+    -p n + 1/Re sym(grad u) n integrated over the cylinder with dolfin's form language -- through
+    this package's stand-ins (``dlfn.ds``, ``FacetNormal``, ``grad``, ``.T``, ``dot``, indexing,
+    ``assemble``), against the device kernel nsfem_boundary_force and the oracle's facet integral."""
+    import _native as nat
+    seen = []
+
+    def hook(problem):
+        pressure, velocity = problem._get_pressure(), problem._get_velocity()
+        surface = dlfn.ds(domain=problem._mesh, subdomain_data=problem._boundary_markers,
+                          subdomain_id=problem._sides["cylinder"])
+        n = dlfn.FacetNormal(problem._mesh)
+        strain = dlfn.Constant(0.5) * (dlfn.grad(velocity) + dlfn.grad(velocity).T)
+        t = -pressure * n + 1 / 100.0 * dlfn.dot(strain, n)
+        cd, cl = 2.0 * dlfn.assemble(-t[0] * surface), 2.0 * dlfn.assemble(-t[1] * surface)
+        # the same functional from the device kernel, its wrapper on the problem class and the oracle
+        solver = problem._get_solver()
+        mesh = problem._mesh
+        facets = problem._boundary_markers.facets_with_id(problem._sides["cylinder"])
+        fc, fl = mesh.facet_cell_local(facets)
+        force, _, perimeter = solver._ctx.boundary_force(fc, fl, 0.5 / 100.0, 1.0, nat.U0, nat.P)
+        wrapped = problem._compute_boundary_force(problem._sides["cylinder"], symmetric_gradient_factor=0.5)
+        f_o, _, perim_o = fo.boundary_functionals(oracle_space(solver), mesh.facets[facets], mesh.facet_cell[facets],
+                                                  velocity.vector(), pressure.vector(), 0.5 / 100.0, 1.0)
+        seen.append((cd, cl, force, wrapped, f_o, perimeter, perim_o))
+
+    spec = CASES["dfg"](m=2, refine=2, steps=4)
+    spec.update(postprocessing=2, hook=hook)
+    problem = build_problem(spec)
+    problem.solve_problem()
+    assert len(seen) == 2
+    for cd, cl, force, wrapped, f_o, perimeter, perim_o in seen:
+        scale = max(abs(cd), abs(cl))
+        assert abs(cd + 2.0 * force[0]) < 1e-11 * scale and abs(cl + 2.0 * force[1]) < 1e-11 * scale
+        assert np.abs(np.asarray(wrapped) - force).max() == 0.0
+        assert np.abs(force - f_o).max() < 1e-12 * np.abs(f_o).max() and abs(perimeter - perim_o) < 1e-13
+        assert cd > 0.5                   # impulsively started flow: large positive drag
+
+
+def test_bernoulli_potential_projection_and_mass_flux_through_the_form_language():
+    """The post-processing of the reference's gravity-driven test problem
+    (tests/test_stationary_solvers.py:84-110): Bernoulli potential 1/2 u.u + p + g.x / Fr^2 projected
+    on CG1 (mass solve on the device) and the total mass flux dot(n, u) ds -- checked against the
+    hydrostatic state (u = 0: the potential is p + g.x / Fr^2, exactly P1) and Gauss' theorem."""
+    out = {}
+
+    def hook(problem):
+        pressure, velocity = problem._get_pressure(), problem._get_velocity()
+        position = dlfn.Expression(("x[0]", "x[1]"), degree=1)
+        potential_energy = dlfn.dot(problem._body_force, position)
+        phi = dlfn.Constant(0.5) * dlfn.dot(velocity, velocity)
+        phi += pressure + potential_energy / dlfn.Constant(problem._coefficient_handler.Fr) ** 2
+        field = dlfn.project(phi, dlfn.FunctionSpace(problem._mesh, "CG", 1))
+        field.rename("Bernoulli potential", "")
+        problem._add_to_field_output(field)
+        normal = dlfn.FacetNormal(problem._mesh)
+        dA = dlfn.Measure("ds", domain=problem._mesh, subdomain_data=problem._boundary_markers)
+        out["flux"] = dlfn.assemble(dlfn.dot(normal, velocity) * dA)
+        out["field"] = field
+
+    spec = CASES["stationary_gravity_box"]()
+    spec["hook"] = hook
+    problem = build_problem(spec)
+    problem.solve_problem()
+    solver = problem._get_solver()
+    dm = solver._dofmap
+    u, p = solver.solution.split()
+    import _native as nat
+    assert abs(out["flux"] - solver._ctx.operator_apply(nat.OP_DIV, u.vector()).sum()) < 1e-10
+    # nodal check of the projection: the integrand is (numerically) P1 up to the tiny velocity part
+    X1 = dm.p1_coords
+    uv = u.nodal_values()
+    expect = p.vector() + (-X1[:, 1]) / 100.0
+    vals = out["field"].values
+    assert vals.shape == (problem._mesh.num_vertices(), )
+    assert np.abs(vals - expect[dm.p1_vertex_node]).max() < 1e-8 + 0.51 * np.abs(uv).max() ** 2
+
+
 # ------------------------------------------------------------------------- rotating frames
 def _circular_couette(X, ri, ro):
     r = np.hypot(X[:, 0], X[:, 1])

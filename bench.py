@@ -293,6 +293,7 @@ def tgv3d_bench(args):
     opts.momentum.precond = opts.poisson.precond = 1
     opts.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
     opts.newton_forcing = args.newton_forcing
+    opts.pressure_extrapolation = 1 if args.pressure_start == "extrapolated" else 0
     dt = args.dt if args.dt != 1.0e-3 else 0.25 / n
 
     def one_step(i):
@@ -410,6 +411,7 @@ def cavity3d_bench(args):
     opts.momentum.precond = opts.poisson.precond = 1
     opts.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
     opts.newton_forcing = args.newton_forcing
+    opts.pressure_extrapolation = 1 if args.pressure_start == "extrapolated" else 0
     opts.matrix_free = args.matrix_free
     dt = args.dt if args.dt != 1.0e-3 else 0.5 / n          # CFL ~ 0.5 for the unit lid speed
 
@@ -720,6 +722,7 @@ def cavity_ipcs_bench(args):
         o.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
         o.newton_forcing = args.newton_forcing
         o.matrix_free = args.matrix_free
+        o.pressure_extrapolation = 1 if args.pressure_start == "extrapolated" else 0
         return o
 
     def exact_opts():
@@ -776,6 +779,20 @@ def cavity_ipcs_bench(args):
     elapsed, its, comm_per_step = timed_run(opts)
     steps_per_s = args.steps / elapsed
     u_fast, p_fast = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"metric": "dof_updates_per_sec", "value": steps_per_s * n_dofs, "unit": "DoF-updates/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                              "scaling": "strong" if strong else "weak", "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "cavity-ipcs %dx%d, timed steps only (profiling aid)" % (n, ny_global),
+                                         "newton_its_per_step": float(its[0]), "bicgstab_its_per_step": float(its[1]),
+                                         "poisson_cg_its_per_step": float(its[2])},
+                              "roofline": {"frac": None, "ms_per_launch": None}}))
+        ctx.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     # ---- validation of what was timed: the SAME W + K steps from the same start with
     # direct-solver accuracy (rtol 1e-12, exact Newton, Jacobi-CG mass solve, untruncated cycle);
@@ -942,6 +959,9 @@ def main():
                     help="CPU baseline ladder n:steps,... (cavity cells per side : timed steps); the default "
                          "is ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling aid: only the warm-up and timed steps (no validation rerun, no in-situ / "
+                         "cold-cache kernel timing, no CPU baseline); the JSON line lacks those entries")
     ap.add_argument("--no-multigrid", action="store_true")
     ap.add_argument("--mg-degree", type=int, default=None,
                     help="Chebyshev smoother degree (default: 2 on structured meshes, 3 on the DFG mesh)")
@@ -951,6 +971,8 @@ def main():
                     help="velocity Jacobian in the step driver: 0 auto, 1 assembled, 2 matrix-free")
     ap.add_argument("--mass-solver", choices=("chebyshev", "cg"), default="chebyshev",
                     help="velocity-correction mass solve: Chebyshev with a-priori bounds (no dots) or Jacobi-CG")
+    ap.add_argument("--pressure-start", choices=("extrapolated", "previous"), default="extrapolated",
+                    help="start vector of the projection-step CG: 2 p_n - p_(n-1) or p_n")
     ap.add_argument("--halo-mode", choices=("relaxed", "exact"), default="relaxed",
                     help="N > 1: multigrid smoothing with one halo exchange per smoothing sequence "
                          "(frozen ghosts in between) or per SpMV (the serial algorithm)")

@@ -145,7 +145,10 @@ typedef struct {
   int32_t matrix_free;          /* velocity Jacobian inside the step drivers: 0 auto (= matrix-
                                    free: L x + linearised convection by an element kernel),
                                    1 assembled block CSR, 2 matrix-free                      */
-  int32_t reserved;
+  int32_t pressure_extrapolation; /* IPCS projection step: start the CG iteration from the linear
+                                   extrapolation 2 p_n - p_(n-1) instead of p_n (the reference's direct
+                                   solve has no initial guess; the converged pressure is the same, the
+                                   iteration starts closer to it).  0 = off (default)               */
 } nsfem_step_opts;
 
 #define NSFEM_MAX_NEWTON 64

@@ -61,7 +61,8 @@ class StepOpts(C.Structure):
                 ("newton_max_iter", C.c_int32), ("convective_form", C.c_int32),
                 ("momentum", KrylovOpts), ("poisson", KrylovOpts), ("correction", KrylovOpts),
                 ("picard", C.c_int32), ("allow_nonconvergence", C.c_int32),
-                ("newton_forcing", C.c_double), ("matrix_free", C.c_int32), ("reserved", C.c_int32)]
+                ("newton_forcing", C.c_double), ("matrix_free", C.c_int32),
+                ("pressure_extrapolation", C.c_int32)]
 
 
 class StepInfo(C.Structure):

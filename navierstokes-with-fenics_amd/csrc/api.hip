@@ -383,6 +383,7 @@ extern "C" int nsfem_set_state(nsfem_ctx* ctx, int slot, const double* host, int
   NSFEM_HIP(hipStreamSynchronize(ctx->stream));
   if (slot == NSFEM_BODY_FORCE) ctx->have_body_force = true;
   if (slot == NSFEM_TRACTION) ctx->have_traction = true;
+  if (slot == NSFEM_P || slot == NSFEM_P_OLD || slot == NSFEM_P2_OLD) ctx->pressure_history = 0;
   API_END(ctx)
 }
 
@@ -734,15 +735,18 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
 }
 
 // rhs = A_p p_old - alpha0/k D u* ; start vector p = p_old with Dirichlet values
-static void poisson_assemble(nsfem_ctx* c) {
+static void poisson_assemble(nsfem_ctx* c, bool extrapolate = false) {
   hipStream_t s = c->stream;
   const int64_t np = npre(c);
   launch_spmv(s, c->Ap, 1, c->state[NSFEM_P_OLD].p, c->rhs_p.p, nullptr, MASK_NONE);
   launch_spmv(s, c->Dv, 1, c->state[NSFEM_USTAR].p, c->tmp_p.p, nullptr, MASK_NONE);
   launch_axpby(s, np, 1.0, c->rhs_p.p, -c->alpha[0] / c->k, c->tmp_p.p, c->rhs_p.p);
   if (c->ghost_p.p) launch_zero_ghost(s, np, c->mask_p.p, c->rhs_p.p);
-  NSFEM_HIP(hipMemcpyAsync(c->state[NSFEM_P].p, c->state[NSFEM_P_OLD].p, sizeof(double) * np,
-                           hipMemcpyDeviceToDevice, s));
+  if (extrapolate && c->pressure_history >= 2)       // start vector 2 p_n - p_(n-1)
+    launch_axpby(s, np, 2.0, c->state[NSFEM_P_OLD].p, -1.0, c->state[NSFEM_P2_OLD].p, c->state[NSFEM_P].p);
+  else
+    NSFEM_HIP(hipMemcpyAsync(c->state[NSFEM_P].p, c->state[NSFEM_P_OLD].p, sizeof(double) * np,
+                             hipMemcpyDeviceToDevice, s));
   launch_set_values(s, c->nbc_p, c->bc_p_dofs.p, c->bc_p_vals.p, c->state[NSFEM_P].p);
   if (!c->dinv_p_ready) {
     launch_inv_diag(s, c->Ap, 1, c->mask_p.p, c->dinv_p.p);
@@ -1451,7 +1455,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   if (!converged) throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
   // ---- projection step
   {
-    poisson_assemble(ctx);
+    poisson_assemble(ctx, opts->pressure_extrapolation != 0);
     nsfem_solve_info si;
     int rc = poisson_solve(ctx, hinted(opts->poisson, ctx->hint_poi), si);
     ctx->hint_poi = next_hint(si, opts->poisson);
@@ -1623,8 +1627,11 @@ extern "C" int nsfem_advance(nsfem_ctx* ctx, int scheme) {
   NSFEM_HIP(hipMemcpyAsync(ctx->state[NSFEM_U1].p, ctx->state[NSFEM_U0].p,
                            sizeof(double) * nvel(ctx), hipMemcpyDeviceToDevice, s));
   if (scheme == 0) {
+    // (p_(n-1) is kept for the optional extrapolated start vector of the projection step)
+    std::swap(ctx->state[NSFEM_P2_OLD].p, ctx->state[NSFEM_P_OLD].p);
     NSFEM_HIP(hipMemcpyAsync(ctx->state[NSFEM_P_OLD].p, ctx->state[NSFEM_P].p,
                              sizeof(double) * npre(ctx), hipMemcpyDeviceToDevice, s));
+    if (ctx->pressure_history < 2) ctx->pressure_history++;
   } else {
     std::swap(ctx->state[NSFEM_P2_OLD].p, ctx->state[NSFEM_P_OLD].p);
     NSFEM_HIP(hipMemcpyAsync(ctx->state[NSFEM_P_OLD].p, ctx->state[NSFEM_P].p,

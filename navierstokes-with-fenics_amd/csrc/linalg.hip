@@ -46,6 +46,8 @@ struct SpmvArgs {
                    // (smoother step with frozen ghost values), 2 computed like free rows
   int skip0, skipn; // stream kernel: logical row blocks >= skip0 are shifted by skipn
   int phase;       // 0 all row blocks, 1 interior blocks only, 2 halo-adjacent blocks only
+  double* y2;      // EPI_STORE only, non-null: the first Chebyshev step from a zero start on the vector
+                   // just produced (a restricted residual): d = y2 = c1 * dinv * y  (fused k_cheb_first)
   int ident;       // smoother step: rows flagged 1 take y = b (identity rows of a preconditioner for a
                    // Newton matrix with dolfin-style Dirichlet rows) instead of 0
   int dbg;         // NSFEM_SPMV_DEBUG (measurement experiments only; wrong results): 1 = gather from
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
         a.y[idx] = a.ghost == 1 ? x[idx] : 0.0;
       } else {
         a.y[idx] = 0.0;
+        if (EPI == EPI_STORE && a.y2) a.d[idx] = a.y2[idx] = 0.0;
       }
     } else if (EPI == EPI_RESID) {
       // identity rows: b - x ; zero rows: 0
@@ -141,6 +144,11 @@ __global__ __launch_bounds__(256) void k_spmv(int n_rows, const int32_t* __restr
       if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
       else val *= a.c2;
       a.y[idx] = val;
+      if (a.y2) {
+        const double dn = m ? 0.0 : a.c1 * a.dinv[idx] * val;
+        a.d[idx] = dn;
+        a.y2[idx] = dn;
+      }
     }
   }
 }
@@ -261,6 +269,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream_v1(int n_rblk, const int32_
         a.y[idx] = a.ghost == 1 ? (first ? px : x[idx]) : 0.0;
       } else {
         a.y[idx] = 0.0;
+        if (EPI == EPI_STORE && a.y2) a.d[idx] = a.y2[idx] = 0.0;
       }
     } else if (EPI == EPI_RESID) {
       const double bv = first ? pb : a.b[idx];
@@ -287,6 +296,11 @@ __global__ __launch_bounds__(256) void k_spmv_stream_v1(int n_rblk, const int32_
       if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
       else val *= a.c2;
       a.y[idx] = val;
+      if (a.y2) {
+        const double dn = m ? 0.0 : a.c1 * a.dinv[idx] * val;
+        a.d[idx] = dn;
+        a.y2[idx] = dn;
+      }
     }
   }
 }
@@ -434,6 +448,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int4* __r
         a.y[idx] = a.ghost == 1 ? (first ? px : x[idx]) : 0.0;
       } else {
         a.y[idx] = 0.0;
+        if (EPI == EPI_STORE && a.y2) a.d[idx] = a.y2[idx] = 0.0;
       }
     } else if (EPI == EPI_RESID) {
       const double bv = first ? pb : a.b[idx];
@@ -460,6 +475,11 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int4* __r
       if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
       else val *= a.c2;
       a.y[idx] = val;
+      if (a.y2) {
+        const double dn = m ? 0.0 : a.c1 * a.dinv[idx] * val;
+        a.d[idx] = dn;
+        a.y2[idx] = dn;
+      }
     }
   }
 }
@@ -555,6 +575,7 @@ __global__ __launch_bounds__(256) void k_spmv_sell(int n_rows, int n_slices, int
         a.y[idx] = a.ghost == 1 ? x[idx] : 0.0;
       } else {
         a.y[idx] = 0.0;
+        if (EPI == EPI_STORE && a.y2) a.d[idx] = a.y2[idx] = 0.0;
       }
     } else if (EPI == EPI_RESID) {
       if (m) val = (a.maskmode == MASK_IDENTITY) ? a.b[idx] - x[idx] : 0.0;
@@ -578,6 +599,11 @@ __global__ __launch_bounds__(256) void k_spmv_sell(int n_rows, int n_slices, int
       if (m) val = (a.maskmode == MASK_IDENTITY) ? x[idx] : 0.0;
       else val *= a.c2;
       a.y[idx] = val;
+      if (a.y2) {
+        const double dn = m ? 0.0 : a.c1 * a.dinv[idx] * val;
+        a.d[idx] = dn;
+        a.y2[idx] = dn;
+      }
     }
   }
 }
@@ -922,6 +948,7 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
   a.skipn = 0;
   a.phase = 0;
   a.ident = 0;
+  a.y2 = nullptr;
   static const int dbg = [] {
     const char* e = std::getenv("NSFEM_SPMV_DEBUG");
     return e ? std::atoi(e) : 0;
@@ -935,6 +962,15 @@ void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, doub
   SpmvArgs a = make_args(x, nullptr, y, rowmask, maskmode);
   a.ghost = ghost;
   a.phase = phase;
+  spmv_dispatch<EPI_STORE>(s, A, nv, a);
+}
+// y = A x (rows flagged in rowmask -> 0) and, fused, the first Chebyshev-Jacobi step from a zero
+// start on y:  d = x1 = c2 dinv y
+void launch_spmv_cheb_first(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
+                            const uint8_t* rowmask, const double* dinv, double c2, double* d,
+                            double* x1) {
+  SpmvArgs a = make_args(x, nullptr, y, rowmask, MASK_ZERO);
+  a.dinv = dinv; a.d = d; a.c1 = c2; a.y2 = x1;
   spmv_dispatch<EPI_STORE>(s, A, nv, a);
 }
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,

@@ -426,13 +426,19 @@ void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1
 // `steps` Chebyshev steps on A x = b.  x_in == nullptr: zero initial guess.  The result
 // is written to x_out (which may alias x_in only when steps >= 2).
 void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
-                       double* x_out, int steps, bool ghosts_valid, bool ident_last) {
+                       double* x_out, int steps, bool ghosts_valid, bool ident_last, bool first_done) {
   const int64_t n = (int64_t)L.n * nv;
   double rho = 0.0, c1, c2;
   const double* cur = x_in;
   const bool relaxed = relaxed_halo && comm_active() && L.has_halo;
   bool filled = ghosts_valid && relaxed;
-  for (int k = 0; k < steps; ++k) {
+  int k0 = 0;
+  if (first_done) {                 // step 0 (from zero) came out of the restriction kernel: x1 in L.xa
+    cheb_coeffs(L, 0, 0.0, c1, c2, rho);
+    cur = L.xa.p;
+    k0 = 1;
+  }
+  for (int k = k0; k < steps; ++k) {
     double rho_new;
     cheb_coeffs(L, k, rho, c1, c2, rho_new);
     rho = rho_new;
@@ -485,11 +491,32 @@ void Multigrid::halo_fill(hipStream_t s, const MGLevel& L, const double* v) {
   if (comm_active() && L.has_halo) comm->exchange(s, L.halo, const_cast<double*>(v), nv);
 }
 
-void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
+// does level l begin its work with a smoothing sequence from a zero start vector?
+bool Multigrid::starts_from_zero(size_t l) const {
+  if (truncated() && l + 1 == active) return true;
+  if (l + 1 == lv.size()) return !(comm_active() && !smoother_only) && !dense_coarse;
+  return (pre_degree >= 0 ? pre_degree : degree) > 0;
+}
+
+bool Multigrid::restrict_to(hipStream_t s, size_t l, const double* src) {
+  MGLevel& L = lv[l];
+  MGLevel& C = lv[l + 1];
+  static const bool fuse = std::getenv("NSFEM_NO_FUSED_FIRST") == nullptr;
+  if (fuse && starts_from_zero(l + 1)) {
+    double c1, c2, rho;
+    cheb_coeffs(C, 0, 0.0, c1, c2, rho);
+    launch_spmv_cheb_first(s, *L.R, nv, src, C.b.p, C.mask, C.dinv.p, c2, C.d.p, C.xa.p);
+    return true;
+  }
+  launch_spmv(s, *L.R, nv, src, C.b.p, C.mask, MASK_ZERO);
+  return false;
+}
+
+void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool first_done) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
   if (truncated() && l + 1 == active) {
-    smooth(s, L, b, nullptr, x, trunc_steps, false, identity_rows && l == 0 && trunc_steps >= 2);
+    smooth(s, L, b, nullptr, x, trunc_steps, false, identity_rows && l == 0 && trunc_steps >= 2, first_done);
     return;
   }
   if (l + 1 == lv.size()) {
@@ -530,18 +557,19 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
                          coarse_inv.p, b, x);
       NSFEM_HIP(hipGetLastError());
     } else {
-      smooth(s, L, b, nullptr, x, coarse_steps);
+      smooth(s, L, b, nullptr, x, coarse_steps, false, false, first_done);
     }
     return;
   }
   MGLevel& C = lv[l + 1];
   const int pre = pre_degree >= 0 ? pre_degree : degree;
+  bool child_first = false;
   if (pre > 0) {
-    smooth(s, L, b, nullptr, x, pre);
+    smooth(s, L, b, nullptr, x, pre, false, false, first_done);
     halo_fill(s, L, x);
     launch_residual(s, *L.A, nv, x, b, L.r.p, L.mask, MASK_ZERO);
     halo_fill(s, L, L.r.p);
-    launch_spmv(s, *L.R, nv, L.r.p, C.b.p, C.mask, MASK_ZERO);
+    child_first = restrict_to(s, l, L.r.p);
   } else {            // no pre-smoothing: x = 0, the residual is b itself
     const double* src = b;
     if (comm_active() && L.has_halo) {
@@ -551,9 +579,9 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x) {
       halo_fill(s, L, L.r.p);
       src = L.r.p;
     }
-    launch_spmv(s, *L.R, nv, src, C.b.p, C.mask, MASK_ZERO);
+    child_first = restrict_to(s, l, src);
   }
-  vcycle(s, l + 1, C.b.p, C.x.p);
+  vcycle(s, l + 1, C.b.p, C.x.p, child_first);
   halo_fill(s, C, C.x.p);
   const bool relaxed = relaxed_halo && comm_active() && L.has_halo;
   // relaxed mode: the ghost rows of x take part in the prolongation -- interpolated from the

@@ -167,6 +167,9 @@ enum MaskMode { MASK_NONE = 0, MASK_IDENTITY = 1, MASK_ZERO = 2 };
 // row blocks that touch no ghost column (Pattern::int_b0..int_b1), 2 the remaining row blocks
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
                  const uint8_t* rowmask, int maskmode, int ghost = 0, int phase = 0);
+void launch_spmv_cheb_first(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
+                            const uint8_t* rowmask, const double* dinv, double c2, double* d,
+                            double* x1);
 // y = b - A x  (same arguments + b)
 void launch_residual(hipStream_t s, const BlockMat& A, int nv, const double* x,
                      const double* b, double* y, const uint8_t* rowmask, int maskmode, int phase = 0);
@@ -493,9 +496,13 @@ struct Multigrid : Precond {
   void setup_work(hipStream_t s);
   void refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular);
   void apply(hipStream_t s, const double* r, double* z) override;
-  void vcycle(hipStream_t s, size_t l, const double* b, double* x);
+  void vcycle(hipStream_t s, size_t l, const double* b, double* x, bool first_done = false);
   void smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
-              int steps, bool ghosts_valid = false, bool ident_last = false);
+              int steps, bool ghosts_valid = false, bool ident_last = false, bool first_done = false);
+  // restriction to level l + 1 fused with the first smoothing step there (when that level starts
+  // from zero): returns true when L[l+1].xa / .d already hold step 0
+  bool restrict_to(hipStream_t s, size_t l, const double* src);
+  bool starts_from_zero(size_t l) const;
   void cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1, double& c2,
                    double& rho) const;
 };
@@ -633,6 +640,7 @@ struct nsfem_ctx {
     ~Probe() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
   } conv_probe;
   bool mf_active = false;           // the running step driver applies the Jacobian matrix-free
+  int pressure_history = 0;         // IPCS: pressure levels shifted since the state was last set (0..2)
   struct MixedOp : nsfem::Operator {
     nsfem_ctx* c = nullptr;
     void apply(hipStream_t s, const double* x, double* y) override;

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k3_conv_jac(int nc, const double* __restr
 // forms: 0 standard (grad u) u; 1 rotational curl(u) x u; 2 divergence + 1/2 div(u) u; 3 skew-symmetric
 //   1/2 [ (grad u) u . phi - ((grad phi) u) . u ]
 template <int FORM, int LIN>
-__global__ __launch_bounds__(256) void k3_conv_cell(int nc, const double* __restrict__ vx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3_conv_cell(int nc, const double* __restrict__ vx,
                                                     const int32_t* __restrict__ p2,
                                                     const double* __restrict__ u,
                                                     const double* __restrict__ v, double cc,

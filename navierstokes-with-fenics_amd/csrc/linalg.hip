@@ -561,11 +561,26 @@ __global__ __launch_bounds__(256) void k_spmv_sell(int n_rows, int n_slices, int
       }
     }
   }
-  if (!live) return;
+  // epilogue with coalesced vector traffic: the wave's 64 rows x NV outputs are the CONTIGUOUS
+  // entries 64 NV slice .. 64 NV (slice + 1) of the vectors; in pass p lane l handles entry
+  // e = 64 p + l, whose sum lives in lane e / NV (component e % NV) -- fetched with a shuffle, so
+  // every load / store of b, dinv, d, x, y touches whole cache lines (a lane-per-row epilogue
+  // writes 8-byte pieces 8 NV bytes apart: measured 2.4x the algorithmic write traffic)
+  (void)live;
+  (void)row;
+  const size_t ebase = (size_t)slice * 64 * NV;
 #pragma unroll
-  for (int o = 0; o < NV; ++o) {
-    const size_t idx = (size_t)row * NV + o;
-    double val = acc[o];
+  for (int p = 0; p < NV; ++p) {
+    const int e = p * 64 + lane;
+    const int owner = e / NV, comp = e % NV;
+    double val = 0.0;
+#pragma unroll
+    for (int o = 0; o < NV; ++o) {
+      const double t = __shfl(acc[o], owner, 64);
+      if (comp == o) val = t;
+    }
+    if (slice * 64 + owner >= n_rows) continue;
+    const size_t idx = ebase + e;
     int m_ = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
     if (m_ == 2 && a.ghost == 2) m_ = 0;
     const bool m = m_ != 0;
@@ -802,13 +817,14 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
 #define NSFEM_SELL_LAUNCH(NV, U, PIPE)                                                               \
   hipLaunchKernelGGL((k_spmv_sell<NV, EPI, U, PIPE>), dim3(grid), dim3(256), 0, s, p.n_rows,         \
                      p.n_slices, nwg, p.sell_ptr.p, p.sell_col.p, A.sell_vals.p, a, xs)
-    // tuning switch (smoother epilogue only): NSFEM_SELL_VARIANT = 0 (U 4), 1 (U 8), 2 (U 8 pipelined,
-    // default), 3 (U 12 pipelined / U 10 for 3 components)
+    // tuning switch (smoother epilogue only): NSFEM_SELL_VARIANT = 0 (groups of 4 entries, 8 waves
+    // per SIMD: default -- measured 247-253 us on the 3D n = 64 smoothing launch), 1 (groups of 8:
+    // 264 us), 2 (8, software pipelined: 255-263 us), 3 (12 / 10 pipelined: 256-267 us)
     static const int variant = [] {
       const char* e = std::getenv("NSFEM_SELL_VARIANT");
-      return e ? std::atoi(e) : 2;
+      return e ? std::atoi(e) : 0;
     }();
-    const int var = EPI == EPI_CHEB ? variant : 2;
+    const int var = EPI == EPI_CHEB ? variant : 0;
 #define NSFEM_SELL_NV(NV, UBIG)                        \
   do {                                                 \
     if (var == 0) NSFEM_SELL_LAUNCH(NV, 4, 0);         \

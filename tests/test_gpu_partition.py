@@ -351,6 +351,39 @@ def test_bench_through_rccl_single_rank():
         assert line["config"][key] == line2["config"][key]
 
 
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()          # (does not initialise the GPU on this image)
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("scaling,overlap", [("strong", "on"), ("weak", "off")])
+def test_two_rccl_ranks_on_two_gpus_reproduce_the_single_gpu_run(scaling, overlap):
+    """Real multi-rank RCCL (grouped ncclSend / ncclRecv halo exchange + ncclAllReduce), one
+    process per GPU through torch.distributed.run, exactly as the driver launches bench.py:
+    same iteration counts as the one-GPU run of the same global mesh (strong scaling) and a
+    validated line.  Skipped on one-GPU boxes -- there the partitioned algorithm is covered by the
+    in-process ranks above."""
+    port = "29563" if scaling == "strong" else "29564"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--cells", "128", "--steps", "4", "--warmup", "2", "--scaling", scaling, "--overlap", overlap,
+           "--halo-mode", "exact", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling
+    assert line["config"]["validation"]["max_rel_diff_velocity_vs_exact"] < 1e-6
+    assert line["config"]["comm_per_step_rank0"]["exchanges"] > 0
+    if scaling == "strong":
+        one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "128", "--steps", "4",
+                              "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+        assert one.returncode == 0, one.stderr[-3000:]
+        ref = json.loads(one.stdout.strip().splitlines()[-1])
+        for key in ("newton_its_per_step", "bicgstab_its_per_step", "poisson_cg_its_per_step"):
+            assert abs(line["config"][key] - ref["config"][key]) <= 0.26, key
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_chebyshev_mass_solve_matches_cg(dim):
     """correction.precond = 2: Chebyshev iteration on diag(M)^-1 M with Wathen's element bounds

@@ -198,9 +198,65 @@ def dfg_bdf_bench(args):
     ctx.close()
 
 
+class _ThreadRanks:
+    """torch.distributed look-alike for ranks that are THREADS of this process sharing one GPU
+    (--local-ranks N): a functional rehearsal of the N-rank code paths of every workload on a
+    one-GPU box -- partitions, halo exchanges, all-reduces, the bench's own reductions -- through
+    the in-process communicator (nsfem_comm_attach_local).  Not a performance mode: the ranks
+    serialise on one device and every collective synchronises the host."""
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.group = nat.local_group_create(world)
+        self._barrier = threading.Barrier(world)
+        self._slots = [None] * world
+        self._tls = threading.local()
+
+    def bind(self, rank):
+        self._tls.rank = rank
+
+    def barrier(self):
+        self._barrier.wait()
+
+    def all_reduce(self, t, op="sum"):
+        self._slots[self._tls.rank] = t.clone()
+        self._barrier.wait()
+        acc = self._slots[0].clone()
+        for other in self._slots[1:]:
+            acc = acc + other if op == "sum" else acc.maximum(other)
+        self._barrier.wait()
+        t.copy_(acc)
+
+    def broadcast_object_list(self, objs, src=0):
+        self._slots[self._tls.rank] = list(objs)
+        self._barrier.wait()
+        objs[:] = self._slots[src]
+        self._barrier.wait()
+
+    def destroy_process_group(self):
+        pass
+
+
+def _attach_comm(ctx, dist, rank, world):
+    """one RCCL rank per process -- or, for thread ranks, the in-process communicator"""
+    if isinstance(dist, _ThreadRanks):
+        ctx.attach_local_comm(dist.group, rank)
+        return
+    ids = [nat.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ctx.attach_rccl_comm(ids[0], rank, world)
+
+
 def _init_dist(args):
     """(rank, world, local_rank, torch.distributed | None): gloo bootstrap used only for the
     unique-id broadcast, the barrier and the MAX reduction of the bench contract"""
+    threads = getattr(args, "thread_ranks", None)
+    if threads is not None:
+        return args.thread_rank, threads.world, 0, threads
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -266,9 +322,7 @@ def tgv3d_bench(args):
         mesh, dm = part.mesh, part.dofmap
         device = 0 if os.environ.get("NSFEM_SHARE_GPU") else local_rank
         ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1, device)
-        ids = [nat.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.attach_rccl_comm(ids[0], rank, world)
+        _attach_comm(ctx, dist, rank, world)
         levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
         n_dofs = 3 * part.n_p2_global + part.n_p1_global
     _apply_truncation(ctx, args)
@@ -384,9 +438,7 @@ def cavity3d_bench(args):
     device = 0 if os.environ.get("NSFEM_SHARE_GPU") else local_rank
     ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1, device)
     if dist is not None:
-        ids = [nat.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.attach_rccl_comm(ids[0], rank, world)
+        _attach_comm(ctx, dist, rank, world)
     levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
     X = dm.p2_coords
     on = (np.abs(X[:, 2]) < 1e-12) | (np.abs(X[:, 2] - zlen) < 1e-12)
@@ -474,8 +526,8 @@ def cavity3d_bench(args):
 
 
 def channel3d_bdf_bench(args):
-    """BASELINE.json configs[4] on ONE GPU: 3D channel, 2 : 1 : 1 box [0,2] x [0,1]^2 cut into
-    (2n, n, n) cubes x 6 Kuhn tetrahedra (the reference has simplices only), inlet
+    """BASELINE.json configs[4]: 3D channel, 2 : 1 : 1 box [0,2] x [0,1]^2 cut into (2n, n, n)
+    cubes x 6 Kuhn tetrahedra (the reference has simplices only), inlet
     u_x = 16 y (1 - y) z (1 - z) at x = 0, no-slip side walls, natural outflow at x = 2,
     Re = 1000 (--reynolds), fully implicit BDF-2 on the mixed P2^3 x P1 system
     (source/ns_bdf_solver.py:36-106): Newton with the reference's criterion, BiCGStab on the mixed
@@ -483,39 +535,49 @@ def channel3d_bdf_bench(args):
     Schur Laplacian of the open outlet.  Impulsive start from rest.  Checked invariants: Newton
     converged in every step; discrete mass balance (flux in + out + walls = 0, the continuity
     rows tested with the constant P1 function); inflow flux = integral of the interpolated inlet
-    profile (-4/9 + O(h^4))."""
-    import grid_generator as gg
-    from fem_mesh import TaylorHoodDofMap
-    from multigrid import attach_hierarchy, attach_schur_laplacian
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        raise SystemExit("channel3d-bdf is a single-GPU workload (the algebraic Schur Laplacian of the "
-                         "open outlet is assembled for one rank; see DESIGN.md)")
+    profile (-4/9 + O(h^4)).
+
+    N > 1: slabs of cube layers along z over RCCL.  --scaling strong: the same box, n / N layers
+    per rank; weak (default): a duct [0,2] x [0,1] x [0,N] of (2n, n, n N) cubes, n layers per
+    rank, inlet profile 16 y (1 - y) (z / N)(1 - z / N).  Every rank holds only its additive part
+    of the algebraic Schur Laplacian (multigrid.attach_schur_laplacian(part=...))."""
+    from fem_mesh import Mesh
+    from multigrid import attach_schur_laplacian
+    from partition import SlabPartition, global_dof_counts
+    rank, world, local_rank, dist = _init_dist(args)
     n = args.n
+    strong = args.scaling == "strong" or world == 1
+    nz, zlen = (n, 1.0) if strong else (n * world, float(world))
     t_setup = time.perf_counter()
-    mesh, marks = gg.hyper_rectangle((0.0, 0.0, 0.0), (2.0, 1.0, 1.0), (2 * n, n, n))
-    from fem_mesh import preferred_p2_order
-    dm = TaylorHoodDofMap(mesh, reorder=preferred_p2_order(3))
-    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
-    levels = attach_hierarchy(ctx, mesh, args.mg_degree, args.mg_eig_ratio)
-    M = gg.HyperRectangleBoundaryMarkers
-    inlet = np.unique(dm.facet_p2_nodes(marks.facets_with_id(M.left.value)))
-    walls = np.unique(np.concatenate([dm.facet_p2_nodes(marks.facets_with_id(m.value)).ravel()
-                                      for m in (M.bottom, M.top, M.back, M.front)]))
-    Xi = dm.p2_coords[inlet]
-    prof = 16.0 * Xi[:, 1] * (1.0 - Xi[:, 1]) * Xi[:, 2] * (1.0 - Xi[:, 2])
+    part = SlabPartition((0.0, 0.0, 0.0), (2.0, 1.0, zlen), 2 * n, n, nz, rank, world,
+                         coarsest=args.coarsest if args.coarsest else 4)
+    mesh, dm = part.mesh, part.dofmap
+    device = 0 if os.environ.get("NSFEM_SHARE_GPU") else local_rank
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1, device)
+    if dist is not None:
+        _attach_comm(ctx, dist, rank, world)
+    levels = part.attach(ctx, args.mg_degree, args.mg_eig_ratio)
+    X = dm.p2_coords
+    near = lambda v, c: np.abs(v - c) < 1e-12
+    inlet = np.nonzero(near(X[:, 0], 0.0))[0]
+    walls = np.nonzero(near(X[:, 1], 0.0) | near(X[:, 1], 1.0) | near(X[:, 2], 0.0) | near(X[:, 2], zlen))[0]
+    profile = lambda P: 16.0 * P[..., 1] * (1.0 - P[..., 1]) * (P[..., 2] / zlen) * (1.0 - P[..., 2] / zlen)
     # list order of the reference's DirichletBC.apply: the inlet first, the walls win on shared edges
     bd = np.concatenate([3 * inlet, 3 * inlet + 1, 3 * inlet + 2,
                          3 * walls, 3 * walls + 1, 3 * walls + 2]).astype(np.int32)
-    bv = np.concatenate([prof, np.zeros(2 * inlet.size + 3 * walls.size)])
+    bv = np.concatenate([profile(X[inlet]), np.zeros(2 * inlet.size + 3 * walls.size)])
     ctx.set_coeffs(1.0, 1.0, 1.0 / args.reynolds)
     ctx.set_dirichlet(nat.VELOCITY, bd, bv)
     ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
     ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
     t_schur = time.perf_counter()
-    attach_schur_laplacian(ctx, np.unique(bd))
+    attach_schur_laplacian(ctx, np.unique(bd), part=part)
     t_schur = time.perf_counter() - t_schur
     t_setup = time.perf_counter() - t_setup
+    n2g, n1g = global_dof_counts(2 * n, n, nz)
+    n_dofs = 3 * n2g + n1g
     _apply_truncation(ctx, args)
+    ctx.set_overlap(args.overlap == "on")
     opts = ctx.default_step_opts()
     opts.momentum.rtol, opts.momentum.precond, opts.momentum.max_iter = args.krylov_rtol, 1, 500
     opts.newton_forcing = args.newton_forcing
@@ -531,6 +593,9 @@ def channel3d_bdf_bench(args):
     for i in range(args.warmup):
         one_step(i)
     ctx.synchronize()
+    if dist is not None:
+        dist.barrier()
+    ctx.comm_stats(reset=True)
     t0 = time.perf_counter()
     newton = kry = 0
     all_converged, worst = True, 0.0
@@ -542,28 +607,45 @@ def channel3d_bdf_bench(args):
         all_converged &= bool(info.converged) and (r[-1] < 1e-10 or r[-1] / r[0] < 1e-9)
         worst = max(worst, r[-1] / r[0])
     ctx.synchronize()
+    if dist is not None:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
+    comm_per_step = {k: v / args.steps for k, v in ctx.comm_stats().items()}
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
     sps = args.steps / elapsed
-    # ---- invariants of the computed state
+    # ---- invariants of the computed state: boundary facets of the box whose cell lies in this
+    # rank's own layers, summed over the ranks
     nu = 1.0 / args.reynolds
-    flux = {}
-    for name, m in (("inlet", M.left), ("outlet", M.right), ("bottom", M.bottom), ("top", M.top),
-                    ("back", M.back), ("front", M.front)):
-        fc, fl = mesh.facet_cell_local(marks.facets_with_id(m.value))
-        _, flux[name], _ = ctx.boundary_force(fc, fl, nu, 0.0, nat.U0, nat.P)
-    balance = abs(sum(flux.values())) / abs(flux["inlet"])
+    own_top = mesh.coords[:, 2].min() + part.fine.own_rows * (zlen / nz)
+    fb = np.nonzero(mesh.facet_on_boundary)[0]
+    mid = mesh.facet_midpoints()[fb]
+    cz = mesh.coords[mesh.cells[mesh.facet_cell[fb]].astype(np.int64)][:, :, 2].mean(axis=1)
+    mine = cz < own_top
+    sides = {"inlet": near(mid[:, 0], 0.0), "outlet": near(mid[:, 0], 2.0), "bottom": near(mid[:, 1], 0.0),
+             "top": near(mid[:, 1], 1.0), "back": near(mid[:, 2], 0.0), "front": near(mid[:, 2], zlen)}
+    local = []
+    for name in sides:
+        fc, fl = mesh.facet_cell_local(fb[sides[name] & mine])
+        local.append(ctx.boundary_force(fc, fl, nu, 0.0, nat.U0, nat.P)[1] if fc.size else 0.0)
     # inflow: minus the integral of the P2 nodal interpolant of the inlet profile (face rule: area / 3
-    # x the three edge-midpoint values); it tends to the analytic -4/9 like h^4
-    fin = marks.facets_with_id(M.left.value)
-    mid = dm.facet_p2_nodes(fin)[:, 3:]
-    Xm = dm.p2_coords[mid]
-    pm = 16.0 * Xm[..., 1] * (1.0 - Xm[..., 1]) * Xm[..., 2] * (1.0 - Xm[..., 2])
+    # x the three edge-midpoint values); it tends to the analytic -4/9 (x N, weak scaling) like h^4
+    fin = fb[sides["inlet"] & mine]
+    Xm = dm.p2_coords[dm.facet_p2_nodes(fin)[:, 3:]] if fin.size else np.zeros((0, 3, 3))
     tri = mesh.coords[mesh.facets[fin].astype(np.int64)]
     area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
-    inflow_expected = -float((area / 3.0 * pm.sum(axis=1)).sum())
-    inflow_err = abs(flux["inlet"] - inflow_expected)
+    local.append(-float((area / 3.0 * profile(Xm).sum(axis=1)).sum()))
     u = ctx.get_state(nat.U0).reshape(-1, 3)
-    finite = bool(np.isfinite(u).all())
+    total = ctx.comm_allreduce(local, "sum")
+    flux = dict(zip(sides, (float(v) for v in total[:6])))
+    inflow_expected = float(total[6])
+    balance = abs(sum(flux.values())) / abs(flux["inlet"])
+    inflow_err = abs(flux["inlet"] - inflow_expected)
+    umax, bad = ctx.comm_allreduce([float(np.abs(u).max()), 0.0 if np.isfinite(u).all() else 1.0], "max")
+    finite = bad == 0.0
     # ---- dominant kernel: finest-level Chebyshev smoothing step of the velocity multigrid inside the
     # block preconditioner (scalar P2 operator on 3 interleaved components), in situ + cache-cold
     ctx.profile_smoother(True)
@@ -574,40 +656,48 @@ def channel3d_bdf_bench(args):
     ms_conv, n_conv, nbytes_conv = ctx.profile_convection(False)
     ms_cold, _ = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 50)
     achieved = nbytes / (ms_sm * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "dof_updates_per_sec", "value": sps * dm.n_dofs, "unit": "DoF-updates/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic", "time_steps_per_sec": sps,
-        "config": {"workload": "3D channel flow Re=%g, 2:1:1 box, %dx%dx%d cubes x 6 Kuhn tetrahedra (%d cells, "
-                               "%d dofs), BDF-2 monolithic, parabolic inlet, natural outflow, dt=%g, "
-                               "impulsive start" % (args.reynolds, 2 * n, n, n, mesh.num_cells(), dm.n_dofs, dt),
-                   "n_dofs": dm.n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
-                   "newton_forcing": args.newton_forcing,
-                   "preconditioner": "block-triangular (V-cycle velocity block, Cahouet-Chabard Schur with "
-                                     "the algebraic pressure Laplacian D diag(M)^-1 D^T), %d coarse P1 levels" % levels,
-                   "parallelism": "1 GPU", "newton_its_per_step": newton / args.steps,
-                   "bicgstab_its_per_step": kry / args.steps, "host_setup_s": t_setup,
-                   "host_schur_laplacian_s": t_schur,
-                   "invariants": {"newton_converged_every_step": all_converged,
-                                  "worst_newton_reduction": worst,
-                                  "flux": flux, "mass_balance_rel": balance,
-                                  "inflow_flux_error_vs_interpolated_profile": inflow_err,
-                                  "inflow_flux_minus_analytic_4_9": flux["inlet"] + 4.0 / 9.0,
-                                  "max_velocity": float(np.abs(u).max()), "finite": finite}},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<1,1,3,3> (finest-level Chebyshev smoothing step of the "
-                                               "velocity multigrid, scalar P2 operator on 3 interleaved components)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_sm,
-                     "launches_timed": n_sm, "timing": "in situ, HIP-event pairs around the smoothing sequences of 2 steps",
-                     "cold_cache": {"achieved": nbytes / (ms_cold * 1e-3) / 1e9,
-                                    "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_cold}},
-        "assembly": {"kernel": "k3_conv_cell<FORM,1> + node gather (matrix-free convection action)",
-                     "achieved": nbytes_conv / (ms_conv * 1e-3) / 1e9 if n_conv else None, "unit": "GB/s",
-                     "frac": nbytes_conv / (ms_conv * 1e-3) / 1e9 / HBM_PEAK_GBS if n_conv else None,
-                     "algorithmic_bytes_per_application": nbytes_conv, "ms_per_application": ms_conv,
-                     "applications_timed": n_conv}}))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "dof_updates_per_sec", "value": sps * n_dofs, "unit": "DoF-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / sps,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "time_steps_per_sec": sps,
+            "config": {"workload": "3D channel flow Re=%g, %g:1:%g box, %dx%dx%d cubes x 6 Kuhn tetrahedra (%d cells, "
+                                   "%d dofs), BDF-2 monolithic, parabolic inlet, natural outflow, dt=%g, "
+                                   "impulsive start" % (args.reynolds, 2.0, zlen, 2 * n, n, nz, 12 * n * n * nz,
+                                                        n_dofs, dt),
+                       "n_dofs": n_dofs, "newton_tol": 1e-10, "krylov_rtol": args.krylov_rtol,
+                       "newton_forcing": args.newton_forcing,
+                       "preconditioner": "block-triangular (V-cycle velocity block, Cahouet-Chabard Schur with "
+                                         "the algebraic pressure Laplacian D diag(M)^-1 D^T%s), %d coarse P1 levels" % (
+                                             "" if world == 1 else ", additive rank parts", levels),
+                       "parallelism": "1 GPU" if world == 1 else
+                       "%d slabs of %d cube layers, RCCL halo exchange (forward + reverse-add, overlap %s) + all-reduce" % (
+                           world, nz // world, args.overlap),
+                       "newton_its_per_step": newton / args.steps,
+                       "bicgstab_its_per_step": kry / args.steps, "host_setup_s": t_setup,
+                       "host_schur_laplacian_s": t_schur, "comm_per_step_rank0": comm_per_step,
+                       "invariants": {"newton_converged_every_step": all_converged,
+                                      "worst_newton_reduction": worst,
+                                      "flux": flux, "mass_balance_rel": balance,
+                                      "inflow_flux_error_vs_interpolated_profile": inflow_err,
+                                      "inflow_flux_minus_analytic": flux["inlet"] + 4.0 / 9.0 * zlen,
+                                      "max_velocity": float(umax), "finite": bool(finite)}},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_sell<1,3,...> (finest-level Chebyshev smoothing step of the "
+                                                   "velocity multigrid, scalar P2 operator on 3 interleaved components)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_sm,
+                         "launches_timed": n_sm, "timing": "in situ, HIP-event pairs around the smoothing sequences of 2 steps",
+                         "cold_cache": {"achieved": nbytes / (ms_cold * 1e-3) / 1e9,
+                                        "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_cold}},
+            "assembly": {"kernel": "k3_conv_cell<FORM,1> + node gather (matrix-free convection action)",
+                         "achieved": nbytes_conv / (ms_conv * 1e-3) / 1e9 if n_conv else None, "unit": "GB/s",
+                         "frac": nbytes_conv / (ms_conv * 1e-3) / 1e9 / HBM_PEAK_GBS if n_conv else None,
+                         "algorithmic_bytes_per_application": nbytes_conv, "ms_per_application": ms_conv,
+                         "applications_timed": n_conv}}))
     ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
     if not (all_converged and finite and balance < 1e-6 and inflow_err < 1e-10):
         raise SystemExit("channel3d-bdf: invariant violated (converged %s, finite %s, mass balance %.2e, "
                          "inflow error %.2e)" % (all_converged, finite, balance, inflow_err))
@@ -695,9 +785,7 @@ def cavity_ipcs_bench(args):
     ctx = nat.NsfemContext(part.mesh.coords, part.mesh.cells, dm.p2_dofmap, dm.p1_dofmap,
                            dm.n_p2, dm.n_p1, device)
     if dist is not None:
-        ids = [nat.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.attach_rccl_comm(ids[0], rank, world)
+        _attach_comm(ctx, dist, rank, world)
     mg_levels = None
     n2g, n1g = global_dof_counts(n, ny_global)
     if not args.no_multigrid:
@@ -989,9 +1077,43 @@ def main():
                          "2:1:1 box, BDF-2 monolithic, open outlet)")
     ap.add_argument("--dfg-refine", type=int, default=5)
     ap.add_argument("--reynolds", type=float, default=1000.0, help="channel3d-bdf: Reynolds number")
+    ap.add_argument("--local-ranks", type=int, default=0,
+                    help="functional rehearsal of the N-rank paths on ONE GPU: N threads of this process, "
+                         "in-process communicator (no RCCL; not a performance mode)")
     args = ap.parse_args()
+    if args.local_ranks > 1:
+        import copy
+        import threading
+        args.gpus = args.local_ranks
+        args.no_cpu_baseline = True
+        shared = _ThreadRanks(args.local_ranks)
+        failures = []
+
+        def rank_main(r):
+            mine = copy.copy(args)
+            mine.thread_ranks, mine.thread_rank = shared, r
+            shared.bind(r)
+            try:
+                _run_workload(mine)
+            except BaseException as exc:       # a dead rank would leave the others in a barrier
+                import traceback
+                traceback.print_exc()
+                failures.append((r, exc))
+                os._exit(3)
+
+        workers = [threading.Thread(target=rank_main, args=(r,)) for r in range(args.local_ranks)]
+        for w in workers:
+            w.start()
+        for w in workers:
+            w.join()
+        nat.local_group_destroy(shared.group)
+        return None
+    return _run_workload(args)
+
+
+def _run_workload(args):
     if args.workload == "dfg-bdf":
-        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or getattr(args, "thread_ranks", None) is not None:
             raise SystemExit("the dfg-bdf workload is a single-GPU configuration")
         return dfg_bdf_bench(args)
     if args.workload.startswith("cavity3d"):

@@ -252,6 +252,17 @@ int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* level);
  * boundary is open (constants in the kernel: the coarse solve uses the pseudo-inverse) */
 int nsfem_mg_set_schur_operator(nsfem_ctx* ctx, int level, int32_t n, const int32_t* rowptr,
                                 const int32_t* col, const double* val, int singular);
+/* partitioned meshes (additive != 0, call before nsfem_mg_set_schur_operator): the operators are
+ * the rank's ADDITIVE parts  D_r W_r D_r^T  (W_r = 1 / M_v,jj on the velocity dofs the rank owns,
+ * 0 on ghosts and Dirichlet dofs), ghost rows included, and their Galerkin coarsenings with the
+ * rank-local prolongations: their sum over the ranks is the operator.  Products run as forward
+ * halo exchange -> local product -> reverse (add) exchange; the global coarsest matrix is the
+ * all-reduced dense sum of the coarsest parts (the partition must not carry a replicated tail).
+ * `singular` must be the same on every rank (nsfem_comm_allreduce). */
+int nsfem_mg_set_schur_mode(nsfem_ctx* ctx, int additive);
+/* sum (op = 0) / max (op = 1) over the ranks of `count` (<= 1024) host doubles, in place;
+ * single contexts: a no-op */
+int nsfem_comm_allreduce(nsfem_ctx* ctx, double* values, int count, int op);
 /* partitioned hierarchies: the GLOBAL coarsest mesh (solved redundantly on every rank);
  * offset = global id of this rank's local coarsest node 0 */
 int nsfem_mg_set_global_coarse(nsfem_ctx* ctx, int32_t n_vertices, int32_t n_cells,

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse", "nsfem_mg_set_global_coarse_constrained",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -180,6 +180,8 @@ def load_library(path=None):
         "nsfem_mg_set_schur_operator": (C.c_int, [vp, C.c_int, C.c_int32, C.POINTER(C.c_int32),
                                                   C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                                   C.c_int]),
+        "nsfem_mg_set_schur_mode": (C.c_int, [vp, C.c_int]),
+        "nsfem_comm_allreduce": (C.c_int, [vp, pd, C.c_int, C.c_int]),
         "nsfem_mg_set_global_coarse": (C.c_int, [vp, i32, i32, pd, pi, i64]),
         "nsfem_mg_set_global_coarse_constrained": (C.c_int, [vp, i32, i32, pd, pi, pi, i32, i64]),
         "nsfem_set_partition": (C.c_int, [vp, C.POINTER(PartitionDesc)]),
@@ -422,6 +424,16 @@ class NsfemContext:
         self._check(self._lib.nsfem_mg_set_schur_operator(self._h, int(level), csr.shape[0],
                                                           _ip(rp), _ip(ci), _dp(cv),
                                                           1 if singular else 0))
+
+    def mg_set_schur_mode(self, additive):
+        """partitioned meshes: the Schur operators set afterwards are this rank's additive parts"""
+        self._check(self._lib.nsfem_mg_set_schur_mode(self._h, 1 if additive else 0))
+
+    def comm_allreduce(self, values, op="sum"):
+        """sum / max over the ranks of a few host doubles (a copy; single contexts: unchanged)"""
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._check(self._lib.nsfem_comm_allreduce(self._h, _dp(v), int(v.size), 1 if op == "max" else 0))
+        return v
 
     def mg_add_global_level(self, coords, cells, p_rowptr, p_col, p_val, dofmap=None):
         """coarser level of the replicated hierarchy below the global coarsest mesh"""

@@ -1041,7 +1041,36 @@ extern "C" int nsfem_mg_set_schur_operator(nsfem_ctx* ctx, int level, int32_t n,
   op->mat.sell_update(s);
   NSFEM_HIP(hipStreamSynchronize(s));
   ctx->mg_s.lv[level].A = &op->mat;
+  ctx->mg_s.lv[level].additive = ctx->schur_additive;
   ctx->mg_s_dirty = true;
+  API_END(ctx)
+}
+
+// Partitioned meshes: the operators handed to nsfem_mg_set_schur_operator AFTER this call are the
+// rank's additive parts A_r = D_r W_r D_r^T (W_r: 1 / M_v,jj on the velocity dofs this rank owns,
+// 0 elsewhere), ghost rows included; the hierarchy applies them with a forward halo exchange of
+// the input and a reverse (add) exchange of the ghost rows of the product.
+extern "C" int nsfem_mg_set_schur_mode(nsfem_ctx* ctx, int additive) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx, "null argument");
+  ctx->schur_additive = additive != 0;
+  API_END(ctx)
+}
+
+// max (op = 1) or sum (op = 0) over the ranks of `count` host doubles (set-up-time agreement on
+// flags and bounds; single contexts: a no-op)
+extern "C" int nsfem_comm_allreduce(nsfem_ctx* ctx, double* values, int count, int op) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && values && count > 0 && count <= 1024, "bad argument");
+  if (ctx->distributed()) {
+    hipStream_t s = ctx->stream;
+    DevBuf<double> tmp;
+    tmp.upload(values, (size_t)count, s);
+    if (op) ctx->comm->allreduce_max(s, tmp.p, count);
+    else ctx->comm->allreduce_sum(s, tmp.p, count);
+    NSFEM_HIP(hipMemcpyAsync(values, tmp.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+  }
   API_END(ctx)
 }
 
@@ -1553,8 +1582,9 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
   ctx->conv_form = opts->convective_form;
-  NSFEM_REQUIRE(!ctx->distributed() || ctx->schur_singular < 0,
-                "the algebraic Schur Laplacian is not partitioned (open boundaries: use IPCS on several GPUs)");
+  NSFEM_REQUIRE(!ctx->distributed() || ctx->schur_singular < 0 || ctx->schur_additive,
+                "partitioned meshes take the algebraic Schur Laplacian as additive rank parts "
+                "(nsfem_mg_set_schur_mode)");
   NSFEM_REQUIRE(ctx->mg_built, "the monolithic step needs the multigrid hierarchy "
                                "(block preconditioner): call nsfem_mg_finalize");
   nsfem_step_info& inf = info ? *info : local;

@@ -54,6 +54,19 @@ __global__ __launch_bounds__(256) void k_reduce_ranks(int64_t n, int size, PtrPa
   }
 }
 
+__global__ __launch_bounds__(256) void k_add_range(int64_t n, const double* __restrict__ src,
+                                                   double* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+static void add_range(hipStream_t s, int64_t n, const double* src, double* dst) {
+  if (n <= 0) return;
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_add_range, dim3(grid), dim3(256), 0, s, n, src, dst);
+  NSFEM_HIP(hipGetLastError());
+}
+
 struct LocalComm : Comm {
   LocalGroup* g = nullptr;
   DevBuf<double> scratch;
@@ -98,6 +111,29 @@ struct LocalComm : Comm {
     NSFEM_HIP(hipStreamSynchronize(s));
     g->barrier();      // neighbours may now overwrite their send ranges
   }
+  void exchange_add(hipStream_t s, const HaloRange& h, double* vec, int width) override {
+    count_exchange_add(h, width);
+    NSFEM_HIP(hipStreamSynchronize(s));
+    g->ptr[rank] = vec;
+    g->halo[rank] = h;
+    g->barrier();
+    const int above = up(), below = down();
+    // pull: my send-up range is the rank above's ghost range below, and vice versa
+    if (h.send_up_cnt > 0 && above >= 0) {
+      const HaloRange& o = g->halo[above];
+      NSFEM_REQUIRE(o.recv_below_cnt == h.send_up_cnt, "halo size mismatch (above, add)");
+      add_range(s, h.send_up_cnt * width, g->ptr[above] + o.recv_below_off * width,
+                vec + h.send_up_off * width);
+    }
+    if (h.send_down_cnt > 0 && below >= 0) {
+      const HaloRange& o = g->halo[below];
+      NSFEM_REQUIRE(o.recv_above_cnt == h.send_down_cnt, "halo size mismatch (below, add)");
+      add_range(s, h.send_down_cnt * width, g->ptr[below] + o.recv_above_off * width,
+                vec + h.send_down_off * width);
+    }
+    NSFEM_HIP(hipStreamSynchronize(s));
+    g->barrier();      // neighbours may now overwrite their ghost ranges
+  }
 };
 
 // ------------------------------------------------------------------- RcclComm
@@ -110,6 +146,7 @@ struct LocalComm : Comm {
 
 struct RcclComm : Comm {
   ncclComm_t comm = nullptr;
+  DevBuf<double> stage;          // receive buffer of exchange_add
   ~RcclComm() override {
     if (comm) (void)ncclCommDestroy(comm);
   }
@@ -142,6 +179,30 @@ struct RcclComm : Comm {
       NSFEM_NCCL(ncclRecv(vec + h.recv_above_off * width, (size_t)(h.recv_above_cnt * width),
                           ncclDouble, above, comm, s));
     NSFEM_NCCL(ncclGroupEnd());
+  }
+  void exchange_add(hipStream_t s, const HaloRange& h, double* vec, int width) override {
+    count_exchange_add(h, width);
+    const int above = up(), below = down();
+    NSFEM_REQUIRE(!(periodic && size == 1), "a periodic partition needs at least two RCCL ranks");
+    const size_t n_up = above >= 0 ? (size_t)(h.send_up_cnt * width) : 0;      // what the rank above holds for me
+    const size_t n_dn = below >= 0 ? (size_t)(h.send_down_cnt * width) : 0;
+    if (stage.n < n_up + n_dn) {
+      NSFEM_HIP(hipStreamSynchronize(s));
+      stage.alloc(n_up + n_dn);
+    }
+    // same ordering rule as in `exchange`: sends up-then-down, receives below-then-above
+    NSFEM_NCCL(ncclGroupStart());
+    if (above >= 0 && h.recv_above_cnt > 0)
+      NSFEM_NCCL(ncclSend(vec + h.recv_above_off * width, (size_t)(h.recv_above_cnt * width),
+                          ncclDouble, above, comm, s));
+    if (below >= 0 && h.recv_below_cnt > 0)
+      NSFEM_NCCL(ncclSend(vec + h.recv_below_off * width, (size_t)(h.recv_below_cnt * width),
+                          ncclDouble, below, comm, s));
+    if (n_dn > 0) NSFEM_NCCL(ncclRecv(stage.p + n_up, n_dn, ncclDouble, below, comm, s));
+    if (n_up > 0) NSFEM_NCCL(ncclRecv(stage.p, n_up, ncclDouble, above, comm, s));
+    NSFEM_NCCL(ncclGroupEnd());
+    add_range(s, (int64_t)n_up, stage.p, vec + h.send_up_off * width);
+    add_range(s, (int64_t)n_dn, stage.p + n_up, vec + h.send_down_off * width);
   }
 };
 

@@ -31,6 +31,84 @@ __global__ __launch_bounds__(256) void k_cheb_first(int64_t n, const double* __r
   }
 }
 
+// additive levels (the product t = A x comes from apply_additive): smoother update, residual,
+// diagonal / absolute row sums of the local part, dense scatter of the coarsest part
+__global__ __launch_bounds__(256) void k_cheb_update(int64_t n, const double* __restrict__ t,
+                                                     const double* __restrict__ b,
+                                                     const double* __restrict__ dinv,
+                                                     const uint8_t* __restrict__ mask, double c1,
+                                                     double c2, double* __restrict__ d,
+                                                     const double* __restrict__ x,
+                                                     double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    double dn = 0.0, xn = 0.0;
+    if (!(mask && mask[i])) {
+      dn = c2 * dinv[i] * (b[i] - t[i]);
+      if (c1 != 0.0) dn += c1 * d[i];
+      xn = x[i] + dn;
+    }
+    d[i] = dn;
+    out[i] = xn;
+  }
+}
+__global__ __launch_bounds__(256) void k_resid_update(int64_t n, const double* __restrict__ t,
+                                                      const double* __restrict__ b,
+                                                      const uint8_t* __restrict__ mask,
+                                                      double* __restrict__ r) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    r[i] = (mask && mask[i]) ? 0.0 : b[i] - t[i];
+}
+// out[row] = a_ii (what = 0) or sum_j |a_ij| (what = 1) of a scalar CSR matrix
+__global__ __launch_bounds__(256) void k_row_measure(int n_rows, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ diag,
+                                                     const double* __restrict__ vals, int what,
+                                                     double* __restrict__ out) {
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    if (what == 0) s = vals[diag[row]];
+    else
+      for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) s += fabs(vals[k]);
+    out[row] = s;
+  }
+}
+__global__ __launch_bounds__(256) void k_invert_masked(int64_t n, const double* __restrict__ t,
+                                                       const uint8_t* __restrict__ mask,
+                                                       double* __restrict__ dinv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dinv[i] = ((mask && mask[i]) || t[i] == 0.0) ? 0.0 : 1.0 / t[i];
+}
+__global__ __launch_bounds__(256) void k_max_product(int64_t n, const double* __restrict__ t,
+                                                     const double* __restrict__ dinv,
+                                                     const uint8_t* __restrict__ mask,
+                                                     double* __restrict__ parts) {
+  __shared__ double sh[256];
+  double best = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    if (!(mask && mask[i])) best = fmax(best, t[i] * dinv[i]);
+  sh[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
+}
+// dense[(off + i) % n_glob][(off + j) % n_glob] += a_ij
+__global__ __launch_bounds__(256) void k_scatter_dense(int n_rows, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const double* __restrict__ vals, int64_t off,
+                                                       int n_glob, double* __restrict__ dense) {
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += gridDim.x * blockDim.x) {
+    const size_t gi = (size_t)((off + row) % n_glob);
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+      atomicAdd(&dense[gi * n_glob + (size_t)((off + col[k]) % n_glob)], vals[k]);   // (wrapped tiny periodic levels: rows may coincide)
+  }
+}
+
 // x[(row, v)] = sum_c Ainv[v][c][row] b[(c, v)]   (Ainv symmetric, stored per component)
 __global__ __launch_bounds__(256) void k_dense_apply(int n, int nv,
                                                      const double* __restrict__ Ainv,
@@ -232,6 +310,7 @@ void Multigrid::setup_work(hipStream_t s) {
     MGLevel& L = lv[l];
     const size_t n = (size_t)L.n * nv;
     for (DevBuf<double>* b : {&L.xa, &L.xb, &L.r, &L.d, &L.dinv}) { b->alloc(n); b->zero(s); }
+    if (L.additive) { L.t.alloc(n); L.t.zero(s); }
     if (l > 0) {
       L.x.alloc(n); L.x.zero(s);
       L.b.alloc(n); L.b.zero(s);
@@ -258,9 +337,27 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
       NSFEM_HIP(hipMemcpyAsync(L.own_mask.p, cur.data(), n, hipMemcpyHostToDevice, s));
       NSFEM_HIP(hipStreamSynchronize(s));
     }
-    launch_inv_diag(s, *L.A, nv, L.mask, L.dinv.p);
-    hipLaunchKernelGGL(k_gershgorin, dim3(kParts), dim3(256), 0, s, L.A->pat->n_rows, nv,
-                       L.A->pat->rowptr.p, L.A->vals.p, L.mask, L.dinv.p, parts.p);
+    if (L.additive) {
+      // diagonal and absolute row sums of the whole operator: local parts, ghost rows added at
+      // the owners (sum_r sum_j |a^r_ij| >= sum_j |a_ij|: still a Gershgorin bound)
+      NSFEM_REQUIRE(nv == 1 && L.A->br == 1, "additive multigrid levels are scalar");
+      if (!L.t.p) { L.t.alloc(n); L.t.zero(s); }
+      const Pattern& p = *L.A->pat;
+      const int g = std::min((p.n_rows + 255) / 256, 2048);
+      hipLaunchKernelGGL(k_row_measure, dim3(g), dim3(256), 0, s, p.n_rows, p.rowptr.p, p.diag.p,
+                         L.A->vals.p, 0, L.t.p);
+      if (comm_active() && L.has_halo) comm->exchange_add(s, L.halo, L.t.p, 1);
+      hipLaunchKernelGGL(k_invert_masked, dim3(g), dim3(256), 0, s, (int64_t)n, L.t.p, L.mask, L.dinv.p);
+      hipLaunchKernelGGL(k_row_measure, dim3(g), dim3(256), 0, s, p.n_rows, p.rowptr.p, p.diag.p,
+                         L.A->vals.p, 1, L.t.p);
+      if (comm_active() && L.has_halo) comm->exchange_add(s, L.halo, L.t.p, 1);
+      hipLaunchKernelGGL(k_max_product, dim3(kParts), dim3(256), 0, s, (int64_t)n, L.t.p, L.dinv.p,
+                         L.mask, parts.p);
+    } else {
+      launch_inv_diag(s, *L.A, nv, L.mask, L.dinv.p);
+      hipLaunchKernelGGL(k_gershgorin, dim3(kParts), dim3(256), 0, s, L.A->pat->n_rows, nv,
+                         L.A->pat->rowptr.p, L.A->vals.p, L.mask, L.dinv.p, parts.p);
+    }
     NSFEM_HIP(hipGetLastError());
     NSFEM_HIP(hipMemcpyAsync(hp.data(), parts.p, sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
     NSFEM_HIP(hipStreamSynchronize(s));
@@ -364,6 +461,8 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
   comm->allreduce_sum(s, gb.p, (int64_t)gm.size());
   NSFEM_HIP(hipMemcpyAsync(gm.data(), gb.p, sizeof(double) * gm.size(), hipMemcpyDeviceToHost, s));
   NSFEM_HIP(hipStreamSynchronize(s));
+  NSFEM_REQUIRE(!(tail && C.additive), "additive (algebraic Schur) levels need a dense global coarsest "
+                                       "problem: build the partition without a replicated tail");
   if (tail) {                      // replicated hierarchy instead of one dense solve
     std::vector<uint8_t> gmask(gm.size());
     for (size_t i = 0; i < gm.size(); ++i) gmask[i] = gm[i] > 0.5 ? 1 : 0;
@@ -373,9 +472,26 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
   }
   const Pattern& p = *globA->pat;
   NSFEM_REQUIRE(p.n_rows == n, "global coarsest operator size mismatch");
-  std::vector<double> v((size_t)p.nnz);
-  NSFEM_HIP(hipMemcpyAsync(v.data(), globA->vals.p, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
-  NSFEM_HIP(hipStreamSynchronize(s));
+  std::vector<double> v((size_t)p.nnz), full;
+  if (C.additive) {
+    // the global coarsest operator is the sum of the ranks' coarsest parts: scatter into a dense
+    // matrix in the global numbering, all-reduce
+    NSFEM_REQUIRE(nv == 1, "additive multigrid levels are scalar");
+    DevBuf<double> dense;
+    dense.alloc((size_t)n * n);
+    dense.zero(s);
+    const Pattern& cp = *C.A->pat;
+    hipLaunchKernelGGL(k_scatter_dense, dim3((cp.n_rows + 255) / 256), dim3(256), 0, s, cp.n_rows,
+                       cp.rowptr.p, cp.col.p, C.A->vals.p, glob_off, n, dense.p);
+    NSFEM_HIP(hipGetLastError());
+    comm->allreduce_sum(s, dense.p, (int64_t)n * n);
+    full.resize((size_t)n * n);
+    NSFEM_HIP(hipMemcpyAsync(full.data(), dense.p, sizeof(double) * full.size(), hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+  } else {
+    NSFEM_HIP(hipMemcpyAsync(v.data(), globA->vals.p, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+  }
   std::vector<double> all((size_t)nv * n * n);
   for (int c = 0; c < nv; ++c) {
     std::vector<double> a((size_t)n * n, 0.0);
@@ -383,9 +499,14 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
     for (int i = 0; i < n; ++i) {
       const bool mi = gm[(size_t)i * nv + c] > 0.5;
       any_mask |= mi;
-      for (int k = p.h_rowptr[i]; k < p.h_rowptr[i + 1]; ++k) {
-        const int j = p.h_col[k];
-        if (!mi && !(gm[(size_t)j * nv + c] > 0.5)) a[(size_t)i * n + j] = v[k];
+      if (C.additive) {
+        for (int j = 0; j < n; ++j)
+          if (!mi && !(gm[(size_t)j * nv + c] > 0.5)) a[(size_t)i * n + j] = full[(size_t)i * n + j];
+      } else {
+        for (int k = p.h_rowptr[i]; k < p.h_rowptr[i + 1]; ++k) {
+          const int j = p.h_col[k];
+          if (!mi && !(gm[(size_t)j * nv + c] > 0.5)) a[(size_t)i * n + j] = v[k];
+        }
       }
       if (mi) a[(size_t)i * n + i] = 1.0;
     }
@@ -427,6 +548,10 @@ void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1
 // is written to x_out (which may alias x_in only when steps >= 2).
 void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
                        double* x_out, int steps, bool ghosts_valid, bool ident_last, bool first_done) {
+  if (L.additive) {
+    smooth_additive(s, L, b, x_in, x_out, steps, first_done);
+    return;
+  }
   const int64_t n = (int64_t)L.n * nv;
   double rho = 0.0, c1, c2;
   const double* cur = x_in;
@@ -482,6 +607,48 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
     NSFEM_HIP(hipEventRecord(prof_ev[prof_n + 1], s));
     prof_n += 2;
     prof_open = false;
+  }
+  if (cur != x_out)
+    NSFEM_HIP(hipMemcpyAsync(x_out, cur, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+}
+
+// t = A x on an additive level: ghosts of x filled, every local row multiplied, the ghost rows'
+// partial sums added at their owners (ghost entries of t are left as partial sums: every consumer
+// masks them)
+void Multigrid::apply_additive(hipStream_t s, MGLevel& L, const double* x, double* t) {
+  halo_fill(s, L, x);
+  launch_spmv(s, *L.A, nv, x, t, nullptr, MASK_NONE, 0, 0);
+  if (comm_active() && L.has_halo) comm->exchange_add(s, L.halo, t, nv);
+}
+
+void Multigrid::smooth_additive(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
+                                double* x_out, int steps, bool first_done) {
+  const int64_t n = (int64_t)L.n * nv;
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  double rho = 0.0, c1, c2;
+  const double* cur = x_in;
+  int k0 = 0;
+  if (first_done) {
+    cheb_coeffs(L, 0, 0.0, c1, c2, rho);
+    cur = L.xa.p;
+    k0 = 1;
+  }
+  for (int k = k0; k < steps; ++k) {
+    double rho_new;
+    cheb_coeffs(L, k, rho, c1, c2, rho_new);
+    rho = rho_new;
+    double* out;
+    if (k == steps - 1 && (x_out != cur)) out = x_out;
+    else out = (cur == L.xa.p) ? L.xb.p : L.xa.p;
+    if (cur == nullptr) {
+      hipLaunchKernelGGL(k_cheb_first, dim3(grid), dim3(256), 0, s, n, b, L.dinv.p, L.mask, c2, L.d.p, out);
+    } else {
+      apply_additive(s, L, cur, L.t.p);
+      hipLaunchKernelGGL(k_cheb_update, dim3(grid), dim3(256), 0, s, n, L.t.p, b, L.dinv.p, L.mask,
+                         c1, c2, L.d.p, cur, out);
+    }
+    NSFEM_HIP(hipGetLastError());
+    cur = out;
   }
   if (cur != x_out)
     NSFEM_HIP(hipMemcpyAsync(x_out, cur, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
@@ -566,8 +733,15 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
   bool child_first = false;
   if (pre > 0) {
     smooth(s, L, b, nullptr, x, pre, false, false, first_done);
-    halo_fill(s, L, x);
-    launch_residual(s, *L.A, nv, x, b, L.r.p, L.mask, MASK_ZERO);
+    if (L.additive) {
+      apply_additive(s, L, x, L.t.p);
+      hipLaunchKernelGGL(k_resid_update, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256),
+                         0, s, n, L.t.p, b, L.mask, L.r.p);
+      NSFEM_HIP(hipGetLastError());
+    } else {
+      halo_fill(s, L, x);
+      launch_residual(s, *L.A, nv, x, b, L.r.p, L.mask, MASK_ZERO);
+    }
     halo_fill(s, L, L.r.p);
     child_first = restrict_to(s, l, L.r.p);
   } else {            // no pre-smoothing: x = 0, the residual is b itself

@@ -336,6 +336,10 @@ struct Comm {
   virtual void allreduce_max(hipStream_t s, double* dev, int64_t count) = 0;
   // fill the ghost ranges of `vec` (width entries per node) from the neighbouring ranks
   virtual void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) = 0;
+  // the reverse of `exchange`: the values this rank holds in its ghost ranges are ADDED to the
+  // owners' entries (their send ranges) -- products with operators that are stored as rank-local
+  // additive parts (A = sum_r A_r), where every rank computes partial sums for its ghost rows
+  virtual void exchange_add(hipStream_t s, const HaloRange& h, double* vec, int width) = 0;
   // ---- overlap of the exchange with the interior rows of the product that consumes `vec`:
   // exchange_begin orders the exchange after everything queued on `s` so far and runs it on the
   // communicator's own stream; exchange_end makes `s` wait for its completion.  Between the two
@@ -366,6 +370,10 @@ struct Comm {
   // traffic counters (calls / payload bytes this rank sends), read through nsfem_comm_stats
   int64_t n_allreduce = 0, n_exchange = 0, bytes_allreduce = 0, bytes_exchange = 0;
   void count_allreduce(int64_t count) { ++n_allreduce; bytes_allreduce += 8 * count; }
+  void count_exchange_add(const HaloRange& h, int width) {
+    ++n_exchange;
+    bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.recv_above_cnt : 0) + (down() >= 0 ? h.recv_below_cnt : 0));
+  }
   void count_exchange(const HaloRange& h, int width) {
     ++n_exchange;
     bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.send_up_cnt : 0) + (down() >= 0 ? h.send_down_cnt : 0));
@@ -441,6 +449,12 @@ struct MGLevel {
   const std::vector<uint8_t>* h_ghost = nullptr;   // per node: nonzero = ghost
   HaloRange halo;
   bool has_halo = false;
+  // partitioned meshes, operators without an element-local form (the algebraic Schur Laplacian
+  // D diag(M)^-1 D^T): A holds this rank's ADDITIVE part -- the sum over the ranks of the parts,
+  // ghost rows included, is the operator.  Products: fill the ghosts of x, multiply every local
+  // row, add the ghost rows at their owners (Comm::exchange_add).
+  bool additive = false;
+  DevBuf<double> t;              // additive levels: the product before the smoother update
 };
 
 struct Multigrid : Precond {
@@ -493,6 +507,9 @@ struct Multigrid : Precond {
   bool truncated() const { return active > 0 && active < lv.size(); }
   void refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>& cur, bool singular);
   void halo_fill(hipStream_t s, const MGLevel& L, const double* v);
+  void apply_additive(hipStream_t s, MGLevel& L, const double* x, double* t);
+  void smooth_additive(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
+                       int steps, bool first_done);
   void setup_work(hipStream_t s);
   void refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular);
   void apply(hipStream_t s, const double* r, double* z) override;
@@ -613,6 +630,7 @@ struct nsfem_ctx {
     nsfem::BlockMat mat;
   };
   std::vector<CsrOp*> schur_ops;               // owned
+  bool schur_additive = false;                 // operators of nsfem_mg_set_schur_operator are rank parts
   int schur_singular = -1;                     // -1: geometric hierarchy (singular iff no Dirichlet set)
   // monolithic BDF system: mixed operator, block preconditioner and their data
   nsfem::Multigrid mg_s, mg_m;                 // Schur Laplacian V-cycle, pressure-mass smoother

@@ -172,29 +172,51 @@ def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None, peri
     return len(levels)
 
 
-def attach_schur_laplacian(ctx, velocity_bc_dofs):
+def attach_schur_laplacian(ctx, velocity_bc_dofs, part=None):
     """Algebraic pressure Laplacian of the monolithic scheme's Schur-complement preconditioner:
     A_L = D_f diag(M_v)^{-1} D_f^T on the fine P1 space (D_f = divergence block without the
     Dirichlet velocity columns, M_v = P2 mass matrix) and its Galerkin coarsenings P^T A P along
     the hierarchy ``attach_hierarchy`` installed.  Set-up-time host work (scipy sparse products of
     operators exported from the device); the per-step path only sees the resulting CSR levels.
-    A_L is singular (constants) exactly when every velocity boundary dof is constrained."""
+    A_L is singular (constants) exactly when every velocity boundary dof is constrained.
+
+    ``part`` (a partition of partition.py with more than one rank, already attached): every rank
+    builds its ADDITIVE part from the columns of the velocity dofs it owns,
+        A_r = D[:, owned] diag(1 / m)[owned] D[:, owned]^T        (sum over the ranks = A_L),
+    ghost rows included -- all pressure nodes next to an owned velocity dof are local, and so are
+    the cells the entries D_ij and m_j of an owned j are integrated over -- and coarsens it with its
+    own prolongations.  No rank ever sees a neighbour's matrix entries; the device adds the ghost
+    rows of every product at their owners (nsfem_mg_set_schur_mode)."""
     import scipy.sparse as sp
     import _native as nat
     D = ctx.operator_csr(nat.OP_DIV).tocsc()                        # n_p1 x (dim n_p2)
     m = ctx.operator_csr(nat.OP_MASS_P2).diagonal()
-    w = np.repeat(1.0 / m, D.shape[1] // m.size)                    # node-interleaved components
+    width = D.shape[1] // m.size
+    w = np.repeat(1.0 / m, width)                                   # node-interleaved components
     free = np.ones(D.shape[1], dtype=bool)
     free[np.asarray(velocity_bc_dofs, dtype=np.int64)] = False
     w[~free] = 0.0
+    additive = part is not None and part.size > 1
+    if additive:
+        w[~np.repeat(np.asarray(part.p2_owned, dtype=bool), width)] = 0.0
+        ctx.mg_set_schur_mode(True)
+
+    def with_diagonal(A):
+        """every row stores its diagonal (ghost rows of a rank part may not touch it)"""
+        B = (A + sp.identity(A.shape[0], format="csr")).tocsr()
+        B.setdiag(B.diagonal() - 1.0)
+        B.sort_indices()
+        return B
+
     A = (D @ sp.diags(w) @ D.T).tocsr()
     ones = np.ones(A.shape[0])
-    singular = bool(np.abs(A @ ones).max() <= 1e-10 * np.abs(A.diagonal()).max())
-    ctx.mg_set_schur_operator(0, A, singular)
+    local = float(np.abs(A @ ones).max() / max(np.abs(A.diagonal()).max(), 1e-300))
+    singular = bool(ctx.comm_allreduce([local], "max")[0] <= 1e-10)
+    ctx.mg_set_schur_operator(0, with_diagonal(A) if additive else A, singular)
     for l, (n_coarse, (rowptr, col, val)) in enumerate(ctx.mg_prolongations):
         P = sp.csr_matrix((val, col, rowptr), shape=(A.shape[0], n_coarse))
         A = (P.T @ A @ P).tocsr()
-        ctx.mg_set_schur_operator(l + 1, A, singular)
+        ctx.mg_set_schur_operator(l + 1, with_diagonal(A) if additive else A, singular)
     return singular
 
 

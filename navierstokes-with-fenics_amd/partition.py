@@ -142,9 +142,11 @@ class StripPartition:
         n2g, n1g = global_dof_counts(self.nx, self.ny)
         ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, self.p2_halo,
                           self.p1_halo, n2g, n1g)
+        ctx.mg_prolongations = []                      # kept for attach_schur_laplacian(ctx, ..., part=self)
         for lev, (rowptr, col, val) in self.levels:
             ctx.mg_add_level(lev.mesh.coords, lev.mesh.cells, rowptr, col, val,
                              ghost=lev.p1_ghost, halo=lev.p1_halo)
+            ctx.mg_prolongations.append((lev.n_p1, (rowptr, col, val)))
         cx, cy = self.coarse_global_shape
         from fem_mesh import rectangle_mesh
         cg = rectangle_mesh(self.p0, self.p1, cx, cy)
@@ -263,9 +265,11 @@ class SlabPartition:
         n2g, n1g = global_dof_counts(self.nx, self.ny, self.nz)
         ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, self.p2_halo,
                           self.p1_halo, n2g, n1g)
+        ctx.mg_prolongations = []                      # kept for attach_schur_laplacian(ctx, ..., part=self)
         for lev, (rowptr, col, val) in self.levels:
             ctx.mg_add_level(lev.mesh.coords, lev.mesh.cells, rowptr, col, val,
                              ghost=lev.p1_ghost, halo=lev.p1_halo)
+            ctx.mg_prolongations.append((lev.n_p1, (rowptr, col, val)))
         cg = box_mesh(self.p0, self.p1, *self.coarse_global_shape)
         ctx.mg_set_global_coarse(cg.coords, cg.cells, self.coarse_global_offset)
         for mesh, (rowptr, col, val) in self.global_tail:

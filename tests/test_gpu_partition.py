@@ -331,6 +331,143 @@ def test_partitioned_3d_slabs_equal_single_context(scheme, problem):
     nat.local_group_destroy(group)
 
 
+@pytest.mark.parametrize("dim,size", [(3, 2), (3, 4), (2, 2), (2, 4)])
+def test_partitioned_algebraic_schur_laplacian_equals_single_context(dim, size, capsys):
+    """BASELINE configs[4] in small on several ranks, with the preconditioner the single-GPU channel
+    runs use: the ALGEBRAIC Schur Laplacian D diag(M)^-1 D^T (open outlet: no pressure Dirichlet
+    set anywhere).  Every rank holds only its additive part (columns of the velocity dofs it owns)
+    and its Galerkin coarsenings; products run as forward exchange -> local rows -> reverse (add)
+    exchange.  Checks: (1) the parts sum to the single-context operator on every level it can be
+    compared on, (2) the partitioned monolithic steps equal the single-context ones, with the same
+    iteration counts; the halo / all-reduce counts per step are printed."""
+    from fem_mesh import TaylorHoodDofMap, box_mesh, rectangle_mesh
+    from multigrid import attach_schur_laplacian
+    from partition import SlabPartition, StripPartition
+    n, nsteps, k = (8, 2, 0.02) if dim == 3 else (32, 2, 0.02)
+    if dim == 3:
+        mesh = box_mesh((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n)
+    else:
+        mesh = rectangle_mesh((0.0, 0.0), (1.0, 1.0), n, n)
+    dm = TaylorHoodDofMap(mesh)
+
+    def bc(dmap):
+        X = dmap.p2_coords
+        on = np.zeros(dmap.n_p2, dtype=bool)
+        for a in range(dim):
+            on |= (np.abs(X[:, a]) < 1e-12)
+            if a != 0:
+                on |= (np.abs(X[:, a] - 1.0) < 1e-12)          # x = 1 stays open
+        nodes = np.nonzero(on)[0]
+        inlet = (np.abs(X[nodes, 0]) < 1e-12)
+        prof = 4.0 * X[nodes, 1] * (1 - X[nodes, 1])
+        if dim == 3:
+            prof = prof * 4.0 * X[nodes, 2] * (1 - X[nodes, 2])
+        ux = np.where(inlet, prof, 0.0)
+        return (np.concatenate([dim * nodes + a for a in range(dim)]).astype(np.int32),
+                np.concatenate([ux] + [np.zeros(nodes.size)] * (dim - 1)))
+
+    def run(ctx, dmap, out, key, part=None):
+        ctx.set_coeffs(1.0, 1.0, 0.02)
+        dofs, vals = bc(dmap)
+        ctx.set_dirichlet(nat.VELOCITY, dofs, vals)
+        singular = attach_schur_laplacian(ctx, dofs, part=part)
+        assert not singular
+        opts = ctx.default_step_opts()
+        opts.momentum.rtol = 1e-12
+        opts.momentum.precond = 1
+        infos = []
+        ctx.comm_stats(reset=True)
+        for step in range(nsteps):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
+            infos.append(ctx.step_bdf(opts))
+            ctx.advance(1)
+        out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos, ctx.comm_stats())
+
+    ref = {}
+    ctx0 = context(mesh, dm)
+    attach_hierarchy(ctx0, mesh, coarsest=4 if dim == 3 else 8)
+    run(ctx0, dm, ref, 0)
+    u_ref, p_ref, inf_ref, _ = ref[0]
+    ctx0.close()
+    group = nat.local_group_create(size)
+    if dim == 3:
+        parts = [SlabPartition((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), n, n, n, r, size, coarsest=4) for r in range(size)]
+    else:
+        parts = [StripPartition((0.0, 0.0), (1.0, 1.0), n, n, r, size, coarsest=8) for r in range(size)]
+    assert len(parts[0].levels) >= 1
+    ctxs = []
+    for r, part in enumerate(parts):
+        pdm = part.dofmap
+        c = nat.NsfemContext(part.mesh.coords, part.mesh.cells, pdm.p2_dofmap, pdm.p1_dofmap,
+                             pdm.n_p2, pdm.n_p1)
+        c.attach_local_comm(group, r)
+        ctxs.append(c)
+    out, errors = {}, []
+
+    def worker(r):
+        try:
+            parts[r].attach(ctxs[r])
+            run(ctxs[r], parts[r].dofmap, out, r, part=parts[r])
+        except BaseException as exc:
+            import traceback
+            traceback.print_exc()
+            errors.append((r, repr(exc)))
+            os._exit(17)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    u = np.zeros_like(u_ref)
+    p = np.zeros_like(p_ref)
+    for r, part in enumerate(parts):
+        ul, pl, infos, stats = out[r]
+        u.reshape(-1, dim)[part.p2_global[part.p2_owned]] = ul.reshape(-1, dim)[part.p2_owned]
+        p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
+        for a, b in zip(infos, inf_ref):
+            assert a.newton_iterations == b.newton_iterations
+            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= 1
+        with capsys.disabled():
+            its = sum(i.krylov_iterations_momentum for i in infos)
+            print(f"\n[algebraic Schur, {dim}D, rank {r}/{size}] per step: "
+                  f"{stats['allreduce_calls'] / nsteps:.0f} all-reduces ({stats['allreduce_bytes'] / nsteps / 1e3:.1f} kB), "
+                  f"{stats['exchanges'] / nsteps:.0f} halo exchanges incl. reverse adds "
+                  f"({stats['exchange_bytes'] / nsteps / 1e6:.2f} MB), {its / nsteps:.1f} BiCGStab iterations")
+    assert rel(u, u_ref) < 1e-10
+    assert rel(p, p_ref) < 1e-9
+    for c in ctxs:
+        c.close()
+    nat.local_group_destroy(group)
+
+
+def test_channel_bench_thread_ranks_match_the_single_rank_run():
+    """bench.py --workload channel3d-bdf (BASELINE configs[4]) on 1 rank and on 2 / 4 thread ranks
+    (--local-ranks: the N-rank code path of the bench -- slabs, additive Schur parts, the reductions
+    of its invariants -- through the in-process communicator on one GPU), strong scaling = the
+    same mesh: same Newton counts, the same boundary fluxes, invariants green on every run."""
+    def run(extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "channel3d-bdf", "--cells", "8",
+               "--steps", "3", "--warmup", "1", "--krylov-rtol", "1e-10", "--newton-forcing", "0",
+               "--no-cpu-baseline"] + extra
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return json.loads(res.stdout.strip().splitlines()[-1])
+    one = run([])
+    assert one["n_gpus"] == 1 and one["config"]["invariants"]["mass_balance_rel"] < 1e-6
+    for ranks in (2, 4):
+        many = run(["--local-ranks", str(ranks), "--scaling", "strong"])
+        assert many["n_gpus"] == ranks and many["scaling"] == "strong"
+        assert many["config"]["n_dofs"] == one["config"]["n_dofs"]
+        assert many["config"]["newton_its_per_step"] == one["config"]["newton_its_per_step"]
+        fa, fb = many["config"]["invariants"]["flux"], one["config"]["invariants"]["flux"]
+        for side in fb:
+            assert abs(fa[side] - fb[side]) < 1e-8 * abs(fb["inlet"]), side
+        stats = many["config"]["comm_per_step_rank0"]
+        assert stats["exchanges"] > 0 and stats["allreduce_calls"] > 0
+
+
 def test_bench_through_rccl_single_rank():
     """bench.py with the RCCL communicator attached (1 rank): ncclCommInitRank, the all-reduces
     of every dot product and the torch.distributed(gloo) bootstrap all run for real."""

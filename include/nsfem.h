@@ -316,6 +316,26 @@ typedef struct {
                                 the lower neighbour of rank 0, halo exchanges wrap around */
 } nsfem_partition_desc;
 int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* part);
+/* Unstructured partitions (recursive coordinate bisection, partition.GraphPartition): a rank has
+ * any number of neighbours and its ghost / send nodes are index lists.  For neighbour k (rank
+ * neighbour[k]) this rank sends the nodes send_idx[send_ptr[k] .. send_ptr[k+1]) -- owned here,
+ * ghost there -- and receives into recv_idx[recv_ptr[k] .. recv_ptr[k+1]); both sides order a
+ * pair's list by global node id, so the k-th value sent is the k-th value received.
+ * target 0: P2 nodes, 1: P1 nodes of the context (call nsfem_set_partition first, with zeroed
+ * nsfem_halo ranges), 2 + l: P1 nodes of multigrid level l (after its nsfem_mg_add_level, ghost
+ * flags given there).  Before nsfem_mg_finalize. */
+typedef struct {
+  int32_t n_neighbours;
+  const int32_t* neighbour;  /* [n_neighbours] */
+  const int64_t* send_ptr;   /* [n_neighbours + 1] */
+  const int32_t* send_idx;
+  const int64_t* recv_ptr;   /* [n_neighbours + 1] */
+  const int32_t* recv_idx;
+} nsfem_halo_lists;
+int nsfem_set_halo_lists(nsfem_ctx* ctx, int target, const nsfem_halo_lists* lists);
+/* unstructured partitions: global id (in the mesh of nsfem_mg_set_global_coarse, offset 0) of every
+ * node of the local coarsest level */
+int nsfem_mg_set_global_index(nsfem_ctx* ctx, int32_t n_local, const int32_t* local_to_global);
 int nsfem_comm_unique_id(char* id128 /* 128 bytes out */);
 int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int rank, int size);
 int nsfem_comm_local_create(int size, void** group);

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse", "nsfem_mg_set_global_coarse_constrained",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -86,6 +86,12 @@ class Halo(C.Structure):
                 setattr(h, key + "_off", int(d[key][0]))
                 setattr(h, key + "_cnt", int(d[key][1]))
         return h
+
+
+class HaloLists(C.Structure):
+    _fields_ = [("n_neighbours", C.c_int32), ("neighbour", C.POINTER(C.c_int32)),
+                ("send_ptr", C.POINTER(C.c_int64)), ("send_idx", C.POINTER(C.c_int32)),
+                ("recv_ptr", C.POINTER(C.c_int64)), ("recv_idx", C.POINTER(C.c_int32))]
 
 
 class MgLevelDesc(C.Structure):
@@ -181,6 +187,8 @@ def load_library(path=None):
                                                   C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                                   C.c_int]),
         "nsfem_mg_set_schur_mode": (C.c_int, [vp, C.c_int]),
+        "nsfem_set_halo_lists": (C.c_int, [vp, C.c_int, C.POINTER(HaloLists)]),
+        "nsfem_mg_set_global_index": (C.c_int, [vp, i32, pi]),
         "nsfem_comm_allreduce": (C.c_int, [vp, pd, C.c_int, C.c_int]),
         "nsfem_mg_set_global_coarse": (C.c_int, [vp, i32, i32, pd, pi, i64]),
         "nsfem_mg_set_global_coarse_constrained": (C.c_int, [vp, i32, i32, pd, pi, pi, i32, i64]),
@@ -473,6 +481,23 @@ class NsfemContext:
                           g1.ctypes.data_as(C.POINTER(C.c_uint8)), Halo.from_dict(p2_halo),
                           Halo.from_dict(p1_halo), int(n_p2_global), int(n_p1_global), 1 if periodic else 0)
         self._check(self._lib.nsfem_set_partition(self._h, C.byref(d)))
+
+    def set_halo_lists(self, target, lists):
+        """index-list halo of an unstructured partition; ``lists`` = dict(neighbour, send_ptr,
+        send_idx, recv_ptr, recv_idx); target 0 P2 nodes, 1 P1 nodes, 2 + l multigrid level l"""
+        nb = np.ascontiguousarray(lists["neighbour"], dtype=np.int32)
+        sp = np.ascontiguousarray(lists["send_ptr"], dtype=np.int64)
+        si = np.ascontiguousarray(lists["send_idx"], dtype=np.int32)
+        rp = np.ascontiguousarray(lists["recv_ptr"], dtype=np.int64)
+        ri = np.ascontiguousarray(lists["recv_idx"], dtype=np.int32)
+        assert sp.size == nb.size + 1 and rp.size == nb.size + 1 and sp[-1] == si.size and rp[-1] == ri.size
+        p64 = C.POINTER(C.c_int64)
+        d = HaloLists(int(nb.size), _ip(nb), sp.ctypes.data_as(p64), _ip(si), rp.ctypes.data_as(p64), _ip(ri))
+        self._check(self._lib.nsfem_set_halo_lists(self._h, int(target), C.byref(d)))
+
+    def mg_set_global_index(self, local_to_global):
+        idx = np.ascontiguousarray(local_to_global, dtype=np.int32)
+        self._check(self._lib.nsfem_mg_set_global_index(self._h, int(idx.size), _ip(idx)))
 
     def attach_local_comm(self, group, rank):
         self._check(self._lib.nsfem_comm_attach_local(self._h, group, rank))

@@ -357,6 +357,7 @@ extern "C" int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const i
     if (changed) { ctx->dinv_m_ready = false; ctx->mg_v_dirty = true; }
   } else {
     ctx->nbc_p = (int)d.size();
+    ctx->bc_p_any = -1;            // partitioned meshes: agreed on by all ranks at the next solve
     if (changed) { ctx->dinv_p_ready = false; ctx->mg_p_dirty = true; }
   }
   prev.swap(d);
@@ -754,6 +755,26 @@ static void poisson_assemble(nsfem_ctx* c, bool extrapolate = false) {
   }
 }
 
+// is the pressure pinned by a Dirichlet value ANYWHERE?  On partitioned meshes a rank may hold
+// none of the outlet nodes (unstructured partitions): all ranks must take the same branch in the
+// solver (mean projection of the singular problem = an all-reduce), so the flag is all-reduced
+// once after every nsfem_set_dirichlet(PRESSURE) -- which every rank calls, if only with n = 0.
+static bool pressure_pinned_anywhere(nsfem_ctx* c) {
+  if (!c->distributed()) return c->nbc_p > 0;
+  if (c->bc_p_any < 0) {
+    hipStream_t s = c->stream;
+    c->kw.ensure(nvel(c));
+    double* parts = c->kw.parts.p;
+    double v = c->nbc_p > 0 ? 1.0 : 0.0;
+    NSFEM_HIP(hipMemcpyAsync(parts, &v, sizeof(double), hipMemcpyHostToDevice, s));
+    c->comm->allreduce_max(s, parts, 1);
+    NSFEM_HIP(hipMemcpyAsync(&v, parts, sizeof(double), hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+    c->bc_p_any = v > 0.5 ? 1 : 0;
+  }
+  return c->bc_p_any > 0;
+}
+
 static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
   LinOp op;
   op.A = &c->Ap;
@@ -768,7 +789,7 @@ static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_i
     op.prec = &c->mg_p;
   }
   op.graph_epoch = c->graph_epoch;
-  return pcg(c->stream, c->kw, op, c->rhs_p.p, c->state[NSFEM_P].p, o, info, c->nbc_p == 0);
+  return pcg(c->stream, c->kw, op, c->rhs_p.p, c->state[NSFEM_P].p, o, info, !pressure_pinned_anywhere(c));
 }
 
 // rhs = M u* - k/alpha0 G (p - p_old) ; start vector u0 = u* with Dirichlet values
@@ -1127,6 +1148,67 @@ extern "C" int nsfem_mg_set_global_coarse_constrained(nsfem_ctx* ctx, int32_t n_
   API_END(ctx)
 }
 
+// unstructured partitions: the local coarsest level maps into the global coarsest mesh through
+// an index list instead of an offset
+extern "C" int nsfem_mg_set_global_index(nsfem_ctx* ctx, int32_t n_local, const int32_t* local_to_global) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && local_to_global && n_local > 0, "bad argument");
+  NSFEM_REQUIRE(!ctx->mg_built, "hierarchy already finalized");
+  NSFEM_REQUIRE(ctx->global_coarse, "set the global coarsest mesh first (nsfem_mg_set_global_coarse)");
+  for (int i = 0; i < n_local; ++i)
+    NSFEM_REQUIRE(local_to_global[i] >= 0 && local_to_global[i] < ctx->global_coarse->n, "global id out of range");
+  ctx->h_glob_idx.assign(local_to_global, local_to_global + n_local);
+  ctx->glob_idx.upload(ctx->h_glob_idx, ctx->stream);
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  API_END(ctx)
+}
+
+// halo of an unstructured partition as index lists; target 0: P2 nodes, 1: P1 nodes of the
+// context (after nsfem_set_partition), 2 + l: P1 nodes of multigrid level l (after its
+// nsfem_mg_add_level); before nsfem_mg_finalize
+extern "C" int nsfem_set_halo_lists(nsfem_ctx* ctx, int target, const nsfem_halo_lists* d) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && d && d->n_neighbours >= 0, "bad argument");
+  NSFEM_REQUIRE(!ctx->mg_built, "set the halo lists before nsfem_mg_finalize");
+  int64_t n_nodes = 0;
+  HaloRange* h = nullptr;
+  if (target == 0) { h = &ctx->halo_p2; n_nodes = ctx->mesh.n_p2; }
+  else if (target == 1) { h = &ctx->halo_p1; n_nodes = ctx->mesh.n_p1; }
+  else {
+    NSFEM_REQUIRE(target >= 2 && target - 2 < (int)ctx->coarse.size(), "no such multigrid level");
+    h = &ctx->coarse[target - 2]->halo;
+    n_nodes = ctx->coarse[target - 2]->n;
+    ctx->coarse[target - 2]->has_halo = true;
+  }
+  HaloLists* L = new HaloLists();
+  ctx->halo_lists.push_back(L);
+  const int nn = d->n_neighbours;
+  NSFEM_REQUIRE(nn == 0 || (d->neighbour && d->send_ptr && d->recv_ptr), "null list");
+  L->nbr.assign(d->neighbour, d->neighbour + nn);
+  L->send_ptr.assign(1, 0);
+  L->recv_ptr.assign(1, 0);
+  if (nn > 0) {
+    L->send_ptr.assign(d->send_ptr, d->send_ptr + nn + 1);
+    L->recv_ptr.assign(d->recv_ptr, d->recv_ptr + nn + 1);
+  }
+  NSFEM_REQUIRE(L->send_ptr[0] == 0 && L->recv_ptr[0] == 0, "list pointers start at 0");
+  for (int k = 0; k < nn; ++k) {
+    NSFEM_REQUIRE(L->nbr[k] >= 0 && L->send_ptr[k + 1] >= L->send_ptr[k] && L->recv_ptr[k + 1] >= L->recv_ptr[k],
+                  "malformed halo lists");
+  }
+  for (int64_t i = 0; i < L->n_send(); ++i)
+    NSFEM_REQUIRE(d->send_idx[i] >= 0 && d->send_idx[i] < n_nodes, "send index out of range");
+  for (int64_t i = 0; i < L->n_recv(); ++i)
+    NSFEM_REQUIRE(d->recv_idx[i] >= 0 && d->recv_idx[i] < n_nodes, "receive index out of range");
+  if (L->n_send() > 0) L->send_idx.upload(d->send_idx, (size_t)L->n_send(), ctx->stream);
+  if (L->n_recv() > 0) L->recv_idx.upload(d->recv_idx, (size_t)L->n_recv(), ctx->stream);
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
+  *h = HaloRange();
+  h->lists = L;
+  ctx->mg_mv.lv.clear();
+  API_END(ctx)
+}
+
 extern "C" int nsfem_set_partition(nsfem_ctx* ctx, const nsfem_partition_desc* d) {
   API_BEGIN
   NSFEM_REQUIRE(ctx && d && d->p2_ghost && d->p1_ghost, "null argument");
@@ -1212,6 +1294,11 @@ static void wire_partition(nsfem_ctx* ctx, Multigrid& mg, size_t first_p1, bool 
   mg.globA = momentum ? &ctx->global_coarse->Lc : &ctx->global_coarse->K;
   mg.n_glob = ctx->global_coarse->n;
   mg.glob_off = ctx->glob_off;
+  if (!ctx->h_glob_idx.empty()) {
+    NSFEM_REQUIRE((int)ctx->h_glob_idx.size() == mg.lv.back().n, "global index list does not match the coarsest level");
+    mg.glob_idx = ctx->glob_idx.p;
+    mg.h_glob_idx = &ctx->h_glob_idx;
+  }
   if (!ctx->global_tail.empty()) {          // replicated hierarchy below the global coarse mesh
     Multigrid& t = momentum ? ctx->mg_v_tail : ctx->mg_p_tail;
     t.nv = mg.nv; t.degree = mg.degree; t.pre_degree = mg.pre_degree; t.eig_ratio = mg.eig_ratio;
@@ -1230,7 +1317,7 @@ static void wire_partition(nsfem_ctx* ctx, Multigrid& mg, size_t first_p1, bool 
     mg.tail = &t;
   }
   mg.glob_wrap = ctx->partition_periodic;
-  NSFEM_REQUIRE(mg.glob_off >= 0 && (mg.glob_wrap || mg.glob_off + mg.lv.back().n <= mg.n_glob),
+  NSFEM_REQUIRE(mg.glob_idx || (mg.glob_off >= 0 && (mg.glob_wrap || mg.glob_off + mg.lv.back().n <= mg.n_glob)),
                 "local coarsest level does not fit into the global coarsest mesh");
 }
 

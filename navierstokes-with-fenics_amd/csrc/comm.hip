@@ -27,6 +27,7 @@ struct LocalGroup {
   uint64_t gen = 0;
   double* ptr[kMaxLocalRanks] = {nullptr};
   HaloRange halo[kMaxLocalRanks];
+  int kind[kMaxLocalRanks] = {0};     // which collective every rank entered (checked after the barrier)
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const uint64_t g = gen;
@@ -67,14 +68,48 @@ static void add_range(hipStream_t s, int64_t n, const double* src, double* dst) 
   NSFEM_HIP(hipGetLastError());
 }
 
+// list halos: dst[didx[i]] (op)= src[sidx[i]] for `width` interleaved values per node; a null index
+// array means the identity (packed staging buffers)
+__global__ __launch_bounds__(256) void k_move_idx(int64_t n, int width, const double* __restrict__ src,
+                                                  const int32_t* __restrict__ sidx,
+                                                  double* __restrict__ dst,
+                                                  const int32_t* __restrict__ didx, int add) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * width;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / width;
+    const int c = (int)(t % width);
+    const int64_t si = (sidx ? (int64_t)sidx[i] : i) * width + c, di = (didx ? (int64_t)didx[i] : i) * width + c;
+    if (add) dst[di] += src[si];
+    else dst[di] = src[si];
+  }
+}
+static void move_idx(hipStream_t s, int64_t n, int width, const double* src, const int32_t* sidx,
+                     double* dst, const int32_t* didx, bool add) {
+  if (n <= 0) return;
+  const int grid = (int)std::min<int64_t>((n * width + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_move_idx, dim3(grid), dim3(256), 0, s, n, width, src, sidx, dst, didx, add ? 1 : 0);
+  NSFEM_HIP(hipGetLastError());
+}
+
 struct LocalComm : Comm {
   LocalGroup* g = nullptr;
   DevBuf<double> scratch;
+  // the ranks are threads that meet at a barrier: a rank-local branch around a collective would
+  // pair an all-reduce with a halo exchange silently -- compare what everybody entered
+  void check_same_collective(int mine) {
+    for (int r = 0; r < size; ++r)
+      if (g->kind[r] != mine)
+        throw Error(NSFEM_ERR_COMM, "collective mismatch: rank " + std::to_string(rank) + " entered kind " +
+                                        std::to_string(mine) + ", rank " + std::to_string(r) + " kind " +
+                                        std::to_string(g->kind[r]) + " (1/2 all-reduce sum/max, 3 exchange, 4 reverse add)");
+  }
   void reduce(hipStream_t s, double* dev, int64_t count, int op) {
     count_allreduce(count);
     NSFEM_HIP(hipStreamSynchronize(s));
     g->ptr[rank] = dev;
+    g->kind[rank] = 1 + op;
     g->barrier();
+    check_same_collective(1 + op);
     if (scratch.n < (size_t)count) scratch.alloc((size_t)count);
     PtrPack pk;
     for (int r = 0; r < kMaxLocalRanks; ++r) pk.p[r] = r < size ? g->ptr[r] : nullptr;
@@ -84,15 +119,53 @@ struct LocalComm : Comm {
     NSFEM_HIP(hipStreamSynchronize(s));
     g->barrier();      // everybody has read everybody's input
     NSFEM_HIP(hipMemcpyAsync(dev, scratch.p, sizeof(double) * count, hipMemcpyDeviceToDevice, s));
+    static const bool trace = std::getenv("NSFEM_COMM_TRACE") != nullptr;
+    if (trace) {
+      std::vector<double> h((size_t)count);
+      NSFEM_HIP(hipMemcpyAsync(h.data(), scratch.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+      NSFEM_HIP(hipStreamSynchronize(s));
+      double sum = 0.0;
+      for (double v : h) sum += v;
+      fprintf(stderr, "[rank %d] allreduce #%lld count %lld op %d sum %.17g\n", rank, (long long)n_allreduce,
+              (long long)count, op, sum);
+    }
   }
   void allreduce_sum(hipStream_t s, double* dev, int64_t count) override { reduce(s, dev, count, 0); }
   void allreduce_max(hipStream_t s, double* dev, int64_t count) override { reduce(s, dev, count, 1); }
   void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) override {
     count_exchange(h, width);
+    static const bool trace = std::getenv("NSFEM_COMM_TRACE") != nullptr;
+    if (trace)
+      fprintf(stderr, "[rank %d] exchange #%lld width %d lists %lld/%lld\n", rank, (long long)n_exchange, width,
+              h.lists ? (long long)h.lists->n_send() : -1LL, h.lists ? (long long)h.lists->n_recv() : -1LL);
     NSFEM_HIP(hipStreamSynchronize(s));
     g->ptr[rank] = vec;
     g->halo[rank] = h;
+    g->kind[rank] = 3;
     g->barrier();
+    check_same_collective(3);
+    if (h.lists) {                 // pull every neighbour's send list into my ghost entries
+      const HaloLists& me = *h.lists;
+      for (size_t k = 0; k < me.nbr.size(); ++k) {
+        const int q = me.nbr[k];
+        const HaloLists* o = g->halo[q].lists;
+        NSFEM_REQUIRE(o, "neighbour without list halo");
+        const int m = o->find(rank);
+        const int64_t cnt = me.recv_ptr[k + 1] - me.recv_ptr[k];
+        if (!(m >= 0 && o->send_ptr[m + 1] - o->send_ptr[m] == cnt))
+          throw Error(NSFEM_ERR_ARG, "list halo size mismatch: rank " + std::to_string(rank) + " expects " +
+                                         std::to_string(cnt) + " from rank " + std::to_string(q) + ", which sends " +
+                                         std::to_string(m >= 0 ? o->send_ptr[m + 1] - o->send_ptr[m] : -1) +
+                                         " (width " + std::to_string(width) + ", my lists " +
+                                         std::to_string(me.n_send()) + "/" + std::to_string(me.n_recv()) + ", its " +
+                                         std::to_string(o->n_send()) + "/" + std::to_string(o->n_recv()) + ")");
+        move_idx(s, cnt, width, g->ptr[q], o->send_idx.p + o->send_ptr[m], vec,
+                 me.recv_idx.p + me.recv_ptr[k], false);
+      }
+      NSFEM_HIP(hipStreamSynchronize(s));
+      g->barrier();
+      return;
+    }
     const int above = up(), below = down();
     if (h.recv_above_cnt > 0 && above >= 0) {
       const HaloRange& o = g->halo[above];
@@ -116,7 +189,25 @@ struct LocalComm : Comm {
     NSFEM_HIP(hipStreamSynchronize(s));
     g->ptr[rank] = vec;
     g->halo[rank] = h;
+    g->kind[rank] = 4;
     g->barrier();
+    check_same_collective(4);
+    if (h.lists) {                 // add every neighbour's ghost copies of my nodes (one launch per neighbour:
+      const HaloLists& me = *h.lists;          //  a node may be a ghost on several ranks)
+      for (size_t k = 0; k < me.nbr.size(); ++k) {
+        const int q = me.nbr[k];
+        const HaloLists* o = g->halo[q].lists;
+        NSFEM_REQUIRE(o, "neighbour without list halo");
+        const int m = o->find(rank);
+        const int64_t cnt = me.send_ptr[k + 1] - me.send_ptr[k];
+        NSFEM_REQUIRE(m >= 0 && o->recv_ptr[m + 1] - o->recv_ptr[m] == cnt, "list halo size mismatch (add)");
+        move_idx(s, cnt, width, g->ptr[q], o->recv_idx.p + o->recv_ptr[m], vec,
+                 me.send_idx.p + me.send_ptr[k], true);
+      }
+      NSFEM_HIP(hipStreamSynchronize(s));
+      g->barrier();
+      return;
+    }
     const int above = up(), below = down();
     // pull: my send-up range is the rank above's ghost range below, and vice versa
     if (h.send_up_cnt > 0 && above >= 0) {
@@ -158,8 +249,42 @@ struct RcclComm : Comm {
     count_allreduce(count);
     NSFEM_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclMax, comm, s));
   }
+  DevBuf<double> pack_out, pack_in;   // list halos: packed send / receive buffers
+  void ensure_stage(hipStream_t s, DevBuf<double>& b, size_t n) {
+    if (b.n >= n) return;
+    NSFEM_HIP(hipStreamSynchronize(s));
+    if (cs) NSFEM_HIP(hipStreamSynchronize(cs));
+    b.alloc(n + n / 4);
+  }
+  // forward = true: owners -> ghosts; false: ghosts -> owners (added there)
+  void exchange_lists(hipStream_t s, const HaloLists& L, double* vec, int width, bool forward) {
+    const std::vector<int64_t>& out_ptr = forward ? L.send_ptr : L.recv_ptr;
+    const std::vector<int64_t>& in_ptr = forward ? L.recv_ptr : L.send_ptr;
+    const int32_t* out_idx = forward ? L.send_idx.p : L.recv_idx.p;
+    const int32_t* in_idx = forward ? L.recv_idx.p : L.send_idx.p;
+    const int64_t n_out = out_ptr.back(), n_in = in_ptr.back();
+    ensure_stage(s, pack_out, (size_t)(n_out * width));
+    ensure_stage(s, pack_in, (size_t)(n_in * width));
+    move_idx(s, n_out, width, vec, out_idx, pack_out.p, nullptr, false);
+    NSFEM_NCCL(ncclGroupStart());
+    for (size_t k = 0; k < L.nbr.size(); ++k) {
+      const int64_t so = out_ptr[k] * width, sc = (out_ptr[k + 1] - out_ptr[k]) * width;
+      const int64_t ro = in_ptr[k] * width, rc = (in_ptr[k + 1] - in_ptr[k]) * width;
+      if (sc > 0) NSFEM_NCCL(ncclSend(pack_out.p + so, (size_t)sc, ncclDouble, L.nbr[k], comm, s));
+      if (rc > 0) NSFEM_NCCL(ncclRecv(pack_in.p + ro, (size_t)rc, ncclDouble, L.nbr[k], comm, s));
+    }
+    NSFEM_NCCL(ncclGroupEnd());
+    if (forward) {
+      move_idx(s, n_in, width, pack_in.p, nullptr, vec, in_idx, false);
+    } else {
+      for (size_t k = 0; k < L.nbr.size(); ++k)      // per neighbour: a node may be sent to several ranks
+        move_idx(s, in_ptr[k + 1] - in_ptr[k], width, pack_in.p + in_ptr[k] * width, nullptr, vec,
+                 in_idx + in_ptr[k], true);
+    }
+  }
   void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) override {
     count_exchange(h, width);
+    if (h.lists) { exchange_lists(s, *h.lists, vec, width, true); return; }
     const int above = up(), below = down();
     NSFEM_REQUIRE(!(periodic && size == 1), "a periodic partition needs at least two RCCL ranks");
     // sends first (up, then down), receives in the order the peers send (from below = its
@@ -182,6 +307,7 @@ struct RcclComm : Comm {
   }
   void exchange_add(hipStream_t s, const HaloRange& h, double* vec, int width) override {
     count_exchange_add(h, width);
+    if (h.lists) { exchange_lists(s, *h.lists, vec, width, false); return; }
     const int above = up(), below = down();
     NSFEM_REQUIRE(!(periodic && size == 1), "a periodic partition needs at least two RCCL ranks");
     const size_t n_up = above >= 0 ? (size_t)(h.send_up_cnt * width) : 0;      // what the rank above holds for me

@@ -97,16 +97,36 @@ __global__ __launch_bounds__(256) void k_max_product(int64_t n, const double* __
   }
   if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
 }
-// dense[(off + i) % n_glob][(off + j) % n_glob] += a_ij
+// dense[g(i)][g(j)] += a_ij with g(i) = idx[i] (unstructured partitions) or (off + i) % n_glob
 __global__ __launch_bounds__(256) void k_scatter_dense(int n_rows, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col,
                                                        const double* __restrict__ vals, int64_t off,
-                                                       int n_glob, double* __restrict__ dense) {
+                                                       const int32_t* __restrict__ idx, int n_glob,
+                                                       double* __restrict__ dense) {
   for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += gridDim.x * blockDim.x) {
-    const size_t gi = (size_t)((off + row) % n_glob);
-    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
-      atomicAdd(&dense[gi * n_glob + (size_t)((off + col[k]) % n_glob)], vals[k]);   // (wrapped tiny periodic levels: rows may coincide)
+    const size_t gi = idx ? (size_t)idx[row] : (size_t)((off + row) % n_glob);
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+      const size_t gj = idx ? (size_t)idx[col[k]] : (size_t)((off + col[k]) % n_glob);
+      atomicAdd(&dense[gi * n_glob + gj], vals[k]);   // (wrapped tiny periodic levels: rows may coincide)
+    }
   }
+}
+// global coarse vector <-> local coarsest level through an index list (nv values per node)
+__global__ __launch_bounds__(256) void k_glob_scatter_add(int64_t n, int nv, const double* __restrict__ b,
+                                                          const int32_t* __restrict__ idx,
+                                                          double* __restrict__ gb) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * nv;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const double v = b[t];
+    if (v != 0.0) gb[(int64_t)idx[t / nv] * nv + t % nv] += v;       // (ghost entries are zero; owned ids are unique)
+  }
+}
+__global__ __launch_bounds__(256) void k_glob_gather(int64_t n, int nv, const double* __restrict__ gx,
+                                                     const int32_t* __restrict__ idx,
+                                                     double* __restrict__ x) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * nv;
+       t += (int64_t)gridDim.x * blockDim.x)
+    x[t] = gx[(int64_t)idx[t / nv] * nv + t % nv];
 }
 
 // x[(row, v)] = sum_c Ainv[v][c][row] b[(c, v)]   (Ainv symmetric, stored per component)
@@ -454,7 +474,7 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
   std::vector<double> gm((size_t)n * nv, 0.0);
   for (int i = 0; i < C.n; ++i)
     for (int v = 0; v < nv; ++v)
-      if (cur[(size_t)i * nv + v] == 1) gm[(((size_t)glob_off + i) % (size_t)n) * nv + v] = 1.0;
+      if (cur[(size_t)i * nv + v] == 1) gm[glob_of((size_t)i) * nv + v] = 1.0;
   gb.alloc((size_t)n * nv);
   gx.alloc((size_t)n * nv);
   NSFEM_HIP(hipMemcpyAsync(gb.p, gm.data(), sizeof(double) * gm.size(), hipMemcpyHostToDevice, s));
@@ -482,7 +502,7 @@ void Multigrid::refresh_global_coarse(hipStream_t s, const std::vector<uint8_t>&
     dense.zero(s);
     const Pattern& cp = *C.A->pat;
     hipLaunchKernelGGL(k_scatter_dense, dim3((cp.n_rows + 255) / 256), dim3(256), 0, s, cp.n_rows,
-                       cp.rowptr.p, cp.col.p, C.A->vals.p, glob_off, n, dense.p);
+                       cp.rowptr.p, cp.col.p, C.A->vals.p, glob_off, glob_idx, n, dense.p);
     NSFEM_HIP(hipGetLastError());
     comm->allreduce_sum(s, dense.p, (int64_t)n * n);
     full.resize((size_t)n * n);
@@ -694,9 +714,14 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
       // (periodic partitions: the local level may run past the end of the global numbering and
       // continue at its start -- two segments)
       const int64_t ntot = (int64_t)n_glob * nv, off = (int64_t)glob_off * nv;
+      const int ggrid = (int)std::min<int64_t>((n + 255) / 256, 1024);
       // owned entries only (ghost entries of b are zero; on tiny periodic levels a ghost plane may
       // even coincide with an owned plane of the same rank, so plain copies could overwrite data):
       // segment-wise ADD into the zeroed global vector
+      if (glob_idx) {
+        hipLaunchKernelGGL(k_glob_scatter_add, dim3(ggrid), dim3(256), 0, s, (int64_t)L.n, nv, b, glob_idx, gb.p);
+        NSFEM_HIP(hipGetLastError());
+      } else
       for (int64_t pos = 0; pos < n;) {
         const int64_t g = (off + pos) % ntot, len = std::min<int64_t>(n - pos, ntot - g);
         launch_axpby(s, len, 1.0, gb.p + g, 1.0, b + pos, gb.p + g);
@@ -710,6 +735,11 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
         hipLaunchKernelGGL(k_dense_apply, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, n_glob, nv,
                            coarse_inv.p, gb.p, gx.p);
         NSFEM_HIP(hipGetLastError());
+      }
+      if (glob_idx) {
+        hipLaunchKernelGGL(k_glob_gather, dim3(ggrid), dim3(256), 0, s, (int64_t)L.n, nv, gx.p, glob_idx, x);
+        NSFEM_HIP(hipGetLastError());
+        return;
       }
       for (int64_t pos = 0; pos < n;) {
         const int64_t g = (off + pos) % ntot, len = std::min<int64_t>(n - pos, ntot - g);

@@ -321,9 +321,25 @@ struct Precond {
 };
 
 // ---- partitioned meshes: halo ranges (node units) and the communicator interface ---------
+// general halo of an unstructured partition: per neighbouring rank the nodes this rank sends
+// (owned here, ghost there) and receives (ghost here), both in the order of the global node ids
+struct HaloLists {
+  std::vector<int32_t> nbr;
+  std::vector<int64_t> send_ptr, recv_ptr;       // [nbr.size() + 1]
+  DevBuf<int32_t> send_idx, recv_idx;
+  int64_t n_send() const { return send_ptr.empty() ? 0 : send_ptr.back(); }
+  int64_t n_recv() const { return recv_ptr.empty() ? 0 : recv_ptr.back(); }
+  int find(int rank) const {
+    for (size_t k = 0; k < nbr.size(); ++k)
+      if (nbr[k] == rank) return (int)k;
+    return -1;
+  }
+};
+// strips / slabs: two neighbours, contiguous ranges (no packing); `lists` set: index lists instead
 struct HaloRange {
   int64_t send_up_off = 0, send_up_cnt = 0, recv_above_off = 0, recv_above_cnt = 0;
   int64_t send_down_off = 0, send_down_cnt = 0, recv_below_off = 0, recv_below_cnt = 0;
+  const HaloLists* lists = nullptr;
 };
 struct Comm {
   int rank = 0, size = 1;
@@ -372,10 +388,12 @@ struct Comm {
   void count_allreduce(int64_t count) { ++n_allreduce; bytes_allreduce += 8 * count; }
   void count_exchange_add(const HaloRange& h, int width) {
     ++n_exchange;
+    if (h.lists) { bytes_exchange += 8 * (int64_t)width * h.lists->n_recv(); return; }
     bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.recv_above_cnt : 0) + (down() >= 0 ? h.recv_below_cnt : 0));
   }
   void count_exchange(const HaloRange& h, int width) {
     ++n_exchange;
+    if (h.lists) { bytes_exchange += 8 * (int64_t)width * h.lists->n_send(); return; }
     bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.send_up_cnt : 0) + (down() >= 0 ? h.send_down_cnt : 0));
   }
 };
@@ -473,6 +491,12 @@ struct Multigrid : Precond {
   const BlockMat* globA = nullptr;
   int n_glob = 0;
   int64_t glob_off = 0;
+  // unstructured partitions: global id of every local coarsest node instead of offset + i
+  const int32_t* glob_idx = nullptr;
+  const std::vector<int32_t>* h_glob_idx = nullptr;
+  size_t glob_of(size_t i) const {
+    return h_glob_idx ? (size_t)(*h_glob_idx)[i] : ((size_t)glob_off + i) % (size_t)n_glob;
+  }
   bool glob_wrap = false;        // periodic partitions: the local coarsest level wraps around the global numbering
   DevBuf<double> gb, gx;
   // when the global coarsest mesh is too large for a dense solve it carries its own REPLICATED
@@ -604,6 +628,9 @@ struct nsfem_ctx {
   double mg_trunc_ratio = 4.0;                 // > 0: truncate the velocity cycle where nu K_ii <= ratio * alpha M_ii
   double mg_trunc_tol = 0.1;
   int64_t glob_off = 0;
+  std::vector<int32_t> h_glob_idx;             // unstructured partitions: local coarsest node -> global id
+  nsfem::DevBuf<int32_t> glob_idx;
+  std::vector<nsfem::HaloLists*> halo_lists;   // owned (nsfem_set_halo_lists)
   bool partition_periodic = false;
   bool overlap = false;                        // halo exchanges under the interior rows (nsfem_set_overlap)
   double area_global = 0.0;                    // measure of the whole (partitioned) domain, lazily all-reduced
@@ -630,6 +657,7 @@ struct nsfem_ctx {
     nsfem::BlockMat mat;
   };
   std::vector<CsrOp*> schur_ops;               // owned
+  int bc_p_any = -1;                           // partitioned: pressure Dirichlet dofs on any rank (-1 unknown)
   bool schur_additive = false;                 // operators of nsfem_mg_set_schur_operator are rank parts
   int schur_singular = -1;                     // -1: geometric hierarchy (singular iff no Dirichlet set)
   // monolithic BDF system: mixed operator, block preconditioner and their data
@@ -670,6 +698,7 @@ struct nsfem_ctx {
   ~nsfem_ctx() {
     if (comm) comm->release_streams();
     for (P1Level* p : coarse) delete p;
+    for (nsfem::HaloLists* h : halo_lists) delete h;
     for (CsrOp* p : schur_ops) delete p;
     for (P1Level* p : global_tail) delete p;
     delete global_coarse;

@@ -196,14 +196,18 @@ class TaylorHoodDofMap:
     (SURVEY.md R4): fields are compared by coordinates, never by index.
     """
 
-    def __init__(self, mesh, reorder=True, periodic_map=None):
+    def __init__(self, mesh, reorder=True, periodic_map=None, class_key=None):
         """reorder: True / "lex" lexicographic lattice order (strip / slab partitions rely on it:
         halos are contiguous ranges); "parity" = structured meshes only (``mesh.structured``):
         nodes grouped by the parity class of their half-lattice index (vertices, then the edge
         types), lexicographic inside a class -- consecutive rows of every P2 operator then have
         equal length and their k-th columns are consecutive ids, which is what the SELL-64 SpMV
         kernel (csrc/linalg.hip: k_spmv_sell) needs for a fully coalesced x gather; falls back to
-        "lex" on general meshes; False keeps the entity order."""
+        "lex" on general meshes; False keeps the entity order.
+        class_key (lexicographic order only): one integer per entity (vertices, then edges), the
+        slowest sort key -- unstructured partitions number interior nodes first, then the nodes
+        next to ghosts, then the ghosts, so that the rows which can run under a halo exchange form
+        one contiguous range."""
         self.mesh = mesh
         nv, ne = mesh.num_vertices(), mesh.num_edges()
         xy = np.concatenate([mesh.coords, mesh.edge_midpoints()], axis=0)      # entity order
@@ -230,7 +234,10 @@ class TaylorHoodDofMap:
         elif reorder:
             scale = 1.0 / max(mesh.hmin(), 1e-300)
             q = np.round(xy * (4.0 * scale)).astype(np.int64)      # robust lexicographic key
-            order = np.lexsort(tuple(q[:, k] for k in range(dim)))   # x fastest, last axis slowest
+            keys = tuple(q[:, k] for k in range(dim))                # x fastest, last axis slowest
+            if class_key is not None:
+                keys = keys + (np.asarray(class_key, dtype=np.int64),)
+            order = np.lexsort(keys)
             ent_to_node = np.empty(n_ent, dtype=np.int64)
             ent_to_node[order] = np.arange(n_ent)
         else:

@@ -552,3 +552,222 @@ def _constrain_prolongation(P, f_dof, c_dof):
     Pp.sum_duplicates()
     Pp.sort_indices()
     return Pp.indptr.astype(np.int32), Pp.indices.astype(np.int32), Pp.data.copy()
+
+
+# ---------------------------------------------------------------------------------------------
+# unstructured meshes (BASELINE configs[2]: DFG channel): recursive coordinate bisection of the
+# COARSEST mesh of a refinement hierarchy, inherited by the children -- the partitions of all
+# levels are nested by construction.  Halos are index lists (nsfem_set_halo_lists), any number of
+# neighbours per rank.
+# ---------------------------------------------------------------------------------------------
+def recursive_bisection(points, n_parts):
+    """owner [n] in 0 .. n_parts-1 by recursive coordinate bisection: split along the longest
+    axis of the bounding box at the count-weighted median; n_parts need not be a power of two."""
+    points = np.asarray(points, dtype=np.float64)
+    owner = np.zeros(points.shape[0], dtype=np.int64)
+
+    def split(idx, first, count):
+        if count == 1:
+            owner[idx] = first
+            return
+        left = count // 2
+        pts = points[idx]
+        axis = int(np.argmax(pts.max(axis=0) - pts.min(axis=0)))
+        order = np.argsort(pts[:, axis], kind="stable")
+        cut = int(round(idx.size * left / count))
+        split(idx[order[:cut]], first, left)
+        split(idx[order[cut:]], first + left, count - left)
+
+    split(np.arange(points.shape[0]), 0, int(n_parts))
+    return owner
+
+
+class GraphLevel:
+    """one level of one rank: local sub-mesh (global vertex order kept), ghost flags, halo lists"""
+
+
+def _halo_lists(rank, size, global_ids, owner_of, local_on, local_index):
+    """index lists of one node family.  global_ids: ascending global ids of MY local nodes;
+    owner_of[g]: owning rank; local_on[q][g]: node g is local on rank q; local_index: my local
+    index of every entry of global_ids.  Both sides of a pair order by global id."""
+    own = owner_of[global_ids]
+    nbr, sp, si, rp, ri = [], [0], [], [0], []
+    for q in range(size):
+        if q == rank:
+            continue
+        recv = local_index[own == q]
+        send = local_index[(own == rank) & local_on[q][global_ids]]
+        if recv.size == 0 and send.size == 0:
+            continue
+        nbr.append(q)
+        si.append(send)
+        ri.append(recv)
+        sp.append(sp[-1] + send.size)
+        rp.append(rp[-1] + recv.size)
+    cat = lambda parts: np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
+    return dict(neighbour=np.asarray(nbr, dtype=np.int32), send_ptr=np.asarray(sp, dtype=np.int64),
+                send_idx=cat(si), recv_ptr=np.asarray(rp, dtype=np.int64), recv_idx=cat(ri))
+
+
+class GraphPartition:
+    """Rank ``rank`` of ``size`` of an unstructured triangle mesh with a refinement hierarchy
+    (``fine_mesh.mg_levels`` of multigrid.refinement_hierarchy; children of cell c are 4c .. 4c+3).
+
+    * cells: the coarsest cells are split by recursive coordinate bisection of their centroids,
+      every finer cell belongs to its parent's rank;
+    * nodes (vertices, and edge midpoints on the finest level): owned by the LOWEST rank among the
+      cells that contain them;
+    * local cells of a level: every cell that contains a node the rank owns (its owned rows are
+      then complete) plus, on coarser levels, the parents of all local cells of the next finer
+      level (every local fine node then finds its whole prolongation row on the rank);
+    * the coarsest mesh is replicated (global coarse solve), local coarsest nodes map into it by
+      an index list.
+    Same attributes as the strip / slab partitions (mesh, dofmap, p*_ghost, p*_owned, levels)."""
+
+    periodic = False
+
+    def __init__(self, fine_mesh, rank, size, markers=None):
+        import scipy.sparse as sp
+        from fem_mesh import FacetMarkers, Mesh
+        assert fine_mesh._dim == 2, "refinement hierarchies exist for triangle meshes"
+        hierarchy = getattr(fine_mesh, "mg_levels", [])
+        meshes = [fine_mesh] + [m for m, _ in hierarchy]
+        prolongs = [P for _, P in hierarchy]
+        nlev = len(meshes)
+        self.rank, self.size = rank, size
+        self.global_meshes = meshes
+        cell_owner = [None] * nlev
+        cell_owner[-1] = recursive_bisection(meshes[-1].coords[meshes[-1].cells.astype(np.int64)].mean(axis=1), size)
+        for l in range(nlev - 2, -1, -1):
+            cell_owner[l] = np.repeat(cell_owner[l + 1], 4)
+            assert cell_owner[l].size == meshes[l].num_cells(), "not a red-refinement hierarchy"
+        self.cell_owner = cell_owner
+        # node owners and, for every rank, the local cells / nodes of every level
+        vown, vloc, cloc = [], [], []
+        for l, m in enumerate(meshes):
+            c = m.cells.astype(np.int64)
+            vo = np.full(m.num_vertices(), size, dtype=np.int64)
+            np.minimum.at(vo, c.ravel(), np.repeat(cell_owner[l], 3))
+            vown.append(vo)
+        ce = fine_mesh.cell_edges.astype(np.int64)
+        eown = np.full(fine_mesh.num_edges(), size, dtype=np.int64)
+        np.minimum.at(eown, ce.ravel(), np.repeat(cell_owner[0], 3))
+        for l, m in enumerate(meshes):
+            c = m.cells.astype(np.int64)
+            loc = np.zeros((size, m.num_cells()), dtype=bool)
+            for q in range(size):
+                loc[q] = (vown[l][c] == q).any(axis=1)
+                if l == 0:
+                    loc[q] |= (eown[ce] == q).any(axis=1)
+                else:
+                    loc[q] |= cloc[l - 1][q].reshape(-1, 4).any(axis=1)
+            cloc.append(loc)
+            vl = np.zeros((size, m.num_vertices()), dtype=bool)
+            for q in range(size):
+                vl[q][c[loc[q]].ravel()] = True
+            vloc.append(vl)
+        eloc = np.zeros((size, fine_mesh.num_edges()), dtype=bool)
+        for q in range(size):
+            eloc[q][ce[cloc[0][q]].ravel()] = True
+        # ---- my local meshes.  Local vertex order: interior vertices first, then the owned ones
+        # next to a ghost, then the ghosts (global order inside a class): the rows that reference no
+        # ghost column -- those that can run under a halo exchange -- are one contiguous range
+        self.level_vertices = []
+        made = []
+        for l, m in enumerate(meshes):
+            lv = np.nonzero(vloc[l][rank])[0]                      # ascending global ids
+            lc = np.nonzero(cloc[l][rank])[0]
+            gc = m.cells[lc].astype(np.int64)
+            ghost_g = vown[l] != rank
+            cls = np.zeros(m.num_vertices(), dtype=np.int64)
+            cls[gc[ghost_g[gc].any(axis=1)].ravel()] = 1
+            cls[ghost_g] = 2
+            order = np.lexsort((lv, cls[lv]))
+            lv_local = lv[order]                                   # global id of local vertex i
+            g2l = np.full(m.num_vertices(), -1, dtype=np.int64)
+            g2l[lv_local] = np.arange(lv.size)
+            local = Mesh(m.coords[lv_local], g2l[gc].astype(np.int32))
+            lev = GraphLevel()
+            lev.mesh, lev.vertices, lev.cells, lev.g2l = local, lv_local, lc, g2l
+            lev.n_p1 = lv.size
+            lev.p1_ghost = (vown[l][lv_local] != rank).astype(np.uint8)
+            lev.p1_lists = _halo_lists(rank, size, lv, vown[l], vloc[l], g2l[lv])
+            made.append(lev)
+            self.level_vertices.append(lv_local)
+        self.fine = fine = made[0]
+        self.mesh = fine.mesh
+        # global edge id of every local edge
+        nvg = fine_mesh.num_vertices()
+        ge_key = fine_mesh.edges[:, 0].astype(np.int64) * nvg + fine_mesh.edges[:, 1]    # sorted (np.unique)
+        le = fine.vertices[fine.mesh.edges.astype(np.int64)]
+        key = le.min(axis=1) * nvg + le.max(axis=1)
+        ge = np.searchsorted(ge_key, key)
+        assert np.array_equal(ge_key[ge], key)
+        self.edge_global = ge
+        nv_loc = fine.vertices.size
+        ent_global = np.concatenate([fine.vertices, nvg + ge])              # entity order of the local mesh
+        ent_owner = np.concatenate([vown[0], eown])
+        ent_ghost = ent_owner[ent_global] != rank
+        cell_ent = np.concatenate([fine.mesh.cells.astype(np.int64), nv_loc + fine.mesh.cell_edges.astype(np.int64)], axis=1)
+        ent_class = np.zeros(ent_global.size, dtype=np.int64)
+        ent_class[cell_ent[ent_ghost[cell_ent].any(axis=1)].ravel()] = 1
+        ent_class[ent_ghost] = 2
+        self.dofmap = dm = TaylorHoodDofMap(fine.mesh, class_key=ent_class)
+        ent_dof = np.concatenate([dm.vertex_node, dm.edge_node])
+        order = np.argsort(ent_global, kind="stable")
+        self.p2_entity_global = np.empty(dm.n_p2, dtype=np.int64)           # local P2 node -> global entity id
+        self.p2_entity_global[ent_dof] = ent_global
+        ghost2 = np.zeros(dm.n_p2, dtype=np.uint8)
+        ghost2[ent_dof] = ent_ghost
+        self.p2_ghost = ghost2
+        self.p1_ghost = fine.p1_ghost
+        self.p2_owned, self.p1_owned = ghost2 == 0, fine.p1_ghost == 0
+        ent_local = [np.concatenate([vloc[0][q], eloc[q]]) for q in range(size)]
+        self.p2_lists = _halo_lists(rank, size, ent_global[order], ent_owner, ent_local, ent_dof[order])
+        self.p1_lists = fine.p1_lists
+        self.p1_global = fine.vertices
+        self.n_p2_global = nvg + fine_mesh.num_edges()
+        self.n_p1_global = nvg
+        # local facet markers: the global marker of every local edge (cut edges are interior: 0)
+        self.markers = None
+        if markers is not None:
+            self.markers = FacetMarkers(fine.mesh, 0)
+            self.markers.values[:] = markers.values[ge]
+            # a cut edge is a boundary edge of the local mesh but not of the domain
+            fine.mesh.facet_on_boundary = fine.mesh.facet_on_boundary & fine_mesh.facet_on_boundary[ge]
+            fine.mesh.edge_on_boundary = fine.mesh.facet_on_boundary
+        # ---- coarse levels with rank-local prolongations
+        self.levels = []
+        for l in range(1, nlev):
+            rowptr, col, val = prolongs[l - 1]
+            nf, ncoarse = meshes[l - 1].num_vertices(), meshes[l].num_vertices()
+            P = sp.csr_matrix((val, col, rowptr), shape=(nf, ncoarse))[made[l - 1].vertices]
+            P = P.tocoo()
+            cols = made[l].g2l[P.col]
+            assert (cols >= 0).all(), "a local fine node interpolates from a coarse node the rank does not hold"
+            Pl = sp.csr_matrix((P.data, (P.row, cols)), shape=(made[l - 1].n_p1, made[l].n_p1))
+            Pl.sort_indices()
+            self.levels.append((made[l], (Pl.indptr.astype(np.int32), Pl.indices.astype(np.int32), Pl.data.copy())))
+        self.coarse_global_index = made[-1].vertices
+
+    def p2_global(self, global_dofmap):
+        """local P2 node -> node of a TaylorHoodDofMap of the GLOBAL fine mesh (comparisons)"""
+        ent_to_node = np.concatenate([global_dofmap.vertex_node, global_dofmap.edge_node])
+        return ent_to_node[self.p2_entity_global]
+
+    def attach(self, ctx, degree=None, eig_ratio=None):
+        ctx.set_partition(self.rank, self.size, self.p2_ghost, self.p1_ghost, None, None,
+                          self.n_p2_global, self.n_p1_global)
+        ctx.set_halo_lists(0, self.p2_lists)
+        ctx.set_halo_lists(1, self.p1_lists)
+        ctx.mg_prolongations = []
+        for l, (lev, (rowptr, col, val)) in enumerate(self.levels):
+            ctx.mg_add_level(lev.mesh.coords, lev.mesh.cells, rowptr, col, val, ghost=lev.p1_ghost, halo=None)
+            ctx.set_halo_lists(2 + l, lev.p1_lists)
+            ctx.mg_prolongations.append((lev.n_p1, (rowptr, col, val)))
+        cg = self.global_meshes[-1]
+        ctx.mg_set_global_coarse(cg.coords, cg.cells, 0)
+        ctx.mg_set_global_index(self.coarse_global_index)
+        # general (graded, curved) meshes: 3 smoothing steps over a ratio of 16 (multigrid.attach_hierarchy)
+        ctx.mg_finalize(3 if degree is None else degree, 16.0 if eig_ratio is None else eig_ratio)
+        return len(self.levels)

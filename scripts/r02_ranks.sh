@@ -1,13 +1,13 @@
 #!/bin/bash
-# rehearsal of the N-rank bench paths on one GPU (thread ranks, in-process communicator)
 cd /root/repo
 O=gpurun_out/r02t; mkdir -p $O
 run() { name=$1; shift; timeout -k 10 600 python bench.py "$@" > $O/$name.json 2> $O/$name.err || { echo "FAILED $name"; tail -20 $O/$name.err; exit 1; }; python scripts/show_bench.py $O/$name.json 2>/dev/null | head -30; }
-run ch_n16_1 --workload channel3d-bdf --cells 16 --steps 5 --warmup 2 --no-cpu-baseline
-run ch_n16_2strong --workload channel3d-bdf --cells 16 --steps 5 --warmup 2 --local-ranks 2 --scaling strong
-run ch_n16_4strong --workload channel3d-bdf --cells 16 --steps 5 --warmup 2 --local-ranks 4 --scaling strong
-run ch_n16_2weak --workload channel3d-bdf --cells 16 --steps 5 --warmup 2 --local-ranks 2
-run cav_2 --cells 128 --steps 5 --warmup 2 --local-ranks 2
-run cav_4s --cells 256 --steps 5 --warmup 2 --local-ranks 4 --scaling strong
-run tgv_2 --workload tgv3d-ipcs --cells 16 --steps 5 --warmup 2 --local-ranks 2
-run c3d_2 --workload cavity3d-ipcs --cells 16 --steps 5 --warmup 2 --local-ranks 2
+run dfg_r3_1 --workload dfg-bdf --dfg-refine 3 --steps 5 --warmup 2 --no-cpu-baseline
+run dfg_r3_2 --workload dfg-bdf --dfg-refine 3 --steps 5 --warmup 2 --local-ranks 2
+run dfg_r3_4 --workload dfg-bdf --dfg-refine 3 --steps 5 --warmup 2 --local-ranks 4
+python - <<'PY'
+import json
+for n in ("dfg_r3_1","dfg_r3_2","dfg_r3_4"):
+    c=json.load(open("gpurun_out/r02t/%s.json"%n))["config"]
+    print(n, c["drag_lift_reference_formula"], c["net_boundary_mass_flux"], c["cylinder_perimeter_of_the_mesh"], c["host_setup_s"], c["comm_per_step_rank0"])
+PY

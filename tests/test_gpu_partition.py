@@ -442,6 +442,121 @@ def test_partitioned_algebraic_schur_laplacian_equals_single_context(dim, size, 
     nat.local_group_destroy(group)
 
 
+@pytest.mark.parametrize("scheme,size,overlap", [("ipcs", 2, False), ("ipcs", 4, True), ("bdf", 2, False), ("bdf", 3, True)])
+def test_rcb_partitioned_dfg_channel_equals_single_context(scheme, size, overlap):
+    """BASELINE configs[2] geometry (DFG channel with the cylinder, unstructured triangles, two
+    red refinements) cut by recursive coordinate bisection of the coarsest cells
+    (partition.GraphPartition): index-list halos with any number of neighbours
+    (nsfem_set_halo_lists), rank-local prolongations of the refinement hierarchy, the replicated
+    coarsest mesh addressed through an index list -- 2 / 3 / 4 in-process ranks reproduce the
+    single-context IPCS and monolithic BDF-2 steps (open outlet: pressure Dirichlet values in IPCS,
+    additive parts of the algebraic Schur Laplacian in the monolithic scheme)."""
+    import grid_generator as gg
+    from fem_mesh import TaylorHoodDofMap
+    from multigrid import attach_schur_laplacian
+    from partition import GraphPartition
+    mesh, marks = gg.dfg_channel(4, 2)
+    dm = TaylorHoodDofMap(mesh)
+    M = gg.DFGBoundaryMarkers
+    nsteps, k, H = 2, 0.05, 4.1
+
+    def bc(dmap, mk):
+        inlet = np.unique(dmap.facet_p2_nodes(mk.facets_with_id(M.inlet.value)))
+        walls = np.unique(np.concatenate([dmap.facet_p2_nodes(mk.facets_with_id(m.value)).ravel()
+                                          for m in (M.bottom, M.top, M.cylinder)]))
+        y = dmap.p2_coords[inlet, 1]
+        prof = 6.0 * y * (H - y) / H ** 2
+        dofs = np.concatenate([2 * inlet, 2 * inlet + 1, 2 * walls, 2 * walls + 1])
+        vals = np.concatenate([prof, np.zeros(inlet.size + 2 * walls.size)])
+        # walls win on shared nodes (list order of DirichletBC.apply)
+        _, first = np.unique(dofs[::-1], return_index=True)
+        keep = dofs.size - 1 - first
+        return dofs[keep].astype(np.int32), vals[keep]
+
+    def run(ctx, dmap, mk, out, key, part=None):
+        ctx.set_coeffs(1.0, 1.0, 0.05)
+        dofs, vals = bc(dmap, mk)
+        ctx.set_dirichlet(nat.VELOCITY, dofs, vals)
+        outlet = np.unique(dmap.facet_p1_nodes(mk.facets_with_id(M.outlet.value))).astype(np.int32)
+        if scheme == "ipcs":
+            ctx.set_dirichlet(nat.PRESSURE, outlet, np.zeros(outlet.size))
+        else:
+            ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+            ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+            assert not attach_schur_laplacian(ctx, dofs, part=part)
+        if part is not None:
+            ctx.set_overlap(overlap)
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-12
+        opts.momentum.precond = opts.poisson.precond = 1
+        infos = []
+        ctx.comm_stats(reset=True)
+        for step in range(nsteps):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), k)
+            infos.append(ctx.step_ipcs(opts) if scheme == "ipcs" else ctx.step_bdf(opts))
+            ctx.advance(0 if scheme == "ipcs" else 1)
+        out[key] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), infos, ctx.comm_stats(),
+                    ctx.comm_overlapped() if part is not None else 0)
+
+    ref = {}
+    ctx0 = context(mesh, dm)
+    assert attach_hierarchy(ctx0, mesh) == 2
+    run(ctx0, dm, marks, ref, 0)
+    u_ref, p_ref, inf_ref, _, _ = ref[0]
+    ctx0.close()
+    group = nat.local_group_create(size)
+    parts = [GraphPartition(mesh, r, size, marks) for r in range(size)]
+    assert sum(int(p.p2_owned.sum()) for p in parts) == dm.n_p2
+    assert sum(int(p.p1_owned.sum()) for p in parts) == dm.n_p1
+    assert max(len(p.p2_lists["neighbour"]) for p in parts) >= (2 if size > 2 else 1)
+    ctxs = []
+    for r, part in enumerate(parts):
+        pdm = part.dofmap
+        c = nat.NsfemContext(part.mesh.coords, part.mesh.cells, pdm.p2_dofmap, pdm.p1_dofmap,
+                             pdm.n_p2, pdm.n_p1)
+        c.attach_local_comm(group, r)
+        ctxs.append(c)
+    out, errors = {}, []
+
+    def worker(r):
+        try:
+            assert parts[r].attach(ctxs[r]) == 2
+            run(ctxs[r], parts[r].dofmap, parts[r].markers, out, r, part=parts[r])
+        except BaseException as exc:
+            import traceback
+            traceback.print_exc()
+            errors.append((r, repr(exc)))
+            os._exit(17)
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    u = np.zeros_like(u_ref)
+    p = np.zeros_like(p_ref)
+    for r, part in enumerate(parts):
+        ul, pl, infos, stats, overlapped = out[r]
+        g2 = part.p2_global(dm)
+        u.reshape(-1, 2)[g2[part.p2_owned]] = ul.reshape(-1, 2)[part.p2_owned]
+        p[part.p1_global[part.p1_owned]] = pl[part.p1_owned]
+        for a, b in zip(infos, inf_ref):
+            assert a.newton_iterations == b.newton_iterations
+            # (BiCGStab on the mixed system to rtol 1e-12: ~30 iterations per Newton step, whose count
+            #  moves by one or two with the summation order of the partitioned dot products)
+            assert abs(a.krylov_iterations_momentum - b.krylov_iterations_momentum) <= max(1, 0.05 * b.krylov_iterations_momentum)
+            assert abs(a.krylov_iterations_poisson - b.krylov_iterations_poisson) <= 1
+        assert stats["exchanges"] > 0
+        assert (overlapped > 0) == overlap
+    assert rel(u, u_ref) < 1e-9
+    assert rel(p, p_ref) < 1e-8
+    for c in ctxs:
+        c.close()
+    nat.local_group_destroy(group)
+
+
 def test_channel_bench_thread_ranks_match_the_single_rank_run():
     """bench.py --workload channel3d-bdf (BASELINE configs[4]) on 1 rank and on 2 / 4 thread ranks
     (--local-ranks: the N-rank code path of the bench -- slabs, additive Schur parts, the reductions

@@ -583,6 +583,32 @@ def test_channel_bench_thread_ranks_match_the_single_rank_run():
         assert stats["exchanges"] > 0 and stats["allreduce_calls"] > 0
 
 
+def test_dfg_bench_thread_ranks_match_the_single_rank_run():
+    """bench.py --workload dfg-bdf (BASELINE configs[2]) on 1 rank and on 2 / 3 thread ranks
+    (recursive-bisection parts, index-list halos, additive Schur parts): the drag / lift
+    coefficients -- integrated per rank over the cylinder facets of its own cells and summed --
+    and the net boundary mass flux agree with the single-rank run."""
+    def run(extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "dfg-bdf", "--dfg-refine", "2",
+               "--steps", "3", "--warmup", "1", "--krylov-rtol", "1e-10", "--newton-forcing", "0",
+               "--no-cpu-baseline"] + extra
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return json.loads(res.stdout.strip().splitlines()[-1])
+    one = run([])
+    assert one["n_gpus"] == 1
+    for ranks in (2, 3):
+        many = run(["--local-ranks", str(ranks)])
+        assert many["n_gpus"] == ranks and many["scaling"] == "strong"
+        assert many["config"]["n_dofs"] == one["config"]["n_dofs"]
+        assert many["config"]["newton_its_per_step"] == one["config"]["newton_its_per_step"]
+        for key in ("drag_lift_reference_formula", "drag_lift_newtonian_stress"):
+            assert np.abs(np.array(many["config"][key]) - np.array(one["config"][key])).max() < 1e-7
+        assert abs(many["config"]["cylinder_perimeter_of_the_mesh"] - one["config"]["cylinder_perimeter_of_the_mesh"]) < 1e-12
+        assert abs(many["config"]["net_boundary_mass_flux"]) < 1e-9
+        assert many["config"]["comm_per_step_rank0"]["exchanges"] > 0
+
+
 def test_bench_through_rccl_single_rank():
     """bench.py with the RCCL communicator attached (1 rank): ncclCommInitRank, the all-reduces
     of every dot product and the torch.distributed(gloo) bootstrap all run for real."""

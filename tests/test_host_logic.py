@@ -576,3 +576,106 @@ def test_form_language_functionals_on_host_functions():
         xe = dlfn.Expression("x[0]", degree=1)
         val = dlfn.assemble(xe ** 2 * p * dlfn.dx(domain=mesh))
         assert abs(val - (1 / 3 + 2 / 4 - 0.5 / 3)) < 1e-14
+
+
+@pytest.mark.parametrize("size", [2, 3, 5])
+def test_graph_partition_of_the_dfg_hierarchy_host_side(size):
+    """partition.GraphPartition (unstructured meshes, recursive coordinate bisection) without a
+    device: balanced coarse cells, every node owned exactly once, the two sides of every
+    neighbour pair list the same global nodes in the same order on every level, an emulated halo
+    exchange + reverse add reproduce global vectors, the rank-local prolongations are the rows of
+    the global one, and the interior-first numbering puts all ghosts at the end."""
+    import scipy.sparse as sp
+    import grid_generator as gg
+    from partition import GraphPartition, recursive_bisection
+    pts = np.random.default_rng(3).random((1000, 2))
+    own = recursive_bisection(pts, size)
+    counts = np.bincount(own, minlength=size)
+    assert counts.max() - counts.min() <= size               # balanced to rounding at every split
+    mesh, marks = gg.dfg_channel(4, 2)
+    dm = TaylorHoodDofMap(mesh)
+    parts = [GraphPartition(mesh, r, size, marks) for r in range(size)]
+    assert sum(int(p.p2_owned.sum()) for p in parts) == dm.n_p2
+    assert sum(int(p.p1_owned.sum()) for p in parts) == dm.n_p1
+    coarse_counts = np.bincount(parts[0].cell_owner[-1], minlength=size)
+    assert coarse_counts.max() - coarse_counts.min() <= size
+    # ownership is a partition of unity in the global numbering
+    seen = np.zeros(dm.n_p2, dtype=int)
+    for p in parts:
+        g2 = p.p2_global(dm)
+        assert np.abs(p.dofmap.p2_coords - dm.p2_coords[g2]).max() < 1e-12
+        seen[g2[p.p2_owned]] += 1
+        # ghosts last, interior rows first
+        first_ghost = int(np.argmax(p.p2_ghost != 0)) if p.p2_ghost.any() else p.p2_ghost.size
+        assert not p.p2_ghost[:first_ghost].any() and p.p2_ghost[first_ghost:].all()
+    assert (seen == 1).all()
+
+    def families(p):
+        yield p.p2_lists, p.p2_global(dm), dm.n_p2
+        yield p.p1_lists, p.p1_global, dm.n_p1
+        for l, (lev, _) in enumerate(p.levels):
+            yield lev.p1_lists, lev.vertices, p.global_meshes[l + 1].num_vertices()
+
+    fams = [list(families(p)) for p in parts]
+    rng = np.random.default_rng(0)
+    for f in range(len(fams[0])):
+        n_glob = fams[0][f][2]
+        xg = rng.standard_normal(n_glob)
+        local = []
+        for r, p in enumerate(parts):
+            lists, gid, _ = fams[r][f]
+            ghost = np.ones(gid.size, dtype=bool)
+            x = xg[gid].copy()
+            # which of my nodes are ghosts: everything in a receive list
+            mask = np.zeros(gid.size, dtype=bool)
+            mask[lists["recv_idx"]] = True
+            x[mask] = np.nan                                   # to be filled by the exchange
+            local.append((x, mask))
+        # forward exchange: owners -> ghosts
+        for r in range(size):
+            lists, gid, _ = fams[r][f]
+            for k, q in enumerate(lists["neighbour"]):
+                lq, gq, _ = fams[q][f]
+                m = list(lq["neighbour"]).index(r)
+                s_idx = lq["send_idx"][lq["send_ptr"][m]:lq["send_ptr"][m + 1]]
+                r_idx = lists["recv_idx"][lists["recv_ptr"][k]:lists["recv_ptr"][k + 1]]
+                assert np.array_equal(gq[s_idx], gid[r_idx])
+                assert not local[q][1][s_idx].any()             # only owned values are sent
+                local[r][0][r_idx] = local[q][0][s_idx]
+        for r in range(size):
+            assert np.array_equal(local[r][0], xg[fams[r][f][1]])
+        # reverse add: every local copy contributes 1 -> owners end up with the multiplicity
+        mult = np.zeros(n_glob)
+        for r in range(size):
+            mult[fams[r][f][1]] += 1.0
+        acc = [np.ones(fams[r][f][1].size) for r in range(size)]
+        for r in range(size):
+            lists, gid, _ = fams[r][f]
+            for k, q in enumerate(lists["neighbour"]):
+                lq = fams[q][f][0]
+                m = list(lq["neighbour"]).index(r)
+                s_idx = lists["send_idx"][lists["send_ptr"][k]:lists["send_ptr"][k + 1]]
+                r_idx = lq["recv_idx"][lq["recv_ptr"][m]:lq["recv_ptr"][m + 1]]
+                np.add.at(acc[r], s_idx, 1.0)
+                assert r_idx.size == s_idx.size
+        for r in range(size):
+            gid, mask = fams[r][f][1], local[r][1]
+            assert np.array_equal(acc[r][~mask], mult[gid][~mask])
+    # rank-local prolongations = rows / columns of the global ones
+    for p in parts:
+        fine_vertices = p.fine.vertices
+        for l, (lev, (rowptr, col, val)) in enumerate(p.levels):
+            gr, gc, gv = mesh.mg_levels[l][1]
+            G = sp.csr_matrix((gv, gc, gr), shape=(p.global_meshes[l].num_vertices(), p.global_meshes[l + 1].num_vertices()))
+            L = sp.csr_matrix((val, col, rowptr), shape=(fine_vertices.size, lev.n_p1))
+            assert abs(G[fine_vertices][:, lev.vertices] - L).max() < 1e-15
+            assert np.allclose(np.asarray(L.sum(axis=1)).ravel(), 1.0)      # complete rows
+            fine_vertices = lev.vertices
+    # the local markers are the global ones: boundary nodes found per rank add up to the global set
+    cyl = gg.DFGBoundaryMarkers.cylinder.value
+    glob = set(np.unique(dm.facet_p2_nodes(marks.facets_with_id(cyl))).tolist())
+    found = set()
+    for p in parts:
+        loc = np.unique(p.dofmap.facet_p2_nodes(p.markers.facets_with_id(cyl)))
+        found |= set(p.p2_global(dm)[loc].tolist())
+    assert found == glob

@@ -435,7 +435,17 @@ def tgv3d_bench(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, err = float(t[0]), float(t[1])
     sps = args.steps / elapsed
-    ms_spmv, nbytes = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 100) if world == 1 else (float("nan"), 0)
+    # dominant kernel: finest-level smoothing launch of the velocity multigrid, in situ (HIP-event pairs
+    # around the smoothing sequences of 2 further steps) and cache-cold (flush-interleaved)
+    ms_spmv = ms_cold = None
+    nbytes, n_sm, label, extra = 0, 0, "", {}
+    if world == 1:
+        ctx.profile_smoother(True)
+        for i in range(args.warmup + args.steps, args.warmup + args.steps + 2):
+            one_step(i)
+        ms_spmv, n_sm, nbytes = ctx.profile_smoother(False)
+        ms_cold, _ = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 100)
+        label, extra = _smoother_roofline_extras(ctx, 3, ms_spmv, ms_cold)
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9 if world == 1 else None
     if rank != 0:
         ctx.close()
@@ -458,11 +468,14 @@ def tgv3d_bench(args):
                    "bicgstab_its_per_step": kry / args.steps, "poisson_cg_its_per_step": poi / args.steps,
                    "max_abs_velocity_error_vs_analytic": err, "host_setup_s": t_setup,
                    "comm_per_step_rank0": comm_per_step},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<1,1,3,3> (finest-level Chebyshev smoothing step, "
-                                               "scalar P2 operator on 3 components; launches interleaved with a cache-flushing SpMV, nsfem_time_spmv)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv if world == 1 else None}}))
+        "roofline": dict({"bound": "hbm", "kernel": label,
+                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                          "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv, "launches_timed": n_sm,
+                          "timing": "in situ, HIP-event pairs around the smoothing sequences of 2 steps",
+                          "cold_cache": {"achieved": nbytes / (ms_cold * 1e-3) / 1e9,
+                                         "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "ms_per_launch": ms_cold} if ms_cold else None}, **extra)}))
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -706,6 +719,7 @@ def channel3d_bdf_bench(args):
     ms_conv, n_conv, nbytes_conv = ctx.profile_convection(False)
     ms_cold, _ = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 50)
     achieved = nbytes / (ms_sm * 1e-3) / 1e9
+    label, extra = _smoother_roofline_extras(ctx, 3, ms_sm, ms_cold)
     if rank == 0:
         print(json.dumps({
             "metric": "dof_updates_per_sec", "value": sps * n_dofs, "unit": "DoF-updates/s",
@@ -733,13 +747,14 @@ def channel3d_bdf_bench(args):
                                       "inflow_flux_error_vs_interpolated_profile": inflow_err,
                                       "inflow_flux_minus_analytic": flux["inlet"] + 4.0 / 9.0 * zlen,
                                       "max_velocity": float(umax), "finite": bool(finite)}},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_sell<1,3,...> (finest-level Chebyshev smoothing step of the "
-                                                   "velocity multigrid, scalar P2 operator on 3 interleaved components)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_sm,
-                         "launches_timed": n_sm, "timing": "in situ, HIP-event pairs around the smoothing sequences of 2 steps",
-                         "cold_cache": {"achieved": nbytes / (ms_cold * 1e-3) / 1e9,
-                                        "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_cold}},
+            "roofline": dict({"bound": "hbm", "kernel": label,
+                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": None, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_sm,
+                              "launches_timed": n_sm,
+                              "timing": "in situ, HIP-event pairs around the smoothing sequences of 2 steps",
+                              "cold_cache": {"achieved": nbytes / (ms_cold * 1e-3) / 1e9,
+                                             "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "ms_per_launch": ms_cold}}, **extra),
             "assembly": {"kernel": "k3_conv_cell<FORM,1> + node gather (matrix-free convection action)",
                          "achieved": nbytes_conv / (ms_conv * 1e-3) / 1e9 if n_conv else None, "unit": "GB/s",
                          "frac": nbytes_conv / (ms_conv * 1e-3) / 1e9 / HBM_PEAK_GBS if n_conv else None,
@@ -751,6 +766,32 @@ def channel3d_bdf_bench(args):
     if not (all_converged and finite and balance < 1e-6 and inflow_err < 1e-10):
         raise SystemExit("channel3d-bdf: invariant violated (converged %s, finite %s, mass balance %.2e, "
                          "inflow error %.2e)" % (all_converged, finite, balance, inflow_err))
+
+
+def _smoother_roofline_extras(ctx, nv, ms_in_situ, ms_cold=None):
+    """(kernel label, dict of extra roofline keys) of the finest-level smoothing launch of the velocity
+    multigrid -- which kernel runs (nsfem_smoother_info) and, for the stencil-dictionary kernel, the
+    rate a CSR stream of the same operator would need to be as fast (continuity with round 1)"""
+    info = ctx.smoother_info()
+    if info["kind"] == "stencil-dictionary":
+        label = ("k_spmv_dict<%d,3,4>: finest-level Chebyshev-Jacobi smoothing step y = x + c1 d + c2 dinv (b - L x) on "
+                 "the stencil-dictionary copy of the scalar P2 operator L (%d distinct rows, longest %d, %s), %d "
+                 "interleaved components: 1 byte per row + the vectors instead of 12 bytes per nonzero" % (
+                     nv, info["stencils"], info["longest_row"],
+                     "bitwise equal to the CSR values" if info["bitwise_exact"] else "equal to 2^-40", nv))
+        extra = {"csr_equivalent": {
+            "note": "what a CSR stream of the same operator (12 B per nonzero + vectors) would have to sustain to "
+                    "match this launch time; comparable with the round-1 figures of k_spmv_stream / k_spmv_sell",
+            "algorithmic_bytes_per_launch": info["csr_bytes"],
+            "achieved": info["csr_bytes"] / (ms_in_situ * 1e-3) / 1e9 if ms_in_situ else None,
+            "frac": info["csr_bytes"] / (ms_in_situ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_in_situ else None,
+            "cold_cache_frac": info["csr_bytes"] / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_cold else None}}
+    else:
+        label = ("%s<1,%d,...>: finest-level Chebyshev-Jacobi smoothing step y = x + c1 d + c2 dinv (b - L x) on the "
+                 "scalar P2 operator L, %d interleaved components" % (
+                     "k_spmv_sell" if info["kind"] == "sell-64" else "k_spmv_stream_v1", nv, nv))
+        extra = {}
+    return label, extra
 
 
 def _apply_truncation(ctx, args):
@@ -1000,7 +1041,8 @@ def cavity_ipcs_bench(args):
             # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE;
             # the symbol is launched on every multigrid level, the finest-level launches are the maxima
             c = json.load(open(pmc))
-            key = "void nsfem::k_spmv_stream<1, 1, 2, 3>"
+            key = "void nsfem::k_spmv_dict<2, 3, 4>" if ctx.smoother_info()["kind"] == "stencil-dictionary" \
+                else "void nsfem::k_spmv_stream_v1<1, 1, 2, 3>"
             if key in c["fetch"] and key in c["write"]:
                 traffic = (2.0 * c["fetch"][key]["max_KB"] + c["write"][key]["max_KB"]) * 1024.0
                 traffic_source = "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: " \
@@ -1008,6 +1050,8 @@ def cavity_ipcs_bench(args):
                                  "Infinity-Cache hits as well)" % tag
                 break
     tol_fields = 1.0e-6
+    smoother_label, smoother_extra = (_smoother_roofline_extras(ctx, 2, ms_spmv, cold["ms_per_launch"] if cold else None)
+                                      if mg_levels is not None else ("", {}))
     out = {
         "metric": "dof_updates_per_sec", "value": steps_per_s * n_dofs, "unit": "DoF-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1041,10 +1085,7 @@ def cavity_ipcs_bench(args):
                    "bicgstab_its_per_step": float(its[1]), "poisson_cg_its_per_step": float(its[2]),
                    "comm_per_step_rank0": comm_per_step},
         "roofline": {"bound": "hbm",
-                     "kernel": "k_spmv_stream<1,1,2,3>, finest multigrid level: Chebyshev-Jacobi smoothing step "
-                               "y = x + c1 d + c2 dinv (b - L x) on the scalar P2 operator L (%.2f M nnz), "
-                               "both velocity components" % (ctx.operator_nnz(nat.OP_MASS_P2) / 1e6) if mg_levels is not None else
-                               "k_spmv_stream<2,2,1,0> (momentum Jacobian)",
+                     "kernel": smoother_label if mg_levels is not None else "k_spmv_stream_v1<2,2,1,0> (momentum Jacobian)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv,
@@ -1064,6 +1105,7 @@ def cavity_ipcs_bench(args):
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(_parse_cpu_samples(args.cpu_samples), args.dt, n_dofs)
+    out["roofline"].update(smoother_extra)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

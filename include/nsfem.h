@@ -402,6 +402,15 @@ int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* 
                            int64_t* algorithmic_bytes);
 int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                     int64_t* algorithmic_bytes);
+/* which finest-level smoothing kernel of the velocity multigrid runs: out = {kind (0 CSR-stream,
+ * 1 SELL-64, 2 stencil dictionary), dictionary entries, longest row (negative: the dictionary
+ * reproduces the matrix bit for bit and every product uses it), algorithmic bytes a CSR
+ * stream of the same operator moves per smoothing launch}.  The stencil dictionary (lattice
+ * meshes: rows with equal column offsets and values to 2^-40 of the largest entry share one entry;
+ * a launch reads one byte per row instead of 12 bytes per nonzero) is used by smoothing steps and
+ * Newton-Jacobian products only -- never by a residual or a linear operator whose solution is
+ * returned; NSFEM_DICT=0 disables it. */
+int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]);
 /* in-situ HIP-event timing of the matrix-free convection action of the velocity Jacobian inside
  * the Newton-Krylov solves (element kernel k_conv_cell / k3_conv_cell + node gather = the
  * per-iteration "assembly" of the fused step drivers; replaces the dolfin assemble(J) call of

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse", "nsfem_mg_set_global_coarse_constrained",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_smoother_info", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
 )
@@ -187,6 +187,7 @@ def load_library(path=None):
                                                   C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                                   C.c_int]),
         "nsfem_mg_set_schur_mode": (C.c_int, [vp, C.c_int]),
+        "nsfem_smoother_info": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "nsfem_set_halo_lists": (C.c_int, [vp, C.c_int, C.POINTER(HaloLists)]),
         "nsfem_mg_set_global_index": (C.c_int, [vp, i32, pi]),
         "nsfem_comm_allreduce": (C.c_int, [vp, pd, C.c_int, C.c_int]),
@@ -432,6 +433,14 @@ class NsfemContext:
         self._check(self._lib.nsfem_mg_set_schur_operator(self._h, int(level), csr.shape[0],
                                                           _ip(rp), _ip(ci), _dp(cv),
                                                           1 if singular else 0))
+
+    def smoother_info(self):
+        """finest-level smoothing kernel of the velocity multigrid: dict(kind, stencils, longest_row,
+        csr_bytes) -- kind "csr-stream" | "sell-64" | "stencil-dictionary" """
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.nsfem_smoother_info(self._h, out))
+        return dict(kind=("csr-stream", "sell-64", "stencil-dictionary")[int(out[0])], stencils=int(out[1]),
+                    longest_row=abs(int(out[2])), bitwise_exact=int(out[2]) < 0, csr_bytes=int(out[3]))
 
     def mg_set_schur_mode(self, additive):
         """partitioned meshes: the Schur operators set afterwards are this rank's additive parts"""

@@ -440,6 +440,19 @@ static void ensure_L(nsfem_ctx* c) {
   // L = alpha0/k M + c_viscous K   (scalar P2; acts on all velocity components)
   const double a = c->alpha[0] / c->k, b = c->coef[2];
   launch_scale_combine(c->stream, c->p22.nnz, a, c->M2.vals.p, b, c->K2.vals.p, c->L.vals.p);
+  if (!c->dict22_tried) {
+    // stencil dictionary of the scalar P2 operators (lattice meshes only): shared by every
+    // a M + b K; used by the smoothing steps of the velocity multigrid
+    c->dict22_tried = true;
+    if (build_stencil_dict(c->stream, c->p22, c->M2.vals.p, c->K2.vals.p, c->dict22)) {
+      c->L.dict = &c->dict22;
+      c->Lprec.dict = &c->dict22;
+      if (c->dict22.exact) {       // the Chebyshev / CG mass solves may use it too
+        c->M2.dict = &c->dict22;
+        c->M2.sell_update(c->stream);
+      }
+    }
+  }
   c->L.sell_update(c->stream);
   // preconditioner version: (alpha0/k + shift) M + c_viscous K -- the multigrid hierarchy of the
   // velocity block is built on it.  shift = 0 (all transient problems): the operator itself.
@@ -455,6 +468,16 @@ static void ensure_L(nsfem_ctx* c) {
   if (c->mg_built) {
     c->mg_v.lv[0].A = c->prec_shift != 0.0 ? &c->Lprec : &c->L;
     launch_scale_combine(c->stream, c->p11.nnz, ap, c->Mp.vals.p, b, c->Ap.vals.p, c->Lc0.vals.p);
+    if (!c->dict11_tried) {        // the fine P1 level of both hierarchies (smoothing steps)
+      c->dict11_tried = true;
+      if (build_stencil_dict(c->stream, c->p11, c->Mp.vals.p, c->Ap.vals.p, c->dict11)) {
+        c->Lc0.dict = &c->dict11;
+        c->Ap.dict = &c->dict11;
+        c->Ap.sell_update(c->stream);
+        c->Mp.dict = &c->dict11;
+        c->Mp.sell_update(c->stream);
+      }
+    }
     c->Lc0.sell_update(c->stream);
     for (nsfem_ctx::P1Level* lv : c->coarse) {
       launch_scale_combine(c->stream, lv->pat.nnz, ap, lv->M.vals.p, b, lv->K.vals.p, lv->Lc.vals.p);
@@ -675,7 +698,7 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   // (row mask, MASK_IDENTITY); every later contribution leaves the flagged rows untouched
   (void)nv;
   product_with_halo(c->distributed() ? c->comm : nullptr, &c->halo_p2, dim, s, x, c->L.pat,
-                    [&](int phase) { launch_spmv(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, 0, phase); });
+                    [&](int phase) { launch_spmv(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, 0, phase, 1); });
   if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, c->mask_v.p);
   const double cc = cc_of(c);
   if (cc != 0.0) {
@@ -2052,6 +2075,18 @@ extern "C" int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, dou
 // pair on the context's stream.  enable != 0: start (discarding earlier samples); enable == 0:
 // stop and return the average launch duration, the number of launches and the algorithmic bytes
 // per launch.
+// algorithmic bytes of one Chebyshev smoothing launch with operator A on nv interleaved vectors.
+// Vectors: x, b, dinv, d read; d, x_out written (8 bytes each) + 1 mask byte per entry.  Matrix: a
+// CSR stream (12 bytes per nonzero + row pointers) or -- stencil-dictionary copy -- one byte per
+// row + the dictionary once.
+static int64_t smoother_launch_bytes(const BlockMat& A, int nv, bool csr_equivalent) {
+  const Pattern& p = *A.pat;
+  const int64_t n = (int64_t)p.n_rows * nv;
+  if (A.dict_ready && !csr_equivalent)
+    return (int64_t)p.n_rows + (int64_t)A.dict->n_stencils * (A.dict->lmax * 12 + 4) + n * (6 * 8 + 1);
+  return (int64_t)p.nnz * 12 + (int64_t)(p.n_rows + 1) * 4 + n * (6 * 8 + 1);
+}
+
 extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* launches,
                                       int64_t* algorithmic_bytes) {
   API_BEGIN
@@ -2079,11 +2114,24 @@ extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms
   const int64_t n_launch = mg.prof_launches;
   if (avg_ms) *avg_ms = n_launch ? total / (double)n_launch : 0.0;
   if (launches) *launches = n_launch;
-  if (algorithmic_bytes) {
-    const Pattern& p = *mg.lv[0].A->pat;
-    const int64_t n = (int64_t)p.n_rows * mg.nv;
-    *algorithmic_bytes = (int64_t)p.nnz * 12 + (int64_t)(p.n_rows + 1) * 4 + n * (6 * 8 + 1);
-  }
+  if (algorithmic_bytes) *algorithmic_bytes = smoother_launch_bytes(*mg.lv[0].A, mg.nv, false);
+  API_END(ctx)
+}
+
+// which finest-level smoothing kernel of the velocity multigrid runs, and what a CSR stream of the
+// same operator would move: out = {kind (0 CSR-stream, 1 SELL-64, 2 stencil dictionary),
+// dictionary entries, longest row, CSR-equivalent algorithmic bytes of one smoothing launch}
+extern "C" int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out, "null argument");
+  NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
+  ensure_L(ctx);
+  const Multigrid& mg = ctx->mg_v;
+  const BlockMat& A = *mg.lv[0].A;
+  out[0] = A.dict_ready ? 2 : (A.sell_ready ? 1 : 0);
+  out[1] = A.dict_ready ? A.dict->n_stencils : 0;
+  out[2] = A.dict_ready ? (A.dict->exact ? -A.dict->lmax : A.dict->lmax) : 0;
+  out[3] = smoother_launch_bytes(A, mg.nv, true);
   API_END(ctx)
 }
 
@@ -2209,12 +2257,8 @@ extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_
     (void)hipEventDestroy(e1);
     const double ms = t_both - t_flush;
     *ms_per_launch = (double)ms / reps;
-    if (algorithmic_bytes) {
-      const int64_t n = (int64_t)p.n_rows * nv;
-      // matrix (value + column per nonzero, row pointers) + x, b, dinv, d (read), d, y (written)
-      // + the row mask
-      *algorithmic_bytes = (int64_t)p.nnz * 12 + (int64_t)(p.n_rows + 1) * 4 + n * (6 * 8 + 1);
-    }
+    (void)p;
+    if (algorithmic_bytes) *algorithmic_bytes = smoother_launch_bytes(*L0.A, nv, false);
     return NSFEM_OK;
   }
   int nv;

@@ -20,6 +20,7 @@
 //     consume the scalar re-reduce them in a fixed order (bitwise reproducible,
 //     no atomics, no extra launch, no host round trip for alpha/beta/omega).
 #include "nsfem_internal.hpp"
+#include <unordered_map>
 
 namespace nsfem {
 
@@ -50,6 +51,8 @@ struct SpmvArgs {
                    // just produced (a restricted residual): d = y2 = c1 * dinv * y  (fused k_cheb_first)
   int ident;       // smoother step: rows flagged 1 take y = b (identity rows of a preconditioner for a
                    // Newton matrix with dolfin-style Dirichlet rows) instead of 0
+  int dict_ok;     // the product may use the matrix's stencil-dictionary copy (smoothing steps only:
+                   // the copy equals the CSR matrix to the dedupe tolerance, not bitwise)
   int dbg;         // NSFEM_SPMV_DEBUG (measurement experiments only; wrong results): 1 = gather from
                    // the chunk's own rows (perfectly local x), 2 = skip the x gather altogether
 };
@@ -693,7 +696,261 @@ void build_sell(Pattern& p, hipStream_t s) {
   }
 }
 
+// ---------------------------------------------------------------- stencil dictionary
+// One row per lane; lane l of wave w handles row 64 w + l.  A workgroup (256 consecutive rows) uses
+// only a handful of dictionary entries (lattice numberings: 2 to ~12): they are copied into LDS
+// first, every row then needs ONE byte (its entry's position in the workgroup's list).  Per
+// nonzero: offset + value from LDS (lanes of the same class read the same address: broadcast) and
+// the NV-wide gather of x at row + offset (consecutive lanes, consecutive nodes: coalesced).  The
+// vector operands of the epilogue are requested BEFORE the gather loop -- one row per lane means
+// one latency chain per wave, so everything independent is put in flight at once.  No matrix
+// stream at all: a launch moves 1 byte per row plus the vectors.  Epilogue as in the SELL kernel
+// (shuffle-coalesced).
+constexpr int kDictLocal = 32;       // dictionary entries a workgroup may use
+template <int NV, int EPI, int U>
+__global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const uint8_t* __restrict__ lid,
+                                                   const int32_t* __restrict__ wg_ptr,
+                                                   const int32_t* __restrict__ wg_list,
+                                                   const int32_t* __restrict__ slen,
+                                                   const int32_t* __restrict__ soff,
+                                                   const double* __restrict__ sval, int lmax,
+                                                   SpmvArgs a) {
+  extern __shared__ double sh_dict[];
+  double* __restrict__ lv = sh_dict;                                   // [kDictLocal * lmax] values
+  int* __restrict__ lo = reinterpret_cast<int*>(sh_dict + kDictLocal * lmax);   // offsets
+  int* __restrict__ ll = lo + kDictLocal * lmax;                       // lengths
+  // XCD x (workgroups b = x mod 8) walks its own contiguous row range
+  const int per = gridDim.x >> 3;
+  const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (wg >= n_wg) return;                                              // (whole workgroup)
+  const int l0 = wg_ptr[wg], nl = wg_ptr[wg + 1] - l0;
+  for (int t = threadIdx.x; t < nl * lmax; t += 256) {
+    const int j = t / lmax, k = t - j * lmax;
+    const size_t g = (size_t)wg_list[l0 + j] * lmax + k;
+    lv[t] = sval[g];
+    lo[t] = soff[g];
+  }
+  if ((int)threadIdx.x < nl) ll[threadIdx.x] = slen[wg_list[l0 + threadIdx.x]];
+  const int wave = wg * 4 + ((int)threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int row = wave * 64 + lane;
+  const bool live = row < n_rows;
+  const double* __restrict__ x = a.x;
+  const int st = live ? lid[row] : 0;
+  // epilogue operands of this lane's NV output entries (see below for the entry <-> lane map)
+  const size_t ebase = (size_t)wave * 64 * NV;
+  int pm[NV];
+  double pb[NV], pdi[NV], pd[NV], px[NV];
+#pragma unroll
+  for (int p = 0; p < NV; ++p) {
+    const int e = p * 64 + lane;
+    const bool in = wave * 64 + e / NV < n_rows;
+    const size_t idx = ebase + e;
+    pm[p] = (in && a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    pb[p] = (in && EPI != EPI_STORE) ? a.b[idx] : 0.0;
+    pdi[p] = (in && EPI == EPI_CHEB) ? a.dinv[idx] : 0.0;
+    pd[p] = (in && EPI == EPI_CHEB && a.c1 != 0.0) ? a.d[idx] : 0.0;
+    px[p] = in ? x[idx] : 0.0;
+  }
+  __syncthreads();
+  double acc[NV];
+#pragma unroll
+  for (int o = 0; o < NV; ++o) acc[o] = 0.0;
+  const int L = live ? ll[st] : 0;
+  const int* __restrict__ op = lo + st * lmax;
+  const double* __restrict__ vp = lv + st * lmax;
+  for (int k = 0; k < L; k += U) {
+    int c[U];
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k + u < L ? k + u : L - 1;        // past the end: last entry again, weight 0
+      c[u] = row + op[kk];
+      const double t = vp[kk];
+      v[u] = k + u < L ? t : 0.0;
+    }
+    double xv[U][NV];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NV; ++t) xv[u][t] = x[(size_t)c[u] * NV + t];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NV; ++t) acc[t] += v[u] * xv[u][t];
+  }
+  // the wave's 64 rows x NV outputs are the CONTIGUOUS entries 64 NV wave .. of the vectors; in
+  // pass p lane l handles entry e = 64 p + l, whose sum lives in lane e / NV (component e % NV)
+#pragma unroll
+  for (int p = 0; p < NV; ++p) {
+    const int e = p * 64 + lane;
+    const int owner = e / NV, comp = e % NV;
+    double val = 0.0;
+#pragma unroll
+    for (int o = 0; o < NV; ++o) {
+      const double t = __shfl(acc[o], owner, 64);
+      if (comp == o) val = t;
+    }
+    if (wave * 64 + owner >= n_rows) continue;
+    const size_t idx = ebase + e;
+    int m_ = pm[p];
+    if (m_ == 2 && a.ghost == 2) m_ = 0;
+    const bool m = m_ != 0;
+    if (m_ == 2) {
+      if (EPI == EPI_CHEB) {
+        a.d[idx] = 0.0;
+        a.y[idx] = a.ghost == 1 ? px[p] : 0.0;
+      } else {
+        a.y[idx] = 0.0;
+      }
+    } else if (EPI == EPI_RESID) {
+      if (m) val = (a.maskmode == MASK_IDENTITY) ? pb[p] - px[p] : 0.0;
+      else val = pb[p] - val;
+      a.y[idx] = val;
+    } else if (EPI == EPI_CHEB) {
+      double dn = 0.0, xn = 0.0;
+      if (!m) {
+        dn = a.c2 * pdi[p] * (pb[p] - val);
+        if (a.c1 != 0.0) dn += a.c1 * pd[p];
+        xn = px[p] + dn;
+      } else if (a.ident) {
+        xn = pb[p];
+      }
+      a.d[idx] = dn;
+      a.y[idx] = xn;
+    } else {
+      if (m) val = (a.maskmode == MASK_IDENTITY) ? px[p] : 0.0;
+      else val *= a.c2;
+      a.y[idx] = val;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dict_fill(int64_t len, const int32_t* __restrict__ src,
+                                                   const double* __restrict__ csr,
+                                                   double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int sidx = src[i];
+    out[i] = sidx >= 0 ? csr[sidx] : 0.0;
+  }
+}
+
+bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
+                        StencilDict& d) {
+  d.n_stencils = 0;
+  static const bool enabled = [] {
+    const char* e = std::getenv("NSFEM_DICT");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  if (!enabled || p.n_rows < 4096 || p.h_rowptr.empty() || p.n_rows != p.n_cols) return false;
+  const int n = p.n_rows;
+  std::vector<double> va((size_t)p.nnz), vb;
+  NSFEM_HIP(hipMemcpyAsync(va.data(), dev_a, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
+  if (dev_b) {
+    vb.resize((size_t)p.nnz);
+    NSFEM_HIP(hipMemcpyAsync(vb.data(), dev_b, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
+  }
+  NSFEM_HIP(hipStreamSynchronize(s));
+  double sa = 0.0, sb = 0.0;
+  for (double v : va) sa = std::max(sa, std::fabs(v));
+  for (double v : vb) sb = std::max(sb, std::fabs(v));
+  if (!(sa > 0.0)) return false;
+  const double qa = std::ldexp(1.0, 41) / sa, qb = sb > 0.0 ? std::ldexp(1.0, 41) / sb : 0.0;
+  const double ta = std::ldexp(sa, -40), tb = std::ldexp(sb, -40);
+  std::unordered_map<uint64_t, std::vector<int>> seen;
+  seen.reserve(1 << 14);
+  std::vector<int32_t> sid((size_t)n), rep;
+  auto mix = [](uint64_t h, uint64_t v) { return (h ^ v) * 0x100000001b3ULL; };
+  int lmax = 0;
+  const int limit = std::max(64, n / 8);            // more distinct rows than that: not a lattice
+  bool exact = true;                                // every row equals its representative bit for bit
+  for (int r = 0; r < n; ++r) {
+    const int b = p.h_rowptr[r], e = p.h_rowptr[r + 1];
+    uint64_t h = mix(0xcbf29ce484222325ULL, (uint64_t)(e - b));
+    for (int k = b; k < e; ++k) {
+      h = mix(h, (uint64_t)(uint32_t)(p.h_col[k] - r));
+      h = mix(h, (uint64_t)std::llround(va[k] * qa));
+      if (dev_b) h = mix(h, (uint64_t)std::llround(vb[k] * qb));
+    }
+    std::vector<int>& cand = seen[h];
+    int found = -1;
+    for (int c : cand) {
+      const int rr = rep[c], bb = p.h_rowptr[rr];
+      if (p.h_rowptr[rr + 1] - bb != e - b) continue;
+      bool same = true, bitwise = true;
+      for (int k = 0; k < e - b && same; ++k) {
+        same = (p.h_col[bb + k] - rr == p.h_col[b + k] - r) && std::fabs(va[bb + k] - va[b + k]) <= ta &&
+               (!dev_b || std::fabs(vb[bb + k] - vb[b + k]) <= tb);
+        bitwise = bitwise && va[bb + k] == va[b + k] && (!dev_b || vb[bb + k] == vb[b + k]);
+      }
+      if (same) {
+        found = c;
+        exact = exact && bitwise;
+        break;
+      }
+    }
+    if (found < 0) {
+      found = (int)rep.size();
+      if (found >= limit) return false;
+      rep.push_back(r);
+      cand.push_back(found);
+      lmax = std::max(lmax, e - b);
+    }
+    sid[r] = found;
+  }
+  const int ns = (int)rep.size();
+  std::vector<int32_t> len((size_t)ns), off((size_t)ns * lmax, 0), src((size_t)ns * lmax, -1);
+  for (int c = 0; c < ns; ++c) {
+    const int rr = rep[c], bb = p.h_rowptr[rr];
+    len[c] = p.h_rowptr[rr + 1] - bb;
+    for (int k = 0; k < len[c]; ++k) {
+      off[(size_t)c * lmax + k] = p.h_col[bb + k] - rr;
+      src[(size_t)c * lmax + k] = bb + k;
+    }
+  }
+  // per workgroup of 256 rows: the dictionary entries it uses and every row's position in that list
+  const int n_wg = (n + 255) / 256;
+  std::vector<int32_t> wg_ptr((size_t)n_wg + 1, 0), wg_list;
+  std::vector<uint8_t> lid((size_t)n);
+  for (int w = 0; w < n_wg; ++w) {
+    const size_t first = wg_list.size();
+    for (int r = w * 256; r < std::min(n, w * 256 + 256); ++r) {
+      size_t j = first;
+      while (j < wg_list.size() && wg_list[j] != sid[r]) ++j;
+      if (j == wg_list.size()) {
+        if (j - first >= (size_t)kDictLocal) return false;      // no locality: not a lattice numbering
+        wg_list.push_back(sid[r]);
+      }
+      lid[r] = (uint8_t)(j - first);
+    }
+    wg_ptr[w + 1] = (int32_t)wg_list.size();
+  }
+  d.n_rows = n;
+  d.n_stencils = ns;
+  d.lmax = lmax;
+  d.exact = exact;
+  d.lid.upload(lid, s);
+  d.wg_ptr.upload(wg_ptr, s);
+  d.wg_list.upload(wg_list, s);
+  d.sid.upload(sid, s);
+  d.len.upload(len, s);
+  d.off.upload(off, s);
+  d.src.upload(src, s);
+  NSFEM_HIP(hipStreamSynchronize(s));
+  return true;
+}
+
 void BlockMat::sell_update(hipStream_t s) {
+  dict_ready = false;
+  if (dict && dict->n_stencils > 0 && pat && br == 1 && bc == 1 && dict->n_rows == pat->n_rows) {
+    const int64_t len = (int64_t)dict->n_stencils * dict->lmax;
+    if (dict_vals.n != (size_t)len) dict_vals.alloc((size_t)len);
+    hipLaunchKernelGGL(k_dict_fill, dim3((int)std::min<int64_t>((len + 255) / 256, 4096)), dim3(256), 0, s,
+                       len, dict->src.p, vals.p, dict_vals.p);
+    NSFEM_HIP(hipGetLastError());
+    dict_ready = true;
+  }
   sell_ready = false;
   if (!pat || pat->n_slices == 0 || br != 1 || bc != 1) return;
   if (sell_vals.n != (size_t)pat->sell_len) sell_vals.alloc((size_t)pat->sell_len);
@@ -785,6 +1042,21 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     const char* e = std::getenv("NSFEM_SPMV_STREAM");
     return e ? std::atoi(e) : -1;          // -1: per-shape default
   }();
+  if (A.dict_ready && (a_in.dict_ok || A.dict->exact) && a_in.phase == 0 && EPI != EPI_ACCUM && !(EPI == EPI_STORE && a_in.y2) && nv >= 1 && nv <= 3) {
+    const StencilDict& d = *A.dict;
+    const int n_wg = (d.n_rows + 255) / 256;
+    const int grid = (n_wg + 7) & ~7;
+    const size_t lds = (size_t)kDictLocal * d.lmax * 12 + kDictLocal * 4;
+#define NSFEM_DICT_LAUNCH(NV)                                                                          \
+  hipLaunchKernelGGL((k_spmv_dict<NV, EPI, 4>), dim3(grid), dim3(256), lds, s, d.n_rows, n_wg, d.lid.p, \
+                     d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.lmax, a_in)
+    if (nv == 1) NSFEM_DICT_LAUNCH(1);
+    else if (nv == 2) NSFEM_DICT_LAUNCH(2);
+    else NSFEM_DICT_LAUNCH(3);
+#undef NSFEM_DICT_LAUNCH
+    NSFEM_HIP(hipGetLastError());
+    return;
+  }
   if (A.sell_ready && p.n_slices > 0 && A.br == 1 && A.bc == 1 && nv >= 1 && nv <= 3) {
     SpmvArgs a = a_in;
     const int nwg_all = (p.n_slices + 3) / 4;
@@ -964,6 +1236,7 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
   a.skipn = 0;
   a.phase = 0;
   a.ident = 0;
+  a.dict_ok = 0;
   a.y2 = nullptr;
   static const int dbg = [] {
     const char* e = std::getenv("NSFEM_SPMV_DEBUG");
@@ -974,10 +1247,11 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
 }
 
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                 const uint8_t* rowmask, int maskmode, int ghost, int phase) {
+                 const uint8_t* rowmask, int maskmode, int ghost, int phase, int dict_ok) {
   SpmvArgs a = make_args(x, nullptr, y, rowmask, maskmode);
   a.ghost = ghost;
   a.phase = phase;
+  a.dict_ok = dict_ok;
   spmv_dispatch<EPI_STORE>(s, A, nv, a);
 }
 // y = A x (rows flagged in rowmask -> 0) and, fused, the first Chebyshev-Jacobi step from a zero
@@ -1021,6 +1295,7 @@ void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x,
   a.ghost = ghost;
   a.phase = phase;
   a.ident = ident;
+  a.dict_ok = 1;
   spmv_dispatch<EPI_CHEB>(s, A, nv, a);
 }
 

@@ -120,10 +120,38 @@ void build_inverse_index(int n_targets, int64_t n_sources,
                          std::vector<int32_t>& ptr, std::vector<int32_t>& idx);
 
 // block matrix on a pattern; vals[nnz][BR][BC] row-major blocks
+// Stencil dictionary of a scalar matrix family on one pattern (structured meshes): rows whose
+// (column offsets, values) agree to 2^-40 (of the largest entry) share one dictionary entry, so a product reads ONE
+// 4-byte id per row instead of 12 bytes per nonzero -- on the lattice meshes of the benchmark
+// configurations a P2 operator has a few dozen (2D) to a few thousand (3D, slab-blocked parity
+// numbering) distinct rows.  Built once per pattern from the constant matrices it will combine
+// (mass and stiffness: any a M + b K has the same dictionary); the value table of a matrix is a
+// gather from the CSR values of the representative rows (dict_update, device only).  The
+// compressed copy differs from the CSR matrix by the dedupe tolerance: unless `exact` it is used by
+// multigrid SMOOTHING and Newton-Jacobian products only, never by a residual or a linear operator
+// whose solution is returned.
+struct StencilDict {
+  int n_rows = 0, n_stencils = 0, lmax = 0;
+  bool exact = false;      // every row equals its representative BITWISE (meshes with a binary spacing): the
+                           // dictionary copy is the matrix itself and every product may use it
+  DevBuf<int32_t> sid;     // [n_rows] dictionary entry of every row
+  DevBuf<uint8_t> lid;     // [n_rows] its position in the list of the row's workgroup (256 rows)
+  DevBuf<int32_t> wg_ptr, wg_list;   // per workgroup: the entries it uses (<= 32)
+  DevBuf<int32_t> len;     // [n_stencils]
+  DevBuf<int32_t> off;     // [n_stencils * lmax] column - row
+  DevBuf<int32_t> src;     // [n_stencils * lmax] CSR position in the representative row (-1: padding)
+};
+// false: the rows do not repeat (unstructured mesh) -- no dictionary
+bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
+                        StencilDict& d);
+
 struct BlockMat {
   const Pattern* pat = nullptr;
   int br = 1, bc = 1;
   DevBuf<double> vals;
+  const StencilDict* dict = nullptr;      // set: sell_update() also refreshes dict_vals
+  DevBuf<double> dict_vals;               // [n_stencils * lmax]
+  bool dict_ready = false;
   // copy of the values in the pattern's SELL-64 order (scalar matrices on patterns that have one);
   // refreshed by sell_update() after every change of `vals` -- the SpMV kernels use it only while
   // sell_ready is set
@@ -165,8 +193,10 @@ enum MaskMode { MASK_NONE = 0, MASK_IDENTITY = 1, MASK_ZERO = 2 };
 // ghost: treatment of rows flagged 2 (ghost rows of a partitioned mesh): 0 output 0, 2 computed
 // phase (partitioned meshes, halo exchange overlapped with the product): 0 all rows, 1 only the
 // row blocks that touch no ghost column (Pattern::int_b0..int_b1), 2 the remaining row blocks
+// dict_ok: the product may run on the matrix's stencil-dictionary copy (equal to the CSR values to
+// 2^-40 of the largest entry): Newton-Jacobian products and smoothing steps only
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
-                 const uint8_t* rowmask, int maskmode, int ghost = 0, int phase = 0);
+                 const uint8_t* rowmask, int maskmode, int ghost = 0, int phase = 0, int dict_ok = 0);
 void launch_spmv_cheb_first(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
                             const uint8_t* rowmask, const double* dinv, double c2, double* d,
                             double* x1);
@@ -657,6 +687,10 @@ struct nsfem_ctx {
     nsfem::BlockMat mat;
   };
   std::vector<CsrOp*> schur_ops;               // owned
+  nsfem::StencilDict dict22;                   // rows of the scalar P2 operators (ensure_L)
+  bool dict22_tried = false;
+  nsfem::StencilDict dict11;                   // rows of the scalar P1 operators of the fine mesh
+  bool dict11_tried = false;
   int bc_p_any = -1;                           // partitioned: pressure Dirichlet dofs on any rank (-1 unknown)
   bool schur_additive = false;                 // operators of nsfem_mg_set_schur_operator are rank parts
   int schur_singular = -1;                     // -1: geometric hierarchy (singular iff no Dirichlet set)

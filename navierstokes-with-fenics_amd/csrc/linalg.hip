@@ -839,10 +839,8 @@ __global__ __launch_bounds__(256) void k_dict_fill(int64_t len, const int32_t* _
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
                         StencilDict& d) {
   d.n_stencils = 0;
-  static const bool enabled = [] {
-    const char* e = std::getenv("NSFEM_DICT");
-    return e ? std::atoi(e) != 0 : true;
-  }();
+  const char* env = std::getenv("NSFEM_DICT");        // (read per context: tests switch it)
+  const bool enabled = env ? std::atoi(env) != 0 : true;
   if (!enabled || p.n_rows < 4096 || p.h_rowptr.empty() || p.n_rows != p.n_cols) return false;
   const int n = p.n_rows;
   std::vector<double> va((size_t)p.nnz), vb;

@@ -809,7 +809,7 @@ def test_sell_kernel_on_parity_numbering_equals_csr_kernel_on_lattice_numbering(
     import subprocess
     import sys
     if os.environ.get("NSFEM_SELL") != "2":            # 2: SELL on every qualifying pattern (2D too)
-        env = dict(os.environ, NSFEM_SELL="2")
+        env = dict(os.environ, NSFEM_SELL="2", NSFEM_DICT="0")     # (the dictionary kernel would pre-empt SELL)
         here = os.path.abspath(__file__)
         node = "%s::test_sell_kernel_on_parity_numbering_equals_csr_kernel_on_lattice_numbering[%d-%d]" % (here, dim, n)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", node],
@@ -858,3 +858,78 @@ def test_sell_kernel_on_parity_numbering_equals_csr_kernel_on_lattice_numbering(
     assert rel(ua, ub) < 1e-9 and rel(pa - pa.mean(), pb - pb.mean()) < 1e-8
     for a, b in zip(ia, ib):
         assert a[0] == b[0] and abs(a[1] - b[1]) <= 1 and abs(a[2] - b[2]) <= 1
+
+
+@pytest.mark.parametrize("dim,n,exact,order", [(2, 64, True, True), (2, 48, False, True), (3, 32, True, "parity"),
+                                                (3, 24, False, True)])
+def test_stencil_dictionary_kernel_equals_the_csr_kernels(dim, n, exact, order, monkeypatch):
+    """Lattice meshes: the scalar P2 / P1 operators are stored a second time as a stencil dictionary
+    (rows with equal column offsets and values share one entry; k_spmv_dict reads one byte per row
+    instead of 12 bytes per nonzero).  With a binary mesh spacing (n = 64, 32) every row equals its
+    representative BIT FOR BIT and every product uses the dictionary; otherwise (n = 48, 24: equal
+    to 2^-40) only smoothing steps and Newton-Jacobian products do.  (The slab-blocked parity
+    numbering of tetrahedral meshes needs n >= 32 for a workgroup to see <= 32 distinct rows; the
+    lexicographic numbering has 64 distinct rows at any size.)  Same problem with
+    NSFEM_DICT=0 (CSR-stream / SELL kernels) and with the dictionary: same iteration counts, fields
+    equal to solver tolerance; exported CSR matrices against dictionary products; an unstructured
+    mesh gets no dictionary."""
+    import grid_generator as gg
+    from fem_mesh import TaylorHoodDofMap, box_mesh, rectangle_mesh
+    from multigrid import attach_hierarchy
+    mesh = rectangle_mesh((0.0, 0.0), (1.0, 1.0), n, n) if dim == 2 else box_mesh((0, 0, 0), (1, 1, 1), n, n, n)
+    mesh.structured = ((0.0,) * dim, (1.0,) * dim) + (n,) * dim
+    dm = TaylorHoodDofMap(mesh, reorder=order)
+    X = dm.p2_coords
+    on = np.zeros(dm.n_p2, bool)
+    for a in range(dim):
+        on |= (np.abs(X[:, a]) < 1e-12) | (np.abs(X[:, a] - 1.0) < 1e-12)
+    nodes = np.nonzero(on)[0]
+    lid = np.abs(X[nodes, dim - 1] - 1.0) < 1e-12
+    dofs = np.concatenate([dim * nodes + a for a in range(dim)]).astype(np.int32)
+    vals = np.concatenate([np.where(lid, 1.0, 0.0)] + [np.zeros(nodes.size)] * (dim - 1))
+    rng = np.random.default_rng(5)
+    xm = rng.standard_normal(dm.n_p2)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NSFEM_DICT", mode)
+        ctx = context(mesh, dm)
+        attach_hierarchy(ctx, mesh, coarsest=4 if dim == 2 else 2)
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, dofs, vals)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-11
+        opts.momentum.precond = opts.poisson.precond = 1
+        opts.correction.precond = 2
+        its = []
+        for step in range(3):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), 0.01)
+            info = ctx.step_ipcs(opts)
+            ctx.advance(0)
+            its.append((info.newton_iterations, info.krylov_iterations_momentum, info.krylov_iterations_poisson))
+        info_s = ctx.smoother_info()
+        # products with the mass matrix after the steps (the dictionary is attached by then)
+        M = ctx.operator_csr(nat.OP_MASS_P2)
+        assert rel(ctx.operator_apply(nat.OP_MASS_P2, xm), M @ xm) < 1e-13
+        out[mode] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), its, info_s)
+        ctx.close()
+    u0, p0, its0, s0 = out["0"]
+    u1, p1, its1, s1 = out["1"]
+    assert s0["kind"] != "stencil-dictionary"
+    assert s1["kind"] == "stencil-dictionary" and s1["bitwise_exact"] == exact
+    assert 0 < s1["stencils"] < dm.n_p2 // 8 and s1["csr_bytes"] > 0
+    for a, b in zip(its0, its1):
+        assert a[0] == b[0] and abs(a[1] - b[1]) <= 1 and abs(a[2] - b[2]) <= 1
+    assert rel(u1, u0) < 1e-9
+    assert rel(p1 - p1.mean(), p0 - p0.mean()) < 1e-8
+    if dim == 2 and exact:
+        monkeypatch.setenv("NSFEM_DICT", "1")
+        dmesh, _ = gg.dfg_channel(4, 3)
+        ddm = TaylorHoodDofMap(dmesh)
+        c = context(dmesh, ddm)
+        attach_hierarchy(c, dmesh)
+        c.set_coeffs(1.0, 1.0, 0.01)
+        c.set_bdf((1.0, -1.0, 0.0), 0.01)
+        assert ddm.n_p2 > 4096 and c.smoother_info()["kind"] != "stencil-dictionary"
+        c.close()

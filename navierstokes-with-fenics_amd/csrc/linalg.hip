@@ -721,8 +721,9 @@ __global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const u
   int* __restrict__ ll = lo + kDictLocal * lmax;                       // lengths
   // XCD x (workgroups b = x mod 8) walks its own contiguous row range
   const int per = gridDim.x >> 3;
-  const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (wg >= n_wg) return;                                              // (whole workgroup)
+  if (wg >= a.skip0) wg += a.skipn;            // partitioned product split into interior / halo-adjacent groups
   const int l0 = wg_ptr[wg], nl = wg_ptr[wg + 1] - l0;
   for (int t = threadIdx.x; t < nl * lmax; t += 256) {
     const int j = t / lmax, k = t - j * lmax;
@@ -999,6 +1000,24 @@ void build_rowblocks(Pattern& p, hipStream_t s) {
 
 void mark_interior_blocks(Pattern& p, const std::vector<uint8_t>& ghost_cols) {
   p.int_b0 = p.int_b1 = 0;
+  p.wg_w0 = p.wg_w1 = 0;
+  if ((int)ghost_cols.size() == p.n_cols && !p.h_rowptr.empty()) {
+    // groups of 256 consecutive rows (workgroups of the stencil-dictionary kernel)
+    const int nwg = (p.n_rows + 255) / 256;
+    int b0 = 0, b1 = 0, r0 = 0;
+    for (int b = 0; b <= nwg; ++b) {
+      bool dirty = b == nwg;
+      if (!dirty)
+        for (int k = p.h_rowptr[std::min(p.n_rows, b * 256)]; k < p.h_rowptr[std::min(p.n_rows, b * 256 + 256)] && !dirty; ++k)
+          dirty = ghost_cols[p.h_col[k]] != 0;
+      if (dirty) {
+        if (b - r0 > b1 - b0) { b0 = r0; b1 = b; }
+        r0 = b + 1;
+      }
+    }
+    p.wg_w0 = b0;
+    p.wg_w1 = b1;
+  }
   if (p.n_rblk == 0 || (int)ghost_cols.size() != p.n_cols) return;
   int best0 = 0, best1 = 0, run0 = 0;
   for (int b = 0; b <= p.n_rblk; ++b) {
@@ -1040,14 +1059,28 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     const char* e = std::getenv("NSFEM_SPMV_STREAM");
     return e ? std::atoi(e) : -1;          // -1: per-shape default
   }();
-  if (A.dict_ready && (a_in.dict_ok || A.dict->exact) && a_in.phase == 0 && EPI != EPI_ACCUM && !(EPI == EPI_STORE && a_in.y2) && nv >= 1 && nv <= 3) {
+  if (A.dict_ready && (a_in.dict_ok || A.dict->exact) && EPI != EPI_ACCUM && !(EPI == EPI_STORE && a_in.y2) && nv >= 1 && nv <= 3) {
     const StencilDict& d = *A.dict;
-    const int n_wg = (d.n_rows + 255) / 256;
+    const int n_all = (d.n_rows + 255) / 256;
+    int n_wg = n_all;
+    SpmvArgs a = a_in;
+    a.skip0 = n_all;
+    a.skipn = 0;
+    if (a.phase == 1) {                    // interior workgroups only: shift the logical index
+      n_wg = p.wg_w1 - p.wg_w0;
+      a.skip0 = 0;
+      a.skipn = p.wg_w0;
+    } else if (a.phase == 2) {
+      n_wg = n_all - (p.wg_w1 - p.wg_w0);
+      a.skip0 = p.wg_w0;
+      a.skipn = p.wg_w1 - p.wg_w0;
+    }
+    if (n_wg <= 0) return;
     const int grid = (n_wg + 7) & ~7;
     const size_t lds = (size_t)kDictLocal * d.lmax * 12 + kDictLocal * 4;
 #define NSFEM_DICT_LAUNCH(NV)                                                                          \
   hipLaunchKernelGGL((k_spmv_dict<NV, EPI, 4>), dim3(grid), dim3(256), lds, s, d.n_rows, n_wg, d.lid.p, \
-                     d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.lmax, a_in)
+                     d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.lmax, a)
     if (nv == 1) NSFEM_DICT_LAUNCH(1);
     else if (nv == 2) NSFEM_DICT_LAUNCH(2);
     else NSFEM_DICT_LAUNCH(3);

@@ -105,6 +105,7 @@ struct Pattern {
   int n_slices = 0;
   int64_t sell_len = 0;
   int sell_w0 = 0, sell_w1 = 0;           // interior workgroups (4 slices each), see int_b0/int_b1
+  int wg_w0 = 0, wg_w1 = 0;   // longest run of 256-row groups without a ghost column (dictionary kernel)
   // contiguous workgroup ranges of the 8 XCDs, balanced by (padded) nonzeros: the parity-class
   // numberings group rows of very different length (3D vertex rows 65, edge rows 14-32 entries),
   // an equal-count split would leave one XCD with 2-3 times the work of the others

@@ -1082,6 +1082,8 @@ extern "C" int nsfem_mg_set_schur_operator(nsfem_ctx* ctx, int level, int32_t n,
   op->mat.pat = &p;
   op->mat.br = op->mat.bc = 1;
   op->mat.vals.upload(val, (size_t)p.nnz, s);
+  NSFEM_HIP(hipStreamSynchronize(s));
+  if (build_stencil_dict(s, p, op->mat.vals.p, nullptr, op->dict)) op->mat.dict = &op->dict;
   op->mat.sell_update(s);
   NSFEM_HIP(hipStreamSynchronize(s));
   ctx->mg_s.lv[level].A = &op->mat;
@@ -1640,8 +1642,8 @@ void nsfem_ctx::MixedOp::apply(hipStream_t s, const double* x, double* y) {
   }
   if (c->mf_active) c->mom_mf.apply(s, x, y);          // (exchanges the velocity part itself)
   else launch_spmv(s, c->J, 1, x, y, c->mask_v.p, MASK_IDENTITY);
-  launch_spmv_axpy(s, c->DT, 1, -cp, x + nv, y, c->mask_v.p);
-  launch_spmv_scaled(s, c->Dv, 1, -cp, x, y + nv);
+  launch_spmv_axpy(s, c->DT, 1, -cp, x + nv, y, c->mask_v.p, 1);       // (Jacobian product: dictionary copies allowed)
+  launch_spmv_scaled(s, c->Dv, 1, -cp, x, y + nv, 1);
   launch_copy_at(s, c->nbc_p, c->bc_p_dofs.p, x + nv, y + nv);
   if (c->ghost_p.p) launch_zero_ghost(s, np, c->mask_p.p, y + nv);
 }
@@ -1660,7 +1662,7 @@ void nsfem_ctx::BlockPrec::apply(hipStream_t s, const double* r, double* z) {
   launch_copy_at(s, c->nbc_p, c->bc_p_dofs.p, rp, zp);
   if (c->distributed()) c->comm->exchange(s, c->halo_p1, zp, 1);
   NSFEM_HIP(hipMemcpyAsync(c->tmp_v.p, r, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
-  launch_spmv_axpy(s, c->DT, 1, cp, zp, c->tmp_v.p, c->mask_v.p);
+  launch_spmv_axpy(s, c->DT, 1, cp, zp, c->tmp_v.p, c->mask_v.p, 1);   // (preconditioner)
   if (c->ghost_p.p) launch_zero_ghost(s, np, c->mask_p.p, zp);      // keep ghost entries out of the dots
   c->mg_v.apply(s, c->tmp_v.p, z);        // (identity rows on the Dirichlet dofs: Multigrid::identity_rows)
 }
@@ -1709,6 +1711,18 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   ctx->mixed_op.n = nv + np;
   ctx->block_prec.c = ctx;
   ctx->picard = opts->picard != 0;
+  if (!ctx->dictD_tried) {          // lattice meshes: dictionary copies of the divergence blocks
+    ctx->dictD_tried = true;
+    const int dim = ctx->mesh.dim;
+    if (build_stencil_dict(s, ctx->p21, ctx->DT.vals.p, nullptr, ctx->dict21, dim, true)) {
+      ctx->DT.dict = &ctx->dict21;
+      ctx->DT.sell_update(s);
+    }
+    if (build_stencil_dict(s, ctx->p12, ctx->Dv.vals.p, nullptr, ctx->dict12, dim, true)) {
+      ctx->Dv.dict = &ctx->dict12;
+      ctx->Dv.sell_update(s);
+    }
+  }
   momentum_begin_step(ctx, false);
   double r = bdf_residual(ctx);
   const double r0 = r;

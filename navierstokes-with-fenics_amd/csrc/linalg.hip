@@ -714,11 +714,11 @@ __global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const u
                                                    const int32_t* __restrict__ slen,
                                                    const int32_t* __restrict__ soff,
                                                    const double* __restrict__ sval, int lmax,
-                                                   SpmvArgs a) {
+                                                   int max_local, SpmvArgs a) {
   extern __shared__ double sh_dict[];
-  double* __restrict__ lv = sh_dict;                                   // [kDictLocal * lmax] values
-  int* __restrict__ lo = reinterpret_cast<int*>(sh_dict + kDictLocal * lmax);   // offsets
-  int* __restrict__ ll = lo + kDictLocal * lmax;                       // lengths
+  double* __restrict__ lv = sh_dict;                                   // [max_local * lmax] values
+  int* __restrict__ lo = reinterpret_cast<int*>(sh_dict + (size_t)max_local * lmax);   // offsets
+  int* __restrict__ ll = lo + max_local * lmax;                        // lengths
   // XCD x (workgroups b = x mod 8) walks its own contiguous row range
   const int per = gridDim.x >> 3;
   int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -827,28 +827,119 @@ __global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const u
   }
 }
 
-__global__ __launch_bounds__(256) void k_dict_fill(int64_t len, const int32_t* __restrict__ src,
+// Rectangular block operators between the P2 and P1 numberings (divergence 1 x dim blocks, its
+// transpose dim x 1): same scheme, the column of entry k is cbase[row] + offset_k, a table entry
+// holds BR * BC values.  EPI_STORE: y = c2 A x; EPI_ACCUM: y += c2 A x on rows not flagged.
+template <int BR, int BC, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_dict_blk(int n_rows, int n_wg, const uint8_t* __restrict__ lid,
+                                                       const int32_t* __restrict__ cbase,
+                                                       const int32_t* __restrict__ wg_ptr,
+                                                       const int32_t* __restrict__ wg_list,
+                                                       const int32_t* __restrict__ slen,
+                                                       const int32_t* __restrict__ soff,
+                                                       const double* __restrict__ sval, int lmax,
+                                                       int max_local, SpmvArgs a) {
+  constexpr int BS = BR * BC;
+  extern __shared__ double sh_dict[];
+  double* __restrict__ lv = sh_dict;                                          // [max_local * lmax * BS]
+  int* __restrict__ lo = reinterpret_cast<int*>(sh_dict + (size_t)max_local * lmax * BS);
+  int* __restrict__ ll = lo + max_local * lmax;
+  const int per = gridDim.x >> 3;
+  const int wg = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (wg >= n_wg) return;
+  const int l0 = wg_ptr[wg], nl = wg_ptr[wg + 1] - l0;
+  for (int t = threadIdx.x; t < nl * lmax; t += 256) {
+    const int j = t / lmax, k = t - j * lmax;
+    const size_t g = (size_t)wg_list[l0 + j] * lmax + k;
+    lo[t] = soff[g];
+#pragma unroll
+    for (int q = 0; q < BS; ++q) lv[(size_t)t * BS + q] = sval[g * BS + q];
+  }
+  if ((int)threadIdx.x < nl) ll[threadIdx.x] = slen[wg_list[l0 + threadIdx.x]];
+  const int wave = wg * 4 + ((int)threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int row = wave * 64 + lane;
+  const bool live = row < n_rows;
+  const double* __restrict__ x = a.x;
+  const int st = live ? lid[row] : 0;
+  const int cb = live ? cbase[row] : 0;
+  __syncthreads();
+  double acc[BR];
+#pragma unroll
+  for (int o = 0; o < BR; ++o) acc[o] = 0.0;
+  const int L = live ? ll[st] : 0;
+  const int* __restrict__ op = lo + st * lmax;
+  const double* __restrict__ vp = lv + (size_t)st * lmax * BS;
+  constexpr int U = 4;
+  for (int k = 0; k < L; k += U) {
+    double xv[U][BC];
+    int kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      kk[u] = k + u < L ? k + u : L - 1;
+      const int c = cb + op[kk[u]];
+#pragma unroll
+      for (int t = 0; t < BC; ++t) xv[u][t] = x[(size_t)c * BC + t];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double w = k + u < L ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 0; r < BR; ++r)
+#pragma unroll
+        for (int t = 0; t < BC; ++t) acc[r] += w * vp[(size_t)kk[u] * BS + r * BC + t] * xv[u][t];
+    }
+  }
+  const size_t ebase = (size_t)wave * 64 * BR;
+#pragma unroll
+  for (int p = 0; p < BR; ++p) {
+    const int e = p * 64 + lane;
+    const int owner = e / BR, comp = e % BR;
+    double val = 0.0;
+#pragma unroll
+    for (int o = 0; o < BR; ++o) {
+      const double t = __shfl(acc[o], owner, 64);
+      if (comp == o) val = t;
+    }
+    if (wave * 64 + owner >= n_rows) continue;
+    const size_t idx = ebase + e;
+    int m_ = (a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
+    if (m_ == 2 && a.ghost == 2) m_ = 0;
+    if (m_ == 2) {
+      a.y[idx] = 0.0;
+    } else if (EPI == EPI_ACCUM) {
+      if (!m_) a.y[idx] += a.c2 * val;
+      else if (a.maskmode == MASK_ZERO) a.y[idx] = 0.0;
+    } else {
+      a.y[idx] = m_ ? 0.0 : a.c2 * val;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dict_fill(int64_t len, int bsz, const int32_t* __restrict__ src,
                                                    const double* __restrict__ csr,
                                                    double* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len * bsz;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int sidx = src[i];
-    out[i] = sidx >= 0 ? csr[sidx] : 0.0;
+    const int sidx = src[i / bsz];
+    out[i] = sidx >= 0 ? csr[(size_t)sidx * bsz + i % bsz] : 0.0;
   }
 }
 
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
-                        StencilDict& d) {
+                        StencilDict& d, int bsz, bool rect) {
   d.n_stencils = 0;
+  d.max_local = 0;
   const char* env = std::getenv("NSFEM_DICT");        // (read per context: tests switch it)
   const bool enabled = env ? std::atoi(env) != 0 : true;
-  if (!enabled || p.n_rows < 4096 || p.h_rowptr.empty() || p.n_rows != p.n_cols) return false;
+  if (!enabled || p.n_rows < 4096 || p.h_rowptr.empty() || (!rect && p.n_rows != p.n_cols)) return false;
   const int n = p.n_rows;
-  std::vector<double> va((size_t)p.nnz), vb;
-  NSFEM_HIP(hipMemcpyAsync(va.data(), dev_a, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
+  const size_t nval = (size_t)p.nnz * bsz;
+  std::vector<double> va(nval), vb;
+  NSFEM_HIP(hipMemcpyAsync(va.data(), dev_a, sizeof(double) * nval, hipMemcpyDeviceToHost, s));
   if (dev_b) {
-    vb.resize((size_t)p.nnz);
-    NSFEM_HIP(hipMemcpyAsync(vb.data(), dev_b, sizeof(double) * p.nnz, hipMemcpyDeviceToHost, s));
+    vb.resize(nval);
+    NSFEM_HIP(hipMemcpyAsync(vb.data(), dev_b, sizeof(double) * nval, hipMemcpyDeviceToHost, s));
   }
   NSFEM_HIP(hipStreamSynchronize(s));
   double sa = 0.0, sb = 0.0;
@@ -864,24 +955,32 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
   int lmax = 0;
   const int limit = std::max(64, n / 8);            // more distinct rows than that: not a lattice
   bool exact = true;                                // every row equals its representative bit for bit
+  // column offsets are taken relative to the row itself (square operators) or to the row's first
+  // column (rectangular blocks between the P2 and P1 numberings)
+  auto origin = [&](int r) { return rect ? (p.h_rowptr[r + 1] > p.h_rowptr[r] ? p.h_col[p.h_rowptr[r]] : 0) : r; };
   for (int r = 0; r < n; ++r) {
-    const int b = p.h_rowptr[r], e = p.h_rowptr[r + 1];
+    const int b = p.h_rowptr[r], e = p.h_rowptr[r + 1], o_r = origin(r);
     uint64_t h = mix(0xcbf29ce484222325ULL, (uint64_t)(e - b));
     for (int k = b; k < e; ++k) {
-      h = mix(h, (uint64_t)(uint32_t)(p.h_col[k] - r));
-      h = mix(h, (uint64_t)std::llround(va[k] * qa));
-      if (dev_b) h = mix(h, (uint64_t)std::llround(vb[k] * qb));
+      h = mix(h, (uint64_t)(uint32_t)(p.h_col[k] - o_r));
+      for (int j = 0; j < bsz; ++j) {
+        h = mix(h, (uint64_t)std::llround(va[(size_t)k * bsz + j] * qa));
+        if (dev_b) h = mix(h, (uint64_t)std::llround(vb[(size_t)k * bsz + j] * qb));
+      }
     }
     std::vector<int>& cand = seen[h];
     int found = -1;
     for (int c : cand) {
-      const int rr = rep[c], bb = p.h_rowptr[rr];
+      const int rr = rep[c], bb = p.h_rowptr[rr], o_rr = origin(rr);
       if (p.h_rowptr[rr + 1] - bb != e - b) continue;
       bool same = true, bitwise = true;
       for (int k = 0; k < e - b && same; ++k) {
-        same = (p.h_col[bb + k] - rr == p.h_col[b + k] - r) && std::fabs(va[bb + k] - va[b + k]) <= ta &&
-               (!dev_b || std::fabs(vb[bb + k] - vb[b + k]) <= tb);
-        bitwise = bitwise && va[bb + k] == va[b + k] && (!dev_b || vb[bb + k] == vb[b + k]);
+        same = p.h_col[bb + k] - o_rr == p.h_col[b + k] - o_r;
+        for (int j = 0; j < bsz && same; ++j) {
+          const size_t i0 = (size_t)(bb + k) * bsz + j, i1 = (size_t)(b + k) * bsz + j;
+          same = std::fabs(va[i0] - va[i1]) <= ta && (!dev_b || std::fabs(vb[i0] - vb[i1]) <= tb);
+          bitwise = bitwise && va[i0] == va[i1] && (!dev_b || vb[i0] == vb[i1]);
+        }
       }
       if (same) {
         found = c;
@@ -904,7 +1003,7 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
     const int rr = rep[c], bb = p.h_rowptr[rr];
     len[c] = p.h_rowptr[rr + 1] - bb;
     for (int k = 0; k < len[c]; ++k) {
-      off[(size_t)c * lmax + k] = p.h_col[bb + k] - rr;
+      off[(size_t)c * lmax + k] = p.h_col[bb + k] - origin(rr);
       src[(size_t)c * lmax + k] = bb + k;
     }
   }
@@ -924,6 +1023,14 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
       lid[r] = (uint8_t)(j - first);
     }
     wg_ptr[w + 1] = (int32_t)wg_list.size();
+    d.max_local = std::max(d.max_local, (int)(wg_list.size() - first));
+  }
+  d.bsz = bsz;
+  d.rect = rect;
+  if (rect) {
+    std::vector<int32_t> cb((size_t)n);
+    for (int r = 0; r < n; ++r) cb[r] = origin(r);
+    d.cbase.upload(cb, s);
   }
   d.n_rows = n;
   d.n_stencils = ns;
@@ -942,11 +1049,11 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
 
 void BlockMat::sell_update(hipStream_t s) {
   dict_ready = false;
-  if (dict && dict->n_stencils > 0 && pat && br == 1 && bc == 1 && dict->n_rows == pat->n_rows) {
+  if (dict && dict->n_stencils > 0 && pat && br * bc == dict->bsz && dict->n_rows == pat->n_rows) {
     const int64_t len = (int64_t)dict->n_stencils * dict->lmax;
-    if (dict_vals.n != (size_t)len) dict_vals.alloc((size_t)len);
-    hipLaunchKernelGGL(k_dict_fill, dim3((int)std::min<int64_t>((len + 255) / 256, 4096)), dim3(256), 0, s,
-                       len, dict->src.p, vals.p, dict_vals.p);
+    if (dict_vals.n != (size_t)(len * dict->bsz)) dict_vals.alloc((size_t)(len * dict->bsz));
+    hipLaunchKernelGGL(k_dict_fill, dim3((int)std::min<int64_t>((len * dict->bsz + 255) / 256, 4096)), dim3(256),
+                       0, s, len, dict->bsz, dict->src.p, vals.p, dict_vals.p);
     NSFEM_HIP(hipGetLastError());
     dict_ready = true;
   }
@@ -1059,7 +1166,29 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     const char* e = std::getenv("NSFEM_SPMV_STREAM");
     return e ? std::atoi(e) : -1;          // -1: per-shape default
   }();
-  if (A.dict_ready && (a_in.dict_ok || A.dict->exact) && EPI != EPI_ACCUM && !(EPI == EPI_STORE && a_in.y2) && nv >= 1 && nv <= 3) {
+  if (A.dict_ready && A.dict->rect && (a_in.dict_ok || A.dict->exact) && a_in.phase == 0 && nv == 1 &&
+      (EPI == EPI_STORE || EPI == EPI_ACCUM) && !a_in.y2) {
+    const StencilDict& d = *A.dict;
+    const int n_wg = (d.n_rows + 255) / 256;
+    const int grid = (n_wg + 7) & ~7;
+    const size_t lds = (size_t)d.max_local * d.lmax * (8 * d.bsz + 4) + (size_t)d.max_local * 4 + 8;
+#define NSFEM_DICTB(BR, BC)                                                                              \
+  hipLaunchKernelGGL((k_spmv_dict_blk<BR, BC, EPI>), dim3(grid), dim3(256), lds, s, d.n_rows, n_wg,     \
+                     d.lid.p, d.cbase.p, d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p,      \
+                     d.lmax, d.max_local, a_in)
+    bool done = true;
+    if (A.br == 3 && A.bc == 1) NSFEM_DICTB(3, 1);
+    else if (A.br == 1 && A.bc == 3) NSFEM_DICTB(1, 3);
+    else if (A.br == 2 && A.bc == 1) NSFEM_DICTB(2, 1);
+    else if (A.br == 1 && A.bc == 2) NSFEM_DICTB(1, 2);
+    else done = false;
+#undef NSFEM_DICTB
+    if (done) {
+      NSFEM_HIP(hipGetLastError());
+      return;
+    }
+  }
+  if (A.dict_ready && !A.dict->rect && A.br == 1 && A.bc == 1 && (a_in.dict_ok || A.dict->exact) && EPI != EPI_ACCUM && !(EPI == EPI_STORE && a_in.y2) && nv >= 1 && nv <= 3) {
     const StencilDict& d = *A.dict;
     const int n_all = (d.n_rows + 255) / 256;
     int n_wg = n_all;
@@ -1077,10 +1206,10 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     }
     if (n_wg <= 0) return;
     const int grid = (n_wg + 7) & ~7;
-    const size_t lds = (size_t)kDictLocal * d.lmax * 12 + kDictLocal * 4;
+    const size_t lds = (size_t)d.max_local * d.lmax * 12 + (size_t)d.max_local * 4;
 #define NSFEM_DICT_LAUNCH(NV)                                                                          \
   hipLaunchKernelGGL((k_spmv_dict<NV, EPI, 4>), dim3(grid), dim3(256), lds, s, d.n_rows, n_wg, d.lid.p, \
-                     d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.lmax, a)
+                     d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.lmax, d.max_local, a)
     if (nv == 1) NSFEM_DICT_LAUNCH(1);
     else if (nv == 2) NSFEM_DICT_LAUNCH(2);
     else NSFEM_DICT_LAUNCH(3);
@@ -1307,15 +1436,17 @@ void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const doub
   spmv_dispatch<EPI_ACCUM>(s, A, nv, a);
 }
 void launch_spmv_scaled(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
-                        double* y) {
+                        double* y, int dict_ok) {
   SpmvArgs a = make_args(x, nullptr, y, nullptr, MASK_NONE);
   a.c2 = scale;
+  a.dict_ok = dict_ok;
   spmv_dispatch<EPI_STORE>(s, A, nv, a);
 }
 void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
-                      double* y, const uint8_t* skipmask) {
+                      double* y, const uint8_t* skipmask, int dict_ok) {
   SpmvArgs a = make_args(x, nullptr, y, skipmask, MASK_IDENTITY);
   a.c2 = scale;
+  a.dict_ok = dict_ok;
   spmv_dispatch<EPI_ACCUM>(s, A, nv, a);
 }
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,

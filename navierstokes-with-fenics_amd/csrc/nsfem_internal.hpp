@@ -135,6 +135,11 @@ struct StencilDict {
   int n_rows = 0, n_stencils = 0, lmax = 0;
   bool exact = false;      // every row equals its representative BITWISE (meshes with a binary spacing): the
                            // dictionary copy is the matrix itself and every product may use it
+  int bsz = 1;             // doubles per entry (block matrices: br * bc)
+  bool rect = false;       // offsets are relative to the row's FIRST column (rectangular P2 x P1 blocks:
+                           // the two numberings differ), kept per row in cbase; square: relative to the row
+  int max_local = 0;       // most entries any workgroup uses (sizes the LDS copy)
+  DevBuf<int32_t> cbase;   // [n_rows] (rect only)
   DevBuf<int32_t> sid;     // [n_rows] dictionary entry of every row
   DevBuf<uint8_t> lid;     // [n_rows] its position in the list of the row's workgroup (256 rows)
   DevBuf<int32_t> wg_ptr, wg_list;   // per workgroup: the entries it uses (<= 32)
@@ -144,7 +149,7 @@ struct StencilDict {
 };
 // false: the rows do not repeat (unstructured mesh) -- no dictionary
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
-                        StencilDict& d);
+                        StencilDict& d, int bsz = 1, bool rect = false);
 
 struct BlockMat {
   const Pattern* pat = nullptr;
@@ -211,9 +216,9 @@ void launch_spmv_accumulate(hipStream_t s, const BlockMat& A, int nv, const doub
                             const uint8_t* rowmask, int ghost = 0 /* 2: ghost rows accumulate too */);
 // y = scale * A x ;  y += scale * A x on rows not flagged in skipmask (flagged rows untouched)
 void launch_spmv_scaled(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
-                        double* y);
+                        double* y, int dict_ok = 0);
 void launch_spmv_axpy(hipStream_t s, const BlockMat& A, int nv, double scale, const double* x,
-                      double* y, const uint8_t* skipmask);
+                      double* y, const uint8_t* skipmask, int dict_ok = 0);
 void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x, const double* b,
                       const double* dinv, double* d, double c1, double c2, double* xout,
                       const uint8_t* rowmask, int ghost = 0 /* 1: ghost rows keep x */, int phase = 0,
@@ -686,12 +691,15 @@ struct nsfem_ctx {
   struct CsrOp {
     nsfem::Pattern pat;
     nsfem::BlockMat mat;
+    nsfem::StencilDict dict;                   // lattice meshes: smoothing steps run on the dictionary copy
   };
   std::vector<CsrOp*> schur_ops;               // owned
   nsfem::StencilDict dict22;                   // rows of the scalar P2 operators (ensure_L)
   bool dict22_tried = false;
   nsfem::StencilDict dict11;                   // rows of the scalar P1 operators of the fine mesh
   bool dict11_tried = false;
+  nsfem::StencilDict dict21, dict12;           // divergence-transpose / divergence blocks (monolithic scheme)
+  bool dictD_tried = false;
   int bc_p_any = -1;                           // partitioned: pressure Dirichlet dofs on any rank (-1 unknown)
   bool schur_additive = false;                 // operators of nsfem_mg_set_schur_operator are rank parts
   int schur_singular = -1;                     // -1: geometric hierarchy (singular iff no Dirichlet set)

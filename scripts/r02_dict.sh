@@ -1,7 +1,8 @@
 #!/bin/bash
 cd /root/repo
 O=gpurun_out/r02d; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests/test_gpu_partition.py -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
 run() { name=$1; shift; timeout -k 10 900 python bench.py "$@" > $O/$name.json 2> $O/$name.err || { echo "FAILED $name"; tail -5 $O/$name.err; }; python scripts/show_bench.py $O/$name.json 2>/dev/null | head -30; }
-run cavr2 --cells 256 --steps 10 --warmup 3 --local-ranks 2
-NSFEM_DICT=0 run cavr2_csr --cells 256 --steps 10 --warmup 3 --local-ranks 2
+run ch5 --workload channel3d-bdf --cells 48 --steps 5 --warmup 2 --no-cpu-baseline
+run ch5_64 --workload channel3d-bdf --cells 64 --steps 5 --warmup 2 --no-cpu-baseline
+run c3b5 --workload cavity3d-bdf --cells 32 --steps 5 --warmup 2 --no-cpu-baseline
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1; tail -3 $O/tests.log

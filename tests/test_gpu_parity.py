@@ -933,3 +933,54 @@ def test_stencil_dictionary_kernel_equals_the_csr_kernels(dim, n, exact, order, 
         c.set_bdf((1.0, -1.0, 0.0), 0.01)
         assert ddm.n_p2 > 4096 and c.smoother_info()["kind"] != "stencil-dictionary"
         c.close()
+
+
+@pytest.mark.parametrize("dim,n", [(2, 64), (2, 48), (3, 32)])
+def test_block_dictionaries_of_the_monolithic_scheme(dim, n, monkeypatch):
+    """Monolithic BDF-2 steps on lattice meshes: the divergence (1 x dim blocks) and its transpose
+    (dim x 1) get block stencil dictionaries (k_spmv_dict_blk: column = first column of the row +
+    offset, because the P2 and P1 numberings differ) next to the scalar ones; they serve the
+    Newton-Jacobian products and the block preconditioner -- and, bit for bit equal (n = 64, 32),
+    the residual too.  NSFEM_DICT=0 vs default: same Newton counts, BiCGStab counts +-1, fields to
+    solver tolerance."""
+    from fem_mesh import TaylorHoodDofMap, box_mesh, preferred_p2_order, rectangle_mesh
+    from multigrid import attach_hierarchy
+    mesh = rectangle_mesh((0.0, 0.0), (1.0, 1.0), n, n) if dim == 2 else box_mesh((0, 0, 0), (1, 1, 1), n, n, n)
+    mesh.structured = ((0.0,) * dim, (1.0,) * dim) + (n,) * dim
+    dm = TaylorHoodDofMap(mesh, reorder=preferred_p2_order(dim))
+    X = dm.p2_coords
+    on = np.zeros(dm.n_p2, bool)
+    for a in range(dim):
+        on |= (np.abs(X[:, a]) < 1e-12) | (np.abs(X[:, a] - 1.0) < 1e-12)
+    nodes = np.nonzero(on)[0]
+    lid = np.abs(X[nodes, dim - 1] - 1.0) < 1e-12
+    dofs = np.concatenate([dim * nodes + a for a in range(dim)]).astype(np.int32)
+    vals = np.concatenate([np.where(lid, 1.0, 0.0)] + [np.zeros(nodes.size)] * (dim - 1))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NSFEM_DICT", mode)
+        ctx = context(mesh, dm)
+        attach_hierarchy(ctx, mesh, coarsest=4 if dim == 2 else 2)
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, dofs, vals)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        ctx.set_dirichlet(nat.PRESSURE_PRECOND, np.zeros(0, np.int32), np.zeros(0))
+        opts = ctx.default_step_opts()
+        opts.momentum.rtol, opts.momentum.precond = 1e-11, 1
+        its = []
+        for step in range(2):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), 0.01)
+            info = ctx.step_bdf(opts)
+            ctx.advance(1)
+            its.append((info.newton_iterations, info.krylov_iterations_momentum))
+        # the divergence through the C ABI against its exported CSR matrix (dictionary attached by now)
+        D = ctx.operator_csr(nat.OP_DIV)
+        x = np.random.default_rng(1).standard_normal(D.shape[1])
+        assert rel(ctx.operator_apply(nat.OP_DIV, x), D @ x) < 1e-13
+        out[mode] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), its)
+        ctx.close()
+    (u0, p0, its0), (u1, p1, its1) = out["0"], out["1"]
+    for a, b in zip(its0, its1):
+        assert a[0] == b[0] and abs(a[1] - b[1]) <= max(1, 0.05 * a[1])
+    assert rel(u1, u0) < 1e-9
+    assert rel(p1 - p1.mean(), p0 - p0.mean()) < 1e-7

@@ -18,6 +18,9 @@ ctx.set_coeffs(1.0, 1.0, 0.01)
 ctx.set_bdf((1.5, -2.0, 0.5), 1e-3 if dim == 2 else 0.25 / n)
 ms, nb = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 100)
 print("block %s balance %s " % (os.environ.get("PARITY_BLOCK", "-"), os.environ.get("NSFEM_SELL_BALANCE", "1")), end="")
-print("dim %d n %d %-6s SELL=%s variant=%s: smoother cold %.1f us  %.2f TB/s  (%.0f MB)" % (
-    dim, n, order, os.environ.get("NSFEM_SELL", "1"), os.environ.get("NSFEM_SELL_VARIANT", "-"), ms * 1e3, nb / ms / 1e9, nb / 1e6))
+info = ctx.smoother_info()
+print("dim %d n %d %-6s kernel %s (NSFEM_DICT=%s NSFEM_SELL=%s): smoother cold %.1f us  %.2f TB/s of its own algorithmic bytes "
+      "(%.0f MB; CSR-equivalent %.0f MB = %.2f TB/s)" % (
+          dim, n, order, info["kind"], os.environ.get("NSFEM_DICT", "1"), os.environ.get("NSFEM_SELL", "1"), ms * 1e3,
+          nb / ms / 1e9, nb / 1e6, info["csr_bytes"] / 1e6, info["csr_bytes"] / ms / 1e9))
 ctx.close()

@@ -774,10 +774,10 @@ def _smoother_roofline_extras(ctx, nv, ms_in_situ, ms_cold=None):
     rate a CSR stream of the same operator would need to be as fast (continuity with round 1)"""
     info = ctx.smoother_info()
     if info["kind"] == "stencil-dictionary":
-        label = ("k_spmv_dict<%d,3,4>: finest-level Chebyshev-Jacobi smoothing step y = x + c1 d + c2 dinv (b - L x) on "
+        label = ("%s: finest-level Chebyshev-Jacobi smoothing step y = x + c1 d + c2 dinv (b - L x) on "
                  "the stencil-dictionary copy of the scalar P2 operator L (%d distinct rows, longest %d, %s), %d "
                  "interleaved components: 1 byte per row + the vectors instead of 12 bytes per nonzero" % (
-                     nv, info["stencils"], info["longest_row"],
+                     "k_spmv_dict<3,3>" if nv == 3 else "k_spmv_dict_w8<%d,3>" % nv, info["stencils"], info["longest_row"],
                      "bitwise equal to the CSR values" if info["bitwise_exact"] else "equal to 2^-40", nv))
         extra = {"csr_equivalent": {
             "note": "what a CSR stream of the same operator (12 B per nonzero + vectors) would have to sustain to "
@@ -1041,7 +1041,7 @@ def cavity_ipcs_bench(args):
             # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE;
             # the symbol is launched on every multigrid level, the finest-level launches are the maxima
             c = json.load(open(pmc))
-            key = "void nsfem::k_spmv_dict<2, 3, 4>" if ctx.smoother_info()["kind"] == "stencil-dictionary" \
+            key = "void nsfem::k_spmv_dict_w8<2, 3>" if ctx.smoother_info()["kind"] == "stencil-dictionary" \
                 else "void nsfem::k_spmv_stream_v1<1, 1, 2, 3>"
             if key in c["fetch"] and key in c["write"]:
                 traffic = (2.0 * c["fetch"][key]["max_KB"] + c["write"][key]["max_KB"]) * 1024.0

@@ -708,13 +708,13 @@ void build_sell(Pattern& p, hipStream_t s) {
 // (shuffle-coalesced).
 constexpr int kDictLocal = 32;       // dictionary entries a workgroup may use
 template <int NV, int EPI, int U>
-__global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const uint8_t* __restrict__ lid,
-                                                   const int32_t* __restrict__ wg_ptr,
-                                                   const int32_t* __restrict__ wg_list,
-                                                   const int32_t* __restrict__ slen,
-                                                   const int32_t* __restrict__ soff,
-                                                   const double* __restrict__ sval, int lmax,
-                                                   int max_local, SpmvArgs a) {
+__device__ __forceinline__ void spmv_dict_body(int n_rows, int n_wg, const uint8_t* __restrict__ lid,
+                                               const int32_t* __restrict__ wg_ptr,
+                                               const int32_t* __restrict__ wg_list,
+                                               const int32_t* __restrict__ slen,
+                                               const int32_t* __restrict__ soff,
+                                               const double* __restrict__ sval, int lmax,
+                                               int max_local, const SpmvArgs& a) {
   extern __shared__ double sh_dict[];
   double* __restrict__ lv = sh_dict;                                   // [max_local * lmax] values
   int* __restrict__ lo = reinterpret_cast<int*>(sh_dict + (size_t)max_local * lmax);   // offsets
@@ -825,6 +825,28 @@ __global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const u
       a.y[idx] = val;
     }
   }
+}
+
+// two launch shapes of the same body: 4 waves per SIMD with 4 entries in flight per lane (102
+// VGPRs; best for 3 interleaved components: 110 vs 129 us), and 8 waves per SIMD with 2 entries in
+// flight (<= 64 VGPRs; best for 1 - 2 components: 26.7 vs 28.3 us at n = 512)
+template <int NV, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const uint8_t* __restrict__ lid,
+                                                   const int32_t* __restrict__ wg_ptr,
+                                                   const int32_t* __restrict__ wg_list,
+                                                   const int32_t* __restrict__ slen,
+                                                   const int32_t* __restrict__ soff,
+                                                   const double* __restrict__ sval, int lmax,
+                                                   int max_local, SpmvArgs a) {
+  spmv_dict_body<NV, EPI, 4>(n_rows, n_wg, lid, wg_ptr, wg_list, slen, soff, sval, lmax, max_local, a);
+}
+template <int NV, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_spmv_dict_w8(int n_rows, int n_wg, const uint8_t* __restrict__ lid,
+                    const int32_t* __restrict__ wg_ptr, const int32_t* __restrict__ wg_list,
+                    const int32_t* __restrict__ slen, const int32_t* __restrict__ soff,
+                    const double* __restrict__ sval, int lmax, int max_local, SpmvArgs a) {
+  spmv_dict_body<NV, EPI, 2>(n_rows, n_wg, lid, wg_ptr, wg_list, slen, soff, sval, lmax, max_local, a);
 }
 
 // Rectangular block operators between the P2 and P1 numberings (divergence 1 x dim blocks, its
@@ -1207,12 +1229,12 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     if (n_wg <= 0) return;
     const int grid = (n_wg + 7) & ~7;
     const size_t lds = (size_t)d.max_local * d.lmax * 12 + (size_t)d.max_local * 4;
-#define NSFEM_DICT_LAUNCH(NV)                                                                          \
-  hipLaunchKernelGGL((k_spmv_dict<NV, EPI, 4>), dim3(grid), dim3(256), lds, s, d.n_rows, n_wg, d.lid.p, \
+#define NSFEM_DICT_LAUNCH(KERNEL, NV)                                                                  \
+  hipLaunchKernelGGL((KERNEL<NV, EPI>), dim3(grid), dim3(256), lds, s, d.n_rows, n_wg, d.lid.p,        \
                      d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.lmax, d.max_local, a)
-    if (nv == 1) NSFEM_DICT_LAUNCH(1);
-    else if (nv == 2) NSFEM_DICT_LAUNCH(2);
-    else NSFEM_DICT_LAUNCH(3);
+    if (nv == 1) NSFEM_DICT_LAUNCH(k_spmv_dict_w8, 1);
+    else if (nv == 2) NSFEM_DICT_LAUNCH(k_spmv_dict_w8, 2);
+    else NSFEM_DICT_LAUNCH(k_spmv_dict, 3);
 #undef NSFEM_DICT_LAUNCH
     NSFEM_HIP(hipGetLastError());
     return;

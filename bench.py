@@ -36,6 +36,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "navierstokes-with-fenics_amd")
 sys.path[:0] = [PKG]
 
+
+def _ranks_to_spawn(argv):
+    """N when this process was started as plain `python bench.py --gpus N` (N > 1, no launcher
+    environment, no --local-ranks): it then only spawns and supervises the N rank processes"""
+    if "WORLD_SIZE" in os.environ:
+        return 0
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+        elif a == "--local-ranks" or a.startswith("--local-ranks="):
+            return 0
+    return n if n > 1 else 0
+
+
+def _spawn_ranks(argv, n):
+    """`python bench.py --gpus N` as typed: this parent NEVER touches the GPU (no HIP library is
+    loaded, torch is not imported); it starts N fresh child processes -- one rank per GPU, the
+    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR,
+    MASTER_PORT) -- relays rank 0's JSON line and exits non-zero when any child does (the other
+    ranks are then terminated: they would wait in a barrier for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    failed = None
+    try:
+        import threading
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = (r, p.returncode)
+            time.sleep(0.1)
+        for r, p in enumerate(procs):
+            if failed is None and p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        if failed is None:
+            reader.join(timeout=30)
+            sys.stdout.write(b"".join(chunks).decode())
+            sys.stdout.flush()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+        return failed[1] if failed[1] > 0 else 1
+    return 0
+
+
+if __name__ == "__main__" and _ranks_to_spawn(sys.argv[1:]):
+    sys.exit(_spawn_ranks(sys.argv[1:], _ranks_to_spawn(sys.argv[1:])))
+
 import numpy as np  # noqa: E402
 
 # load the HIP library (and with it ROCm's libamdhip64 / librccl) BEFORE torch is imported
@@ -244,8 +315,7 @@ def dfg_bdf_bench(args):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv}}))
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    _finish_dist(dist)
 
 
 class _ThreadRanks:
@@ -296,6 +366,14 @@ def _attach_comm(ctx, dist, rank, world):
     if isinstance(dist, _ThreadRanks):
         ctx.attach_local_comm(dist.group, rank)
         return
+    if os.environ.get("NSFEM_SHARE_GPU"):
+        # several rank PROCESSES on one device (one-GPU box): RCCL refuses that, the host-staged
+        # shared-memory communicator carries the same collectives
+        _attach_comm.counter = getattr(_attach_comm, "counter", 0) + 1
+        names = ["/nsfem_%d_%d" % (os.getpid(), _attach_comm.counter) if rank == 0 else None]
+        dist.broadcast_object_list(names, src=0)
+        ctx.attach_shm_comm(names[0], rank, world)
+        return
     ids = [nat.rccl_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     ctx.attach_rccl_comm(ids[0], rank, world)
@@ -312,17 +390,22 @@ def _init_dist(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and args.gpus != world:
         raise SystemExit("--gpus must equal WORLD_SIZE")
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (
-                             args.gpus, args.gpus, args.gpus))
+    if world == 1 and args.gpus > 1:      # (plain `bench.py --gpus N` never gets here: _spawn_ranks)
+        raise SystemExit("--gpus %d: WORLD_SIZE=1 in the environment contradicts it" % args.gpus)
     dist = None
     if world > 1 or os.environ.get("NSFEM_FORCE_COMM") is not None:
         import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if not dist.is_initialized():     # (one process group for all the workloads of a job)
+            if "MASTER_ADDR" not in os.environ:
+                os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     return rank, world, local_rank, dist
+
+
+def _finish_dist(dist):
+    """the torch process group is shared by the workloads of one job and torn down once, in main()"""
+    if dist is not None and isinstance(dist, _ThreadRanks):
+        dist.destroy_process_group()
 
 
 def tgv3d_bench(args):
@@ -449,7 +532,7 @@ def tgv3d_bench(args):
     achieved = nbytes / (ms_spmv * 1e-3) / 1e9 if world == 1 else None
     if rank != 0:
         ctx.close()
-        dist.destroy_process_group()
+        _finish_dist(dist)
         return
     print(json.dumps({
         "metric": "dof_updates_per_sec", "value": sps * n_dofs, "unit": "DoF-updates/s",
@@ -477,8 +560,7 @@ def tgv3d_bench(args):
                                          "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                          "ms_per_launch": ms_cold} if ms_cold else None}, **extra)}))
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    _finish_dist(dist)
 
 
 def cavity3d_bench(args):
@@ -584,8 +666,7 @@ def cavity3d_bench(args):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms_spmv}}))
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    _finish_dist(dist)
 
 
 def channel3d_bdf_bench(args):
@@ -761,8 +842,7 @@ def channel3d_bdf_bench(args):
                          "algorithmic_bytes_per_application": nbytes_conv, "ms_per_application": ms_conv,
                          "applications_timed": n_conv}}))
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    _finish_dist(dist)
     if not (all_converged and finite and balance < 1e-6 and inflow_err < 1e-10):
         raise SystemExit("channel3d-bdf: invariant violated (converged %s, finite %s, mass balance %.2e, "
                          "inflow error %.2e)" % (all_converged, finite, balance, inflow_err))
@@ -959,19 +1039,18 @@ def cavity_ipcs_bench(args):
     steps_per_s = args.steps / elapsed
     u_fast, p_fast = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
     if args.timed_only:
-        if rank == 0:
-            print(json.dumps({"metric": "dof_updates_per_sec", "value": steps_per_s * n_dofs, "unit": "DoF-updates/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-                              "scaling": "strong" if strong else "weak", "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": "cavity-ipcs %dx%d, timed steps only (profiling aid)" % (n, ny_global),
-                                         "newton_its_per_step": float(its[0]), "bicgstab_its_per_step": float(its[1]),
-                                         "poisson_cg_its_per_step": float(its[2])},
-                              "roofline": {"frac": None, "ms_per_launch": None}}))
         ctx.close()
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        _finish_dist(dist)
+        return {"metric": "dof_updates_per_sec", "value": steps_per_s * n_dofs, "unit": "DoF-updates/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                "scaling": "strong" if strong else "weak", "dtype": "f64", "data": "synthetic",
+                "time_steps_per_sec": steps_per_s,
+                "config": {"workload": "cavity-ipcs %dx%d, timed steps only" % (n, ny_global),
+                           "cells": n, "n_dofs": n_dofs,
+                           "newton_its_per_step": float(its[0]), "bicgstab_its_per_step": float(its[1]),
+                           "poisson_cg_its_per_step": float(its[2]), "comm_per_step_rank0": comm_per_step},
+                "roofline": {"frac": None, "ms_per_launch": None}}
 
     # ---- validation of what was timed: the SAME W + K steps from the same start with
     # direct-solver accuracy (rtol 1e-12, exact Newton, Jacobi-CG mass solve, untruncated cycle);
@@ -1103,17 +1182,96 @@ def cavity_ipcs_bench(args):
                           "frac": nbytes_jac / (ms_jac * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_launch": nbytes_jac, "ms_per_launch": ms_jac},
     }
+    out["roofline"].update(smoother_extra)
+    ctx.close()
+    _finish_dist(dist)
+    if world == 1 and not args.no_solver_classes:
+        # the same W + K steps through the reference's solver surface: IPCSSolver.solve() /
+        # advance_time() inside the InstationaryProblem loop (BASELINE.md section 3 protocol)
+        out["config"].update(solver_surface_run(args, n, u_fast, p_fast))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(_parse_cpu_samples(args.cpu_samples), args.dt, n_dofs)
-    out["roofline"].update(smoother_extra)
-    if rank == 0:
-        print(json.dumps(out))
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
     if max(du_l2, dp_l2) > tol_fields:
         raise SystemExit("bench: the timed fields differ from the exact-solver run by %.2e (velocity) / %.2e "
                          "(pressure) > %.0e" % (du_l2, dp_l2, tol_fields))
+    return out
+
+
+def solver_surface_run(args, n, u_abi, p_abi):
+    """The timed configuration THROUGH THE REFERENCE'S SOLVER SURFACE: an InstationaryProblem
+    subclass with the cavity's hook methods (demo/cavity_flow.py:21-37 set-up), IPCSSolver selected by
+    set_solver_class, the throughput settings passed as `solver_settings`; W warm-up steps run inside
+    solve_problem(), then K steps of the reference's loop body (source/ns_problem.py:711-727:
+    update_coefficients, solver.solve(), advance_time, solver.advance_time) are timed.  Same mesh,
+    same settings, same start as the C-ABI run above: the fields must agree BITWISE."""
+    import contextlib
+    import io
+    from auxiliary_classes import EquationCoefficientHandler
+    from grid_generator import HyperCubeBoundaryMarkers, hyper_cube
+    from ns_ipcs_solver import IPCSSolver
+    from ns_problem import InstationaryProblem, VelocityBCType
+
+    class CavityProblem(InstationaryProblem):
+        def __init__(self):
+            super().__init__(None, start_time=0.0, end_time=args.dt * (args.warmup + args.steps + 8),
+                             desired_start_time_step=args.dt, n_max_steps=max(args.warmup, 1))
+            self._problem_name = "Cavity"
+            self._output_frequency = 0
+            self._postprocessing_frequency = 0
+            self.compute_cfl = False
+            self.set_solver_class(IPCSSolver)
+            parts = [float(v) for v in str(args.mg_truncation).split(",")]
+            self.solver_settings = dict(
+                krylov_rtol=args.krylov_rtol, newton_forcing=args.newton_forcing,
+                pressure_start=args.pressure_start if args.pressure_start == "extrapolated" else "previous",
+                mass_solver=args.mass_solver, mg_truncation=(parts[0], parts[1] if len(parts) > 1 else 0.1),
+                matrix_free={0: None, 1: False, 2: True}[args.matrix_free])
+
+        def setup_mesh(self):
+            self._mesh, self._boundary_markers = hyper_cube(2, n)
+
+        def set_boundary_conditions(self):
+            m = HyperCubeBoundaryMarkers
+            self._bcs = ((VelocityBCType.no_slip, m.left.value, None), (VelocityBCType.no_slip, m.right.value, None),
+                         (VelocityBCType.no_slip, m.bottom.value, None),
+                         (VelocityBCType.constant, m.top.value, (1.0, 0.0)))
+
+        def set_equation_coefficients(self):
+            self._coefficient_handler = EquationCoefficientHandler(Re=100.0)
+
+        def set_initial_conditions(self):
+            self._initial_conditions = {"velocity": (0.0, 0.0), "pressure": 0.0}
+
+    if args.warmup == 0:
+        raise SystemExit("--warmup 0 is not supported by the solver-surface timing (--no-solver-classes)")
+    log = io.StringIO()
+    with contextlib.redirect_stdout(log):
+        problem = CavityProblem()
+        t_setup = time.perf_counter()
+        problem.solve_problem()                       # set-up + the W warm-up steps
+        t_setup = time.perf_counter() - t_setup
+        solver, ts = problem._get_solver(), problem._time_stepping
+        ctx = solver._ctx
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):                   # body of the loop at source/ns_problem.py:711-727
+            problem._set_next_step_size()
+            ts.update_coefficients()
+            solver.solve()
+            ts.advance_time()
+            solver.advance_time()
+        ctx.synchronize()
+        elapsed = time.perf_counter() - t0
+        u, p = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
+        ctx.close()
+    bitwise = bool(np.array_equal(u, u_abi) and np.array_equal(p, p_abi))
+    du = float(np.abs(u - u_abi).max()) if u.shape == u_abi.shape else None
+    return {"ms_per_step_through_solver_classes": 1e3 * elapsed / args.steps,
+            "solver_classes": {"what": "InstationaryProblem hooks + IPCSSolver.solve() / advance_time(), "
+                                       "solver_settings = the throughput settings; %d warm-up steps inside "
+                                       "solve_problem(), then %d timed passes of the loop body" % (args.warmup, args.steps),
+                               "fields_bitwise_equal_to_the_c_abi_run": bitwise,
+                               "max_abs_velocity_difference": du, "set_up_and_warm_up_s": t_setup}}
 
 
 def main():
@@ -1139,6 +1297,13 @@ def main():
                     help="CPU baseline ladder n:steps,... (cavity cells per side : timed steps); the default "
                          "is ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solver-classes", action="store_true",
+                    help="skip the timing of the same steps through IPCSSolver.solve() / advance_time()")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="--gpus N > 1: skip the strong-scaling run that the default job adds to the weak one")
+    ap.add_argument("--strong-cells", type=int, default=None,
+                    help="--gpus N > 1: cells per side of the strong-scaling mesh of the default job "
+                         "(default 960 = 8.3 M dofs; with --cells n: n)")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling aid: only the warm-up and timed steps (no validation rerun, no in-situ / "
                          "cold-cache kernel timing, no CPU baseline); the JSON line lacks those entries")
@@ -1200,7 +1365,13 @@ def main():
             w.join()
         nat.local_group_destroy(shared.group)
         return None
-    return _run_workload(args)
+    try:
+        return _run_workload(args)
+    finally:
+        if "torch.distributed" in sys.modules:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 def _run_workload(args):
@@ -1215,8 +1386,30 @@ def _run_workload(args):
     if args.workload == "channel3d-bdf":
         args.n = args.n or 32
         return channel3d_bdf_bench(args)
+    import copy
+    rank = args.thread_rank if getattr(args, "thread_ranks", None) is not None else int(os.environ.get("RANK", "0"))
+    both = args.gpus > 1 and args.scaling == "weak" and not args.timed_only and not args.no_strong
+    if args.strong_cells is None:
+        args.strong_cells = 960 if args.n in (None, 512) else args.n
     args.n = args.n or (960 if args.scaling == "strong" else 512)
-    return cavity_ipcs_bench(args)
+    out = cavity_ipcs_bench(args)
+    if both:
+        # N > 1: `value` stays the weak-scaling figure (512 x 512 cells per rank, so N = 1 equals the
+        # single-GPU line); north_star's strong-scaling quantity -- ONE 960 x 960 mesh (8.3 M dofs) cut
+        # into N strips -- is measured in the same job and reported beside it
+        a2 = copy.copy(args)
+        a2.scaling, a2.n, a2.timed_only = "strong", args.strong_cells, True
+        st = cavity_ipcs_bench(a2)
+        out["strong"] = {"cells": a2.n, "n_dofs": st["config"]["n_dofs"], "ms_per_step": st["ms_per_step"],
+                         "value": st["value"], "unit": st["unit"], "time_steps_per_sec": st["time_steps_per_sec"],
+                         "steps": st["steps"], "warmup": st["warmup"],
+                         "its_per_step_newton_bicgstab_poisson": [st["config"]["newton_its_per_step"],
+                                                                  st["config"]["bicgstab_its_per_step"],
+                                                                  st["config"]["poisson_cg_its_per_step"]],
+                         "comm_per_step": st["config"]["comm_per_step_rank0"]}
+    if rank == 0:
+        print(json.dumps(out))
+    return None
 
 
 if __name__ == "__main__":

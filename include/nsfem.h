@@ -210,6 +210,27 @@ int nsfem_operator_shape(nsfem_ctx* ctx, int op, int64_t* n_rows, int64_t* n_col
 int nsfem_operator_export(nsfem_ctx* ctx, int op, int32_t* rowptr, int32_t* col, double* val);
 /* y = op * x on the device through the production SpMV kernel (host in/out) */
 int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y);
+/* Test hook (parity tests): ONE product / residual / Chebyshev-Jacobi smoothing sequence of the scalar
+ * lattice operator  a M + b K  (space 0: P2 mass / stiffness of the fine mesh on nv interleaved
+ * components; space 1: P1 mass / stiffness) through a CHOSEN kernel family, on host data -- so that every
+ * SpMV kernel family and every epilogue can be pinned to the oracle's matrices directly.
+ *   family   0 library default, 1 CSR (stream / lane-group), 2 SELL-64, 3 stencil dictionary (one step per
+ *            launch), 4 multi-step lattice kernel (all steps in one launch; epilogue 3 only)
+ *   epilogue 0  y = A x   1  y = b - A x   3  `steps` steps  d = c1[k] d + c2[k] D^-1 (b - A x), x += d
+ *   maskmode 0 none, 1 identity rows, 2 zero rows (flags in `mask`, one per vector entry; flag 2 = ghost)
+ * Outputs: y (result / last iterate), d_out, r_out (b - A y when with_residual), and which family ran. */
+typedef struct {
+  int32_t space, nv, family, epilogue, steps, maskmode, ghost, ident, from_zero, with_residual, dict_ok;
+  int32_t used_family;        /* out */
+  int32_t dict_entries, dict_exact, lattice_w;   /* out: dictionary of the pattern (0: none) */
+  int32_t reserved;
+  double a, b_coef;
+  double c1[8], c2[8];
+  const double *x, *b, *d;    /* host [n * nv]; b, d may be NULL */
+  const uint8_t* mask;        /* host [n * nv] or NULL */
+  double *y, *d_out, *r_out;  /* host [n * nv]; d_out, r_out may be NULL */
+} nsfem_kernel_test;
+int nsfem_kernel_apply(nsfem_ctx* ctx, nsfem_kernel_test* t);
 
 /* ---- multigrid hierarchy (optional).  Coarse P1 levels are added finest-first; each
  * carries its mesh and the prolongation P (CSR, rows = nodes of the previous finer P1
@@ -341,6 +362,11 @@ int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int rank, int size
 int nsfem_comm_local_create(int size, void** group);
 void nsfem_comm_local_destroy(void* group);
 int nsfem_comm_attach_local(nsfem_ctx* ctx, void* group, int rank);
+/* one PROCESS per rank on ranks that SHARE a device (RCCL refuses two ranks on one GPU): host-staged
+ * through the POSIX shared-memory segment `name` ("/..."; rank 0 creates it, slot_bytes per rank,
+ * <= 0: 64 MiB).  Functional rehearsal of the process-per-rank launch on a one-GPU box, not a
+ * performance transport.  Collective over the ranks (returns when all have attached). */
+int nsfem_comm_attach_shm(nsfem_ctx* ctx, const char* name, int rank, int size, int64_t slot_bytes);
 /* communication of this rank since the last reset: out = {all-reduce calls, all-reduce payload
  * bytes, halo exchanges, halo bytes sent}; zeros without a communicator */
 int nsfem_comm_stats(nsfem_ctx* ctx, int64_t out[4], int reset);
@@ -400,6 +426,10 @@ int nsfem_boundary_force(nsfem_ctx* ctx, int velocity_slot, int pressure_slot, i
  * reports average launch duration [ms], number of launches and algorithmic bytes per launch */
 int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* launches,
                            int64_t* algorithmic_bytes);
+/* detail of the window nsfem_profile_smoother just closed: out = {launches, smoothing steps they
+ * ran (the multi-step lattice kernel runs up to 4 per launch), algorithmic bytes they moved in total,
+ * 1 when the lattice kernel ran them} */
+int nsfem_profile_smoother_detail(nsfem_ctx* ctx, int64_t out[4]);
 int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                     int64_t* algorithmic_bytes);
 /* which finest-level smoothing kernel of the velocity multigrid runs: out = {kind (0 CSR-stream,

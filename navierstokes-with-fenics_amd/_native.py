@@ -29,13 +29,13 @@ EXPORTED_SYMBOLS = (
     "nsfem_set_convective_form",
     "nsfem_set_state", "nsfem_get_state", "nsfem_state_size", "nsfem_state_devptr",
     "nsfem_assemble", "nsfem_residual_norm", "nsfem_get_rhs", "nsfem_solve",
-    "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply",
+    "nsfem_operator_shape", "nsfem_operator_export", "nsfem_operator_apply", "nsfem_kernel_apply",
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse", "nsfem_mg_set_global_coarse_constrained",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_smoother_info", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_smoother_info", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_smoother_detail", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
-    "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local",
+    "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local", "nsfem_comm_attach_shm",
 )
 
 
@@ -44,6 +44,16 @@ class MeshDesc(C.Structure):
                 ("n_p2", C.c_int32), ("n_p1", C.c_int32),
                 ("coords", C.POINTER(C.c_double)), ("cells", C.POINTER(C.c_int32)),
                 ("p2_dofmap", C.POINTER(C.c_int32)), ("p1_dofmap", C.POINTER(C.c_int32))]
+
+
+class KernelTest(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("space", "nv", "family", "epilogue", "steps", "maskmode", "ghost", "ident",
+                                          "from_zero", "with_residual", "dict_ok", "used_family", "dict_entries",
+                                          "dict_exact", "lattice_w", "reserved")] + \
+               [("a", C.c_double), ("b_coef", C.c_double), ("c1", C.c_double * 8), ("c2", C.c_double * 8),
+                ("x", C.POINTER(C.c_double)), ("b", C.POINTER(C.c_double)), ("d", C.POINTER(C.c_double)),
+                ("mask", C.POINTER(C.c_uint8)),
+                ("y", C.POINTER(C.c_double)), ("d_out", C.POINTER(C.c_double)), ("r_out", C.POINTER(C.c_double))]
 
 
 class KrylovOpts(C.Structure):
@@ -159,6 +169,7 @@ def load_library(path=None):
                                            C.POINTER(i64)]),
         "nsfem_operator_export": (C.c_int, [vp, C.c_int, pi, pi, pd]),
         "nsfem_operator_apply": (C.c_int, [vp, C.c_int, pd, pd]),
+        "nsfem_kernel_apply": (C.c_int, [vp, C.POINTER(KernelTest)]),
         "nsfem_default_step_opts": (C.c_int, [C.POINTER(StepOpts)]),
         "nsfem_step_ipcs": (C.c_int, [vp, C.POINTER(StepOpts), C.POINTER(StepInfo)]),
         "nsfem_step_bdf": (C.c_int, [vp, C.POINTER(StepOpts), C.POINTER(StepInfo)]),
@@ -178,6 +189,7 @@ def load_library(path=None):
         "nsfem_poisson_solve": (C.c_int, [vp, pd, i64, pi, pd, C.POINTER(KrylovOpts), C.POINTER(SolveInfo)]),
         "nsfem_profile_smoother": (C.c_int, [vp, C.c_int, pd, C.POINTER(i64), C.POINTER(i64)]),
         "nsfem_profile_convection": (C.c_int, [vp, C.c_int, pd, C.POINTER(i64), C.POINTER(i64)]),
+        "nsfem_profile_smoother_detail": (C.c_int, [vp, C.POINTER(i64)]),
         "nsfem_time_spmv": (C.c_int, [vp, C.c_int, C.c_int, pd, C.POINTER(i64)]),
         "nsfem_synchronize": (C.c_int, [vp]),
         "nsfem_mg_add_level": (C.c_int, [vp, C.POINTER(MgLevelDesc)]),
@@ -199,6 +211,7 @@ def load_library(path=None):
         "nsfem_comm_local_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "nsfem_comm_local_destroy": (None, [vp]),
         "nsfem_comm_attach_local": (C.c_int, [vp, vp, C.c_int]),
+        "nsfem_comm_attach_shm": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_int64]),
         "nsfem_mass_solve": (C.c_int, [vp, C.c_int, pd, pd, C.POINTER(KrylovOpts),
                                        C.POINTER(SolveInfo)]),
     }
@@ -439,7 +452,8 @@ class NsfemContext:
         csr_bytes) -- kind "csr-stream" | "sell-64" | "stencil-dictionary" """
         out = (C.c_int64 * 4)()
         self._check(self._lib.nsfem_smoother_info(self._h, out))
-        return dict(kind=("csr-stream", "sell-64", "stencil-dictionary")[int(out[0])], stencils=int(out[1]),
+        return dict(kind=("csr-stream", "sell-64", "stencil-dictionary", "stencil-dictionary")[int(out[0])],
+                    multistep_lattice_kernel=int(out[0]) == 3, stencils=int(out[1]),
                     longest_row=abs(int(out[2])), bitwise_exact=int(out[2]) < 0, csr_bytes=int(out[3]))
 
     def mg_set_schur_mode(self, additive):
@@ -511,6 +525,10 @@ class NsfemContext:
     def attach_local_comm(self, group, rank):
         self._check(self._lib.nsfem_comm_attach_local(self._h, group, rank))
 
+    def attach_shm_comm(self, name, rank, size, slot_bytes=0):
+        """one process per rank on a SHARED device: host-staged shared-memory communicator"""
+        self._check(self._lib.nsfem_comm_attach_shm(self._h, name.encode(), rank, size, int(slot_bytes)))
+
     def attach_rccl_comm(self, unique_id, rank, size):
         assert len(unique_id) == 128
         self._check(self._lib.nsfem_comm_attach_rccl(self._h, unique_id, rank, size))
@@ -558,6 +576,46 @@ class NsfemContext:
         self._check(self._lib.nsfem_operator_apply(self._h, op, _dp(x), _dp(y)))
         return y
 
+    def kernel_apply(self, space, nv, x, a=1.0, b_coef=0.0, family=0, epilogue=0, b=None, d=None, mask=None,
+                     maskmode=0, steps=0, c1=(), c2=(), ghost=0, ident=False, from_zero=False,
+                     with_residual=False, dict_ok=True):
+        """test hook (nsfem_kernel_apply): product / residual / smoothing sequence of a M + b K through a chosen
+        kernel family; returns dict(y, d, r, used_family, dict_entries, dict_exact, lattice_w)"""
+        t = KernelTest()
+        t.space, t.nv, t.family, t.epilogue, t.steps = int(space), int(nv), int(family), int(epilogue), int(steps)
+        t.maskmode, t.ghost, t.ident = int(maskmode), int(ghost), 1 if ident else 0
+        t.from_zero, t.with_residual, t.dict_ok = 1 if from_zero else 0, 1 if with_residual else 0, 1 if dict_ok else 0
+        t.a, t.b_coef = float(a), float(b_coef)
+        for k, v in enumerate(c1):
+            t.c1[k] = float(v)
+        for k, v in enumerate(c2):
+            t.c2[k] = float(v)
+        keep = []
+
+        def arr(v, dtype=np.float64):
+            if v is None:
+                return None
+            v = np.ascontiguousarray(v, dtype=dtype)
+            keep.append(v)
+            return v
+        x = arr(x)
+        n = x.size
+        bb, dd, mm = arr(b), arr(d), arr(mask, np.uint8)
+        y, d_out, r_out = np.empty(n), np.empty(n), np.empty(n)
+        t.x, t.y, t.d_out, t.r_out = _dp(x), _dp(y), _dp(d_out), _dp(r_out)
+        if bb is not None:
+            assert bb.size == n
+            t.b = _dp(bb)
+        if dd is not None:
+            assert dd.size == n
+            t.d = _dp(dd)
+        if mm is not None:
+            assert mm.size == n
+            t.mask = mm.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(self._lib.nsfem_kernel_apply(self._h, C.byref(t)))
+        return dict(y=y, d=d_out, r=r_out, used_family=int(t.used_family), dict_entries=int(t.dict_entries),
+                    dict_exact=bool(t.dict_exact), lattice_w=int(t.lattice_w))
+
     def set_preconditioner_shift(self, shift):
         self._check(self._lib.nsfem_set_preconditioner_shift(self._h, float(shift)))
 
@@ -595,6 +653,12 @@ class NsfemContext:
         self._check(self._lib.nsfem_profile_smoother(self._h, 1 if enable else 0, C.byref(ms),
                                                      C.byref(n), C.byref(nbytes)))
         return None if enable else (ms.value, n.value, nbytes.value)
+
+    def profile_smoother_detail(self):
+        """the window profile_smoother(False) just closed: dict(launches, steps, bytes, lattice)"""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.nsfem_profile_smoother_detail(self._h, out))
+        return dict(launches=int(out[0]), steps=int(out[1]), bytes=int(out[2]), lattice=bool(out[3]))
 
     def profile_convection(self, enable):
         """start (True) / stop (False -> (avg ms per application, applications, algorithmic bytes))

@@ -1017,6 +1017,10 @@ static void fill_p1_level(nsfem_ctx* ctx, nsfem_ctx::P1Level* lv, int n_vertices
   lv->M.init(&lv->pat, 1, 1, s);
   lv->Lc.init(&lv->pat, 1, 1, s);
   launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
+  // lattice levels: stencil dictionary of the level's operators (smoothing steps of both hierarchies;
+  // the multi-step lattice kernel needs it)
+  if (build_stencil_dict(s, lv->pat, lv->M.vals.p, lv->K.vals.p, lv->dict))
+    lv->K.dict = lv->M.dict = lv->Lc.dict = &lv->dict;
   lv->K.sell_update(s);
   lv->M.sell_update(s);
 }
@@ -1290,6 +1294,18 @@ extern "C" int nsfem_comm_attach_rccl(nsfem_ctx* ctx, const char* id128, int ran
   delete ctx->comm;
   ctx->comm = nullptr;
   ctx->comm = make_rccl_comm(id128, rank, size);
+  ctx->comm->periodic = ctx->partition_periodic;
+  ctx->comm->overlap = ctx->overlap;
+  API_END(ctx)
+}
+
+extern "C" int nsfem_comm_attach_shm(nsfem_ctx* ctx, const char* name, int rank, int size, int64_t slot_bytes) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && name, "null argument");
+  NSFEM_HIP(hipSetDevice(ctx->device));
+  delete ctx->comm;
+  ctx->comm = nullptr;
+  ctx->comm = make_shm_comm(name, rank, size, slot_bytes);
   ctx->comm->periodic = ctx->partition_periodic;
   ctx->comm->overlap = ctx->overlap;
   API_END(ctx)
@@ -2084,6 +2100,99 @@ extern "C" int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, dou
   API_END(ctx)
 }
 
+// Test hook: one product / residual / Chebyshev smoothing sequence of a scalar lattice operator
+// a M + b K (P2 or P1 space of the fine mesh) through a CHOSEN kernel family, on host data.  Lets the
+// parity tests pin every SpMV kernel family and every epilogue to the oracle's matrices directly.
+extern "C" int nsfem_kernel_apply(nsfem_ctx* ctx, nsfem_kernel_test* t) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && t && t->x && t->y, "null argument");
+  NSFEM_REQUIRE(t->nv >= 1 && t->nv <= 3 && t->steps >= 0 && t->steps <= 8, "bad kernel test description");
+  hipStream_t s = ctx->stream;
+  const bool p2 = t->space == 0;
+  const Pattern& pat = p2 ? ctx->p22 : ctx->p11;
+  const BlockMat& Mm = p2 ? ctx->M2 : ctx->Mp;
+  const BlockMat& Kk = p2 ? ctx->K2 : ctx->Ap;
+  StencilDict& dict = p2 ? ctx->dict22 : ctx->dict11;
+  bool& tried = p2 ? ctx->dict22_tried : ctx->dict11_tried;
+  bool have_dict = dict.n_stencils > 0;
+  if (!tried) {
+    tried = true;
+    have_dict = build_stencil_dict(s, pat, Mm.vals.p, Kk.vals.p, dict);
+  }
+  BlockMat T;
+  T.init(&pat, 1, 1, s);
+  launch_scale_combine(s, pat.nnz, t->a, Mm.vals.p, t->b_coef, Kk.vals.p, T.vals.p);
+  if (have_dict) T.dict = &dict;
+  T.sell_update(s);
+  const int nv = t->nv;
+  const size_t n = (size_t)pat.n_rows * nv;
+  DevBuf<double> x, b, d, d2, y, y2, r, dinv;
+  DevBuf<uint8_t> mask;
+  x.upload(t->x, n, s);
+  y.alloc(n); y.zero(s);
+  y2.alloc(n); y2.zero(s);
+  r.alloc(n); r.zero(s);
+  b.alloc(n); b.zero(s);
+  d.alloc(n); d.zero(s);
+  d2.alloc(n); d2.zero(s);
+  if (t->b) NSFEM_HIP(hipMemcpyAsync(b.p, t->b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  if (t->d) NSFEM_HIP(hipMemcpyAsync(d.p, t->d, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  if (t->mask) mask.upload(t->mask, n, s);
+  const uint8_t* mk = t->mask ? mask.p : nullptr;
+  int family = t->family;
+  if (family == 1) { T.dict_ready = false; T.sell_ready = false; }
+  else if (family == 2) { T.dict_ready = false; NSFEM_REQUIRE(T.sell_ready, "no SELL-64 layout for this pattern"); }
+  else if (family == 3) { NSFEM_REQUIRE(T.dict_ready, "no stencil dictionary for this pattern"); T.sell_ready = false; }
+  else if (family == 4) { NSFEM_REQUIRE(lattice_smoother_available(T, nv), "no lattice structure for this pattern"); }
+  // what the dispatcher will pick
+  auto picked = [&](bool dict_ok) {
+    if (T.dict_ready && (dict_ok || T.dict->exact) && nv <= 3) return 3;
+    if (T.sell_ready && pat.n_slices > 0) return 2;
+    return 1;
+  };
+  const double* result = y.p;
+  if (t->epilogue == 0) {
+    t->used_family = picked(t->dict_ok != 0);
+    launch_spmv(s, T, nv, x.p, y.p, mk, mk ? t->maskmode : MASK_NONE, t->ghost, 0, t->dict_ok);
+  } else if (t->epilogue == 1) {
+    NSFEM_REQUIRE(t->b, "residual needs b");
+    t->used_family = picked(false);
+    launch_residual(s, T, nv, x.p, b.p, y.p, mk, mk ? t->maskmode : MASK_NONE);
+  } else {
+    NSFEM_REQUIRE(t->b && t->steps >= 1, "smoothing needs b and steps >= 1");
+    if (family == 4) {
+      t->used_family = 4;
+      NSFEM_REQUIRE(t->steps <= lattice_smoother_max_steps(T, t->from_zero != 0, t->with_residual != 0),
+                    "too many steps for one launch of the lattice kernel");
+      launch_cheb_lattice(s, T, nv, t->from_zero ? nullptr : x.p, b.p, (t->d && !t->from_zero) ? d.p : nullptr, y.p,
+                          d2.p, t->with_residual ? r.p : nullptr, mk, t->steps, t->c1, t->c2, t->ident);
+      NSFEM_HIP(hipMemcpyAsync(d.p, d2.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    } else {
+      t->used_family = picked(true);
+      dinv.alloc(n);
+      launch_inv_diag(s, T, nv, mk, dinv.p);
+      const double* cur = x.p;
+      if (t->from_zero) { x.zero(s); d.zero(s); }
+      for (int k = 0; k < t->steps; ++k) {
+        double* out = cur == y.p ? y2.p : y.p;
+        launch_cheb_step(s, T, nv, cur, b.p, dinv.p, d.p, t->c1[k], t->c2[k], out, mk, t->ghost, 0,
+                         t->ident && k == t->steps - 1 ? 1 : 0);
+        cur = out;
+      }
+      result = cur;
+      if (t->with_residual) launch_residual(s, T, nv, cur, b.p, r.p, mk, MASK_ZERO);
+    }
+  }
+  NSFEM_HIP(hipMemcpyAsync(t->y, result, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  if (t->d_out) NSFEM_HIP(hipMemcpyAsync(t->d_out, d.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  if (t->r_out) NSFEM_HIP(hipMemcpyAsync(t->r_out, r.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  t->dict_entries = have_dict ? dict.n_stencils : 0;
+  t->dict_exact = have_dict && dict.exact ? 1 : 0;
+  t->lattice_w = have_dict ? dict.lat_w : 0;
+  API_END(ctx)
+}
+
 // In-situ timing of the dominant kernel: while enabled, every finest-level Chebyshev smoothing
 // launch of the velocity multigrid (k_spmv_stream<1,1,dim,EPI_CHEB>) is bracketed by a HIP-event
 // pair on the context's stream.  enable != 0: start (discarding earlier samples); enable == 0:
@@ -2096,8 +2205,8 @@ extern "C" int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, dou
 static int64_t smoother_launch_bytes(const BlockMat& A, int nv, bool csr_equivalent) {
   const Pattern& p = *A.pat;
   const int64_t n = (int64_t)p.n_rows * nv;
-  if (A.dict_ready && !csr_equivalent)
-    return (int64_t)p.n_rows + (int64_t)A.dict->n_stencils * (A.dict->lmax * 12 + 4) + n * (6 * 8 + 1);
+  if (A.dict_ready && !csr_equivalent)     // (no dinv stream: 1 / diagonal comes from the dictionary)
+    return (int64_t)p.n_rows + (int64_t)A.dict->n_stencils * (A.dict->lmax * 12 + 4) + n * (5 * 8 + 1);
   return (int64_t)p.nnz * 12 + (int64_t)(p.n_rows + 1) * 4 + n * (6 * 8 + 1);
 }
 
@@ -2114,6 +2223,8 @@ extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms
     }
     mg.prof_n = 0;
     mg.prof_launches = 0;
+    mg.prof_steps = 0;
+    mg.prof_bytes = 0;
     mg.prof = true;
     return NSFEM_OK;
   }
@@ -2128,12 +2239,31 @@ extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms
   const int64_t n_launch = mg.prof_launches;
   if (avg_ms) *avg_ms = n_launch ? total / (double)n_launch : 0.0;
   if (launches) *launches = n_launch;
-  if (algorithmic_bytes) *algorithmic_bytes = smoother_launch_bytes(*mg.lv[0].A, mg.nv, false);
+  // (lattice kernel: launches of different shapes -- with / without the carried direction -- were
+  // timed; the average over exactly those launches)
+  if (algorithmic_bytes)
+    *algorithmic_bytes = (mg.prof_bytes > 0 && n_launch > 0) ? mg.prof_bytes / n_launch
+                                                             : smoother_launch_bytes(*mg.lv[0].A, mg.nv, false);
+  API_END(ctx)
+}
+
+// detail of the last nsfem_profile_smoother window: out = {launches, smoothing steps they ran,
+// algorithmic bytes they moved in total, 1 when the multi-step lattice kernel ran them}
+extern "C" int nsfem_profile_smoother_detail(nsfem_ctx* ctx, int64_t out[4]) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out, "null argument");
+  const Multigrid& mg = ctx->mg_v;
+  out[0] = mg.prof_launches;
+  out[1] = mg.prof_steps;
+  out[2] = mg.prof_bytes > 0 ? mg.prof_bytes
+                             : (mg.lv.empty() ? 0 : mg.prof_launches * smoother_launch_bytes(*mg.lv[0].A, mg.nv, false));
+  out[3] = mg.prof_bytes > 0 ? 1 : 0;
   API_END(ctx)
 }
 
 // which finest-level smoothing kernel of the velocity multigrid runs, and what a CSR stream of the
-// same operator would move: out = {kind (0 CSR-stream, 1 SELL-64, 2 stencil dictionary),
+// same operator would move: out = {kind (0 CSR-stream, 1 SELL-64, 2 stencil dictionary, 3 stencil
+// dictionary inside the multi-step lattice kernel),
 // dictionary entries, longest row, CSR-equivalent algorithmic bytes of one smoothing launch}
 extern "C" int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]) {
   API_BEGIN
@@ -2142,7 +2272,7 @@ extern "C" int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]) {
   ensure_L(ctx);
   const Multigrid& mg = ctx->mg_v;
   const BlockMat& A = *mg.lv[0].A;
-  out[0] = A.dict_ready ? 2 : (A.sell_ready ? 1 : 0);
+  out[0] = A.dict_ready ? (mg.lattice_ok(mg.lv[0]) ? 3 : 2) : (A.sell_ready ? 1 : 0);
   out[1] = A.dict_ready ? A.dict->n_stencils : 0;
   out[2] = A.dict_ready ? (A.dict->exact ? -A.dict->lmax : A.dict->lmax) : 0;
   out[3] = smoother_launch_bytes(A, mg.nv, true);
@@ -2240,8 +2370,16 @@ extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_
     MGLevel& L0 = mg.lv[0];
     const Pattern& p = *L0.A->pat;
     const int nv = mg.nv;
+    const bool lattice = mg.lattice_ok(L0);
+    const int lat_steps = mg.degree >= 1 && mg.degree <= 3 ? mg.degree : 3;
     auto step = [&] {
-      launch_cheb_step(s, *L0.A, nv, L0.xa.p, L0.r.p, L0.dinv.p, L0.d.p, 0.3, 0.7, L0.xb.p, L0.mask);
+      if (lattice) {       // the post-smoothing launch of the cycle: `degree` steps from a given iterate
+        const double c1[4] = {0.0, 0.3, 0.3, 0.3}, c2[4] = {0.7, 0.7, 0.7, 0.7};
+        launch_cheb_lattice(s, *L0.A, nv, L0.xa.p, L0.r.p, nullptr, L0.xb.p, nullptr, nullptr, L0.mask,
+                            lat_steps, c1, c2, 0);
+      } else {
+        launch_cheb_step(s, *L0.A, nv, L0.xa.p, L0.r.p, L0.dinv.p, L0.d.p, 0.3, 0.7, L0.xb.p, L0.mask);
+      }
     };
     // In the solver this launch follows other kernels that have streamed hundreds of MB; the
     // operator (145 MB at n = 512) would otherwise sit in the 256 MB Infinity Cache between
@@ -2272,7 +2410,9 @@ extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_
     const double ms = t_both - t_flush;
     *ms_per_launch = (double)ms / reps;
     (void)p;
-    if (algorithmic_bytes) *algorithmic_bytes = smoother_launch_bytes(*L0.A, nv, false);
+    if (algorithmic_bytes)
+      *algorithmic_bytes = lattice ? lattice_launch_bytes(*L0.A, nv, false, false, false, false)
+                                   : smoother_launch_bytes(*L0.A, nv, false);
     return NSFEM_OK;
   }
   int nv;

@@ -8,11 +8,21 @@
 // ncclSend/ncclRecv: point-to-point over the dedicated xGMI link of the neighbour, not a ring
 // collective).  LocalComm implements the same interface for several contexts that live in ONE
 // process on ONE device (one host thread per rank): it exists so that the partitioned algorithm
-// can be tested on a single-GPU box.
+// can be tested on a single-GPU box.  ShmComm does the same for one PROCESS per rank (host-staged
+// through POSIX shared memory): the process-per-rank launch path on ranks that share a device.
 #include "nsfem_internal.hpp"
 #include <rccl/rccl.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace nsfem {
 
@@ -331,6 +341,265 @@ struct RcclComm : Comm {
     add_range(s, (int64_t)n_dn, stage.p + n_up, vec + h.send_down_off * width);
   }
 };
+
+// -------------------------------------------------------------------- ShmComm
+// One PROCESS per rank, host-staged through a POSIX shared-memory segment: the transport for ranks
+// that share one device (RCCL refuses two ranks on one GPU) -- it lets the process-per-rank launch
+// path of bench.py (spawner, rendezvous, partitions, every collective) run end to end on a one-GPU
+// box.  Not a performance path: every collective is device -> host -> device with two barriers.
+// Reductions add the ranks' slots in rank order on every rank: deterministic and identical everywhere.
+struct ShmHeader {
+  std::atomic<int> arrived;
+  std::atomic<unsigned> generation;
+  std::atomic<int> attached;
+  int size;
+  int64_t slot_bytes;
+};
+struct ShmSlotHead {        // start of every rank's slot
+  int64_t kind;             // collective entered (mismatch check, as LocalComm)
+  int64_t n_part;           // number of parts in the slot
+  int64_t peer[64], off[64], cnt[64];   // part k is meant for rank peer[k]: doubles [off, off + cnt)
+};
+
+struct ShmComm : Comm {
+  std::string name;
+  void* base = nullptr;
+  size_t total = 0;
+  ShmHeader* hd = nullptr;
+  int64_t slot_bytes = 0;
+  DevBuf<double> dstage;
+  std::vector<double> hstage;
+  ShmSlotHead* head(int r) const {
+    return reinterpret_cast<ShmSlotHead*>(static_cast<char*>(base) + 4096 + (size_t)r * (size_t)slot_bytes);
+  }
+  double* data(int r) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(head(r)) + sizeof(ShmSlotHead)); }
+  int64_t capacity() const { return (slot_bytes - (int64_t)sizeof(ShmSlotHead)) / 8; }
+  void barrier() {
+    const unsigned g = hd->generation.load(std::memory_order_acquire);
+    if (hd->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == size) {
+      hd->arrived.store(0, std::memory_order_relaxed);
+      hd->generation.fetch_add(1, std::memory_order_acq_rel);
+    } else {
+      int spins = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      while (hd->generation.load(std::memory_order_acquire) == g) {
+        if (++spins > 2000) {
+          std::this_thread::sleep_for(std::chrono::microseconds(50));
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300))
+            throw Error(NSFEM_ERR_COMM, "shared-memory communicator: a rank did not reach the barrier within 300 s");
+        }
+      }
+    }
+  }
+  void check_kind(int64_t mine) {
+    for (int r = 0; r < size; ++r)
+      if (head(r)->kind != mine)
+        throw Error(NSFEM_ERR_COMM, "collective mismatch: rank " + std::to_string(rank) + " entered kind " +
+                                        std::to_string(mine) + ", rank " + std::to_string(r) + " kind " +
+                                        std::to_string(head(r)->kind));
+  }
+  ~ShmComm() override {
+    if (base) {
+      const bool last = hd->attached.fetch_sub(1) == 1;
+      munmap(base, total);
+      if (last || rank == 0) shm_unlink(name.c_str());
+    }
+  }
+  void reduce(hipStream_t s, double* dev, int64_t count, int op) {
+    count_allreduce(count);
+    NSFEM_REQUIRE(count <= capacity(), "all-reduce larger than the shared-memory slot");
+    ShmSlotHead* me = head(rank);
+    me->kind = 1 + op;
+    NSFEM_HIP(hipMemcpyAsync(data(rank), dev, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+    barrier();
+    check_kind(1 + op);
+    hstage.resize((size_t)count);
+    const double* d0 = data(0);
+    for (int64_t i = 0; i < count; ++i) hstage[i] = d0[i];
+    for (int r = 1; r < size; ++r) {
+      const double* d = data(r);
+      if (op) for (int64_t i = 0; i < count; ++i) hstage[i] = std::fmax(hstage[i], d[i]);
+      else for (int64_t i = 0; i < count; ++i) hstage[i] += d[i];
+    }
+    barrier();      // everybody has read everybody's slot
+    NSFEM_HIP(hipMemcpyAsync(dev, hstage.data(), sizeof(double) * count, hipMemcpyHostToDevice, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+  }
+  void allreduce_sum(hipStream_t s, double* dev, int64_t count) override { reduce(s, dev, count, 0); }
+  void allreduce_max(hipStream_t s, double* dev, int64_t count) override { reduce(s, dev, count, 1); }
+
+  // one (peer, device range) per outgoing and per incoming part; `add`: incoming parts are added
+  struct Part { int peer; double* dev; int64_t cnt; const int32_t* idx; int64_t n_idx; };
+  void ensure_dstage(hipStream_t s, size_t n) {
+    if (dstage.n >= n) return;
+    NSFEM_HIP(hipStreamSynchronize(s));
+    dstage.alloc(n + n / 4 + 64);
+  }
+  // out[k]: what this rank hands to out[k].peer; in[k]: what it takes from in[k].peer -- the m-th part
+  // a rank addresses to a peer pairs with the m-th part that peer expects from it (issue order, as RCCL)
+  void swap_parts(hipStream_t s, int64_t kind, const std::vector<Part>& out, const std::vector<Part>& in,
+                  int width, bool add) {
+    ShmSlotHead* me = head(rank);
+    NSFEM_REQUIRE(out.size() <= 64, "too many neighbours for the shared-memory communicator");
+    me->kind = kind;
+    me->n_part = (int64_t)out.size();
+    int64_t o = 0, need = 0;
+    for (const Part& p : out) need += p.cnt;
+    NSFEM_REQUIRE(need <= capacity(), "halo larger than the shared-memory slot");
+    ensure_dstage(s, (size_t)need);
+    for (size_t k = 0; k < out.size(); ++k) {
+      const Part& p = out[k];
+      me->peer[k] = p.peer; me->off[k] = o; me->cnt[k] = p.cnt;
+      if (p.cnt > 0) {
+        if (p.idx) {
+          move_idx(s, p.n_idx, width, p.dev, p.idx, dstage.p + o, nullptr, false);
+          NSFEM_HIP(hipMemcpyAsync(data(rank) + o, dstage.p + o, sizeof(double) * p.cnt, hipMemcpyDeviceToHost, s));
+        } else {
+          NSFEM_HIP(hipMemcpyAsync(data(rank) + o, p.dev, sizeof(double) * p.cnt, hipMemcpyDeviceToHost, s));
+        }
+      }
+      o += p.cnt;
+    }
+    NSFEM_HIP(hipStreamSynchronize(s));
+    barrier();
+    check_kind(kind);
+    int64_t need_in = 0;
+    for (const Part& p : in) need_in += p.cnt;
+    if (add || std::any_of(in.begin(), in.end(), [](const Part& p) { return p.idx != nullptr; }))
+      ensure_dstage(s, (size_t)need_in);
+    std::vector<int> taken(size, 0);
+    int64_t so = 0;
+    for (const Part& p : in) {
+      const ShmSlotHead* h = head(p.peer);
+      int seen = 0, found = -1;
+      for (int64_t k = 0; k < h->n_part; ++k)
+        if (h->peer[k] == rank && seen++ == taken[p.peer]) { found = (int)k; break; }
+      ++taken[p.peer];
+      if (found < 0 || h->cnt[found] != p.cnt)
+        throw Error(NSFEM_ERR_ARG, "halo size mismatch: rank " + std::to_string(rank) + " expects " +
+                                       std::to_string(p.cnt) + " doubles from rank " + std::to_string(p.peer) +
+                                       ", which offers " + std::to_string(found < 0 ? -1 : h->cnt[found]));
+      if (p.cnt > 0) {
+        const double* src = data(p.peer) + h->off[found];
+        if (!add && !p.idx) {
+          NSFEM_HIP(hipMemcpyAsync(p.dev, src, sizeof(double) * p.cnt, hipMemcpyHostToDevice, s));
+        } else {
+          NSFEM_HIP(hipMemcpyAsync(dstage.p + so, src, sizeof(double) * p.cnt, hipMemcpyHostToDevice, s));
+          if (p.idx) move_idx(s, p.n_idx, width, dstage.p + so, nullptr, p.dev, p.idx, add);
+          else add_range(s, p.cnt, dstage.p + so, p.dev);
+        }
+      }
+      so += p.cnt;
+    }
+    NSFEM_HIP(hipStreamSynchronize(s));
+    barrier();      // the slots may be overwritten
+  }
+  void exchange(hipStream_t s, const HaloRange& h, double* vec, int width) override {
+    count_exchange(h, width);
+    std::vector<Part> out, in;
+    if (h.lists) {
+      const HaloLists& L = *h.lists;
+      for (size_t k = 0; k < L.nbr.size(); ++k) {
+        const int64_t ns = L.send_ptr[k + 1] - L.send_ptr[k], nr = L.recv_ptr[k + 1] - L.recv_ptr[k];
+        out.push_back({L.nbr[k], vec, ns * width, L.send_idx.p + L.send_ptr[k], ns});
+        in.push_back({L.nbr[k], vec, nr * width, L.recv_idx.p + L.recv_ptr[k], nr});
+      }
+      for (Part& p : out) if (p.n_idx == 0) p.idx = nullptr;
+      for (Part& p : in) if (p.n_idx == 0) p.idx = nullptr;
+      swap_parts(s, 3, out, in, width, false);
+      return;
+    }
+    const int above = up(), below = down();
+    NSFEM_REQUIRE(!(periodic && size == 1), "a periodic partition needs at least two ranks");
+    // same order as RcclComm::exchange: sends up, down; receives from below, from above
+    if (above >= 0 && h.send_up_cnt > 0) out.push_back({above, vec + h.send_up_off * width, h.send_up_cnt * width, nullptr, 0});
+    if (below >= 0 && h.send_down_cnt > 0) out.push_back({below, vec + h.send_down_off * width, h.send_down_cnt * width, nullptr, 0});
+    if (below >= 0 && h.recv_below_cnt > 0) in.push_back({below, vec + h.recv_below_off * width, h.recv_below_cnt * width, nullptr, 0});
+    if (above >= 0 && h.recv_above_cnt > 0) in.push_back({above, vec + h.recv_above_off * width, h.recv_above_cnt * width, nullptr, 0});
+    swap_parts(s, 3, out, in, width, false);
+  }
+  void exchange_add(hipStream_t s, const HaloRange& h, double* vec, int width) override {
+    count_exchange_add(h, width);
+    std::vector<Part> out, in;
+    if (h.lists) {
+      const HaloLists& L = *h.lists;
+      for (size_t k = 0; k < L.nbr.size(); ++k) {
+        const int64_t ns = L.send_ptr[k + 1] - L.send_ptr[k], nr = L.recv_ptr[k + 1] - L.recv_ptr[k];
+        out.push_back({L.nbr[k], vec, nr * width, nr ? L.recv_idx.p + L.recv_ptr[k] : nullptr, nr});
+        in.push_back({L.nbr[k], vec, ns * width, ns ? L.send_idx.p + L.send_ptr[k] : nullptr, ns});
+      }
+      swap_parts(s, 4, out, in, width, true);
+      return;
+    }
+    const int above = up(), below = down();
+    NSFEM_REQUIRE(!(periodic && size == 1), "a periodic partition needs at least two ranks");
+    // ghost ranges go back to their owners (RcclComm::exchange_add's order)
+    if (above >= 0 && h.recv_above_cnt > 0) out.push_back({above, vec + h.recv_above_off * width, h.recv_above_cnt * width, nullptr, 0});
+    if (below >= 0 && h.recv_below_cnt > 0) out.push_back({below, vec + h.recv_below_off * width, h.recv_below_cnt * width, nullptr, 0});
+    if (below >= 0 && h.send_down_cnt > 0) in.push_back({below, vec + h.send_down_off * width, h.send_down_cnt * width, nullptr, 0});
+    if (above >= 0 && h.send_up_cnt > 0) in.push_back({above, vec + h.send_up_off * width, h.send_up_cnt * width, nullptr, 0});
+    swap_parts(s, 4, out, in, width, true);
+  }
+};
+
+Comm* make_shm_comm(const char* name, int rank, int size, int64_t slot_bytes) {
+  NSFEM_REQUIRE(name && name[0] == '/' && rank >= 0 && rank < size && size <= 64, "bad shared-memory communicator arguments");
+  if (slot_bytes <= 0) slot_bytes = 64ll << 20;
+  slot_bytes = (slot_bytes + 4095) / 4096 * 4096;
+  const size_t total = 4096 + (size_t)size * (size_t)slot_bytes;
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) throw Error(NSFEM_ERR_COMM, std::string("shm_open(create) failed: ") + std::strerror(errno));
+    if (ftruncate(fd, (off_t)total) != 0) {
+      close(fd);
+      shm_unlink(name);
+      throw Error(NSFEM_ERR_COMM, std::string("ftruncate failed: ") + std::strerror(errno));
+    }
+  } else {
+    // rank 0 creates the segment; the caller's rendezvous (bench.py: the broadcast of the name) does not
+    // order that creation before the other ranks' open, so wait for it to appear at its full size
+    for (int tries = 0; tries < 6000; ++tries) {
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= total) break;
+        close(fd);
+        fd = -1;
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    if (fd < 0) throw Error(NSFEM_ERR_COMM, "shared-memory segment of rank 0 did not appear within 60 s");
+  }
+  void* base = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (base == MAP_FAILED) throw Error(NSFEM_ERR_COMM, std::string("mmap failed: ") + std::strerror(errno));
+  ShmComm* c = new ShmComm();
+  c->name = name;
+  c->base = base;
+  c->total = total;
+  c->hd = static_cast<ShmHeader*>(base);
+  c->rank = rank;
+  c->size = size;
+  c->slot_bytes = slot_bytes;
+  if (rank == 0) {           // fresh segments are zero-filled: arrived = generation = attached = 0
+    c->hd->size = size;
+    c->hd->slot_bytes = slot_bytes;
+  }
+  c->hd->attached.fetch_add(1);
+  // first barrier = everybody is attached (and rank 0's header is visible)
+  const auto t0 = std::chrono::steady_clock::now();
+  while (c->hd->attached.load() < size) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+      delete c;
+      throw Error(NSFEM_ERR_COMM, "shared-memory communicator: not all ranks attached within 120 s");
+    }
+  }
+  return c;
+}
 
 Comm* make_local_comm(void* group, int rank) {
   LocalGroup* g = static_cast<LocalGroup*>(group);

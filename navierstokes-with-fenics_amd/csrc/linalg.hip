@@ -713,11 +713,13 @@ __device__ __forceinline__ void spmv_dict_body(int n_rows, int n_wg, const uint8
                                                const int32_t* __restrict__ wg_list,
                                                const int32_t* __restrict__ slen,
                                                const int32_t* __restrict__ soff,
-                                               const double* __restrict__ sval, int lmax,
+                                               const double* __restrict__ sval,
+                                               const int32_t* __restrict__ sdpos, int lmax,
                                                int max_local, const SpmvArgs& a) {
   extern __shared__ double sh_dict[];
   double* __restrict__ lv = sh_dict;                                   // [max_local * lmax] values
-  int* __restrict__ lo = reinterpret_cast<int*>(sh_dict + (size_t)max_local * lmax);   // offsets
+  double* __restrict__ ldi = sh_dict + (size_t)max_local * lmax;       // [max_local] 1 / diagonal
+  int* __restrict__ lo = reinterpret_cast<int*>(ldi + max_local);      // offsets
   int* __restrict__ ll = lo + max_local * lmax;                        // lengths
   // XCD x (workgroups b = x mod 8) walks its own contiguous row range
   const int per = gridDim.x >> 3;
@@ -731,7 +733,16 @@ __device__ __forceinline__ void spmv_dict_body(int n_rows, int n_wg, const uint8
     lv[t] = sval[g];
     lo[t] = soff[g];
   }
-  if ((int)threadIdx.x < nl) ll[threadIdx.x] = slen[wg_list[l0 + threadIdx.x]];
+  if ((int)threadIdx.x < nl) {
+    const int sg = wg_list[l0 + threadIdx.x];
+    ll[threadIdx.x] = slen[sg];
+    if (EPI == EPI_CHEB) {
+      // Jacobi scaling of the smoother: 1 / diagonal of the row's dictionary entry (rows flagged in the
+      // mask never use it) -- no dinv vector is streamed
+      const int dp = sdpos[sg];
+      ldi[threadIdx.x] = dp >= 0 ? 1.0 / sval[(size_t)sg * lmax + dp] : 0.0;
+    }
+  }
   const int wave = wg * 4 + ((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int row = wave * 64 + lane;
@@ -749,7 +760,7 @@ __device__ __forceinline__ void spmv_dict_body(int n_rows, int n_wg, const uint8
     const size_t idx = ebase + e;
     pm[p] = (in && a.maskmode != MASK_NONE) ? a.mask[idx] : 0;
     pb[p] = (in && EPI != EPI_STORE) ? a.b[idx] : 0.0;
-    pdi[p] = (in && EPI == EPI_CHEB) ? a.dinv[idx] : 0.0;
+    pdi[p] = 0.0;
     pd[p] = (in && EPI == EPI_CHEB && a.c1 != 0.0) ? a.d[idx] : 0.0;
     px[p] = in ? x[idx] : 0.0;
   }
@@ -792,6 +803,7 @@ __device__ __forceinline__ void spmv_dict_body(int n_rows, int n_wg, const uint8
       const double t = __shfl(acc[o], owner, 64);
       if (comp == o) val = t;
     }
+    if (EPI == EPI_CHEB) pdi[p] = ldi[__shfl(st, owner, 64)];
     if (wave * 64 + owner >= n_rows) continue;
     const size_t idx = ebase + e;
     int m_ = pm[p];
@@ -836,17 +848,19 @@ __global__ __launch_bounds__(256) void k_spmv_dict(int n_rows, int n_wg, const u
                                                    const int32_t* __restrict__ wg_list,
                                                    const int32_t* __restrict__ slen,
                                                    const int32_t* __restrict__ soff,
-                                                   const double* __restrict__ sval, int lmax,
+                                                   const double* __restrict__ sval,
+                                                   const int32_t* __restrict__ sdpos, int lmax,
                                                    int max_local, SpmvArgs a) {
-  spmv_dict_body<NV, EPI, 4>(n_rows, n_wg, lid, wg_ptr, wg_list, slen, soff, sval, lmax, max_local, a);
+  spmv_dict_body<NV, EPI, 4>(n_rows, n_wg, lid, wg_ptr, wg_list, slen, soff, sval, sdpos, lmax, max_local, a);
 }
 template <int NV, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_spmv_dict_w8(int n_rows, int n_wg, const uint8_t* __restrict__ lid,
                     const int32_t* __restrict__ wg_ptr, const int32_t* __restrict__ wg_list,
                     const int32_t* __restrict__ slen, const int32_t* __restrict__ soff,
-                    const double* __restrict__ sval, int lmax, int max_local, SpmvArgs a) {
-  spmv_dict_body<NV, EPI, 2>(n_rows, n_wg, lid, wg_ptr, wg_list, slen, soff, sval, lmax, max_local, a);
+                    const double* __restrict__ sval, const int32_t* __restrict__ sdpos, int lmax,
+                    int max_local, SpmvArgs a) {
+  spmv_dict_body<NV, EPI, 2>(n_rows, n_wg, lid, wg_ptr, wg_list, slen, soff, sval, sdpos, lmax, max_local, a);
 }
 
 // Rectangular block operators between the P2 and P1 numberings (divergence 1 x dim blocks, its
@@ -938,6 +952,288 @@ __global__ __launch_bounds__(256) void k_spmv_dict_blk(int n_rows, int n_wg, con
   }
 }
 
+// ------------------------------------------------------------- multi-step lattice smoother
+// S Chebyshev-Jacobi steps of a scalar lattice operator (2D lexicographic numbering, stencil
+// dictionary with (dj, di) offsets) on NV interleaved components in ONE launch.  A workgroup owns
+// an output tile T of TX x TY lattice nodes.  It stages the start vector on the extended tile
+// E = T (+) G, G = R * Mv nodes in every direction (R = stencil reach, Mv = number of operator
+// applications of the launch), in LDS ONCE, then runs the steps out of LDS: stage m computes the
+// new iterate on T (+) R (Mv - m) -- the halo shrinks by the reach per stage, its nodes are
+// computed redundantly by the neighbouring tiles -- writes it back to LDS and goes on.  b, d and the
+// new iterate of a thread's nodes stay in registers; the Jacobi scaling is 1 / diagonal of the
+// row's dictionary entry.  Per launch the vectors are read and written once instead of once per
+// step, and the 9 - 19 gathers per row and step come from LDS instead of the L1 / L2 path that
+// bounds the one-step kernel (k_spmv_dict).
+//   from_zero : the start vector is zero -- step 0 is the pointwise  d = x = c2 dinv b  (on E)
+//   r_out     : additionally r = b - A x_S on T (pre-smoothing + residual of a V-cycle leg)
+//   d_in/out  : Chebyshev direction carried across launches of one smoothing sequence
+// Row masks as in the one-step kernel (flag 1: x = d = 0, or x = b on the last step when `ident`);
+// partitioned levels (ghost rows) keep the one-step kernels.
+struct LatticeArgs {
+  int W, H;                 // lattice: row = j * W + i
+  int TX, TY, ntx, ntiles;  // output tile, tiles per lattice line, tiles
+  int R, S, Mv, G;          // reach, steps, operator applications, halo = R * Mv
+  int EW, EH;               // extended tile
+  int from_zero, ident;
+  const double *x_in, *b, *d_in;
+  double *x_out, *d_out, *r_out;
+  const uint8_t *sid, *mask;
+  const int32_t *slen, *spack, *dpos;
+  const double* sval;
+  int lmax, n_st;
+  double c1[4], c2[4];
+};
+
+template <int NV, int K, int NT>
+__global__ __launch_bounds__(NT) void k_cheb_lattice(LatticeArgs a) {
+  extern __shared__ double sh_lat[];
+  typedef double vec __attribute__((ext_vector_type(2)));
+  // LDS: x on E | dictionary entries {value, LDS offset} (16 bytes) | 1 / diagonal | lengths
+  double* __restrict__ xs = sh_lat;
+  const int ne = a.EW * a.EH;
+  vec* __restrict__ ent = reinterpret_cast<vec*>(xs + (((size_t)ne * NV + 1) & ~(size_t)1));
+  double* __restrict__ ldi = reinterpret_cast<double*>(ent + (size_t)a.n_st * a.lmax);
+  int* __restrict__ ll = reinterpret_cast<int*>(ldi + a.n_st);
+  const int tid = threadIdx.x;
+  // XCD x (workgroups b = x mod 8) walks its own contiguous range of tiles
+  const int per = gridDim.x >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tile >= a.ntiles) return;                                   // (whole workgroup)
+  const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
+  const int i0 = tx * a.TX, j0 = ty * a.TY;
+  const int i1 = min(i0 + a.TX, a.W), j1 = min(j0 + a.TY, a.H);
+  const int G = a.G;
+  for (int t = tid; t < a.n_st * a.lmax; t += NT) {
+    const int pk = a.spack[t];
+    vec e;
+    e.x = a.sval[t];
+    e.y = __longlong_as_double((long long)(((pk >> 5) - 8) * a.EW + ((pk & 31) - 8)));
+    ent[t] = e;
+  }
+  for (int t = tid; t < a.n_st; t += NT) {
+    ll[t] = a.slen[t];
+    const int dp = a.dpos[t];
+    ldi[t] = dp >= 0 ? 1.0 / a.sval[(size_t)t * a.lmax + dp] : 0.0;
+  }
+  if (!a.from_zero) {
+    for (int e = tid; e < ne; e += NT) {
+      const int lj = e / a.EW, li = e - lj * a.EW;
+      const int gj = j0 - G + lj, gi = i0 - G + li;
+      const bool in = gj >= 0 && gj < a.H && gi >= 0 && gi < a.W;
+      const size_t row = (size_t)gj * a.W + gi;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) xs[(size_t)e * NV + c] = in ? a.x_in[row * NV + c] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (a.from_zero) {                    // step 0 from a zero start: pointwise on all of E
+    for (int e = tid; e < ne; e += NT) {
+      const int lj = e / a.EW, li = e - lj * a.EW;
+      const int gj = j0 - G + lj, gi = i0 - G + li;
+      const bool in = gj >= 0 && gj < a.H && gi >= 0 && gi < a.W;
+      const size_t row = (size_t)gj * a.W + gi;
+      const double di = in ? ldi[a.sid[row]] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        double v = 0.0;
+        if (in && !(a.mask && a.mask[row * NV + c])) v = a.c2[0] * di * a.b[row * NV + c];
+        else if (in && a.ident && a.S == 1) v = a.b[row * NV + c];
+        xs[(size_t)e * NV + c] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the nodes this thread owns: the box T (+) Go, Go = R (Mv - 1) (clipped to the lattice)
+  const int Go = a.R * max(a.Mv - 1, 0);
+  const int OW = a.TX + 2 * Go, OH = a.TY + 2 * Go;
+  int loc[K], ring[K], st[K], mk[K];
+  double bq[K][NV], dq[K][NV], xq[K][NV];
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const int o = q * NT + tid;
+    const int oj = o / OW, oi = o - oj * OW;
+    const int gj = j0 - Go + oj, gi = i0 - Go + oi;
+    const bool act = o < OW * OH && gj >= 0 && gj < a.H && gi >= 0 && gi < a.W;
+    loc[q] = (oj + G - Go) * a.EW + (oi + G - Go);
+    // distance to the output tile (0 inside); inactive nodes get a distance no stage reaches
+    const int ex = max(max(i0 - gi, gi - (i1 - 1)), 0), ey = max(max(j0 - gj, gj - (j1 - 1)), 0);
+    ring[q] = act ? max(ex, ey) : 0x3fffffff;
+    st[q] = 0;
+    mk[q] = 0;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) bq[q][c] = dq[q][c] = xq[q][c] = 0.0;
+    if (act) {
+      const size_t row = (size_t)gj * a.W + gi;
+      st[q] = a.sid[row];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        bq[q][c] = a.b[row * NV + c];
+        if (a.mask && a.mask[row * NV + c]) mk[q] |= 1 << c;
+        if (a.from_zero) dq[q][c] = xq[q][c] = xs[(size_t)loc[q] * NV + c];
+        else if (a.d_in) dq[q][c] = a.d_in[row * NV + c];
+      }
+    }
+  }
+  const int n_smooth = a.S - a.from_zero;           // smoothing stages with an operator application
+  for (int m = 1; m <= a.Mv; ++m) {
+    const int lim = a.R * (a.Mv - m);
+    const bool smoothing = m <= n_smooth;
+    const int kstep = m - 1 + a.from_zero;
+    const double c1 = smoothing ? a.c1[kstep] : 0.0, c2 = smoothing ? a.c2[kstep] : 0.0;
+    const bool last = smoothing && kstep == a.S - 1;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      if (ring[q] > lim) continue;
+      double acc[NV];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc[c] = 0.0;
+      const int L = ll[st[q]];
+      const vec* __restrict__ ep = ent + (size_t)st[q] * a.lmax;
+      for (int k = 0; k < L; k += 2) {
+        const int k1 = k + 1 < L ? k + 1 : L - 1;
+        const vec e0 = ep[k], e1 = ep[k1];
+        const int o0 = (int)__double_as_longlong(e0.y), o1 = (int)__double_as_longlong(e1.y);
+        const double w1 = k + 1 < L ? e1.x : 0.0;
+        if (NV == 2) {
+          const vec x0 = reinterpret_cast<const vec*>(xs)[loc[q] + o0];
+          const vec x1 = reinterpret_cast<const vec*>(xs)[loc[q] + o1];
+          acc[0] += e0.x * x0.x;
+          acc[NV - 1] += e0.x * x0.y;
+          acc[0] += w1 * x1.x;
+          acc[NV - 1] += w1 * x1.y;
+        } else {
+          const double x0 = xs[loc[q] + o0], x1 = xs[loc[q] + o1];
+          acc[0] += e0.x * x0;
+          acc[0] += w1 * x1;
+        }
+      }
+      if (smoothing) {
+        const double di = ldi[st[q]];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          double dn = 0.0, xn = 0.0;
+          if (!((mk[q] >> c) & 1)) {
+            dn = c2 * di * (bq[q][c] - acc[c]);
+            if (c1 != 0.0) dn += c1 * dq[q][c];
+            xn = xs[(size_t)loc[q] * NV + c] + dn;
+          } else if (a.ident && last) {
+            xn = bq[q][c];
+          }
+          dq[q][c] = dn;
+          xq[q][c] = xn;
+        }
+      } else {                          // residual of the smoothed iterate (ring 0 only)
+        const int lj = loc[q] / a.EW, li = loc[q] - lj * a.EW;
+        const size_t row = (size_t)(j0 - G + lj) * a.W + (i0 - G + li);
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          a.r_out[row * NV + c] = ((mk[q] >> c) & 1) ? 0.0 : bq[q][c] - acc[c];
+      }
+    }
+    if (smoothing && m < a.Mv) {
+      __syncthreads();                  // everybody has read the old iterate
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        if (ring[q] <= lim) {
+#pragma unroll
+          for (int c = 0; c < NV; ++c) xs[(size_t)loc[q] * NV + c] = xq[q][c];
+        }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < K; ++q)
+    if (ring[q] == 0) {
+      const int lj = loc[q] / a.EW, li = loc[q] - lj * a.EW;
+      const size_t row = (size_t)(j0 - G + lj) * a.W + (i0 - G + li);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        a.x_out[row * NV + c] = xq[q][c];
+        if (a.d_out) a.d_out[row * NV + c] = dq[q][c];
+      }
+    }
+}
+
+// can `steps` smoothing steps of this level's operator run in the lattice kernel?
+bool lattice_smoother_available(const BlockMat& A, int nv) {
+  static const bool on = [] {
+    const char* e = std::getenv("NSFEM_LATTICE");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  return on && A.dict_ready && A.dict && A.dict->lat_w > 0 && A.br == 1 && A.bc == 1 && (nv == 1 || nv == 2);
+}
+int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid) {
+  // operator applications per launch: at most 3 (reach 2: halo 6) / 4 (reach 1)
+  const int mv_max = A.dict->lat_r >= 2 ? 3 : 4;
+  return std::min(4, mv_max + (from_zero ? 1 : 0) - (with_resid ? 1 : 0));
+}
+
+// `steps` (<= lattice_smoother_max_steps) Chebyshev-Jacobi steps with the coefficients c1[k], c2[k]
+// of steps k0 .. k0 + steps - 1 supplied by the caller; x_in == nullptr: zero start (needs k0 == 0)
+void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
+                         const double* d_in, double* x_out, double* d_out, double* r_out,
+                         const uint8_t* mask, int steps, const double* c1, const double* c2, int ident) {
+  const StencilDict& d = *A.dict;
+  NSFEM_REQUIRE(steps >= 1 && steps <= 4, "lattice smoother: 1..4 steps per launch");
+  NSFEM_REQUIRE(x_out != x_in, "lattice smoother works out of place");
+  LatticeArgs a;
+  a.W = d.lat_w; a.H = d.lat_h; a.R = d.lat_r; a.S = steps;
+  a.from_zero = x_in ? 0 : 1;
+  a.Mv = steps - a.from_zero + (r_out ? 1 : 0);
+  NSFEM_REQUIRE(a.Mv >= 0 && a.Mv * a.R <= 8, "lattice smoother: halo too wide");
+  a.G = a.R * a.Mv;
+  // tile: large lattices 64 x 32 with 512 threads, smaller ones smaller tiles (enough workgroups to
+  // fill 256 CUs); balanced so that the last tile of a line is not a sliver
+  const int64_t nn = (int64_t)a.W * a.H;
+  int tmx, tmy, nt;
+  if (nn >= 600000) { tmx = 64; tmy = 32; nt = 1024; }
+  else if (nn >= 150000) { tmx = 32; tmy = 16; nt = 512; }
+  else { tmx = 16; tmy = 16; nt = 256; }
+  static const int force_tile = [] { const char* e = std::getenv("NSFEM_LATTICE_TILE"); return e ? std::atoi(e) : 0; }();
+  if (force_tile == 1) { tmx = 32; tmy = 32; nt = 1024; }
+  else if (force_tile == 2) { tmx = 32; tmy = 16; nt = 512; }
+  else if (force_tile == 3) { tmx = 64; tmy = 16; nt = 1024; }
+  else if (force_tile == 4) { tmx = 16; tmy = 16; nt = 256; }
+  const int ncx = (a.W + tmx - 1) / tmx, ncy = (a.H + tmy - 1) / tmy;
+  a.TX = (a.W + ncx - 1) / ncx;
+  a.TY = (a.H + ncy - 1) / ncy;
+  a.ntx = (a.W + a.TX - 1) / a.TX;
+  a.ntiles = a.ntx * ((a.H + a.TY - 1) / a.TY);
+  a.EW = a.TX + 2 * a.G;
+  a.EH = a.TY + 2 * a.G;
+  const int Go = a.R * std::max(a.Mv - 1, 0);
+  constexpr int K = 3;
+  NSFEM_REQUIRE((a.TX + 2 * Go) * (a.TY + 2 * Go) <= K * nt, "lattice smoother: tile does not fit the thread block");
+  a.ident = ident;
+  a.x_in = x_in; a.b = b; a.d_in = d_in; a.x_out = x_out; a.d_out = d_out; a.r_out = r_out;
+  a.sid = d.sid8.p; a.mask = mask;
+  a.slen = d.len.p; a.spack = d.pack.p; a.dpos = d.dpos.p; a.sval = A.dict_vals.p;
+  a.lmax = d.lmax; a.n_st = d.n_stencils;
+  for (int k = 0; k < 4; ++k) { a.c1[k] = k < steps ? c1[k] : 0.0; a.c2[k] = k < steps ? c2[k] : 0.0; }
+  const size_t lds = ((((size_t)a.EW * a.EH * nv + 1) & ~(size_t)1)) * 8 + (size_t)d.n_stencils * d.lmax * 16 +
+                     (size_t)d.n_stencils * 12 + 16;
+  const int grid = (a.ntiles + 7) & ~7;
+#define NSFEM_LAT(NV, NT)                                                                              \
+  do {                                                                                                 \
+    static bool attr_set = false;                                                                      \
+    if (!attr_set) {                                                                                   \
+      NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, K, NT>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));         \
+      attr_set = true;                                                                                 \
+    }                                                                                                  \
+    hipLaunchKernelGGL((k_cheb_lattice<NV, K, NT>), dim3(grid), dim3(NT), lds, s, a);                  \
+  } while (0)
+  NSFEM_REQUIRE(lds <= 128 * 1024, "lattice smoother: tile does not fit the LDS");
+  if (nv == 2 && nt == 1024) NSFEM_LAT(2, 1024);
+  else if (nv == 2 && nt == 512) NSFEM_LAT(2, 512);
+  else if (nv == 2) NSFEM_LAT(2, 256);
+  else if (nt == 1024) NSFEM_LAT(1, 1024);
+  else if (nt == 512) NSFEM_LAT(1, 512);
+  else NSFEM_LAT(1, 256);
+#undef NSFEM_LAT
+  NSFEM_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void k_dict_fill(int64_t len, int bsz, const int32_t* __restrict__ src,
                                                    const double* __restrict__ csr,
                                                    double* __restrict__ out) {
@@ -954,7 +1250,10 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
   d.max_local = 0;
   const char* env = std::getenv("NSFEM_DICT");        // (read per context: tests switch it)
   const bool enabled = env ? std::atoi(env) != 0 : true;
-  if (!enabled || p.n_rows < 4096 || p.h_rowptr.empty() || (!rect && p.n_rows != p.n_cols)) return false;
+  // (>= 1024 rows: lattice levels down to 33 x 33 nodes get a dictionary; NSFEM_DICT_MIN_ROWS overrides)
+  const char* env_min = std::getenv("NSFEM_DICT_MIN_ROWS");
+  const int min_rows = env_min ? std::atoi(env_min) : 1024;
+  if (!enabled || p.n_rows < min_rows || p.h_rowptr.empty() || (!rect && p.n_rows != p.n_cols)) return false;
   const int n = p.n_rows;
   const size_t nval = (size_t)p.nnz * bsz;
   std::vector<double> va(nval), vb;
@@ -1065,6 +1364,55 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
   d.len.upload(len, s);
   d.off.upload(off, s);
   d.src.upload(src, s);
+  // position of the diagonal entry of every stencil (square operators)
+  std::vector<int32_t> dpos((size_t)ns, -1);
+  if (!rect)
+    for (int c = 0; c < ns; ++c)
+      for (int k = 0; k < len[c]; ++k)
+        if (off[(size_t)c * lmax + k] == 0) dpos[c] = k;
+  d.dpos.upload(dpos, s);
+  // ---- 2D lattice structure (see StencilDict): the smallest positive offset beyond the in-line
+  // neighbours is (dj, di) = (1, -r), r <= 2, so the line length is one of three candidates; a
+  // candidate is accepted when every offset decomposes and every ROW's entries stay inside the box
+  d.lat_w = d.lat_h = d.lat_r = 0;
+  if (!rect && bsz == 1 && ns <= 64 && lmax <= 32) {
+    int omin = 0;
+    for (int c = 0; c < ns; ++c)
+      for (int k = 0; k < len[c]; ++k) {
+        const int o = off[(size_t)c * lmax + k];
+        if (o > 2 && (omin == 0 || o < omin)) omin = o;
+      }
+    for (int Wc = omin; omin > 0 && Wc <= omin + 2 && d.lat_w == 0; ++Wc) {
+      if (Wc < 8 || n % Wc != 0 || n / Wc < 3) continue;
+      const int Hc = n / Wc;
+      std::vector<int32_t> pk((size_t)ns * lmax, 8 * 32 + 8);
+      bool ok = true;
+      int reach = 0;
+      for (int c = 0; c < ns && ok; ++c)
+        for (int k = 0; k < len[c] && ok; ++k) {
+          const int o = off[(size_t)c * lmax + k];
+          const int dj = (int)std::floor((double)o / Wc + 0.5), di = o - dj * Wc;
+          ok = std::abs(di) <= 2 && std::abs(dj) <= 2;
+          reach = std::max(reach, std::max(std::abs(di), std::abs(dj)));
+          pk[(size_t)c * lmax + k] = (dj + 8) * 32 + (di + 8);
+        }
+      for (int r = 0; r < n && ok; ++r) {
+        const int c = sid[r], i = r % Wc, j = r / Wc;
+        for (int k = 0; k < len[c] && ok; ++k) {
+          const int q = pk[(size_t)c * lmax + k], dj = (q >> 5) - 8, di = (q & 31) - 8;
+          ok = i + di >= 0 && i + di < Wc && j + dj >= 0 && j + dj < Hc;
+        }
+      }
+      if (!ok || reach < 1) continue;
+      d.lat_w = Wc;
+      d.lat_h = Hc;
+      d.lat_r = reach;
+      d.pack.upload(pk, s);
+      std::vector<uint8_t> s8((size_t)n);
+      for (int r = 0; r < n; ++r) s8[r] = (uint8_t)sid[r];
+      d.sid8.upload(s8, s);
+    }
+  }
   NSFEM_HIP(hipStreamSynchronize(s));
   return true;
 }
@@ -1228,10 +1576,11 @@ static void spmv_dispatch(hipStream_t s, const BlockMat& A, int nv, const SpmvAr
     }
     if (n_wg <= 0) return;
     const int grid = (n_wg + 7) & ~7;
-    const size_t lds = (size_t)d.max_local * d.lmax * 12 + (size_t)d.max_local * 4;
+    const size_t lds = (size_t)d.max_local * d.lmax * 12 + (size_t)d.max_local * 12;
 #define NSFEM_DICT_LAUNCH(KERNEL, NV)                                                                  \
   hipLaunchKernelGGL((KERNEL<NV, EPI>), dim3(grid), dim3(256), lds, s, d.n_rows, n_wg, d.lid.p,        \
-                     d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.lmax, d.max_local, a)
+                     d.wg_ptr.p, d.wg_list.p, d.len.p, d.off.p, A.dict_vals.p, d.dpos.p, d.lmax,       \
+                     d.max_local, a)
     if (nv == 1) NSFEM_DICT_LAUNCH(k_spmv_dict_w8, 1);
     else if (nv == 2) NSFEM_DICT_LAUNCH(k_spmv_dict_w8, 2);
     else NSFEM_DICT_LAUNCH(k_spmv_dict, 3);

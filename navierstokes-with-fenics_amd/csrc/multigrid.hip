@@ -329,7 +329,7 @@ void Multigrid::setup_work(hipStream_t s) {
   for (size_t l = 0; l < lv.size(); ++l) {
     MGLevel& L = lv[l];
     const size_t n = (size_t)L.n * nv;
-    for (DevBuf<double>* b : {&L.xa, &L.xb, &L.r, &L.d, &L.dinv}) { b->alloc(n); b->zero(s); }
+    for (DevBuf<double>* b : {&L.xa, &L.xb, &L.r, &L.d, &L.dinv, &L.xc, &L.d2}) { b->alloc(n); b->zero(s); }
     if (L.additive) { L.t.alloc(n); L.t.zero(s); }
     if (l > 0) {
       L.x.alloc(n); L.x.zero(s);
@@ -564,12 +564,77 @@ void Multigrid::cheb_coeffs(const MGLevel& L, int k, double rho_prev, double& c1
   }
 }
 
+bool Multigrid::lattice_ok(const MGLevel& L) const {
+  return !L.additive && !(comm_active() && L.has_halo) && lattice_smoother_available(*L.A, nv);
+}
+
+// algorithmic bytes of one launch of the lattice kernel: one byte per row (dictionary entry), the
+// mask, the dictionary once, and the vectors the launch reads / writes
+int64_t lattice_launch_bytes(const BlockMat& A, int nv, bool from_zero, bool d_in, bool d_out,
+                             bool r_out) {
+  const int64_t rows = A.pat->n_rows, n = rows * nv;
+  const int vecs = (from_zero ? 0 : 1) + 1 /* b */ + 1 /* x_out */ + (d_in ? 1 : 0) + (d_out ? 1 : 0) +
+                   (r_out ? 1 : 0);
+  return rows + n + (int64_t)A.dict->n_stencils * (A.dict->lmax * 12 + 8) + 8 * n * vecs;
+}
+
+void Multigrid::smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
+                               double* x_out, int steps, bool ident_last, double* r_out) {
+  NSFEM_REQUIRE(steps >= 1 && steps <= 64, "smoothing sequence too long");
+  double c1[64], c2[64], rho = 0.0;
+  for (int k = 0; k < steps; ++k) {
+    double rn;
+    cheb_coeffs(L, k, rho, c1[k], c2[k], rn);
+    rho = rn;
+  }
+  const bool timed = prof && &L == &lv[0] && prof_n + 2 <= prof_ev.size();
+  if (timed) NSFEM_HIP(hipEventRecord(prof_ev[prof_n], s));
+  const double* cur = x_in;
+  const double* d_cur = nullptr;
+  int k = 0;
+  while (k < steps) {
+    const bool fz = cur == nullptr;
+    int ns = std::min(steps - k, lattice_smoother_max_steps(*L.A, fz, false));
+    double* rr = nullptr;
+    if (k + ns == steps && r_out) {          // the residual rides along when the halo allows it
+      const int with = lattice_smoother_max_steps(*L.A, fz, true);
+      if (ns <= with) rr = r_out;
+      else ns = std::max(1, std::min(ns - 1, with));
+    }
+    const bool last = k + ns == steps;
+    double* out = last ? x_out : (cur == L.xa.p ? L.xb.p : L.xa.p);
+    double* d_out = last ? nullptr : (d_cur == L.d.p ? L.d2.p : L.d.p);
+    NSFEM_REQUIRE(out != cur, "lattice smoother: the caller must smooth out of place");
+    launch_cheb_lattice(s, *L.A, nv, cur, b, d_cur, out, d_out, rr, L.mask, ns, c1 + k, c2 + k,
+                        ident_last && last ? 1 : 0);
+    if (timed) {
+      ++prof_launches;
+      prof_steps += ns;
+      prof_bytes += lattice_launch_bytes(*L.A, nv, fz, d_cur != nullptr, d_out != nullptr, rr != nullptr);
+    }
+    cur = out;
+    d_cur = d_out;
+    k += ns;
+    if (last && r_out && !rr) {              // (halo too wide for the fused residual)
+      launch_residual(s, *L.A, nv, cur, b, r_out, L.mask, MASK_ZERO);
+    }
+  }
+  if (timed) {
+    NSFEM_HIP(hipEventRecord(prof_ev[prof_n + 1], s));
+    prof_n += 2;
+  }
+}
+
 // `steps` Chebyshev steps on A x = b.  x_in == nullptr: zero initial guess.  The result
 // is written to x_out (which may alias x_in only when steps >= 2).
 void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
                        double* x_out, int steps, bool ghosts_valid, bool ident_last, bool first_done) {
   if (L.additive) {
     smooth_additive(s, L, b, x_in, x_out, steps, first_done);
+    return;
+  }
+  if (!first_done && x_out != x_in && steps >= 1 && lattice_ok(L)) {
+    smooth_lattice(s, L, b, x_in, x_out, steps, ident_last, nullptr);
     return;
   }
   const int64_t n = (int64_t)L.n * nv;
@@ -614,6 +679,7 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
       });
       if (prof_open) {
         ++prof_launches;
+        ++prof_steps;
         if (comm_active() && L.has_halo) {
           NSFEM_HIP(hipEventRecord(prof_ev[prof_n + 1], s));
           prof_n += 2;
@@ -689,7 +755,8 @@ bool Multigrid::restrict_to(hipStream_t s, size_t l, const double* src) {
   MGLevel& L = lv[l];
   MGLevel& C = lv[l + 1];
   static const bool fuse = std::getenv("NSFEM_NO_FUSED_FIRST") == nullptr;
-  if (fuse && starts_from_zero(l + 1)) {
+  // (levels smoothed by the lattice kernel run their first step themselves)
+  if (fuse && starts_from_zero(l + 1) && !lattice_ok(C)) {
     double c1, c2, rho;
     cheb_coeffs(C, 0, 0.0, c1, c2, rho);
     launch_spmv_cheb_first(s, *L.R, nv, src, C.b.p, C.mask, C.dinv.p, c2, C.d.p, C.xa.p);
@@ -699,12 +766,12 @@ bool Multigrid::restrict_to(hipStream_t s, size_t l, const double* src) {
   return false;
 }
 
-void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool first_done) {
+const double* Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool first_done) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
   if (truncated() && l + 1 == active) {
     smooth(s, L, b, nullptr, x, trunc_steps, false, identity_rows && l == 0 && trunc_steps >= 2, first_done);
-    return;
+    return x;
   }
   if (l + 1 == lv.size()) {
     if (comm_active() && !smoother_only) {
@@ -729,7 +796,7 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
       }
       comm->allreduce_sum(s, gb.p, ntot);
       if (tail) {
-        tail->vcycle(s, 0, gb.p, gx.p);
+        (void)tail->vcycle(s, 0, gb.p, gx.p);       // (level 0: the result is in gx)
       } else {
         const int tot = n_glob * nv;
         hipLaunchKernelGGL(k_dense_apply, dim3((tot * 64 + 255) / 256), dim3(256), 0, s, n_glob, nv,
@@ -739,14 +806,14 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
       if (glob_idx) {
         hipLaunchKernelGGL(k_glob_gather, dim3(ggrid), dim3(256), 0, s, (int64_t)L.n, nv, gx.p, glob_idx, x);
         NSFEM_HIP(hipGetLastError());
-        return;
+        return x;
       }
       for (int64_t pos = 0; pos < n;) {
         const int64_t g = (off + pos) % ntot, len = std::min<int64_t>(n - pos, ntot - g);
         NSFEM_HIP(hipMemcpyAsync(x + pos, gx.p + g, sizeof(double) * len, hipMemcpyDeviceToDevice, s));
         pos += len;
       }
-      return;
+      return x;
     }
     if (dense_coarse) {
       const int tot = L.n * nv;
@@ -756,11 +823,31 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
     } else {
       smooth(s, L, b, nullptr, x, coarse_steps, false, false, first_done);
     }
-    return;
+    return x;
   }
   MGLevel& C = lv[l + 1];
   const int pre = pre_degree >= 0 ? pre_degree : degree;
   bool child_first = false;
+  if (lattice_ok(L) && !first_done) {
+    // ---- legs of the cycle on the multi-step lattice kernel: every smoothing sequence is ONE
+    // launch (pre-smoothing from zero together with the residual), always out of place
+    const bool ident = identity_rows && l == 0;
+    if (pre > 0) {
+      double* wb = l == 0 ? L.xc.p : x;           // pre-smoothed iterate (level 0: x is the caller's result)
+      smooth_lattice(s, L, b, nullptr, wb, pre, false, L.r.p);
+      child_first = restrict_to(s, l, L.r.p);
+      const double* xc = vcycle(s, l + 1, C.b.p, C.x.p, child_first);
+      launch_spmv_accumulate(s, *L.P, nv, xc, wb, L.mask, 0);
+      double* out = l == 0 ? x : L.xc.p;
+      smooth_lattice(s, L, b, wb, out, degree, ident, nullptr);
+      return out;
+    }
+    child_first = restrict_to(s, l, b);
+    const double* xc = vcycle(s, l + 1, C.b.p, C.x.p, child_first);
+    launch_spmv(s, *L.P, nv, xc, L.xc.p, L.mask, MASK_ZERO);      // x = P x_c (every row stored)
+    smooth_lattice(s, L, b, L.xc.p, x, degree, ident, nullptr);
+    return x;
+  }
   if (pre > 0) {
     smooth(s, L, b, nullptr, x, pre, false, false, first_done);
     if (L.additive) {
@@ -785,7 +872,8 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
     }
     child_first = restrict_to(s, l, src);
   }
-  vcycle(s, l + 1, C.b.p, C.x.p, child_first);
+  const double* xc = vcycle(s, l + 1, C.b.p, C.x.p, child_first);
+  if (xc != C.x.p) NSFEM_HIP(hipMemcpyAsync(C.x.p, xc, sizeof(double) * (size_t)C.n * nv, hipMemcpyDeviceToDevice, s));
   halo_fill(s, C, C.x.p);
   const bool relaxed = relaxed_halo && comm_active() && L.has_halo;
   // relaxed mode: the ghost rows of x take part in the prolongation -- interpolated from the
@@ -795,11 +883,12 @@ void Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool
   else launch_spmv(s, *L.P, nv, C.x.p, x, L.mask, MASK_ZERO, relaxed ? 2 : 0);   // x = P x_c (every row stored)
   smooth(s, L, b, x, x, degree, relaxed, identity_rows && l == 0);
   (void)n;
+  return x;
 }
 
 void Multigrid::apply(hipStream_t s, const double* r, double* z) {
   NSFEM_REQUIRE(ready, "multigrid hierarchy not refreshed");
-  vcycle(s, 0, r, z);
+  (void)vcycle(s, 0, r, z);                         // (level 0: the result is in z)
 }
 
 }  // namespace nsfem

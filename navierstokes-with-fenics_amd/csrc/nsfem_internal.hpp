@@ -146,6 +146,15 @@ struct StencilDict {
   DevBuf<int32_t> len;     // [n_stencils]
   DevBuf<int32_t> off;     // [n_stencils * lmax] column - row
   DevBuf<int32_t> src;     // [n_stencils * lmax] CSR position in the representative row (-1: padding)
+  DevBuf<int32_t> dpos;    // [n_stencils] position of the diagonal entry inside the stencil (-1: none); the
+                           // smoother kernels take 1 / diagonal from the table instead of streaming a dinv vector
+  // 2D lattice structure (lexicographic numbering, row = j * lat_w + i): every offset is dj * lat_w + di
+  // with |di|, |dj| <= lat_r and every row's entries stay inside the lat_w x lat_h box.  Set (lat_w > 0)
+  // only for square scalar operators with <= 64 stencils: the multi-step lattice smoother
+  // (k_cheb_lattice) keeps a tile of x in LDS and needs (dj, di) to address it.
+  int lat_w = 0, lat_h = 0, lat_r = 0;
+  DevBuf<int32_t> pack;    // [n_stencils * lmax] (dj + 8) * 32 + (di + 8)
+  DevBuf<uint8_t> sid8;    // [n_rows] dictionary entry of every row as one byte
 };
 // false: the rows do not repeat (unstructured mesh) -- no dictionary
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
@@ -223,6 +232,15 @@ void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x,
                       const double* dinv, double* d, double c1, double c2, double* xout,
                       const uint8_t* rowmask, int ghost = 0 /* 1: ghost rows keep x */, int phase = 0,
                       int ident = 0 /* 1: rows flagged 1 take xout = b (identity rows) */);
+
+// multi-step lattice smoother (2D lexicographic lattices with a stencil dictionary; linalg.hip)
+bool lattice_smoother_available(const BlockMat& A, int nv);
+int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid);
+void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
+                         const double* d_in, double* x_out, double* d_out, double* r_out,
+                         const uint8_t* mask, int steps, const double* c1, const double* c2, int ident);
+
+int64_t lattice_launch_bytes(const BlockMat& A, int nv, bool from_zero, bool d_in, bool d_out, bool r_out);
 
 // element kernels
 struct MeshDev {
@@ -494,6 +512,7 @@ struct MGLevel {
   const uint8_t* mask = nullptr; // [n * nv]; level 0 uses the context's mask
   DevBuf<uint8_t> own_mask;
   DevBuf<double> dinv, xa, xb, x, b, r, d;
+  DevBuf<double> xc, d2;         // lattice smoother: out-of-place iterate of a cycle leg, second direction buffer
   double lmax = 2.0;
   double ratio = 0.0;            // > 0: Chebyshev interval [lmax / ratio, lmax] of THIS level (truncated solve)
   const BlockMat* P = nullptr;   // transfer to / from the next coarser level
@@ -546,6 +565,8 @@ struct Multigrid : Precond {
   size_t prof_n = 0;
   bool prof_open = false;        // an event pair is open inside the current smooth() call
   int64_t prof_launches = 0;     // launches covered by the recorded pairs
+  int64_t prof_steps = 0;        // smoothing steps covered (the lattice kernel runs several per launch)
+  int64_t prof_bytes = 0;        // algorithmic bytes of the covered launches (lattice kernel: per launch shape)
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
   bool smoother_only = false;    // the last level is smoothed (coarse_steps), never solved globally
   // preconditioner of a Newton matrix with dolfin-style Dirichlet rows: the result carries z = r on
@@ -573,7 +594,13 @@ struct Multigrid : Precond {
   void setup_work(hipStream_t s);
   void refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular);
   void apply(hipStream_t s, const double* r, double* z) override;
-  void vcycle(hipStream_t s, size_t l, const double* b, double* x, bool first_done = false);
+  // result in x (level 0: always) or in a buffer of the level: the returned pointer says where
+  const double* vcycle(hipStream_t s, size_t l, const double* b, double* x, bool first_done = false);
+  // multi-step lattice kernel (2D lexicographic lattices, serial levels): `steps` Chebyshev steps out of
+  // place, optionally the residual of the result as well
+  bool lattice_ok(const MGLevel& L) const;
+  void smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
+                      int steps, bool ident_last, double* r_out);
   void smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
               int steps, bool ghosts_valid = false, bool ident_last = false, bool first_done = false);
   // restriction to level l + 1 fused with the first smoothing step there (when that level starts
@@ -591,6 +618,7 @@ void launch_overlay_ghost(hipStream_t s, int64_t n, const uint8_t* ghost, uint8_
 // communicators (comm.hip)
 Comm* make_local_comm(void* group, int rank);
 Comm* make_rccl_comm(const char* id128, int rank, int size);
+Comm* make_shm_comm(const char* name, int rank, int size, int64_t slot_bytes);
 
 // Jacobi-preconditioned BiCGStab; x holds the initial guess on entry
 int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* x,
@@ -645,6 +673,7 @@ struct nsfem_ctx {
     nsfem::MeshDev mesh;
     nsfem::Pattern pat;
     nsfem::BlockMat K, M, Lc;
+    nsfem::StencilDict dict;                   // lattice levels: rows of K, M and every combination of them
     nsfem::Transfer to_finer;
     std::vector<uint8_t> h_ghost;              // per node (partitioned meshes)
     nsfem::HaloRange halo;

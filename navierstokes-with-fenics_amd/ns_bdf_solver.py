@@ -65,12 +65,8 @@ class ImplicitBDFSolver(InstationarySolverBase):
         self._ctx.set_dirichlet(nat.PRESSURE_PRECOND, nodes, np.zeros(nodes.size))
 
     def _step_options(self):
-        o = self._ctx.default_step_opts()
-        o.newton_atol = self._tol
-        o.newton_rtol = 10.0 * self._tol
-        o.newton_max_iter = self._maxiter
+        o = self._common_step_options(self._ctx.default_step_opts())
         o.convective_form = _FORM_ID[self._form_convective_term]
-        o.matrix_free = {None: 0, False: 1, True: 2}[getattr(self, "matrix_free", None)]
         o.momentum.rtol = self.krylov_rtol
         o.momentum.max_iter = self.krylov_max_iter
         o.momentum.precond = 1

@@ -75,12 +75,8 @@ class IPCSSolver(InstationarySolverBase):
         self._velocity_correction_solver = _DeviceSystem(self, nat.SYS_CORRECTION)
 
     def _step_options(self):
-        o = self._ctx.default_step_opts()
-        o.newton_atol = self._tol
-        o.newton_rtol = 10.0 * self._tol
-        o.newton_max_iter = self._maxiter
+        o = self._common_step_options(self._ctx.default_step_opts())
         o.convective_form = _FORM_ID[self._form_convective_term]
-        o.matrix_free = {None: 0, False: 1, True: 2}[getattr(self, "matrix_free", None)]
         for k in (o.momentum, o.poisson, o.correction):
             k.rtol = self.krylov_rtol
             k.max_iter = self.krylov_max_iter
@@ -88,7 +84,8 @@ class IPCSSolver(InstationarySolverBase):
             o.momentum.precond = o.poisson.precond = 1
         # velocity correction: Chebyshev iteration with a-priori element bounds (no dot products)
         # unless the Jacobi-CG is asked for
-        o.correction.precond = 2 if getattr(self, "mass_solver", "chebyshev") == "chebyshev" else 0
+        assert self.mass_solver in ("chebyshev", "cg")
+        o.correction.precond = 2 if self.mass_solver == "chebyshev" else 0
         return o
 
     def _solve_time_step(self):
@@ -116,7 +113,7 @@ class IPCSSolver(InstationarySolverBase):
             raise RuntimeError("Newton solver did not converge")
         self.last_newton_residuals = residuals
         self._projection_solver.solve(**mg)
-        cheb = getattr(self, "mass_solver", "chebyshev") == "chebyshev"
+        cheb = self.mass_solver == "chebyshev"
         self._velocity_correction_solver.solve(**dict(kw, precond=2 if cheb else 0))
 
     def set_initial_conditions(self, initial_conditions):

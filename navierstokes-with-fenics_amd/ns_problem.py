@@ -334,6 +334,17 @@ class InstationaryProblem(ProblemBase):
         solver = self._navier_stokes_solver
         if hasattr(self, "solver_matrix_free"):      # Jacobian mode of the device step drivers
             solver.matrix_free = self.solver_matrix_free
+        # settings of the device solves (no counterpart in the reference, which calls sparse LU):
+        # problem.solver_settings = {"krylov_rtol": 1e-8, "newton_forcing": 1e-4, "pressure_start":
+        # "extrapolated", "mass_solver": "chebyshev", "mg_truncation": (4, 0.1)}  -- or the string
+        # "throughput" for exactly the set bench.py times (InstationarySolverBase.throughput_settings)
+        settings = getattr(self, "solver_settings", None)
+        if settings == "throughput":
+            solver.throughput_settings()
+        elif settings:
+            for key, value in dict(settings).items():
+                assert hasattr(solver, key), "unknown solver setting %r" % (key,)
+                setattr(solver, key, value)
         solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
         if hasattr(self, "_body_force"):
             solver.set_body_force(self._body_force)

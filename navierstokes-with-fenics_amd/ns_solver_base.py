@@ -461,6 +461,60 @@ class InstationarySolverBase(SolverBase):
         self.matrix_free = None
         #: geometric multigrid preconditioning of the momentum and Poisson solves
         self.use_multigrid = True
+        # ---- solver settings without a counterpart in the reference (it calls sparse LU); the
+        # defaults are the parity settings (direct-solver accuracy), `throughput_settings()` switches
+        # to the ones bench.py times (SURVEY.md section 8d "throughput runs")
+        #: inexact Newton: every Newton linear solve reduces its residual by this factor only (never
+        #: below a tenth of the nonlinear target); 0.0 = exact Newton with `krylov_rtol`.  The Newton
+        #: loop always stops on the reference's criterion, evaluated on the true nonlinear residual
+        self.newton_forcing = 0.0
+        #: start vector of the IPCS projection-step CG: "previous" (p_n) or "extrapolated" (2 p_n - p_(n-1))
+        self.pressure_start = "previous"
+        #: velocity mass solve of the IPCS correction step: "chebyshev" (a-priori bounds, no dots) or "cg"
+        self.mass_solver = "chebyshev"
+        #: truncated velocity multigrid cycle: None = library default (ratio 4, tolerance 0.1),
+        #: 0 / False = full cycle, R or (R, tol) = truncate where c_v K_ii <= R alpha0/k M_ii
+        self.mg_truncation = None
+
+    def throughput_settings(self, krylov_rtol=1.0e-8, newton_forcing=1.0e-4):
+        """The settings of bench.py's timed steps: Krylov rtol 1e-8, inexact Newton (forcing 1e-4),
+        extrapolated pressure start vector, Chebyshev mass solve, truncated velocity cycle.  The
+        Newton stopping criterion stays the reference's (tol, 10 tol on the true residual)."""
+        self.krylov_rtol = krylov_rtol
+        self.newton_forcing = newton_forcing
+        self.pressure_start = "extrapolated"
+        self.mass_solver = "chebyshev"
+        self.mg_truncation = (4.0, 0.1)
+        return self
+
+    def _push_multigrid_settings(self):
+        """truncation of the velocity cycle -> device (whenever the attribute changed)"""
+        want = self.mg_truncation
+        if want == getattr(self, "_mg_truncation_pushed", "unset") or not hasattr(self, "_ctx"):
+            return
+        if want is None:
+            ratio, tol = 4.0, 0.1
+        elif want is False or want == 0:
+            ratio, tol = 0.0, 0.1
+        elif isinstance(want, (tuple, list)):
+            ratio, tol = float(want[0]), float(want[1])
+        else:
+            ratio, tol = float(want), 0.1
+        self._ctx.mg_set_truncation(ratio, tol)
+        self._mg_truncation_pushed = want
+
+    def _common_step_options(self, o):
+        """fields of nsfem_step_opts shared by the IPCS and the monolithic driver"""
+        o.newton_atol = self._tol
+        o.newton_rtol = 10.0 * self._tol
+        o.newton_max_iter = self._maxiter
+        o.matrix_free = {None: 0, False: 1, True: 2}[getattr(self, "matrix_free", None)]
+        assert self.newton_forcing >= 0.0
+        o.newton_forcing = float(self.newton_forcing)
+        assert self.pressure_start in ("previous", "extrapolated")
+        o.pressure_extrapolation = 1 if self.pressure_start == "extrapolated" else 0
+        self._push_multigrid_settings()
+        return o
 
     # -- state ------------------------------------------------------------------
     def _setup_function_spaces(self):

@@ -354,7 +354,11 @@ extern "C" int nsfem_set_dirichlet(nsfem_ctx* ctx, int field, int32_t n, const i
                                     // updates keep the pointers: captured graphs stay valid)
   if (field == NSFEM_VELOCITY) {
     ctx->nbc_v = (int)d.size();
-    if (changed) { ctx->dinv_m_ready = false; ctx->mg_v_dirty = true; }
+    if (changed) {
+      ctx->dinv_m_ready = false;
+      ctx->mg_v_dirty = true;
+      for (nsfem::MGLevel& L : ctx->mg_mv.lv) L.sidm_for = nullptr;   // (the mass smoother shares mask_v)
+    }
   } else {
     ctx->nbc_p = (int)d.size();
     ctx->bc_p_any = -1;            // partitioned meshes: agreed on by all ranks at the next solve
@@ -2322,7 +2326,11 @@ extern "C" int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_
 extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
                                int64_t* algorithmic_bytes) {
   API_BEGIN
-  NSFEM_REQUIRE(ctx && reps > 0 && ms_per_launch, "bad argument");
+  NSFEM_REQUIRE(ctx && reps != 0 && ms_per_launch, "bad argument");
+  // reps < 0 (smoother only): |reps| back-to-back launches without the cache-flushing launches in
+  // between (the operands stay in the 256 MiB Infinity Cache when they fit)
+  const bool warm = reps < 0;
+  if (warm) reps = -reps;
   if (op == NSFEM_OP_CONVECTION_ACTION) {
     // matrix-free convection action at u = U1 in the direction x = U0, each repetition preceded by
     // a cache-flushing product with the block Jacobian array (timed separately and subtracted)
@@ -2376,7 +2384,7 @@ extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_
       if (lattice) {       // the post-smoothing launch of the cycle: `degree` steps from a given iterate
         const double c1[4] = {0.0, 0.3, 0.3, 0.3}, c2[4] = {0.7, 0.7, 0.7, 0.7};
         launch_cheb_lattice(s, *L0.A, nv, L0.xa.p, L0.r.p, nullptr, L0.xb.p, nullptr, nullptr, L0.mask,
-                            lat_steps, c1, c2, 0);
+                            lat_steps, c1, c2, 0, L0.sidm_for == (const void*)L0.A->dict ? L0.sidm.p : nullptr);
       } else {
         launch_cheb_step(s, *L0.A, nv, L0.xa.p, L0.r.p, L0.dinv.p, L0.d.p, 0.3, 0.7, L0.xb.p, L0.mask);
       }
@@ -2404,10 +2412,22 @@ extern "C" int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_
       NSFEM_HIP(hipEventElapsedTime(&t, e0, e1));
       return (double)t;
     };
-    const double t_both = timed(true), t_flush = timed(false);
+    double ms;
+    if (warm) {
+      for (int i = 0; i < 3; ++i) step();
+      NSFEM_HIP(hipEventRecord(e0, s));
+      for (int i = 0; i < reps; ++i) step();
+      NSFEM_HIP(hipEventRecord(e1, s));
+      NSFEM_HIP(hipEventSynchronize(e1));
+      float t = 0.f;
+      NSFEM_HIP(hipEventElapsedTime(&t, e0, e1));
+      ms = (double)t;
+    } else {
+      const double t_both = timed(true), t_flush = timed(false);
+      ms = t_both - t_flush;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    const double ms = t_both - t_flush;
     *ms_per_launch = (double)ms / reps;
     (void)p;
     if (algorithmic_bytes)

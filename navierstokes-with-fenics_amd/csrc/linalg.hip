@@ -955,15 +955,26 @@ __global__ __launch_bounds__(256) void k_spmv_dict_blk(int n_rows, int n_wg, con
 // ------------------------------------------------------------- multi-step lattice smoother
 // S Chebyshev-Jacobi steps of a scalar lattice operator (2D lexicographic numbering, stencil
 // dictionary with (dj, di) offsets) on NV interleaved components in ONE launch.  A workgroup owns
-// an output tile T of TX x TY lattice nodes.  It stages the start vector on the extended tile
-// E = T (+) G, G = R * Mv nodes in every direction (R = stencil reach, Mv = number of operator
-// applications of the launch), in LDS ONCE, then runs the steps out of LDS: stage m computes the
-// new iterate on T (+) R (Mv - m) -- the halo shrinks by the reach per stage, its nodes are
-// computed redundantly by the neighbouring tiles -- writes it back to LDS and goes on.  b, d and the
-// new iterate of a thread's nodes stay in registers; the Jacobi scaling is 1 / diagonal of the
-// row's dictionary entry.  Per launch the vectors are read and written once instead of once per
-// step, and the 9 - 19 gathers per row and step come from LDS instead of the L1 / L2 path that
-// bounds the one-step kernel (k_spmv_dict).
+// an output tile T of TX x TY lattice nodes and keeps the iterate on the extended tile
+// E = T (+) G, G = R * Mv (R = stencil reach, Mv = operator applications of the launch), in LDS:
+// stage m computes the new iterate on T (+) R (Mv - m) -- the halo shrinks by the reach per stage,
+// its nodes are computed redundantly by the neighbouring tiles -- from one LDS buffer into the
+// other (one barrier per stage).  b, d and the new iterate of a thread's nodes stay in registers;
+// the Jacobi scaling is 1 / diagonal of the row's dictionary entry.  Per launch the vectors are
+// read and written once instead of once per step, and the 9 - 19 gathers per row and step come from
+// LDS instead of the L1 / L2 path that bounds the one-step kernel (k_spmv_dict).
+//
+// Layout (what the measurements on the MI355X forced):
+//   * E is 64 nodes wide and stored SPLIT BY PARITY CLASS (i & 1, j & 1): four planes of 32-word rows.
+//     A wavefront covers two full plane rows, lane l at plane word base + l: its 16-byte reads of a
+//     neighbour are 64 consecutive words (the only conflict-free pattern of ds_read_b128), and its
+//     64 nodes belong to ONE class, i.e. away from the domain boundary to ONE dictionary entry;
+//   * every node of E is owned by one (thread, slot): staging E is the owners' own loads, node
+//     coordinates are shifts and masks of the lane / wave / slot ids (no integer division);
+//   * all slots of a wave belong to the same class, so the entry's values and LDS offsets are
+//     loaded ONCE per wave through the scalar cache (wave-uniform addresses of `const __restrict__`
+//     kernel arguments) and stay in SGPRs for all rows of all stages; waves that touch the domain
+//     boundary (several entries) fall back to per-lane table loads.
 //   from_zero : the start vector is zero -- step 0 is the pointwise  d = x = c2 dinv b  (on E)
 //   r_out     : additionally r = b - A x_S on T (pre-smoothing + residual of a V-cycle leg)
 //   d_in/out  : Chebyshev direction carried across launches of one smoothing sequence
@@ -971,30 +982,196 @@ __global__ __launch_bounds__(256) void k_spmv_dict_blk(int n_rows, int n_wg, con
 // partitioned levels (ghost rows) keep the one-step kernels.
 struct LatticeArgs {
   int W, H;                 // lattice: row = j * W + i
-  int TX, TY, ntx, ntiles;  // output tile, tiles per lattice line, tiles
-  int R, S, Mv, G;          // reach, steps, operator applications, halo = R * Mv
-  int EW, EH;               // extended tile
+  int TX, TY, ntx, ntiles;  // output tile (even dimensions), tiles per lattice line, tiles
+  int R, S, Mv, G, Ge;      // reach, steps, operator applications, halo = R * Mv, halo rounded up to even
+  int EHh;                  // rows of a class plane (= (TY + 2 Ge) / 2); a plane row has 32 words
   int from_zero, ident;
+  int lp, n_st;             // table stride (longest stencil rounded up to a multiple of 4), entries
+  int dbg;                  // NSFEM_LATTICE_DBG (measurement only, wrong results): 1 no stages, 4 no row products
   const double *x_in, *b, *d_in;
   double *x_out, *d_out, *r_out;
   const uint8_t *sid, *mask;
-  const int32_t *slen, *spack, *dpos;
-  const double* sval;
-  int lmax, n_st;
+  const uint8_t* sidm;      // optional: per row  entry | (mask of component c) << (6 + c)  in ONE byte
   double c1[4], c2[4];
 };
 
-template <int NV, int K, int NT>
-__global__ __launch_bounds__(NT) void k_cheb_lattice(LatticeArgs a) {
-  extern __shared__ double sh_lat[];
+// per-slot state of a thread: LDS word, lattice row, packed {ring : 8 | mask bits : 8 | entry : 8}
+// (ring = distance to the output tile, 255: no node), b, d and the newest iterate
+// (slot q of a thread sits 128 LDS words and 8 lattice lines after slot 0; the newest iterate is not kept
+// in registers -- every smoothing stage writes it to LDS, the final store reads it back)
+template <int NV, int K>
+struct LatticeSlots {
+  int self0, grow0, gstep;       // LDS word / lattice row of slot 0, lattice-row stride between slots (8 W)
+  int info[K];
+  double bq[K][NV], dq[K][NV];
+  __device__ __forceinline__ int self(int q) const { return self0 + 128 * q; }
+  __device__ __forceinline__ size_t grow(int q) const { return (size_t)(grow0 + q * gstep); }
+};
+#define LAT_RING(q) ((st.info[q] >> 16) & 255)
+#define LAT_MK(q) ((st.info[q] >> 8) & 255)
+#define LAT_ST(q) (st.info[q] & 255)
+
+// stages of a wave whose nodes share ONE dictionary entry: its LP values and LDS offsets (zero padded
+// tables, LP >= the entry's length) are scalar loads issued once, before the first stage
+template <int NV, int K, int LP>
+__device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, LatticeSlots<NV, K>& st,
+                                                       double* __restrict__ xs0, double* __restrict__ xs1,
+                                                       const double* __restrict__ vp,
+                                                       const int32_t* __restrict__ op, double di) {
   typedef double vec __attribute__((ext_vector_type(2)));
-  // LDS: x on E | dictionary entries {value, LDS offset} (16 bytes) | 1 / diagonal | lengths
-  double* __restrict__ xs = sh_lat;
-  const int ne = a.EW * a.EH;
-  vec* __restrict__ ent = reinterpret_cast<vec*>(xs + (((size_t)ne * NV + 1) & ~(size_t)1));
-  double* __restrict__ ldi = reinterpret_cast<double*>(ent + (size_t)a.n_st * a.lmax);
-  int* __restrict__ ll = reinterpret_cast<int*>(ldi + a.n_st);
-  const int tid = threadIdx.x;
+  double v[LP];
+  int o[LP];
+#pragma unroll
+  for (int k = 0; k < LP; ++k) {
+    v[k] = vp[k];
+    o[k] = op[k];
+  }
+  const int n_smooth = a.S - a.from_zero;
+  for (int m = 1; m <= a.Mv; ++m) {
+    const int lim = a.R * (a.Mv - m);
+    const bool smoothing = m <= n_smooth;
+    const int kstep = m - 1 + a.from_zero;
+    const double c1 = smoothing ? a.c1[kstep] : 0.0, c2 = smoothing ? a.c2[kstep] : 0.0;
+    const bool last = smoothing && kstep == a.S - 1;
+    const double* __restrict__ src = (m & 1) ? xs0 : xs1;
+    double* __restrict__ dst = (m & 1) ? xs1 : xs0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const bool on = LAT_RING(q) <= lim;
+      if (__ballot(on) == 0) continue;               // (wave-uniform)
+      if (!on) continue;
+      double acc[NV];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc[c] = 0.0;
+      if (!(a.dbg & 4)) {
+        if (NV == 2) {
+          const vec* __restrict__ xv = reinterpret_cast<const vec*>(src) + st.self(q);
+#pragma unroll
+          for (int k0 = 0; k0 < LP; k0 += 4) {
+            vec x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = xv[o[k0 + u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              acc[0] += v[k0 + u] * x[u].x;
+              acc[NV - 1] += v[k0 + u] * x[u].y;
+            }
+          }
+        } else {
+          const double* __restrict__ xv = src + st.self(q);
+#pragma unroll
+          for (int k0 = 0; k0 < LP; k0 += 4) {
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = xv[o[k0 + u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[0] += v[k0 + u] * x[u];
+          }
+        }
+      }
+      if (smoothing) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          double dn = 0.0, xn = 0.0;
+          if (!((LAT_MK(q) >> c) & 1)) {
+            dn = c2 * di * (st.bq[q][c] - acc[c]);
+            if (c1 != 0.0) dn += c1 * st.dq[q][c];
+            xn = src[(size_t)st.self(q) * NV + c] + dn;
+          } else if (a.ident && last) {
+            xn = st.bq[q][c];
+          }
+          st.dq[q][c] = dn;
+          dst[(size_t)st.self(q) * NV + c] = xn;
+        }
+      } else {                          // residual of the smoothed iterate (ring 0 only)
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          a.r_out[(size_t)st.grow(q) * NV + c] = ((LAT_MK(q) >> c) & 1) ? 0.0 : st.bq[q][c] - acc[c];
+      }
+    }
+    if (m < a.Mv) __syncthreads();
+  }
+}
+
+// the same for a wave whose nodes use several entries (tiles at the domain boundary): per-lane loads
+template <int NV, int K>
+__device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, LatticeSlots<NV, K>& st,
+                                                       double* __restrict__ xs0, double* __restrict__ xs1,
+                                                       const double* __restrict__ tval,
+                                                       const int32_t* __restrict__ toff,
+                                                       const int32_t* __restrict__ tlen,
+                                                       const double* __restrict__ tdinv, int cls) {
+  typedef double vec __attribute__((ext_vector_type(2)));
+  const int n_smooth = a.S - a.from_zero;
+  for (int m = 1; m <= a.Mv; ++m) {
+    const int lim = a.R * (a.Mv - m);
+    const bool smoothing = m <= n_smooth;
+    const int kstep = m - 1 + a.from_zero;
+    const double c1 = smoothing ? a.c1[kstep] : 0.0, c2 = smoothing ? a.c2[kstep] : 0.0;
+    const bool last = smoothing && kstep == a.S - 1;
+    const double* __restrict__ src = (m & 1) ? xs0 : xs1;
+    double* __restrict__ dst = (m & 1) ? xs1 : xs0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      if (LAT_RING(q) > lim) continue;
+      const int sq = LAT_ST(q);
+      const int L = tlen[sq];
+      const double* __restrict__ vp = tval + (size_t)sq * a.lp;
+      const int32_t* __restrict__ op = toff + ((size_t)sq * 4 + cls) * a.lp;
+      const double di = tdinv[sq];
+      double acc[NV];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc[c] = 0.0;
+      for (int k0 = 0; k0 < L && !(a.dbg & 4); k0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double v = vp[k0 + u];
+          const int o = op[k0 + u];
+          if (NV == 2) {
+            const vec xv = reinterpret_cast<const vec*>(src)[st.self(q) + o];
+            acc[0] += v * xv.x;
+            acc[NV - 1] += v * xv.y;
+          } else {
+            acc[0] += v * src[st.self(q) + o];
+          }
+        }
+      }
+      if (smoothing) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          double dn = 0.0, xn = 0.0;
+          if (!((LAT_MK(q) >> c) & 1)) {
+            dn = c2 * di * (st.bq[q][c] - acc[c]);
+            if (c1 != 0.0) dn += c1 * st.dq[q][c];
+            xn = src[(size_t)st.self(q) * NV + c] + dn;
+          } else if (a.ident && last) {
+            xn = st.bq[q][c];
+          }
+          st.dq[q][c] = dn;
+          dst[(size_t)st.self(q) * NV + c] = xn;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          a.r_out[(size_t)st.grow(q) * NV + c] = ((LAT_MK(q) >> c) & 1) ? 0.0 : st.bq[q][c] - acc[c];
+      }
+    }
+    if (m < a.Mv) __syncthreads();
+  }
+}
+
+// The dictionary tables come as separate `const __restrict__` kernel arguments: only then may the compiler
+// read them through the scalar cache (s_load) at wave-uniform addresses.  tval[st * lp + k] values (0 past
+// the stencil's end), toff[(st * 4 + class) * lp + k] LDS offset of the k-th neighbour, tlen[st],
+// tdinv[st] = 1 / diagonal.  512 threads: waves 2c, 2c + 1 own class c; slot q of wave w covers the plane
+// rows 2 (2 q + (w & 1)) and the next.
+template <int NV, int K, int WPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_t* __restrict__ toff,
+                    const int32_t* __restrict__ tlen, const double* __restrict__ tdinv) {
+  extern __shared__ double sh_lat[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD x (workgroups b = x mod 8) walks its own contiguous range of tiles
   const int per = gridDim.x >> 3;
   const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -1002,159 +1179,113 @@ __global__ __launch_bounds__(NT) void k_cheb_lattice(LatticeArgs a) {
   const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
   const int i0 = tx * a.TX, j0 = ty * a.TY;
   const int i1 = min(i0 + a.TX, a.W), j1 = min(j0 + a.TY, a.H);
-  const int G = a.G;
-  for (int t = tid; t < a.n_st * a.lmax; t += NT) {
-    const int pk = a.spack[t];
-    vec e;
-    e.x = a.sval[t];
-    e.y = __longlong_as_double((long long)(((pk >> 5) - 8) * a.EW + ((pk & 31) - 8)));
-    ent[t] = e;
-  }
-  for (int t = tid; t < a.n_st; t += NT) {
-    ll[t] = a.slen[t];
-    const int dp = a.dpos[t];
-    ldi[t] = dp >= 0 ? 1.0 / a.sval[(size_t)t * a.lmax + dp] : 0.0;
-  }
-  if (!a.from_zero) {
-    for (int e = tid; e < ne; e += NT) {
-      const int lj = e / a.EW, li = e - lj * a.EW;
-      const int gj = j0 - G + lj, gi = i0 - G + li;
-      const bool in = gj >= 0 && gj < a.H && gi >= 0 && gi < a.W;
-      const size_t row = (size_t)gj * a.W + gi;
+  const int ox = i0 - a.Ge, oy = j0 - a.Ge;                       // even: local parity = lattice parity
+  const int plane = 32 * a.EHh;
+  double* __restrict__ xs0 = sh_lat;                              // [4 planes][EHh][32][NV], two buffers
+  double* __restrict__ xs1 = sh_lat + (size_t)4 * plane * NV;
+  const int cls = w >> 1, pi = cls & 1, pj = cls >> 1;
+  const int gi = ox + 2 * (lane & 31) + pi;
+  const bool in_x = gi >= 0 && gi < a.W;
+  const int ex = max(max(i0 - gi, gi - (i1 - 1)), 0);
+  const int Go = a.R * max(a.Mv - 1, 0);
+  const int need = a.from_zero ? a.G : Go;                        // nodes whose b / entry / mask are used
+  LatticeSlots<NV, K> st;
+  unsigned long long differs = 0;
+  int stu = -1;
 #pragma unroll
-      for (int c = 0; c < NV; ++c) xs[(size_t)e * NV + c] = in ? a.x_in[row * NV + c] : 0.0;
+  for (int q = 0; q < K; ++q) {
+    const int pr = 2 * (2 * q + (w & 1)) + (lane >> 5);
+    const int gj = oy + 2 * pr + pj;
+    const bool in = in_x && gj >= 0 && gj < a.H;
+    const int ey = max(max(j0 - gj, gj - (j1 - 1)), 0);
+    const int ring = in ? min(max(ex, ey), 255) : 255;
+    if (q == 0) {
+      st.self0 = cls * plane + pr * 32 + (lane & 31);
+      st.grow0 = gj * a.W + gi;
+      st.gstep = 8 * a.W;
     }
-  }
-  __syncthreads();
-  if (a.from_zero) {                    // step 0 from a zero start: pointwise on all of E
-    for (int e = tid; e < ne; e += NT) {
-      const int lj = e / a.EW, li = e - lj * a.EW;
-      const int gj = j0 - G + lj, gi = i0 - G + li;
-      const bool in = gj >= 0 && gj < a.H && gi >= 0 && gi < a.W;
-      const size_t row = (size_t)gj * a.W + gi;
-      const double di = in ? ldi[a.sid[row]] : 0.0;
+    int stq = 0, mkq = 0;
+    double xv[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) st.bq[q][c] = st.dq[q][c] = xv[c] = 0.0;
+    if (ring <= need) {
+      if (a.sidm) {
+        const int sm = a.sidm[st.grow(q)];
+        stq = sm & 63;
+        mkq = sm >> 6;
+      } else {
+        stq = a.sid[st.grow(q)];
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          if (a.mask && a.mask[(size_t)st.grow(q) * NV + c]) mkq |= 1 << c;
+      }
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        st.bq[q][c] = a.b[(size_t)st.grow(q) * NV + c];
+        if (!a.from_zero && a.d_in && ring <= Go) st.dq[q][c] = a.d_in[(size_t)st.grow(q) * NV + c];
+      }
+    }
+    if (!a.from_zero && ring <= a.G) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) xv[c] = a.x_in[(size_t)st.grow(q) * NV + c];
+    }
+    st.info[q] = (ring << 16) | (mkq << 8) | stq;
+    // do the wave's nodes share their dictionary entry?
+    const bool counts = ring <= need;
+    const unsigned long long who = __ballot(counts);
+    if (who != 0) {
+      if (stu < 0) stu = __builtin_amdgcn_readfirstlane(__shfl(stq, __ffsll((long long)who) - 1, 64));
+      differs |= __ballot(counts && stq != stu);
+    }
+    if (a.from_zero) {                    // step 0 from a zero start: pointwise
+      const double di = ring <= need ? tdinv[stq] : 0.0;
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
         double v = 0.0;
-        if (in && !(a.mask && a.mask[row * NV + c])) v = a.c2[0] * di * a.b[row * NV + c];
-        else if (in && a.ident && a.S == 1) v = a.b[row * NV + c];
-        xs[(size_t)e * NV + c] = v;
+        if (ring <= need) {
+          if (!((mkq >> c) & 1)) v = a.c2[0] * di * st.bq[q][c];
+          else if (a.ident && a.S == 1) v = st.bq[q][c];
+        }
+        xv[c] = v;
+        st.dq[q][c] = (mkq >> c) & 1 ? 0.0 : v;
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NV; ++c) xs0[(size_t)st.self(q) * NV + c] = xv[c];
   }
-  // ---- the nodes this thread owns: the box T (+) Go, Go = R (Mv - 1) (clipped to the lattice)
-  const int Go = a.R * max(a.Mv - 1, 0);
-  const int OW = a.TX + 2 * Go, OH = a.TY + 2 * Go;
-  int loc[K], ring[K], st[K], mk[K];
-  double bq[K][NV], dq[K][NV], xq[K][NV];
-#pragma unroll
-  for (int q = 0; q < K; ++q) {
-    const int o = q * NT + tid;
-    const int oj = o / OW, oi = o - oj * OW;
-    const int gj = j0 - Go + oj, gi = i0 - Go + oi;
-    const bool act = o < OW * OH && gj >= 0 && gj < a.H && gi >= 0 && gi < a.W;
-    loc[q] = (oj + G - Go) * a.EW + (oi + G - Go);
-    // distance to the output tile (0 inside); inactive nodes get a distance no stage reaches
-    const int ex = max(max(i0 - gi, gi - (i1 - 1)), 0), ey = max(max(j0 - gj, gj - (j1 - 1)), 0);
-    ring[q] = act ? max(ex, ey) : 0x3fffffff;
-    st[q] = 0;
-    mk[q] = 0;
-#pragma unroll
-    for (int c = 0; c < NV; ++c) bq[q][c] = dq[q][c] = xq[q][c] = 0.0;
-    if (act) {
-      const size_t row = (size_t)gj * a.W + gi;
-      st[q] = a.sid[row];
-#pragma unroll
-      for (int c = 0; c < NV; ++c) {
-        bq[q][c] = a.b[row * NV + c];
-        if (a.mask && a.mask[row * NV + c]) mk[q] |= 1 << c;
-        if (a.from_zero) dq[q][c] = xq[q][c] = xs[(size_t)loc[q] * NV + c];
-        else if (a.d_in) dq[q][c] = a.d_in[row * NV + c];
-      }
+  __syncthreads();                       // E is staged
+  if (!(a.dbg & 1)) {
+    if (differs == 0 && stu >= 0) {
+      const int L = tlen[stu];
+      const double* __restrict__ vp = tval + (size_t)stu * a.lp;
+      const int32_t* __restrict__ op = toff + ((size_t)stu * 4 + cls) * a.lp;
+      const double di = tdinv[stu];
+      if (L <= 8 && a.lp >= 8) lattice_stages_uniform<NV, K, 8>(a, st, xs0, xs1, vp, op, di);
+      else if (L <= 12 && a.lp >= 12) lattice_stages_uniform<NV, K, 12>(a, st, xs0, xs1, vp, op, di);
+      else if (L <= 20 && a.lp >= 20) lattice_stages_uniform<NV, K, 20>(a, st, xs0, xs1, vp, op, di);
+      else lattice_stages_general<NV, K>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
+    } else {
+      lattice_stages_general<NV, K>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
     }
   }
-  const int n_smooth = a.S - a.from_zero;           // smoothing stages with an operator application
-  for (int m = 1; m <= a.Mv; ++m) {
-    const int lim = a.R * (a.Mv - m);
-    const bool smoothing = m <= n_smooth;
-    const int kstep = m - 1 + a.from_zero;
-    const double c1 = smoothing ? a.c1[kstep] : 0.0, c2 = smoothing ? a.c2[kstep] : 0.0;
-    const bool last = smoothing && kstep == a.S - 1;
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      if (ring[q] > lim) continue;
-      double acc[NV];
-#pragma unroll
-      for (int c = 0; c < NV; ++c) acc[c] = 0.0;
-      const int L = ll[st[q]];
-      const vec* __restrict__ ep = ent + (size_t)st[q] * a.lmax;
-      for (int k = 0; k < L; k += 2) {
-        const int k1 = k + 1 < L ? k + 1 : L - 1;
-        const vec e0 = ep[k], e1 = ep[k1];
-        const int o0 = (int)__double_as_longlong(e0.y), o1 = (int)__double_as_longlong(e1.y);
-        const double w1 = k + 1 < L ? e1.x : 0.0;
-        if (NV == 2) {
-          const vec x0 = reinterpret_cast<const vec*>(xs)[loc[q] + o0];
-          const vec x1 = reinterpret_cast<const vec*>(xs)[loc[q] + o1];
-          acc[0] += e0.x * x0.x;
-          acc[NV - 1] += e0.x * x0.y;
-          acc[0] += w1 * x1.x;
-          acc[NV - 1] += w1 * x1.y;
-        } else {
-          const double x0 = xs[loc[q] + o0], x1 = xs[loc[q] + o1];
-          acc[0] += e0.x * x0;
-          acc[0] += w1 * x1;
-        }
-      }
-      if (smoothing) {
-        const double di = ldi[st[q]];
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-          double dn = 0.0, xn = 0.0;
-          if (!((mk[q] >> c) & 1)) {
-            dn = c2 * di * (bq[q][c] - acc[c]);
-            if (c1 != 0.0) dn += c1 * dq[q][c];
-            xn = xs[(size_t)loc[q] * NV + c] + dn;
-          } else if (a.ident && last) {
-            xn = bq[q][c];
-          }
-          dq[q][c] = dn;
-          xq[q][c] = xn;
-        }
-      } else {                          // residual of the smoothed iterate (ring 0 only)
-        const int lj = loc[q] / a.EW, li = loc[q] - lj * a.EW;
-        const size_t row = (size_t)(j0 - G + lj) * a.W + (i0 - G + li);
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-          a.r_out[row * NV + c] = ((mk[q] >> c) & 1) ? 0.0 : bq[q][c] - acc[c];
-      }
-    }
-    if (smoothing && m < a.Mv) {
-      __syncthreads();                  // everybody has read the old iterate
-#pragma unroll
-      for (int q = 0; q < K; ++q)
-        if (ring[q] <= lim) {
-#pragma unroll
-          for (int c = 0; c < NV; ++c) xs[(size_t)loc[q] * NV + c] = xq[q][c];
-        }
-      __syncthreads();
-    }
-  }
+  // the newest iterate sits in the buffer the last smoothing stage wrote (stage m writes buffer m & 1)
+  const int n_smooth = (a.dbg & 1) ? 0 : a.S - a.from_zero;
+  const double* __restrict__ fin = (n_smooth & 1) ? xs1 : xs0;
 #pragma unroll
   for (int q = 0; q < K; ++q)
-    if (ring[q] == 0) {
-      const int lj = loc[q] / a.EW, li = loc[q] - lj * a.EW;
-      const size_t row = (size_t)(j0 - G + lj) * a.W + (i0 - G + li);
+    if (LAT_RING(q) == 0) {
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
-        a.x_out[row * NV + c] = xq[q][c];
-        if (a.d_out) a.d_out[row * NV + c] = dq[q][c];
+        a.x_out[st.grow(q) * NV + c] = fin[(size_t)st.self(q) * NV + c];
+        if (a.d_out) a.d_out[st.grow(q) * NV + c] = st.dq[q][c];
       }
     }
 }
+#undef LAT_RING
+#undef LAT_MK
+#undef LAT_ST
 
-// can `steps` smoothing steps of this level's operator run in the lattice kernel?
+// can smoothing steps of this operator run in the lattice kernel?
 bool lattice_smoother_available(const BlockMat& A, int nv) {
   static const bool on = [] {
     const char* e = std::getenv("NSFEM_LATTICE");
@@ -1168,11 +1299,38 @@ int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resi
   return std::min(4, mv_max + (from_zero ? 1 : 0) - (with_resid ? 1 : 0));
 }
 
+// LDS offsets of the dictionary's neighbours in the class-split tile of plane dimensions (ewh, ehh):
+// the neighbour (dj, di) of a node of class (pi, pj) lies in the plane of class ((pi + di) & 1,
+// (pj + dj) & 1) at the plane position shifted by (floor((pj + dj) / 2), floor((pi + di) / 2))
+static const int32_t* lattice_offsets(hipStream_t s, const StencilDict& d, int ewh, int ehh) {
+  for (auto& e : d.loff_cache)
+    if (e.ewh == ewh && e.ehh == ehh) return e.buf.p;
+  const int plane = ewh * ehh, lp = (d.lmax + 3) & ~3;
+  std::vector<int32_t> t((size_t)d.n_stencils * 4 * lp, 0);
+  auto fl2 = [](int v) { return v >= 0 ? v / 2 : -((1 - v) / 2); };
+  for (int st = 0; st < d.n_stencils; ++st)
+    for (int c = 0; c < 4; ++c) {
+      const int pi = c & 1, pj = (c >> 1) & 1;
+      for (int k = 0; k < d.h_len[st]; ++k) {
+        const int q = d.h_pack[(size_t)st * d.lmax + k], dj = (q >> 5) - 8, di = (q & 31) - 8;
+        const int c2 = ((pi + di) & 1) | (((pj + dj) & 1) << 1);
+        t[((size_t)st * 4 + c) * lp + k] = (c2 - c) * plane + fl2(pj + dj) * ewh + fl2(pi + di);
+      }
+    }
+  d.loff_cache.emplace_back();
+  StencilDict::LatticeOffsets& e = d.loff_cache.back();
+  e.ewh = ewh;
+  e.ehh = ehh;
+  e.buf.upload(t, s);
+  return e.buf.p;
+}
+
 // `steps` (<= lattice_smoother_max_steps) Chebyshev-Jacobi steps with the coefficients c1[k], c2[k]
-// of steps k0 .. k0 + steps - 1 supplied by the caller; x_in == nullptr: zero start (needs k0 == 0)
+// supplied by the caller; x_in == nullptr: zero start
 void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
                          const double* d_in, double* x_out, double* d_out, double* r_out,
-                         const uint8_t* mask, int steps, const double* c1, const double* c2, int ident) {
+                         const uint8_t* mask, int steps, const double* c1, const double* c2, int ident,
+                         const uint8_t* sidm) {
   const StencilDict& d = *A.dict;
   NSFEM_REQUIRE(steps >= 1 && steps <= 4, "lattice smoother: 1..4 steps per launch");
   NSFEM_REQUIRE(x_out != x_in, "lattice smoother works out of place");
@@ -1182,56 +1340,101 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   a.Mv = steps - a.from_zero + (r_out ? 1 : 0);
   NSFEM_REQUIRE(a.Mv >= 0 && a.Mv * a.R <= 8, "lattice smoother: halo too wide");
   a.G = a.R * a.Mv;
-  // tile: large lattices 64 x 32 with 512 threads, smaller ones smaller tiles (enough workgroups to
-  // fill 256 CUs); balanced so that the last tile of a line is not a sliver
+  a.Ge = (a.G + 1) & ~1;
+  // extended tile: 64 nodes wide, 32 / 24 / 16 lines high (4 / 3 / 2 slots per thread); the output tile is
+  // what the halo leaves, balanced over the lattice so that the last tile of a line is not a sliver
   const int64_t nn = (int64_t)a.W * a.H;
-  int tmx, tmy, nt;
-  if (nn >= 600000) { tmx = 64; tmy = 32; nt = 1024; }
-  else if (nn >= 150000) { tmx = 32; tmy = 16; nt = 512; }
-  else { tmx = 16; tmy = 16; nt = 256; }
-  static const int force_tile = [] { const char* e = std::getenv("NSFEM_LATTICE_TILE"); return e ? std::atoi(e) : 0; }();
-  if (force_tile == 1) { tmx = 32; tmy = 32; nt = 1024; }
-  else if (force_tile == 2) { tmx = 32; tmy = 16; nt = 512; }
-  else if (force_tile == 3) { tmx = 64; tmy = 16; nt = 1024; }
-  else if (force_tile == 4) { tmx = 16; tmy = 16; nt = 256; }
+  // (measured, 2D cavity n = 512, 3 steps on the P2 lattice: 24 lines 43 us warm / 49 us cold, 32 lines
+  // 48 / 56 us -- 21 spilled registers under the 128-VGPR cap and 1040 tiles on 512 workgroup slots)
+  int eh = nn >= 20000 ? 24 : 16;
+  static const int force_eh = [] { const char* e = std::getenv("NSFEM_LATTICE_EH"); return e ? std::atoi(e) : 0; }();
+  if (force_eh == 16 || force_eh == 24 || force_eh == 32) eh = force_eh;
+  while (eh < 32 && eh - 2 * a.Ge < 8) eh += 8;
+  const int tmx = 64 - 2 * a.Ge, tmy = eh - 2 * a.Ge;
+  NSFEM_REQUIRE(tmx >= 2 && tmy >= 2, "lattice smoother: halo too wide for the tile");
   const int ncx = (a.W + tmx - 1) / tmx, ncy = (a.H + tmy - 1) / tmy;
-  a.TX = (a.W + ncx - 1) / ncx;
-  a.TY = (a.H + ncy - 1) / ncy;
+  a.TX = std::min(tmx, (((a.W + ncx - 1) / ncx) + 1) & ~1);
+  a.TY = std::min(tmy, (((a.H + ncy - 1) / ncy) + 1) & ~1);
   a.ntx = (a.W + a.TX - 1) / a.TX;
   a.ntiles = a.ntx * ((a.H + a.TY - 1) / a.TY);
-  a.EW = a.TX + 2 * a.G;
-  a.EH = a.TY + 2 * a.G;
-  const int Go = a.R * std::max(a.Mv - 1, 0);
-  constexpr int K = 3;
-  NSFEM_REQUIRE((a.TX + 2 * Go) * (a.TY + 2 * Go) <= K * nt, "lattice smoother: tile does not fit the thread block");
+  a.EHh = eh / 2;
   a.ident = ident;
   a.x_in = x_in; a.b = b; a.d_in = d_in; a.x_out = x_out; a.d_out = d_out; a.r_out = r_out;
   a.sid = d.sid8.p; a.mask = mask;
-  a.slen = d.len.p; a.spack = d.pack.p; a.dpos = d.dpos.p; a.sval = A.dict_vals.p;
-  a.lmax = d.lmax; a.n_st = d.n_stencils;
+  a.sidm = (sidm && d.n_stencils <= 64 && nv <= 2) ? sidm : nullptr;
+  const int32_t* toff = lattice_offsets(s, d, 32, a.EHh);
+  a.lp = (d.lmax + 3) & ~3;
+  a.n_st = d.n_stencils;
+  NSFEM_REQUIRE(A.lat_vals.n == (size_t)d.n_stencils * a.lp, "lattice value table missing");
+  static const int dbg = [] { const char* e = std::getenv("NSFEM_LATTICE_DBG"); return e ? std::atoi(e) : 0; }();
+  a.dbg = dbg;
   for (int k = 0; k < 4; ++k) { a.c1[k] = k < steps ? c1[k] : 0.0; a.c2[k] = k < steps ? c2[k] : 0.0; }
-  const size_t lds = ((((size_t)a.EW * a.EH * nv + 1) & ~(size_t)1)) * 8 + (size_t)d.n_stencils * d.lmax * 16 +
-                     (size_t)d.n_stencils * 12 + 16;
+  const size_t lds = (size_t)2 * 4 * 32 * a.EHh * nv * 8;
   const int grid = (a.ntiles + 7) & ~7;
-#define NSFEM_LAT(NV, NT)                                                                              \
+  // launch shape (tuning switch NSFEM_LATTICE_SHAPE): 0 = 4 waves per SIMD (<= 128 VGPRs: two workgroups per
+  // CU), 1 = 2 waves per SIMD (no register cap: one workgroup per CU)
+  static const int shape = [] { const char* e = std::getenv("NSFEM_LATTICE_SHAPE"); return e ? std::atoi(e) : 0; }();
+#define NSFEM_LAT(NV, KK, WPE)                                                                         \
   do {                                                                                                 \
     static bool attr_set = false;                                                                      \
     if (!attr_set) {                                                                                   \
-      NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, K, NT>),         \
+      NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, KK, WPE>),       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));         \
       attr_set = true;                                                                                 \
     }                                                                                                  \
-    hipLaunchKernelGGL((k_cheb_lattice<NV, K, NT>), dim3(grid), dim3(NT), lds, s, a);                  \
+    hipLaunchKernelGGL((k_cheb_lattice<NV, KK, WPE>), dim3(grid), dim3(512), lds, s, a,                \
+                       (const double*)A.lat_vals.p, toff, (const int32_t*)d.len.p,                     \
+                       (const double*)A.dict_dinv.p);                                                  \
   } while (0)
-  NSFEM_REQUIRE(lds <= 128 * 1024, "lattice smoother: tile does not fit the LDS");
-  if (nv == 2 && nt == 1024) NSFEM_LAT(2, 1024);
-  else if (nv == 2 && nt == 512) NSFEM_LAT(2, 512);
-  else if (nv == 2) NSFEM_LAT(2, 256);
-  else if (nt == 1024) NSFEM_LAT(1, 1024);
-  else if (nt == 512) NSFEM_LAT(1, 512);
-  else NSFEM_LAT(1, 256);
+#define NSFEM_LAT_K(NV, WPE)                        \
+  do {                                              \
+    if (eh == 32) NSFEM_LAT(NV, 4, WPE);            \
+    else if (eh == 24) NSFEM_LAT(NV, 3, WPE);       \
+    else NSFEM_LAT(NV, 2, WPE);                     \
+  } while (0)
+  if (nv == 2 && shape == 1) NSFEM_LAT_K(2, 2);
+  else if (nv == 2) NSFEM_LAT_K(2, 4);
+  else if (shape == 1) NSFEM_LAT_K(1, 2);
+  else NSFEM_LAT_K(1, 4);
+#undef NSFEM_LAT_K
 #undef NSFEM_LAT
   NSFEM_HIP(hipGetLastError());
+}
+
+// entry | mask bits in one byte per row (the lattice kernel reads one byte instead of 1 + NV)
+__global__ __launch_bounds__(256) void k_lattice_sidm(int n, int nv, const uint8_t* __restrict__ sid,
+                                                      const uint8_t* __restrict__ mask, uint8_t* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int v = sid[i];
+    for (int c = 0; c < nv; ++c)
+      if (mask && mask[(size_t)i * nv + c]) v |= 64 << c;
+    out[i] = (uint8_t)v;
+  }
+}
+void launch_lattice_sidm(hipStream_t s, const BlockMat& A, int nv, const uint8_t* mask, uint8_t* out) {
+  const StencilDict& d = *A.dict;
+  NSFEM_REQUIRE(d.n_stencils <= 64 && nv <= 2, "combined entry / mask byte needs <= 64 entries and <= 2 components");
+  hipLaunchKernelGGL(k_lattice_sidm, dim3(std::min((d.n_rows + 255) / 256, 2048)), dim3(256), 0, s, d.n_rows, nv,
+                     d.sid8.p, mask, out);
+  NSFEM_HIP(hipGetLastError());
+}
+
+// value table of the lattice kernel: rows of lp = lmax rounded up to a multiple of 4, zero padded
+__global__ __launch_bounds__(256) void k_dict_pad(int n_st, int lmax, int lp, const double* __restrict__ vals,
+                                                  double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_st * lp) return;
+  const int st = t / lp, k = t - st * lp;
+  out[t] = k < lmax ? vals[(size_t)st * lmax + k] : 0.0;
+}
+
+// 1 / diagonal of every dictionary entry (the smoother kernels' Jacobi scaling)
+__global__ __launch_bounds__(256) void k_dict_dinv(int n_st, int lmax, const int32_t* __restrict__ dpos,
+                                                   const double* __restrict__ vals, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_st) return;
+  const int dp = dpos[t];
+  out[t] = dp >= 0 ? 1.0 / vals[(size_t)t * lmax + dp] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_dict_fill(int64_t len, int bsz, const int32_t* __restrict__ src,
@@ -1408,6 +1611,8 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
       d.lat_h = Hc;
       d.lat_r = reach;
       d.pack.upload(pk, s);
+      d.h_pack = pk;
+      d.h_len.assign(len.begin(), len.end());
       std::vector<uint8_t> s8((size_t)n);
       for (int r = 0; r < n; ++r) s8[r] = (uint8_t)sid[r];
       d.sid8.upload(s8, s);
@@ -1425,6 +1630,19 @@ void BlockMat::sell_update(hipStream_t s) {
     hipLaunchKernelGGL(k_dict_fill, dim3((int)std::min<int64_t>((len * dict->bsz + 255) / 256, 4096)), dim3(256),
                        0, s, len, dict->bsz, dict->src.p, vals.p, dict_vals.p);
     NSFEM_HIP(hipGetLastError());
+    if (!dict->rect && dict->bsz == 1) {
+      if (dict_dinv.n != (size_t)dict->n_stencils) dict_dinv.alloc((size_t)dict->n_stencils);
+      hipLaunchKernelGGL(k_dict_dinv, dim3((dict->n_stencils + 255) / 256), dim3(256), 0, s, dict->n_stencils,
+                         dict->lmax, dict->dpos.p, dict_vals.p, dict_dinv.p);
+      NSFEM_HIP(hipGetLastError());
+      if (dict->lat_w > 0) {
+        const int lp = (dict->lmax + 3) & ~3;
+        if (lat_vals.n != (size_t)dict->n_stencils * lp) lat_vals.alloc((size_t)dict->n_stencils * lp);
+        hipLaunchKernelGGL(k_dict_pad, dim3((dict->n_stencils * lp + 255) / 256), dim3(256), 0, s, dict->n_stencils,
+                           dict->lmax, lp, dict_vals.p, lat_vals.p);
+        NSFEM_HIP(hipGetLastError());
+      }
+    }
     dict_ready = true;
   }
   sell_ready = false;

@@ -351,6 +351,7 @@ void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool s
   for (size_t l = 0; l < n_used; ++l) {
     MGLevel& L = lv[l];
     L.ratio = 0.0;
+    L.sidm_for = nullptr;          // the masks may change below: the lattice kernel's byte array is rebuilt
     const size_t n = (size_t)L.n * nv;
     NSFEM_REQUIRE(cur.size() == n, "multigrid mask size mismatch");
     if (l > 0 || own_mask0) {
@@ -587,6 +588,18 @@ void Multigrid::smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const
     cheb_coeffs(L, k, rho, c1[k], c2[k], rn);
     rho = rn;
   }
+  // entry | mask byte of the level: rebuilt when the operator's dictionary or the level's masks changed
+  // (Multigrid::refresh resets sidm_for)
+  const uint8_t* sidm = nullptr;
+  if (L.A->dict->n_stencils <= 64 && nv <= 2) {
+    if (L.sidm_for != (const void*)L.A->dict || L.sidm_mask != (const void*)L.mask || L.sidm.n != (size_t)L.n) {
+      if (L.sidm.n != (size_t)L.n) L.sidm.alloc((size_t)L.n);
+      launch_lattice_sidm(s, *L.A, nv, L.mask, L.sidm.p);
+      L.sidm_for = (const void*)L.A->dict;
+      L.sidm_mask = (const void*)L.mask;
+    }
+    sidm = L.sidm.p;
+  }
   const bool timed = prof && &L == &lv[0] && prof_n + 2 <= prof_ev.size();
   if (timed) NSFEM_HIP(hipEventRecord(prof_ev[prof_n], s));
   const double* cur = x_in;
@@ -606,7 +619,7 @@ void Multigrid::smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const
     double* d_out = last ? nullptr : (d_cur == L.d.p ? L.d2.p : L.d.p);
     NSFEM_REQUIRE(out != cur, "lattice smoother: the caller must smooth out of place");
     launch_cheb_lattice(s, *L.A, nv, cur, b, d_cur, out, d_out, rr, L.mask, ns, c1 + k, c2 + k,
-                        ident_last && last ? 1 : 0);
+                        ident_last && last ? 1 : 0, sidm);
     if (timed) {
       ++prof_launches;
       prof_steps += ns;

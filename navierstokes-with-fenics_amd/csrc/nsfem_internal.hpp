@@ -155,6 +155,12 @@ struct StencilDict {
   int lat_w = 0, lat_h = 0, lat_r = 0;
   DevBuf<int32_t> pack;    // [n_stencils * lmax] (dj + 8) * 32 + (di + 8)
   DevBuf<uint8_t> sid8;    // [n_rows] dictionary entry of every row as one byte
+  std::vector<int32_t> h_pack, h_len;     // host copies (offset tables of the lattice kernel's LDS layouts)
+  struct LatticeOffsets {
+    int ewh = 0, ehh = 0;
+    DevBuf<int32_t> buf;   // [n_stencils][4 classes][lmax]
+  };
+  mutable std::vector<LatticeOffsets> loff_cache;   // one table per tile shape in use (built on first use)
 };
 // false: the rows do not repeat (unstructured mesh) -- no dictionary
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
@@ -166,6 +172,8 @@ struct BlockMat {
   DevBuf<double> vals;
   const StencilDict* dict = nullptr;      // set: sell_update() also refreshes dict_vals
   DevBuf<double> dict_vals;               // [n_stencils * lmax]
+  DevBuf<double> dict_dinv;               // [n_stencils] 1 / diagonal (scalar square operators)
+  DevBuf<double> lat_vals;                // [n_stencils * lp] zero-padded rows for the lattice kernel
   bool dict_ready = false;
   // copy of the values in the pattern's SELL-64 order (scalar matrices on patterns that have one);
   // refreshed by sell_update() after every change of `vals` -- the SpMV kernels use it only while
@@ -238,7 +246,10 @@ bool lattice_smoother_available(const BlockMat& A, int nv);
 int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid);
 void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
                          const double* d_in, double* x_out, double* d_out, double* r_out,
-                         const uint8_t* mask, int steps, const double* c1, const double* c2, int ident);
+                         const uint8_t* mask, int steps, const double* c1, const double* c2, int ident,
+                         const uint8_t* sidm = nullptr);
+// out[row] = dictionary entry | (mask of component c) << (6 + c): one byte per row for the lattice kernel
+void launch_lattice_sidm(hipStream_t s, const BlockMat& A, int nv, const uint8_t* mask, uint8_t* out);
 
 int64_t lattice_launch_bytes(const BlockMat& A, int nv, bool from_zero, bool d_in, bool d_out, bool r_out);
 
@@ -513,6 +524,9 @@ struct MGLevel {
   DevBuf<uint8_t> own_mask;
   DevBuf<double> dinv, xa, xb, x, b, r, d;
   DevBuf<double> xc, d2;         // lattice smoother: out-of-place iterate of a cycle leg, second direction buffer
+  DevBuf<uint8_t> sidm;          // lattice smoother: dictionary entry | mask bits, one byte per row
+  const void* sidm_for = nullptr; // (dictionary, mask) pair the byte array was built for
+  const void* sidm_mask = nullptr;
   double lmax = 2.0;
   double ratio = 0.0;            // > 0: Chebyshev interval [lmax / ratio, lmax] of THIS level (truncated solve)
   const BlockMat* P = nullptr;   // transfer to / from the next coarser level

@@ -387,6 +387,10 @@ class NsfemContext:
         return int(out.value)
 
     def mg_set_halo_mode(self, relaxed):
+        """partitioned multigrid cycles: False / "exact" one halo exchange per product (the serial cycle),
+        True / "relaxed" one per smoothing sequence (frozen ghosts in between)"""
+        if isinstance(relaxed, str):
+            relaxed = {"exact": False, "relaxed": True}[relaxed]
         self._check(self._lib.nsfem_mg_set_halo_mode(self._h, 1 if relaxed else 0))
 
     def mg_set_truncation(self, max_ratio, coarse_tol=0.1):

@@ -1489,7 +1489,16 @@ extern "C" int nsfem_comm_stats(nsfem_ctx* ctx, int64_t out[4], int reset) {
   if (ctx->comm) {
     out[0] = ctx->comm->n_allreduce; out[1] = ctx->comm->bytes_allreduce;
     out[2] = ctx->comm->n_exchange; out[3] = ctx->comm->bytes_exchange;
-    if (reset) ctx->comm->n_allreduce = ctx->comm->bytes_allreduce = ctx->comm->n_exchange = ctx->comm->bytes_exchange = 0;
+    if (!ctx->comm->hist.empty() && ctx->comm->rank == 0 && !reset) {
+      static const char* kind[3] = {"all-reduce", "exchange", "reverse-add"};
+      for (auto& e : ctx->comm->hist)
+        std::fprintf(stderr, "[comm hist rank 0] %-11s %9lld B x %lld\n", kind[e.first.first], (long long)e.first.second,
+                     (long long)e.second);
+    }
+    if (reset) {
+      ctx->comm->n_allreduce = ctx->comm->bytes_allreduce = ctx->comm->n_exchange = ctx->comm->bytes_exchange = 0;
+      ctx->comm->hist.clear();
+    }
   }
   API_END(ctx)
 }
@@ -1518,6 +1527,10 @@ extern "C" int nsfem_set_overlap(nsfem_ctx* ctx, int enable) {
 extern "C" int nsfem_mg_set_halo_mode(nsfem_ctx* ctx, int relaxed) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
+  // (tried in round 3 and removed: a "local" mode without any exchange inside the velocity cycle -- smoothing,
+  // residuals and transfers on the rank-local operator, ranks coupled through the global coarse problem only --
+  // cut the exchanges of a strong-scaling step from 187 to 133 but tripled the BiCGStab count (5.2 -> 19.5 on 8
+  // ranks, 960^2) and stalled the Poisson CG altogether: dropped interface contributions in the restriction)
   for (Multigrid* mg : {&ctx->mg_v, &ctx->mg_p, &ctx->mg_s, &ctx->mg_m}) mg->relaxed_halo = relaxed != 0;
   ctx->graph_epoch++;
   API_END(ctx)

@@ -1393,8 +1393,10 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
     else NSFEM_LAT(NV, 2, WPE);                     \
   } while (0)
   if (nv == 2 && shape == 1) NSFEM_LAT_K(2, 2);
+  else if (nv == 2 && shape == 2) NSFEM_LAT_K(2, 6);
   else if (nv == 2) NSFEM_LAT_K(2, 4);
   else if (shape == 1) NSFEM_LAT_K(1, 2);
+  else if (shape == 2) NSFEM_LAT_K(1, 6);
   else NSFEM_LAT_K(1, 4);
 #undef NSFEM_LAT_K
 #undef NSFEM_LAT

@@ -10,6 +10,7 @@
 #include <vector>
 #include <stdexcept>
 #include <functional>
+#include <map>
 #include "../../include/nsfem.h"
 
 namespace nsfem {
@@ -450,16 +451,27 @@ struct Comm {
   }
   // traffic counters (calls / payload bytes this rank sends), read through nsfem_comm_stats
   int64_t n_allreduce = 0, n_exchange = 0, bytes_allreduce = 0, bytes_exchange = 0;
-  void count_allreduce(int64_t count) { ++n_allreduce; bytes_allreduce += 8 * count; }
+  // NSFEM_COMM_HIST=1: calls by (kind, payload bytes) since the last reset, printed by nsfem_comm_stats --
+  // the payload size identifies the level / vector a message belongs to
+  std::map<std::pair<int, int64_t>, int64_t> hist;
+  void tally(int kind, int64_t bytes) {
+    static const bool on = std::getenv("NSFEM_COMM_HIST") != nullptr;
+    if (on) ++hist[{kind, bytes}];
+  }
+  void count_allreduce(int64_t count) { ++n_allreduce; bytes_allreduce += 8 * count; tally(0, 8 * count); }
   void count_exchange_add(const HaloRange& h, int width) {
     ++n_exchange;
-    if (h.lists) { bytes_exchange += 8 * (int64_t)width * h.lists->n_recv(); return; }
-    bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.recv_above_cnt : 0) + (down() >= 0 ? h.recv_below_cnt : 0));
+    const int64_t before = bytes_exchange;
+    if (h.lists) bytes_exchange += 8 * (int64_t)width * h.lists->n_recv();
+    else bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.recv_above_cnt : 0) + (down() >= 0 ? h.recv_below_cnt : 0));
+    tally(2, bytes_exchange - before);
   }
   void count_exchange(const HaloRange& h, int width) {
     ++n_exchange;
-    if (h.lists) { bytes_exchange += 8 * (int64_t)width * h.lists->n_send(); return; }
-    bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.send_up_cnt : 0) + (down() >= 0 ? h.send_down_cnt : 0));
+    const int64_t before = bytes_exchange;
+    if (h.lists) bytes_exchange += 8 * (int64_t)width * h.lists->n_send();
+    else bytes_exchange += 8 * (int64_t)width * ((up() >= 0 ? h.send_up_cnt : 0) + (down() >= 0 ? h.send_down_cnt : 0));
+    tally(1, bytes_exchange - before);
   }
 };
 void launch_zero_ghost(hipStream_t s, int64_t n, const uint8_t* mask, double* x);  // x[mask==2]=0

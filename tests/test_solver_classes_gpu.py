@@ -240,6 +240,63 @@ def test_transient_cavity_fused_and_explicit_seam_agree():
     assert close(ub, ipcs_replay(solver, 5, 0.01).vel[1], 1e-6)
 
 
+def test_throughput_settings_through_the_solver_surface_reproduce_the_c_abi_run_bitwise():
+    """The settings bench.py times -- Krylov rtol 1e-8, inexact Newton (forcing 1e-4), extrapolated pressure
+    start vector, Chebyshev mass solve, truncated velocity cycle -- are attributes of the solver classes
+    (`problem.solver_settings`, `InstationarySolverBase.throughput_settings`).  A cavity run through
+    InstationaryProblem / IPCSSolver.solve() / advance_time() with them must equal, BIT FOR BIT, the same steps
+    driven through the raw C ABI (nsfem_step_ipcs with the same nsfem_step_opts and the (alpha, k) sequence the
+    time-stepping object produced); and it must differ from the default (direct-solver accuracy) run by no more
+    than the Krylov tolerance allows."""
+    import _native as nat
+    from bdf_time_stepping import BDFTimeStepping
+    from multigrid import attach_hierarchy
+    n, steps, dt = 64, 6, 0.002
+    spec = CASES["cavity"](n, steps)
+    spec["clock"] = dict(dt=dt, steps=steps)
+    fast = build_problem(dict(spec))
+    fast.solver_settings = "throughput"
+    fast.compute_cfl = False
+    fast.solve_problem()
+    solver = fast._get_solver()
+    assert solver.newton_forcing == 1e-4 and solver.pressure_start == "extrapolated" and solver.krylov_rtol == 1e-8
+    opts = solver._step_options()
+    assert opts.newton_forcing == 1e-4 and opts.pressure_extrapolation == 1 and opts.correction.precond == 2
+    u_cls, p_cls = solver._ctx.get_state(nat.U1), solver._ctx.get_state(nat.P_OLD)
+    # ---- the same steps through the C ABI on a fresh context
+    dm, mesh = solver._dofmap, solver._mesh
+    ctx = nat.NsfemContext(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap, dm.n_p2, dm.n_p1)
+    attach_hierarchy(ctx, mesh)
+    coef = solver._equation_coefficients
+    ctx.set_coeffs(coef["convective_term"], coef["pressure_term"], coef["viscous_term"])
+    bd, bv = solver._dirichlet_bcs["velocity"]
+    ctx.set_dirichlet(nat.VELOCITY, np.asarray(bd, np.int32), np.asarray(bv, float))
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.mg_set_truncation(4.0, 0.1)
+    ts = BDFTimeStepping(0.0, 1.0, desired_start_time_step=dt)
+    o = ctx.default_step_opts()
+    for k in (o.momentum, o.poisson, o.correction):
+        k.rtol, k.max_iter = 1e-8, solver.krylov_max_iter
+    o.momentum.precond = o.poisson.precond = 1
+    o.correction.precond = 2
+    o.newton_forcing, o.pressure_extrapolation = 1e-4, 1
+    for _ in range(steps):
+        ts.update_coefficients()
+        ctx.set_bdf(list(ts.coefficients(derivative=1)), ts.get_next_step_size())
+        ctx.step_ipcs(o)
+        ts.advance_time()
+        ctx.advance(0)
+    u_abi, p_abi = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
+    ctx.close()
+    assert np.array_equal(u_cls, u_abi) and np.array_equal(p_cls, p_abi)
+    # ---- against the default settings (Krylov rtol 1e-12, exact Newton)
+    exact = build_problem(dict(spec))
+    exact.compute_cfl = False
+    exact.solve_problem()
+    u_ex = exact._get_solver()._ctx.get_state(nat.U1)
+    assert 0.0 < np.linalg.norm(u_cls - u_ex) < 1e-6 * np.linalg.norm(u_ex)
+
+
 def test_bdf_channel_flow_pulsating_inlet():
     problem, solver = solve("bdf_pulsating_channel")
     assert problem._time_stepping.step_number == 10

@@ -980,7 +980,7 @@ def cavity_ipcs_bench(args):
     # halo exchange
     part = StripPartition((0.0, 0.0), (1.0, height), n, ny_global, rank, world,
                           coarsest=args.coarsest if args.coarsest else (_serial_coarsest(n) if world == 1 else 64),
-                          global_coarsest=None if world == 1 else 8)
+                          global_coarsest=None if world == 1 else 8, min_rows=1 if world == 1 else args.min_rows)
     dm = part.dofmap
     device = local_rank
     if os.environ.get("NSFEM_SHARE_GPU"):        # rehearsal of several ranks on a one-GPU box
@@ -1363,6 +1363,9 @@ def main():
                     help="R[,TOL]: truncate the velocity multigrid cycle at the first level with "
                          "c_v K_ii <= R alpha0/k M_ii, solved there by Chebyshev iteration to TOL (0: off)")
     ap.add_argument("--coarsest", type=int, default=0, help="cells across the coarsest multigrid mesh (0: default)")
+    ap.add_argument("--min-rows", type=int, default=16,
+                    help="N > 1 (cavity-ipcs): partitioned multigrid levels keep at least this many cell rows per rank; "
+                         "coarser levels run replicated on every rank (no halo exchanges)")
     ap.add_argument("--workload", choices=("cavity-ipcs", "dfg-bdf", "cavity3d-ipcs", "cavity3d-bdf", "tgv3d-ipcs",
                                            "channel3d-bdf"),
                     default="cavity-ipcs",

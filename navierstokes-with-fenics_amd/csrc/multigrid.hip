@@ -887,7 +887,10 @@ const double* Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double
   }
   const double* xc = vcycle(s, l + 1, C.b.p, C.x.p, child_first);
   if (xc != C.x.p) NSFEM_HIP(hipMemcpyAsync(C.x.p, xc, sizeof(double) * (size_t)C.n * nv, hipMemcpyDeviceToDevice, s));
-  halo_fill(s, C, C.x.p);
+  // (a child solved on the replicated global coarse mesh comes back with its ghost rows filled from the global
+  // solution: no exchange)
+  const bool child_global = l + 2 == lv.size() && !(truncated() && l + 2 == active) && comm_active() && !smoother_only;
+  if (!child_global) halo_fill(s, C, C.x.p);
   const bool relaxed = relaxed_halo && comm_active() && L.has_halo;
   // relaxed mode: the ghost rows of x take part in the prolongation -- interpolated from the
   // (exchanged) coarse ghosts, added to ghost values that were valid before (filled for the

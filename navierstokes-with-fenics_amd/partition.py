@@ -72,7 +72,7 @@ class StripPartition:
     """Everything rank ``rank`` of ``size`` needs: local fine mesh + dof map, ghost masks,
     halo ranges, local multigrid levels with prolongations, and the replicated coarsest mesh."""
 
-    def __init__(self, p0, p1, nx, ny, rank, size, coarsest=8, global_coarsest=None):
+    def __init__(self, p0, p1, nx, ny, rank, size, coarsest=8, global_coarsest=None, min_rows=1):
         assert ny % size == 0, "cell rows must divide evenly over the ranks"
         own = ny // size
         self.rank, self.size = rank, size
@@ -112,7 +112,9 @@ class StripPartition:
         # keeps >= coarsest cells per direction
         self.levels = []          # (StripLevel, prolongation csr to the finer level)
         lx, ly, lown, fine_level = nx, ny, own, self.fine
-        while lx % 2 == 0 and lown % 2 == 0 and lown // 2 >= 1 and min(lx, ly) // 2 >= coarsest:
+        # (``min_rows``: strips thinner than that are all halo -- every product of such a level is a
+        # latency-bound message -- so the partitioned levels end there and the replicated hierarchy takes over)
+        while lx % 2 == 0 and lown % 2 == 0 and lown // 2 >= max(1, min_rows) and min(lx, ly) // 2 >= coarsest:
             cx, cy, cown = lx // 2, ly // 2, lown // 2
             lev = StripLevel(p0, p1, cx, cy, rank * cown, cown, g)
             # prolongation for the (cx, lev.rows) -> (lx, 2 * lev.rows) refinement, truncated

@@ -629,6 +629,60 @@ def test_bench_through_rccl_single_rank():
         assert line["config"][key] == line2["config"][key]
 
 
+def test_bench_spawns_its_own_rank_processes_on_a_shared_gpu():
+    """`python bench.py --gpus 2` AS TYPED (no launcher, no WORLD_SIZE): the parent never touches the GPU, spawns one
+    process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), relays rank
+    0's JSON line and exits 0.  On this one-GPU box the two rank PROCESSES share the device (NSFEM_SHARE_GPU), so the
+    collectives go through the host-staged shared-memory communicator (RCCL refuses two ranks on one GPU); everything
+    else -- gloo rendezvous, partitions, halo exchanges, all-reduces, the weak run AND the strong-scaling run of the
+    same job -- is the code path of a multi-GPU node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NSFEM_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "128", "--steps", "4", "--warmup", "2",
+           "--halo-mode", "exact", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["validation"]["max_rel_diff_velocity_vs_exact"] < 1e-6
+    assert line["config"]["comm_per_step_rank0"]["exchanges"] > 0
+    # north_star's strong-scaling quantity rides in the same line: ONE mesh cut into 2 strips
+    st = line["strong"]
+    assert st["cells"] == 128 and st["value"] > 0 and st["comm_per_step"]["exchanges"] > 0
+    # the strong run is the single-rank mesh: same iteration counts as one rank (exact halo mode)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "128", "--steps", "4", "--warmup", "2",
+                          "--timed-only"], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads(one.stdout.strip().splitlines()[-1])
+    for got, key in zip(st["its_per_step_newton_bicgstab_poisson"],
+                        ("newton_its_per_step", "bicgstab_its_per_step", "poisson_cg_its_per_step")):
+        assert abs(got - ref["config"][key]) <= 0.26, key
+    # a rank that dies takes the job down with a non-zero exit code instead of leaving the others in a barrier
+    bad = subprocess.run(cmd + ["--mg-truncation", "not-a-number"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "rank" in bad.stderr
+
+
+def test_message_counts_of_a_strong_scaling_step_on_eight_ranks():
+    """BASELINE's strong-scaling mesh (960 x 960, 8.3 M dofs) on 8 thread ranks, the N > 1 defaults of bench.py (relaxed
+    halo mode, levels thinner than 16 cell rows per rank replicated, no exchange after a globally solved child): the
+    communicator's own counters per time step.  Round 2: 194 exchanges + 45 all-reduces; the iteration counts must
+    stay those of the coupled cycle."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--local-ranks", "8", "--scaling", "strong", "--cells", "960",
+           "--steps", "4", "--warmup", "2", "--timed-only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.strip().splitlines() if l.startswith("{")][-1])
+    comm = line["config"]["comm_per_step_rank0"]
+    print("\n[strong 960^2, 8 ranks] per step: %.1f halo exchanges (%.2f MB), %.1f all-reduces (%.2f MB); its %s" % (
+        comm["exchanges"], comm["exchange_bytes"] / 1e6, comm["allreduce_calls"], comm["allreduce_bytes"] / 1e6,
+        [line["config"][k] for k in ("newton_its_per_step", "bicgstab_its_per_step", "poisson_cg_its_per_step")]))
+    assert comm["exchanges"] <= 135 and comm["allreduce_calls"] <= 46
+    assert line["config"]["newton_its_per_step"] <= 2.01 and line["config"]["bicgstab_its_per_step"] <= 5.5
+    assert line["config"]["poisson_cg_its_per_step"] <= 7.0
+
+
 def _visible_gpus():
     import torch
     return torch.cuda.device_count()          # (does not initialise the GPU on this image)

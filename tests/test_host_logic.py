@@ -679,3 +679,45 @@ def test_graph_partition_of_the_dfg_hierarchy_host_side(size):
         loc = np.unique(p.dofmap.facet_p2_nodes(p.markers.facets_with_id(cyl)))
         found |= set(p.p2_global(dm)[loc].tolist())
     assert found == glob
+
+
+def test_bench_parent_only_spawns_and_supervises_its_ranks():
+    """`python bench.py --gpus N` without a launcher environment: the parent decides to spawn BEFORE the HIP library or
+    torch is loaded (so it never initialises a GPU), hands every child the rendezvous environment of
+    torch.distributed.run, and turns a failing rank into a non-zero exit code.  In this GPU-less container every rank
+    fails at nsfem_create -- the supervision is what is tested; the working path is the -m gpu test
+    test_bench_spawns_its_own_rank_processes_on_a_shared_gpu."""
+    import ast
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    tree = ast.parse(src)
+    # the decision sits above the first import of the native module
+    body = [n for n in tree.body]
+    first_native = next(i for i, n in enumerate(body) if isinstance(n, ast.Import) and any(a.name == "_native" for a in n.names))
+    spawn_if = next(i for i, n in enumerate(body) if isinstance(n, ast.If) and "_ranks_to_spawn" in ast.unparse(n.test))
+    assert spawn_if < first_native
+    ns = {"__file__": os.path.join(root, "bench.py"), "__name__": "bench_head"}
+    exec(compile(ast.Module([n for n in body[:spawn_if] if isinstance(n, (ast.Import, ast.FunctionDef, ast.Assign))],
+                            type_ignores=[]), "bench_head", "exec"), ns)
+    env_keep = {k: os.environ.pop(k) for k in ("WORLD_SIZE",) if k in os.environ}
+    try:
+        assert ns["_ranks_to_spawn"](["--gpus", "4", "--steps", "3"]) == 4
+        assert ns["_ranks_to_spawn"](["--gpus=2"]) == 2
+        assert ns["_ranks_to_spawn"](["--steps", "3"]) == 0 and ns["_ranks_to_spawn"](["--gpus", "1"]) == 0
+        assert ns["_ranks_to_spawn"](["--gpus", "4", "--local-ranks", "4"]) == 0
+        os.environ["WORLD_SIZE"] = "4"
+        assert ns["_ranks_to_spawn"](["--gpus", "4"]) == 0          # launched by torch.distributed.run: a rank, not a parent
+    finally:
+        os.environ.pop("WORLD_SIZE", None)
+        os.environ.update(env_keep)
+    from gpu_common import have_gpu
+    if have_gpu():
+        pytest.skip("a GPU is present: the spawned ranks would run (covered by the -m gpu test)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "16", "--steps", "1",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert "exited with code" in res.stderr and "no ROCm-capable device" in res.stderr
+    assert res.stdout.strip() == ""

@@ -89,6 +89,7 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   nsfem_ctx* fresh = nullptr;
   API_BEGIN
   NSFEM_REQUIRE(m && out, "null argument");
+  refresh_env_switches();
   *out = nullptr;
   NSFEM_REQUIRE(m->dim == 2 || m->dim == 3, "dim must be 2 (triangles) or 3 (tetrahedra)");
   NSFEM_REQUIRE(m->n_cells > 0 && m->n_vertices > 0 && m->n_p2 > 0 && m->n_p1 > 0, "empty mesh");
@@ -1356,6 +1357,7 @@ static void wire_partition(nsfem_ctx* ctx, Multigrid& mg, size_t first_p1, bool 
     for (size_t l = 0; l < ctx->global_tail.size(); ++l) {
       nsfem_ctx::P1Level* c = ctx->global_tail[l];
       t.lv[l].P = &c->to_finer.P; t.lv[l].R = &c->to_finer.R; t.lv[l].h_inj = &c->to_finer.h_inj;
+      t.lv[l].transfer = &c->to_finer;
       t.lv[l + 1].A = momentum ? &c->Lc : &c->K; t.lv[l + 1].n = c->n;
     }
     t.setup_work(ctx->stream);
@@ -1413,6 +1415,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
     for (size_t l = 0; l < ctx->coarse.size(); ++l) {
       nsfem_ctx::P1Level* c = ctx->coarse[l];
       mg.lv[l].P = &c->to_finer.P; mg.lv[l].R = &c->to_finer.R; mg.lv[l].h_inj = &c->to_finer.h_inj;
+      mg.lv[l].transfer = &c->to_finer;
       mg.lv[l + 1].A = &c->K; mg.lv[l + 1].n = c->n;
     }
     wire_partition(ctx, mg, 0, false);
@@ -1434,11 +1437,13 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
     mg.lv.resize(2 + ctx->coarse.size());
     mg.lv[0].A = &ctx->L; mg.lv[0].n = ctx->mesh.n_p2; mg.lv[0].mask = ctx->mask_v.p;
     mg.lv[0].P = &ctx->t_p2p1.P; mg.lv[0].R = &ctx->t_p2p1.R; mg.lv[0].h_inj = &ctx->t_p2p1.h_inj;
+    mg.lv[0].transfer = &ctx->t_p2p1;
     mg.lv[1].A = &ctx->Lc0; mg.lv[1].n = ctx->mesh.n_p1;
     for (size_t l = 0; l < ctx->coarse.size(); ++l) {
       nsfem_ctx::P1Level* c = ctx->coarse[l];
       mg.lv[l + 1].P = &c->to_finer.P; mg.lv[l + 1].R = &c->to_finer.R;
       mg.lv[l + 1].h_inj = &c->to_finer.h_inj;
+      mg.lv[l + 1].transfer = &c->to_finer;
       mg.lv[l + 2].A = &c->Lc; mg.lv[l + 2].n = c->n;
     }
     wire_partition(ctx, mg, 1, true);
@@ -1455,6 +1460,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
     for (size_t l = 0; l < ctx->coarse.size(); ++l) {
       nsfem_ctx::P1Level* c = ctx->coarse[l];
       mg.lv[l].P = &c->to_finer.P; mg.lv[l].R = &c->to_finer.R; mg.lv[l].h_inj = &c->to_finer.h_inj;
+      mg.lv[l].transfer = &c->to_finer;
       mg.lv[l + 1].A = &c->K; mg.lv[l + 1].n = c->n;
     }
     wire_partition(ctx, mg, 0, false);

@@ -992,6 +992,12 @@ struct LatticeArgs {
   double *x_out, *d_out, *r_out;
   const uint8_t *sid, *mask;
   const uint8_t* sidm;      // optional: per row  entry | (mask of component c) << (6 + c)  in ONE byte
+  // transfers of a multigrid cycle fused into the staging (lattice hierarchies: the coarse lattice is the
+  // even-even sublattice, odd nodes interpolate their two neighbours along x, y or the (1,1) diagonal):
+  const double* xc;         // start vector = [x_in +] P xc  (prolongation of the coarse correction; Wc = (W + 1) / 2)
+  const double* rf;         // right-hand side = R rf  (restriction of the finer level's vector, lattice 2 W - 1 wide),
+  double* b_out;            //   stored to b_out on the output tile for the later launches of the level
+  int Wc, Wf, Hf;
   double c1[4], c2[4];
 };
 
@@ -1188,7 +1194,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   const bool in_x = gi >= 0 && gi < a.W;
   const int ex = max(max(i0 - gi, gi - (i1 - 1)), 0);
   const int Go = a.R * max(a.Mv - 1, 0);
-  const int need = a.from_zero ? a.G : Go;                        // nodes whose b / entry / mask are used
+  const int need = (a.from_zero || a.xc) ? a.G : Go;              // nodes whose b / entry / mask are used
   LatticeSlots<NV, K> st;
   unsigned long long differs = 0;
   int stu = -1;
@@ -1219,15 +1225,50 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
         for (int c = 0; c < NV; ++c)
           if (a.mask && a.mask[(size_t)st.grow(q) * NV + c]) mkq |= 1 << c;
       }
+      if (a.rf) {
+        // b = R rf: the node's own fine value + half of its six fine neighbours (ascending fine index, the
+        // order of the CSR row of R = P^T); rows flagged in the mask get 0
+        const int fi = 2 * gi, fj = 2 * gj;
+        const size_t fb = (size_t)fj * a.Wf + fi;
+        const bool l_ = fi > 0, r_ = fi < a.Wf - 1, d_ = fj > 0, u_ = fj < a.Hf - 1;
 #pragma unroll
-      for (int c = 0; c < NV; ++c) {
-        st.bq[q][c] = a.b[(size_t)st.grow(q) * NV + c];
-        if (!a.from_zero && a.d_in && ring <= Go) st.dq[q][c] = a.d_in[(size_t)st.grow(q) * NV + c];
+        for (int c = 0; c < NV; ++c) {
+          double v = 0.0;
+          if (d_ && l_) v += 0.5 * a.rf[(fb - a.Wf - 1) * NV + c];
+          if (d_) v += 0.5 * a.rf[(fb - a.Wf) * NV + c];
+          if (l_) v += 0.5 * a.rf[(fb - 1) * NV + c];
+          v += a.rf[fb * NV + c];
+          if (r_) v += 0.5 * a.rf[(fb + 1) * NV + c];
+          if (u_) v += 0.5 * a.rf[(fb + a.Wf) * NV + c];
+          if (u_ && r_) v += 0.5 * a.rf[(fb + a.Wf + 1) * NV + c];
+          if ((mkq >> c) & 1) v = 0.0;
+          st.bq[q][c] = v;
+          if (ring == 0) a.b_out[(size_t)st.grow(q) * NV + c] = v;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) st.bq[q][c] = a.b[(size_t)st.grow(q) * NV + c];
       }
+#pragma unroll
+      for (int c = 0; c < NV; ++c)
+        if (!a.from_zero && a.d_in && ring <= Go) st.dq[q][c] = a.d_in[(size_t)st.grow(q) * NV + c];
     }
     if (!a.from_zero && ring <= a.G) {
+      if (a.xc) {
+        // start vector = [x_in +] P xc: even-even nodes copy their coarse node, the others average the two
+        // coarse nodes (I, J) and (I + pi, J + pj); rows flagged in the mask get 0
+        const size_t c0 = (size_t)(gj >> 1) * a.Wc + (gi >> 1), c1 = c0 + pi + (size_t)pj * a.Wc;
 #pragma unroll
-      for (int c = 0; c < NV; ++c) xv[c] = a.x_in[(size_t)st.grow(q) * NV + c];
+        for (int c = 0; c < NV; ++c) {
+          double v = a.xc[c0 * NV + c];
+          if (cls != 0) v = 0.5 * v + 0.5 * a.xc[c1 * NV + c];
+          if (a.x_in) v = a.x_in[(size_t)st.grow(q) * NV + c] + v;
+          xv[c] = (mkq >> c) & 1 ? 0.0 : v;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) xv[c] = a.x_in[(size_t)st.grow(q) * NV + c];
+      }
     }
     st.info[q] = (ring << 16) | (mkq << 8) | stq;
     // do the wave's nodes share their dictionary entry?
@@ -1286,11 +1327,17 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
 #undef LAT_ST
 
 // can smoothing steps of this operator run in the lattice kernel?
+// tuning / test switches, re-read whenever a context is created (tests switch them between contexts)
+static bool g_lattice_on = true, g_lattice_transfers_on = true;
+void refresh_env_switches() {
+  const char* e = std::getenv("NSFEM_LATTICE");
+  g_lattice_on = e ? std::atoi(e) != 0 : true;
+  e = std::getenv("NSFEM_LATTICE_TRANSFERS");
+  g_lattice_transfers_on = e ? std::atoi(e) != 0 : true;
+}
+bool lattice_transfers_enabled() { return g_lattice_transfers_on; }
 bool lattice_smoother_available(const BlockMat& A, int nv) {
-  static const bool on = [] {
-    const char* e = std::getenv("NSFEM_LATTICE");
-    return e ? std::atoi(e) != 0 : true;
-  }();
+  const bool on = g_lattice_on;
   return on && A.dict_ready && A.dict && A.dict->lat_w > 0 && A.br == 1 && A.bc == 1 && (nv == 1 || nv == 2);
 }
 int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid) {
@@ -1330,13 +1377,16 @@ static const int32_t* lattice_offsets(hipStream_t s, const StencilDict& d, int e
 void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
                          const double* d_in, double* x_out, double* d_out, double* r_out,
                          const uint8_t* mask, int steps, const double* c1, const double* c2, int ident,
-                         const uint8_t* sidm) {
+                         const uint8_t* sidm, const double* xc, const double* rf, double* b_out) {
   const StencilDict& d = *A.dict;
   NSFEM_REQUIRE(steps >= 1 && steps <= 4, "lattice smoother: 1..4 steps per launch");
   NSFEM_REQUIRE(x_out != x_in, "lattice smoother works out of place");
+  NSFEM_REQUIRE(!rf || b_out, "fused restriction needs a place to keep the right-hand side");
   LatticeArgs a;
   a.W = d.lat_w; a.H = d.lat_h; a.R = d.lat_r; a.S = steps;
-  a.from_zero = x_in ? 0 : 1;
+  a.from_zero = (x_in || xc) ? 0 : 1;
+  a.xc = xc; a.rf = rf; a.b_out = b_out;
+  a.Wc = (d.lat_w + 1) / 2; a.Wf = 2 * d.lat_w - 1; a.Hf = 2 * d.lat_h - 1;
   a.Mv = steps - a.from_zero + (r_out ? 1 : 0);
   NSFEM_REQUIRE(a.Mv >= 0 && a.Mv * a.R <= 8, "lattice smoother: halo too wide");
   a.G = a.R * a.Mv;

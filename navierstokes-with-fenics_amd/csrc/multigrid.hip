@@ -221,6 +221,8 @@ void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* row
   patP.col.upload(patP.h_col, s);
   P.pat = &patP; P.br = P.bc = 1;
   P.vals.upload(val, (size_t)nnz, s);
+  h_val.assign(val, val + nnz);
+  lattice = -1;
   NSFEM_HIP(hipStreamSynchronize(s));
   // transpose
   std::vector<int32_t> rp((size_t)n_coarse + 1, 0), rc((size_t)nnz);
@@ -247,6 +249,32 @@ void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* row
   R.vals.upload(rv, s);
   build_rowblocks(patP, s);
   build_rowblocks(patR, s);
+}
+
+// Is P the interpolation between a wf x hf lattice (rows, lexicographic) and its even-even sublattice
+// ((wf + 1) / 2 wide): even-even rows one entry 1, the other rows 1/2 at the two coarse nodes (I, J) and
+// (I + (i & 1), J + (j & 1))?  (Checked once, on the host copy; the lattice kernel then applies P and R = P^T
+// from this rule instead of launching the CSR kernels.)
+bool Transfer::is_lattice(int wf, int hf) {
+  if (lattice >= 0) return lattice == 1;
+  lattice = 0;
+  if (wf < 3 || hf < 3 || (wf & 1) == 0 || (hf & 1) == 0) return false;
+  const int wc = (wf + 1) / 2, hc = (hf + 1) / 2;
+  if (patP.n_rows != wf * hf || patP.n_cols != wc * hc || h_val.size() != (size_t)patP.nnz) return false;
+  for (int j = 0; j < hf; ++j)
+    for (int i = 0; i < wf; ++i) {
+      const int r = j * wf + i, b = patP.h_rowptr[r], n = patP.h_rowptr[r + 1] - b;
+      const int pi = i & 1, pj = j & 1, c0 = (j >> 1) * wc + (i >> 1), c1 = c0 + pi + pj * wc;
+      if (!pi && !pj) {
+        if (n != 1 || patP.h_col[b] != c0 || h_val[b] != 1.0) return false;
+      } else {
+        if (n != 2 || h_val[b] != 0.5 || h_val[b + 1] != 0.5) return false;
+        const int a0 = patP.h_col[b], a1 = patP.h_col[b + 1];
+        if (!((a0 == c0 && a1 == c1) || (a0 == c1 && a1 == c0))) return false;
+      }
+    }
+  lattice = 1;
+  return true;
 }
 
 static void invert_dense(std::vector<double>& a, int n) {
@@ -580,7 +608,8 @@ int64_t lattice_launch_bytes(const BlockMat& A, int nv, bool from_zero, bool d_i
 }
 
 void Multigrid::smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const double* x_in,
-                               double* x_out, int steps, bool ident_last, double* r_out) {
+                               double* x_out, int steps, bool ident_last, double* r_out, const double* xc,
+                               const double* rf) {
   NSFEM_REQUIRE(steps >= 1 && steps <= 64, "smoothing sequence too long");
   double c1[64], c2[64], rho = 0.0;
   for (int k = 0; k < steps; ++k) {
@@ -606,7 +635,9 @@ void Multigrid::smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const
   const double* d_cur = nullptr;
   int k = 0;
   while (k < steps) {
-    const bool fz = cur == nullptr;
+    const double* xc_k = k == 0 ? xc : nullptr;          // the first launch applies the fused transfers
+    const double* rf_k = k == 0 ? rf : nullptr;
+    const bool fz = cur == nullptr && xc_k == nullptr;
     int ns = std::min(steps - k, lattice_smoother_max_steps(*L.A, fz, false));
     double* rr = nullptr;
     if (k + ns == steps && r_out) {          // the residual rides along when the halo allows it
@@ -619,11 +650,13 @@ void Multigrid::smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const
     double* d_out = last ? nullptr : (d_cur == L.d.p ? L.d2.p : L.d.p);
     NSFEM_REQUIRE(out != cur, "lattice smoother: the caller must smooth out of place");
     launch_cheb_lattice(s, *L.A, nv, cur, b, d_cur, out, d_out, rr, L.mask, ns, c1 + k, c2 + k,
-                        ident_last && last ? 1 : 0, sidm);
+                        ident_last && last ? 1 : 0, sidm, xc_k, rf_k, rf_k ? const_cast<double*>(b) : nullptr);
     if (timed) {
       ++prof_launches;
       prof_steps += ns;
-      prof_bytes += lattice_launch_bytes(*L.A, nv, fz, d_cur != nullptr, d_out != nullptr, rr != nullptr);
+      // (a fused prolongation replaces the read of x_in by the 4 x smaller coarse vector unless both are read)
+      prof_bytes += lattice_launch_bytes(*L.A, nv, fz || (xc_k && !cur), d_cur != nullptr, d_out != nullptr, rr != nullptr) +
+                    (xc_k ? 2 * (int64_t)L.n * nv : 0);
     }
     cur = out;
     d_cur = d_out;
@@ -779,9 +812,73 @@ bool Multigrid::restrict_to(hipStream_t s, size_t l, const double* src) {
   return false;
 }
 
+bool Multigrid::transfer_lattice(size_t l) {
+  if (!lattice_transfers_enabled() || l + 1 >= lv.size()) return false;
+  MGLevel& L = lv[l];
+  if (!L.transfer || !lattice_ok(L) || !lattice_ok(lv[l + 1])) return false;
+  const StencilDict& df = *L.A->dict;
+  const StencilDict& dc = *lv[l + 1].A->dict;
+  if (dc.lat_w != (df.lat_w + 1) / 2 || dc.lat_h != (df.lat_h + 1) / 2) return false;
+  return L.transfer->is_lattice(df.lat_w, df.lat_h);
+}
+
+// Cycle leg on the multi-step lattice kernel: every smoothing sequence is ONE launch, always out of place;
+// pre-smoothing from zero together with the residual; where the transfer to the next level is the lattice
+// interpolation, the prolongation is applied by the post-smoothing launch's staging and the restriction by
+// the first launch of the coarser level (rf != nullptr: b = R rf has not been formed yet -- this level's
+// first launch forms and stores it).
+const double* Multigrid::vcycle_lattice(hipStream_t s, size_t l, const double* b, double* x, const double* rf) {
+  MGLevel& L = lv[l];
+  if (truncated() && l + 1 == active) {
+    smooth_lattice(s, L, b, nullptr, x, trunc_steps, identity_rows && l == 0 && trunc_steps >= 2, nullptr, nullptr, rf);
+    return x;
+  }
+  if (l + 1 == lv.size()) {                       // smoothed coarsest level
+    smooth_lattice(s, L, b, nullptr, x, coarse_steps, false, nullptr, nullptr, rf);
+    return x;
+  }
+  MGLevel& C = lv[l + 1];
+  const int pre = pre_degree >= 0 ? pre_degree : degree;
+  const bool ident = identity_rows && l == 0;
+  const bool tl = transfer_lattice(l);
+  // the child forms its own right-hand side when it begins with a smoothing launch from zero
+  const bool child_lattice = tl && starts_from_zero(l + 1) &&
+                             !((l + 2 == lv.size()) && !(truncated() && l + 2 == active) && dense_coarse);
+  auto descend = [&](const double* fine) -> const double* {
+    if (child_lattice) return vcycle_lattice(s, l + 1, C.b.p, C.x.p, fine);
+    launch_spmv(s, *L.R, nv, fine, C.b.p, C.mask, MASK_ZERO);
+    return vcycle(s, l + 1, C.b.p, C.x.p, false);
+  };
+  if (pre > 0) {
+    double* wb = l == 0 ? L.xc.p : x;             // pre-smoothed iterate (level 0: x is the caller's result)
+    smooth_lattice(s, L, b, nullptr, wb, pre, false, L.r.p, nullptr, rf);
+    const double* xc = descend(L.r.p);
+    double* out = l == 0 ? x : L.xc.p;
+    if (tl) {
+      smooth_lattice(s, L, b, wb, out, degree, ident, nullptr, xc, nullptr);
+    } else {
+      launch_spmv_accumulate(s, *L.P, nv, xc, wb, L.mask, 0);
+      smooth_lattice(s, L, b, wb, out, degree, ident, nullptr);
+    }
+    return out;
+  }
+  NSFEM_REQUIRE(!rf, "a level without pre-smoothing cannot form its right-hand side in a smoothing launch");
+  const double* xc = descend(b);
+  if (tl) {
+    smooth_lattice(s, L, b, nullptr, x, degree, ident, nullptr, xc, nullptr);
+  } else {
+    launch_spmv(s, *L.P, nv, xc, L.xc.p, L.mask, MASK_ZERO);      // x = P x_c (every row stored)
+    smooth_lattice(s, L, b, L.xc.p, x, degree, ident, nullptr);
+  }
+  return x;
+}
+
 const double* Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double* x, bool first_done) {
   MGLevel& L = lv[l];
   const int64_t n = (int64_t)L.n * nv;
+  if (lattice_ok(L) && !first_done && !(l + 1 == lv.size() && !(truncated() && l + 1 == active) &&
+                                        ((comm_active() && !smoother_only) || dense_coarse)))
+    return vcycle_lattice(s, l, b, x, nullptr);
   if (truncated() && l + 1 == active) {
     smooth(s, L, b, nullptr, x, trunc_steps, false, identity_rows && l == 0 && trunc_steps >= 2, first_done);
     return x;
@@ -841,26 +938,6 @@ const double* Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double
   MGLevel& C = lv[l + 1];
   const int pre = pre_degree >= 0 ? pre_degree : degree;
   bool child_first = false;
-  if (lattice_ok(L) && !first_done) {
-    // ---- legs of the cycle on the multi-step lattice kernel: every smoothing sequence is ONE
-    // launch (pre-smoothing from zero together with the residual), always out of place
-    const bool ident = identity_rows && l == 0;
-    if (pre > 0) {
-      double* wb = l == 0 ? L.xc.p : x;           // pre-smoothed iterate (level 0: x is the caller's result)
-      smooth_lattice(s, L, b, nullptr, wb, pre, false, L.r.p);
-      child_first = restrict_to(s, l, L.r.p);
-      const double* xc = vcycle(s, l + 1, C.b.p, C.x.p, child_first);
-      launch_spmv_accumulate(s, *L.P, nv, xc, wb, L.mask, 0);
-      double* out = l == 0 ? x : L.xc.p;
-      smooth_lattice(s, L, b, wb, out, degree, ident, nullptr);
-      return out;
-    }
-    child_first = restrict_to(s, l, b);
-    const double* xc = vcycle(s, l + 1, C.b.p, C.x.p, child_first);
-    launch_spmv(s, *L.P, nv, xc, L.xc.p, L.mask, MASK_ZERO);      // x = P x_c (every row stored)
-    smooth_lattice(s, L, b, L.xc.p, x, degree, ident, nullptr);
-    return x;
-  }
   if (pre > 0) {
     smooth(s, L, b, nullptr, x, pre, false, false, first_done);
     if (L.additive) {

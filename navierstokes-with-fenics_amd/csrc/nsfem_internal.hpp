@@ -243,12 +243,15 @@ void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x,
                       int ident = 0 /* 1: rows flagged 1 take xout = b (identity rows) */);
 
 // multi-step lattice smoother (2D lexicographic lattices with a stencil dictionary; linalg.hip)
+void refresh_env_switches();            // NSFEM_LATTICE, NSFEM_LATTICE_TRANSFERS (re-read by nsfem_create)
+bool lattice_transfers_enabled();
 bool lattice_smoother_available(const BlockMat& A, int nv);
 int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid);
 void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
                          const double* d_in, double* x_out, double* d_out, double* r_out,
                          const uint8_t* mask, int steps, const double* c1, const double* c2, int ident,
-                         const uint8_t* sidm = nullptr);
+                         const uint8_t* sidm = nullptr, const double* xc = nullptr, const double* rf = nullptr,
+                         double* b_out = nullptr);
 // out[row] = dictionary entry | (mask of component c) << (6 + c): one byte per row for the lattice kernel
 void launch_lattice_sidm(hipStream_t s, const BlockMat& A, int nv, const uint8_t* mask, uint8_t* out);
 
@@ -525,6 +528,9 @@ struct Transfer {
   Pattern patP, patR;
   BlockMat P, R;
   std::vector<int32_t> h_inj;   // coarse node -> coinciding finer-level node
+  std::vector<double> h_val;    // host copy of P's values (lattice check)
+  int lattice = -1;             // P is the lattice interpolation of a (2 Wc - 1)-wide fine lattice: -1 unknown, 0 no, 1 yes
+  bool is_lattice(int wf, int hf);
   void build(hipStream_t s, int n_fine, int n_coarse, const int32_t* rowptr, const int32_t* col,
              const double* val);
 };
@@ -543,6 +549,7 @@ struct MGLevel {
   double ratio = 0.0;            // > 0: Chebyshev interval [lmax / ratio, lmax] of THIS level (truncated solve)
   const BlockMat* P = nullptr;   // transfer to / from the next coarser level
   const BlockMat* R = nullptr;
+  Transfer* transfer = nullptr;  // the object P and R belong to (lattice check), when known
   const std::vector<int32_t>* h_inj = nullptr;
   // partitioned meshes
   const std::vector<uint8_t>* h_ghost = nullptr;   // per node: nonzero = ghost
@@ -625,8 +632,13 @@ struct Multigrid : Precond {
   // multi-step lattice kernel (2D lexicographic lattices, serial levels): `steps` Chebyshev steps out of
   // place, optionally the residual of the result as well
   bool lattice_ok(const MGLevel& L) const;
+  // xc: the start vector is [x_in +] P xc (prolongation fused into the staging); rf: b = R rf is computed by the
+  // first launch and stored to `b` (restriction fused)
   void smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
-                      int steps, bool ident_last, double* r_out);
+                      int steps, bool ident_last, double* r_out, const double* xc = nullptr,
+                      const double* rf = nullptr);
+  bool transfer_lattice(size_t l);      // levels l, l + 1: lattice operators and a lattice interpolation between them
+  const double* vcycle_lattice(hipStream_t s, size_t l, const double* b, double* x, const double* rf);
   void smooth(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,
               int steps, bool ghosts_valid = false, bool ident_last = false, bool first_done = false);
   // restriction to level l + 1 fused with the first smoothing step there (when that level starts

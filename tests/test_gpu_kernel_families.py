@@ -218,3 +218,60 @@ def test_unstructured_mesh_has_no_dictionary_and_no_lattice():
     with pytest.raises(nat.NativeError):
         ctx.kernel_apply(0, 2, x, family=LATTICE, epilogue=3, steps=1, b=x, c1=[0.0], c2=[0.5])
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [64, 48])
+def test_cycles_on_the_lattice_kernel_equal_the_one_step_cycles(n, monkeypatch):
+    """IPCS steps of the cavity with multigrid preconditioning three ways: one-step kernels only (NSFEM_LATTICE=0),
+    the multi-step lattice kernel with explicit transfer launches (NSFEM_LATTICE_TRANSFERS=0), and with the
+    prolongations / restrictions applied inside its staging (default).  Same arithmetic up to summation order:
+    identical Newton counts, Krylov counts within one, fields equal far below the solver tolerance; and the
+    converged fields against the LU oracle."""
+    from gpu_common import box, cavity_bc
+    from multigrid import attach_hierarchy
+    mesh, dm, marks = box(n, n)
+    mesh.structured = ((0.0, 0.0), (1.0, 1.0), n, n)
+    bd, bv = cavity_bc(dm, marks)
+    out = {}
+    for tag, env in (("one-step", {"NSFEM_LATTICE": "0"}), ("lattice", {"NSFEM_LATTICE_TRANSFERS": "0"}), ("fused", {})):
+        for k in ("NSFEM_LATTICE", "NSFEM_LATTICE_TRANSFERS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = context(mesh, dm)
+        attach_hierarchy(ctx, mesh, coarsest=4)
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, bd.astype(np.int32), bv)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        ctx.mg_set_truncation(0.0, 0.1)            # full cycles: every level, every transfer
+        opts = ctx.default_step_opts()
+        for o in (opts.momentum, opts.poisson, opts.correction):
+            o.rtol = 1e-12
+        opts.momentum.precond = opts.poisson.precond = 1
+        opts.correction.precond = 2
+        its = []
+        for step in range(3):
+            ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), 0.01)
+            info = ctx.step_ipcs(opts)
+            ctx.advance(0)
+            its.append((info.newton_iterations, info.krylov_iterations_momentum, info.krylov_iterations_poisson))
+        out[tag] = (ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD), its, ctx.smoother_info())
+        ctx.close()
+    assert not out["one-step"][3]["multistep_lattice_kernel"] and out["fused"][3]["multistep_lattice_kernel"]
+    u0, p0, its0, _ = out["one-step"]
+    for tag in ("lattice", "fused"):
+        u, p, its, _ = out[tag]
+        for a, b in zip(its0, its):
+            assert a[0] == b[0] and abs(a[1] - b[1]) <= 1 and abs(a[2] - b[2]) <= 1, (tag, its0, its)
+        assert rel(u, u0) < 1e-10 and rel(p - p.mean(), p0 - p0.mean()) < 1e-9, tag
+    if n == 48:
+        return
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.IPCSOracle(s, dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None),
+                        refactor_every_step=False)
+    for step in range(3):
+        orc.step(fo.bdf_alpha(step, 1.0), 0.01, (bd, bv))
+        orc.advance()
+    u, p = out["fused"][0], out["fused"][1]
+    assert rel(u, orc.vel[1]) < 1e-8
+    assert rel(p - p.mean(), orc.p_old - orc.p_old.mean()) < 1e-7

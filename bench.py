@@ -798,6 +798,7 @@ def channel3d_bdf_bench(args):
         one_step(i)
     ms_sm, n_sm, nbytes = ctx.profile_smoother(False)
     ms_conv, n_conv, nbytes_conv = ctx.profile_convection(False)
+    nbytes_conv = abs(nbytes_conv)
     ms_cold, _ = ctx.time_spmv(nat.OP_MOMENTUM_SMOOTHER, 50)
     achieved = nbytes / (ms_sm * 1e-3) / 1e9
     label, extra = _smoother_roofline_extras(ctx, 3, ms_sm, ms_cold)
@@ -1122,18 +1123,28 @@ def cavity_ipcs_bench(args):
         else:
             ms_conv_cold = None
         if n_conv:
+            # (a negative byte count flags the element kernel ALONE: on one GPU the per-node sums of its element
+            # vectors run inside the L-product launch, nsfem_profile_convection then brackets k_conv_cell only)
+            cells_only = nbytes_conv < 0
+            nbytes_conv = abs(nbytes_conv)
             ach = nbytes_conv / (ms_conv * 1e-3) / 1e9
-            assembly = {"kernel": "k_conv_cell<FORM,1> + k_res_gather: matrix-free action of the convection "
-                                  "blocks of the velocity Jacobian (the per-Newton-iteration assembly of the "
-                                  "fused step; one thread per cell, element vectors gathered per node in fixed order)",
+            assembly = {"kernel": ("k_conv_cell<FORM,1>: element kernel of the matrix-free action of the convection blocks of "
+                                   "the velocity Jacobian (the per-Newton-iteration assembly of the fused step; one thread "
+                                   "per cell, element vectors stored node-sorted); their per-node sums run inside the "
+                                   "L-product launch k_spmv_dict_w8<2,0> (fused node gather)") if cells_only else
+                                  ("k_conv_cell<FORM,1> + k_res_gather: matrix-free action of the convection "
+                                   "blocks of the velocity Jacobian (the per-Newton-iteration assembly of the "
+                                   "fused step; one thread per cell, element vectors gathered per node in fixed order)"),
                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_application": nbytes_conv,
-                        "bytes_formula": "n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x) + n_dofs_velocity x 16 "
-                                         "(SURVEY.md 8d: vector assembly; the element buffer the two kernels hand "
-                                         "over, 2 x 96 B per cell, is implementation traffic and not counted)",
+                        "bytes_formula": ("n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x + 96 element vector "
+                                          "stored)" if cells_only else
+                                          "n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x) + n_dofs_velocity x 16 "
+                                          "(SURVEY.md 8d: vector assembly; the element buffer the two kernels hand "
+                                          "over, 2 x 96 B per cell, is implementation traffic and not counted)"),
                         "ms_per_application": ms_conv, "applications_timed": n_conv,
                         "timing": "HIP-event pair around each application inside the BiCGStab solves of 5 solver steps"}
-            if ms_conv_cold is not None:
+            if ms_conv_cold is not None and not cells_only:
                 assembly["cold_cache"] = {"achieved": nbytes_conv / (ms_conv_cold * 1e-3) / 1e9,
                                           "frac": nbytes_conv / (ms_conv_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           "ms_per_application": ms_conv_cold}

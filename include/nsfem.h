@@ -446,7 +446,9 @@ int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]);
  * per-iteration "assembly" of the fused step drivers; replaces the dolfin assemble(J) call of
  * ns_ipcs_solver.py:136-147 / ns_bdf_solver.py:88-100): enable != 0 starts sampling, enable == 0
  * stops and reports the average duration [ms] of one application, the number of applications and
- * the algorithmic bytes of one application (SURVEY.md section 8d formula) */
+ * the algorithmic bytes of one application (SURVEY.md section 8d formula).  One GPU, triangles, lattice
+ * mesh: the per-node sums run inside the L-product launch, the event pair then brackets the element
+ * kernel alone -- flagged by a NEGATIVE byte count (minus the element kernel's own bytes) */
 int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* applications,
                              int64_t* algorithmic_bytes);
 /* extreme eigenvalues of diag(M_e)^-1 M_e of the P2 element mass matrix (host arithmetic only) */

@@ -702,10 +702,30 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   // identity rows on the Dirichlet dofs and zero ghost rows come out of the L product itself
   // (row mask, MASK_IDENTITY); every later contribution leaves the flagged rows untouched
   (void)nv;
+  const double cc = cc_of(c);
+  // one GPU, triangles, lattice mesh: the element kernel of the convection action first, then ONE launch of the
+  // dictionary kernel forms L x AND sums the node-sorted element vectors (no separate node gather, y is written
+  // once instead of written, read and written again)
+  if (!c->distributed() && dim == 2 && cc != 0.0 && c->L.dict_ready) {
+    nsfem_ctx::Probe& pr = c->conv_probe;
+    const bool timed = pr.on && pr.n + 2 <= pr.ev.size();
+    if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
+    launch_convection_cells(s, c->mesh, c->state[vel_slot].p, x, cc, c->conv_form, c->picard);
+    if (timed) {
+      NSFEM_HIP(hipEventRecord(pr.ev[pr.n + 1], s));
+      pr.n += 2;
+    }
+    if (launch_spmv_with_gather(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, c->mesh.nptr.p, c->mesh.rbuf.p)) {
+      if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, c->mask_v.p);
+      const double g = coriolis_gamma(c);
+      if (g != 0.0) coriolis_apply(c, g, x, y, c->mask_v.p);
+      return;
+    }
+    // (no dictionary kernel: product, then the gather below re-runs the cheap element kernel)
+  }
   product_with_halo(c->distributed() ? c->comm : nullptr, &c->halo_p2, dim, s, x, c->L.pat,
                     [&](int phase) { launch_spmv(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, 0, phase, 1); });
   if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, c->mask_v.p);
-  const double cc = cc_of(c);
   if (cc != 0.0) {
     nsfem_ctx::Probe& pr = c->conv_probe;
     const bool timed = pr.on && pr.n + 2 <= pr.ev.size();
@@ -2310,6 +2330,16 @@ static int64_t convection_action_bytes(const nsfem_ctx* c) {
   return (int64_t)c->mesh.n_cells * (nl1 * dim * 8 + nl2 * 4 + 2 * nl2 * dim * 8) +
          (int64_t)c->mesh.n_p2 * dim * 16;
 }
+// one GPU, triangles, lattice mesh: the per-node sums run inside the L-product launch (MomentumMF::apply); the
+// probe then brackets the element kernel alone, whose bytes are the per-cell part plus the element vectors it
+// stores (dim * nl2 doubles per cell, summed by the other launch)
+static bool convection_gather_fused(const nsfem_ctx* c) {
+  return !c->distributed() && c->mesh.dim == 2 && c->L.dict_ready;
+}
+static int64_t convection_cells_bytes(const nsfem_ctx* c) {
+  const int64_t dim = c->mesh.dim, nl1 = dim + 1, nl2 = dim == 2 ? 6 : 10;
+  return (int64_t)c->mesh.n_cells * (nl1 * dim * 8 + nl2 * 4 + 2 * nl2 * dim * 8 + nl2 * dim * 8);
+}
 
 // In-situ timing of the matrix-free convection action inside the Newton-Krylov solves (one HIP-event
 // pair around every k_conv_cell<FORM,LIN> + k_res_gather pair on the context's stream).
@@ -2338,7 +2368,8 @@ extern "C" int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_
   const int64_t n = (int64_t)(pr.n / 2);
   if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
   if (applications) *applications = n;
-  if (algorithmic_bytes) *algorithmic_bytes = convection_action_bytes(ctx);
+  if (algorithmic_bytes)
+    *algorithmic_bytes = convection_gather_fused(ctx) ? -convection_cells_bytes(ctx) : convection_action_bytes(ctx);
   API_END(ctx)
 }
 

@@ -749,4 +749,11 @@ void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, 
   NSFEM_HIP(hipGetLastError());
 }
 
+void launch_convection_cells(hipStream_t s, const MeshDev& m, const double* u, const double* v, double cc,
+                             int form, bool picard) {
+  NSFEM_REQUIRE(m.dim == 2, "launch_convection_cells: triangles only");
+  if (picard) launch_conv_cell<2>(s, m, u, v, cc, form);
+  else launch_conv_cell<1>(s, m, u, v, cc, form);
+}
+
 }  // namespace nsfem

@@ -55,6 +55,11 @@ struct SpmvArgs {
                    // the copy equals the CSR matrix to the dedupe tolerance, not bitwise)
   int dbg;         // NSFEM_SPMV_DEBUG (measurement experiments only; wrong results): 1 = gather from
                    // the chunk's own rows (perfectly local x), 2 = skip the x gather altogether
+  // dictionary kernel, EPI_STORE: after the product row r also adds the run gptr[r] .. gptr[r + 1] of
+  // NV-wide entries of gbuf (the node-sorted element vectors of the matrix-free convection action: the node
+  // gather fused into the product with the constant part of the Jacobian); null: off
+  const int32_t* gptr;
+  const double* gbuf;
 };
 struct XcdSplit { int s[9]; };   // SELL kernel: workgroup range [s[x], s[x+1]) of XCD x (s[8] = 0: round robin)
 
@@ -771,6 +776,12 @@ __device__ __forceinline__ void spmv_dict_body(int n_rows, int n_wg, const uint8
   const int L = live ? ll[st] : 0;
   const int* __restrict__ op = lo + st * lmax;
   const double* __restrict__ vp = lv + st * lmax;
+  // (fused node gather: the run's bounds are requested before the stencil loop)
+  int g0 = 0, g1 = 0;
+  if (EPI == EPI_STORE && a.gbuf && live) {
+    g0 = a.gptr[row];
+    g1 = a.gptr[row + 1];
+  }
   for (int k = 0; k < L; k += U) {
     int c[U];
     double v[U];
@@ -790,6 +801,22 @@ __device__ __forceinline__ void spmv_dict_body(int n_rows, int n_wg, const uint8
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < NV; ++t) acc[t] += v[u] * xv[u][t];
+  }
+  if (EPI == EPI_STORE && a.gbuf) {
+    // y = A x (stored value, c2 = 1) + the node's element contributions in ascending order: the sums of the
+    // separate gather kernel; rows flagged in the mask ignore the accumulator below
+    const double* __restrict__ gb = a.gbuf;
+    int k = g0;
+    for (; k + 2 <= g1; k += 2) {
+      double w0[NV], w1[NV];
+#pragma unroll
+      for (int t = 0; t < NV; ++t) { w0[t] = gb[(size_t)k * NV + t]; w1[t] = gb[(size_t)(k + 1) * NV + t]; }
+#pragma unroll
+      for (int t = 0; t < NV; ++t) { acc[t] += w0[t]; acc[t] += w1[t]; }
+    }
+    for (; k < g1; ++k)
+#pragma unroll
+      for (int t = 0; t < NV; ++t) acc[t] += gb[(size_t)k * NV + t];
   }
   // the wave's 64 rows x NV outputs are the CONTIGUOUS entries 64 NV wave .. of the vectors; in
   // pass p lane l handles entry e = 64 p + l, whose sum lives in lane e / NV (component e % NV)
@@ -2044,7 +2071,24 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
     return e ? std::atoi(e) : 0;
   }();
   a.dbg = dbg;
+  a.gptr = nullptr;
+  a.gbuf = nullptr;
   return a;
+}
+
+// y = A x + (node-sorted element contributions gbuf, run gptr[r] .. gptr[r + 1] of row r) with identity rows on
+// the rows flagged in rowmask -- ONE launch of the stencil-dictionary kernel.  false: the matrix has no usable
+// dictionary copy (the caller multiplies and gathers separately).
+bool launch_spmv_with_gather(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
+                             const uint8_t* rowmask, int maskmode, const int32_t* gptr, const double* gbuf) {
+  static const bool on = [] { const char* e = std::getenv("NSFEM_FUSED_GATHER"); return e ? std::atoi(e) != 0 : true; }();
+  if (!on || !A.dict_ready || A.dict->rect || A.br != 1 || A.bc != 1 || nv < 1 || nv > 3) return false;
+  SpmvArgs a = make_args(x, nullptr, y, rowmask, maskmode);
+  a.dict_ok = 1;
+  a.gptr = gptr;
+  a.gbuf = gbuf;
+  spmv_dispatch<EPI_STORE>(s, A, nv, a);
+  return true;
 }
 
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,

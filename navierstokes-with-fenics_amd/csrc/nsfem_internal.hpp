@@ -221,6 +221,8 @@ enum MaskMode { MASK_NONE = 0, MASK_IDENTITY = 1, MASK_ZERO = 2 };
 // 2^-40 of the largest entry): Newton-Jacobian products and smoothing steps only
 void launch_spmv(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
                  const uint8_t* rowmask, int maskmode, int ghost = 0, int phase = 0, int dict_ok = 0);
+bool launch_spmv_with_gather(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
+                             const uint8_t* rowmask, int maskmode, const int32_t* gptr, const double* gbuf);
 void launch_spmv_cheb_first(hipStream_t s, const BlockMat& A, int nv, const double* x, double* y,
                             const uint8_t* rowmask, const double* dinv, double c2, double* d,
                             double* x1);
@@ -323,6 +325,10 @@ void launch_convection_jacobian(hipStream_t s, const MeshDev& m, const Pattern& 
 void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, const double* v,
                               double cc, double* y, int form, bool picard,
                               const uint8_t* skipmask = nullptr);
+// only the element kernel of the action: the element vectors land node-sorted in m.rbuf (runs m.nptr); the
+// caller sums them per node (launch_spmv_with_gather)
+void launch_convection_cells(hipStream_t s, const MeshDev& m, const double* u, const double* v, double cc,
+                             int form, bool picard);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
                                 double* b, int form);
 // per-facet surface force / flux / measure (boundary.hip): out[nf][dim + 2]

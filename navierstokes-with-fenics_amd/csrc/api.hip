@@ -776,6 +776,7 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
     op.prec = &c->mom_prec;
   }
   op.graph_epoch = c->graph_epoch;
+  op.x_zero = true;                 // dx_v was just zeroed
   int rc = bicgstab(s, c->kw, op, c->rhs_v.p, c->dx_v.p, o, info);
   if (rc != NSFEM_OK) return rc;
   double* u = c->state[NSFEM_USTAR].p;
@@ -1805,6 +1806,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     nsfem_solve_info si;
     int& hint = ctx->hint_mom[std::min(it, 3)];
     const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
+    op.x_zero = true;               // dx_m was just zeroed
     int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, hinted(ko, hint), si);
     hint = next_hint(si, ko);
     inf.krylov_iterations_momentum += si.iterations;

@@ -2640,7 +2640,11 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
       });
     }
   };
-  if (op.custom) {
+  if (op.x_zero) {
+    // zero start vector (Newton updates): r = b - A 0 = b, no operator application (A 0 = 0 on every row,
+    // identity rows included)
+    NSFEM_HIP(hipMemcpyAsync(w.r.p, b, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  } else if (op.custom) {
     op.custom->apply(s, x, w.r.p);
     launch_axpby(s, n, 1.0, b, -1.0, w.r.p, w.r.p);
   } else {

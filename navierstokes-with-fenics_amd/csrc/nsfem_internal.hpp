@@ -526,6 +526,8 @@ struct LinOp {
   const uint8_t* ghostmask = nullptr;
   int64_t n_global = 0;             // global length (mean projection)
   uint64_t graph_epoch = 0;         // bumped whenever baked kernel arguments may have changed
+  bool x_zero = false;              // the caller's start vector is all zeros: the start residual is b itself
+                                    // (BiCGStab skips the operator application that would compute b - A 0)
 };
 
 // ---- multigrid ------------------------------------------------------------------

@@ -1342,9 +1342,10 @@ def main():
     ap.add_argument("--newton-forcing", type=float, default=1.0e-4,
                     help="inexact Newton: reduce each Newton linear residual only by this factor "
                          "(0 = exact Newton with --krylov-rtol)")
-    ap.add_argument("--cpu-samples", default="24:4,32:4,48:3,64:3",
-                    help="CPU baseline ladder n:steps,... (cavity cells per side : timed steps); the default "
-                         "is ~15 s of CPU work")
+    ap.add_argument("--cpu-samples", default=None,
+                    help="CPU baseline ladder n:steps,... (cavity cells per side : timed steps); default "
+                         "24:4,32:4,48:3,64:3 (~15 s of CPU work), plus 128:1 (~13 s more, 148,739 dofs: the "
+                         "extrapolation to the workload then spans 16x in size instead of 63x) on hosts with >= 64 cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solver-classes", action="store_true",
                     help="skip the timing of the same steps through IPCSSolver.solve() / advance_time()")
@@ -1390,6 +1391,8 @@ def main():
                     help="functional rehearsal of the N-rank paths on ONE GPU: N threads of this process, "
                          "in-process communicator (no RCCL; not a performance mode)")
     args = ap.parse_args()
+    if args.cpu_samples is None:
+        args.cpu_samples = "24:4,32:4,48:3,64:3" + (",128:1" if (os.cpu_count() or 1) >= 64 else "")
     if args.local_ranks > 1:
         import copy
         import threading

@@ -231,6 +231,30 @@ class TaylorHoodDofMap:
             order = np.lexsort(tuple(q[:, k] for k in range(dim)) + (cls, slab))   # slab slowest, x fastest
             ent_to_node = np.empty(n_ent, dtype=np.int64)
             ent_to_node[order] = np.arange(n_ent)
+        elif reorder and getattr(mesh, "structured", None) is None and class_key is None and \
+                _unstructured_order() in ("morton", "rcm"):
+            # unstructured meshes, locality experiments (NSFEM_P2_ORDER_UNSTRUCTURED = morton | rcm; default lex):
+            # Z-order curve of the node coordinates, or reverse Cuthill-McKee of the P2 node graph
+            self.ordering = _unstructured_order()
+            if self.ordering == "morton":
+                lo, hi = xy.min(axis=0), xy.max(axis=0)
+                q = np.clip(((xy - lo) / np.maximum(hi - lo, 1e-300) * (2 ** 20 - 1)).astype(np.int64), 0, 2 ** 20 - 1)
+                code = np.zeros(n_ent, dtype=np.int64)
+                for bit in range(20):
+                    for a in range(dim):
+                        code |= ((q[:, a] >> bit) & 1) << (dim * bit + a)
+                order = np.argsort(code, kind="stable")
+            else:
+                import scipy.sparse as sp
+                from scipy.sparse.csgraph import reverse_cuthill_mckee
+                ents = np.concatenate([mesh.cells.astype(np.int64), nv + mesh.cell_edges.astype(np.int64)], axis=1)
+                k = ents.shape[1]
+                rows = np.repeat(ents, k, axis=1).ravel()
+                cols = np.tile(ents, (1, k)).ravel()
+                graph = sp.csr_matrix((np.ones(rows.size, dtype=np.int8), (rows, cols)), shape=(n_ent, n_ent))
+                order = np.asarray(reverse_cuthill_mckee(graph, symmetric_mode=True), dtype=np.int64)
+            ent_to_node = np.empty(n_ent, dtype=np.int64)
+            ent_to_node[order] = np.arange(n_ent)
         elif reorder:
             scale = 1.0 / max(mesh.hmin(), 1e-300)
             q = np.round(xy * (4.0 * scale)).astype(np.int64)      # robust lexicographic key
@@ -287,6 +311,11 @@ class TaylorHoodDofMap:
     def facet_p1_nodes(self, facet_ids):
         f = self.mesh.facets[facet_ids].astype(np.int64)
         return self.p1_vertex_node[f]
+
+
+def _unstructured_order():
+    import os
+    return os.environ.get("NSFEM_P2_ORDER_UNSTRUCTURED", "lex")
 
 
 def preferred_p2_order(dim):

@@ -64,13 +64,16 @@ static void upload_pattern(hipStream_t s, HostPattern& h, Pattern& d, bool want_
   if (!h.diag.empty()) d.diag.upload(h.diag, s);
   d.slot.upload(h.slot, s);
   if (want_contrib) {
-    const int64_t nc = (int64_t)h.slot.size() / (h.nr * h.nc), loc = h.nr * h.nc;
-    std::vector<int32_t> ptr, idx;
-    build_inverse_index(d.nnz, nc * loc,
-                        [&](int64_t src) { return h.slot[(size_t)(src % loc) * nc + src / loc]; },
-                        ptr, idx);
-    d.cptr.upload(ptr, s);
-    d.cidx.upload(idx, s);
+    if (h.cptr.empty()) {          // (patterns built without the index: serial fallback)
+      const int64_t nc = (int64_t)h.slot.size() / (h.nr * h.nc), loc = h.nr * h.nc;
+      build_inverse_index(d.nnz, nc * loc,
+                          [&](int64_t src) { return h.slot[(size_t)(src % loc) * nc + src / loc]; },
+                          h.cptr, h.cidx);
+    }
+    d.cptr.upload(h.cptr, s);
+    d.cidx.upload(h.cidx, s);
+    std::vector<int32_t>().swap(h.cptr);
+    std::vector<int32_t>().swap(h.cidx);
   }
   d.h_rowptr.swap(h.rowptr);
   d.h_col.swap(h.col);
@@ -152,7 +155,7 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   // ---- sparsity patterns + slot maps (host), then device copies
   {
     HostPattern h;
-    build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, nl2, m->p2_dofmap, nl2, true, h);
+    build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, nl2, m->p2_dofmap, nl2, true, h, true);
     upload_pattern(s, h, fresh->p22, true);
     {
       std::vector<int32_t> ptr, idx;
@@ -168,11 +171,11 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
       fresh->mesh.ebuf.alloc((size_t)nc * nl2 * nl2 * dim * dim);
       fresh->mesh.rbuf.alloc((size_t)nc * nl2 * dim);
     }
-    build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, nl1, m->p1_dofmap, nl1, true, h);
+    build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, nl1, m->p1_dofmap, nl1, true, h, true);
     upload_pattern(s, h, fresh->p11, true);
-    build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, nl1, m->p2_dofmap, nl2, false, h);
+    build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, nl1, m->p2_dofmap, nl2, false, h, true);
     upload_pattern(s, h, fresh->p12, true);
-    build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, nl2, m->p1_dofmap, nl1, false, h);
+    build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, nl2, m->p1_dofmap, nl1, false, h, true);
     upload_pattern(s, h, fresh->p21, true);
   }
   // ---- constant operators, integrated on the device

@@ -78,9 +78,11 @@ struct HostPattern {
   int n_rows = 0, n_cols = 0, nr = 0, nc = 0;   // nr/nc: local rows/cols per cell
   std::vector<int32_t> rowptr, col, diag;       // diag only for square patterns
   std::vector<int32_t> slot;                    // SoA: [nr*nc][n_cells]
+  std::vector<int32_t> cptr, cidx;              // inverted index of the slot map (want_contrib)
 };
+int host_threads();                             // threads of the host set-up loops (NSFEM_HOST_THREADS)
 void build_pattern(int n_rows, int n_cols, int n_cells, const int32_t* rowmap, int nr,
-                   const int32_t* colmap, int nc, bool want_diag, HostPattern& out);
+                   const int32_t* colmap, int nc, bool want_diag, HostPattern& out, bool want_contrib = false);
 
 struct Pattern {
   int n_rows = 0, n_cols = 0, nnz = 0, nr = 0, nc = 0;

@@ -228,7 +228,25 @@ class TaylorHoodDofMap:
             # planes of x its rows touch), yet 64 consecutive rows still belong to one class
             block = self.parity_block = int(getattr(mesh, "parity_block", 4 if dim == 3 else 16))
             slab = q[:, dim - 1] // block
-            order = np.lexsort(tuple(q[:, k] for k in range(dim)) + (cls, slab))   # slab slowest, x fastest
+            # 3D, wide cross-sections: the class passes over a slab touch ~8 lattice planes of x; when those
+            # exceed an XCD's 4 MiB L2 (257 x 129 nodes x 24 B = 0.8 MB per plane: channel n = 64) every pass
+            # re-fetches them (PMC: 1.9 x the algorithmic bytes).  Blocks of `block_y` lattice lines inside a slab
+            # bound the working set; 0 = off.  NSFEM_PARITY_BLOCK_Y overrides the automatic choice.
+            import os
+            block_y = 0
+            if dim == 3:
+                plane_bytes = float(2 * cells[0] + 1) * float(2 * cells[1] + 1) * 24.0
+                env = os.environ.get("NSFEM_PARITY_BLOCK_Y")
+                if env is not None:
+                    block_y = int(env)
+                elif 8.0 * plane_bytes > 3.0e6:
+                    block_y = 32
+            self.parity_block_y = block_y
+            if block_y > 0:
+                yblk = q[:, 1] // block_y
+                order = np.lexsort(tuple(q[:, k] for k in range(dim)) + (cls, yblk, slab))
+            else:
+                order = np.lexsort(tuple(q[:, k] for k in range(dim)) + (cls, slab))   # slab slowest, x fastest
             ent_to_node = np.empty(n_ent, dtype=np.int64)
             ent_to_node[order] = np.arange(n_ent)
         elif reorder and getattr(mesh, "structured", None) is None and class_key is None and \

@@ -1157,19 +1157,27 @@ def cavity_ipcs_bench(args):
     # counters need rocprofv3); the figure below is read from the committed PMC passes of this very
     # command and labelled so (`traffic_source`), null when no such profile exists for the size
     traffic = traffic_source = None
-    for tag in ("r02", "r01_h"):
-        pmc = os.path.join(ROOT, "profiles", "%s_pmc_fetch_write_size.json" % tag)
+    lattice = mg_levels is not None and ctx.smoother_info().get("multistep_lattice_kernel")
+    for fname in ("r03_a_bench_n512_pmc_fetch_write_size.json", "r02_pmc_fetch_write_size.json"):
+        pmc = os.path.join(ROOT, "profiles", fname)
         if world == 1 and n == 512 and mg_levels is not None and os.path.exists(pmc):
-            # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE;
-            # the symbol is launched on every multigrid level, the finest-level launches are the maxima
+            # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE; a kernel
+            # symbol is launched on several multigrid levels, the finest-level launches are the maxima
             c = json.load(open(pmc))
-            key = "void nsfem::k_spmv_dict_w8<2, 3>" if ctx.smoother_info()["kind"] == "stencil-dictionary" \
-                else "void nsfem::k_spmv_stream_v1<1, 1, 2, 3>"
+            if lattice:
+                key = "void nsfem::k_cheb_lattice<2, 3, 4>"
+                shape = ("; the maxima belong to the launch shape of the Chebyshev mass solve with a carried direction "
+                         "(x, b, d read; x, d written = 85.1 MB algorithmic), not to the %.1f MB average of `algorithmic_"
+                         "bytes_per_launch`" % (nbytes / 1e6))
+            else:
+                key = "void nsfem::k_spmv_dict_w8<2, 3>" if ctx.smoother_info()["kind"] == "stencil-dictionary" \
+                    else "void nsfem::k_spmv_stream_v1<1, 1, 2, 3>"
+                shape = ""
             if key in c["fetch"] and key in c["write"]:
                 traffic = (2.0 * c["fetch"][key]["max_KB"] + c["write"][key]["max_KB"]) * 1024.0
                 traffic_source = "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: " \
-                                 "profiles/%s_pmc_fetch_write_size.json (not measured by this run; counts " \
-                                 "Infinity-Cache hits as well)" % tag
+                                 "profiles/%s (not measured by this run; counts Infinity-Cache hits as well)%s" % (
+                                     fname, shape)
                 break
     tol_fields = 1.0e-6
     smoother_label, smoother_extra = (_smoother_roofline_extras(ctx, 2, ms_spmv, cold["ms_per_launch"] if cold else None)

@@ -451,6 +451,15 @@ int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]);
  * kernel alone -- flagged by a NEGATIVE byte count (minus the element kernel's own bytes) */
 int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* applications,
                              int64_t* algorithmic_bytes);
+/* How the matrix-free action of the velocity Jacobian (NSFEM_OP_MOMENTUM_JAC_MF; the operator of the Newton-Krylov
+ * solves in nsfem_step_ipcs / nsfem_step_bdf, replacing the assembled J of ns_ipcs_solver.py:136-147) runs on this
+ * context: out[0] = 0  L product, element kernel, node gather (three launches: partitioned meshes, tetrahedra,
+ * unstructured meshes); 1  element kernel, then the dictionary product of L sums its node-sorted element vectors;
+ * 2  k_jac_lattice -- one launch (2D lattice meshes in rectangle_mesh numbering on one GPU, gradient-form viscosity,
+ * no rotating frame; NSFEM_JAC_LATTICE=0 disables it).  out[1] = applications through k_jac_lattice so far,
+ * out[2] = its algorithmic bytes per application (u, x read, y written: 48 B per P2 node; 3 B per node of
+ * dictionary ids and masks; 48 B per cell of vertex coordinates), out[3] = 0. */
+int nsfem_jacobian_info(nsfem_ctx* ctx, int64_t out[4]);
 /* extreme eigenvalues of diag(M_e)^-1 M_e of the P2 element mass matrix (host arithmetic only) */
 int nsfem_p2_mass_bounds(int dim, double* lmin, double* lmax);
 int nsfem_synchronize(nsfem_ctx* ctx);

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_default_step_opts", "nsfem_step_ipcs", "nsfem_step_bdf", "nsfem_advance",
     "nsfem_shift_mean_pressure", "nsfem_time_spmv", "nsfem_synchronize", "nsfem_mass_solve",
     "nsfem_mg_add_level", "nsfem_mg_finalize", "nsfem_mg_set_global_coarse", "nsfem_mg_set_global_coarse_constrained",
-    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_smoother_info", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_smoother_detail", "nsfem_profile_convection", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
+    "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_smoother_info", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_smoother_detail", "nsfem_profile_convection", "nsfem_jacobian_info", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local", "nsfem_comm_attach_shm",
 )
@@ -200,6 +200,7 @@ def load_library(path=None):
                                                   C.c_int]),
         "nsfem_mg_set_schur_mode": (C.c_int, [vp, C.c_int]),
         "nsfem_smoother_info": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+        "nsfem_jacobian_info": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "nsfem_set_halo_lists": (C.c_int, [vp, C.c_int, C.POINTER(HaloLists)]),
         "nsfem_mg_set_global_index": (C.c_int, [vp, i32, pi]),
         "nsfem_comm_allreduce": (C.c_int, [vp, pd, C.c_int, C.c_int]),
@@ -663,6 +664,14 @@ class NsfemContext:
         out = (C.c_int64 * 4)()
         self._check(self._lib.nsfem_profile_smoother_detail(self._h, out))
         return dict(launches=int(out[0]), steps=int(out[1]), bytes=int(out[2]), lattice=bool(out[3]))
+
+    def jacobian_info(self):
+        """the matrix-free velocity Jacobian action: dict(path = "three-launch" | "fused-gather" | "lattice-kernel",
+        lattice_launches, lattice_bytes)"""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.nsfem_jacobian_info(self._h, out))
+        return dict(path=("three-launch", "fused-gather", "lattice-kernel")[int(out[0])],
+                    lattice_launches=int(out[1]), lattice_bytes=int(out[2]))
 
     def profile_convection(self, enable):
         """start (True) / stop (False -> (avg ms per application, applications, algorithmic bytes))

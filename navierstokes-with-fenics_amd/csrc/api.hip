@@ -93,6 +93,7 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   API_BEGIN
   NSFEM_REQUIRE(m && out, "null argument");
   refresh_env_switches();
+  refresh_assembly_switches();
   *out = nullptr;
   NSFEM_REQUIRE(m->dim == 2 || m->dim == 3, "dim must be 2 (triangles) or 3 (tetrahedra)");
   NSFEM_REQUIRE(m->n_cells > 0 && m->n_vertices > 0 && m->n_p2 > 0 && m->n_p1 > 0, "empty mesh");
@@ -697,6 +698,18 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
   launch_inv_diag(s, c->J, 1, c->mask_v.p, c->dinv_v.p);
 }
 
+// how the matrix-free Jacobian action runs: 0 = L product, element kernel, node gather; 1 = element kernel, then
+// the L product sums its node-sorted vectors (one GPU, triangles, stencil dictionary); 2 = k_jac_lattice, everything
+// in one launch (lattice mesh in rectangle_mesh numbering, gradient-form viscosity, no rotating frame)
+static int jacobian_path(nsfem_ctx* c) {
+  if (c->distributed() || c->mesh.dim != 2 || cc_of(c) == 0.0 || !c->L.dict_ready) return 0;
+  if (!c->mesh.cl.tried && c->L.dict && c->L.dict->lat_w > 0)
+    build_cell_lattice(c->h_p2map.data(), c->mesh.n_cells, c->L.dict->lat_w, c->L.dict->lat_h, c->mesh.cl);
+  if (!c->traction_form && coriolis_gamma(c) == 0.0 && c->mask_v.p && jacobian_lattice_available(c->mesh, c->L))
+    return 2;
+  return 1;
+}
+
 void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   const int64_t nv = nvel(c);
   const int dim = c->mesh.dim;
@@ -712,6 +725,19 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   if (!c->distributed() && dim == 2 && cc != 0.0 && c->L.dict_ready) {
     nsfem_ctx::Probe& pr = c->conv_probe;
     const bool timed = pr.on && pr.n + 2 <= pr.ev.size();
+    // lattice meshes: element kernel, node sums and L product in one launch (k_jac_lattice)
+    if (jacobian_path(c) == 2) {
+      if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
+      if (launch_jacobian_lattice(s, c->mesh, c->L, c->state[vel_slot].p, x, cc, c->conv_form, c->picard,
+                                  c->mask_v.p, y)) {
+        ++c->jac_lattice_launches;
+        if (timed) {
+          NSFEM_HIP(hipEventRecord(pr.ev[pr.n + 1], s));
+          pr.n += 2;
+        }
+        return;
+      }
+    }
     if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
     launch_convection_cells(s, c->mesh, c->state[vel_slot].p, x, cc, c->conv_form, c->picard);
     if (timed) {
@@ -2324,6 +2350,17 @@ extern "C" int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]) {
   out[1] = A.dict_ready ? A.dict->n_stencils : 0;
   out[2] = A.dict_ready ? (A.dict->exact ? -A.dict->lmax : A.dict->lmax) : 0;
   out[3] = smoother_launch_bytes(A, mg.nv, true);
+  API_END(ctx)
+}
+
+extern "C" int nsfem_jacobian_info(nsfem_ctx* ctx, int64_t out[4]) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out, "null argument");
+  ensure_L(ctx);
+  out[0] = jacobian_path(ctx);
+  out[1] = ctx->jac_lattice_launches;
+  out[2] = jacobian_lattice_bytes(ctx->mesh);
+  out[3] = 0;
   API_END(ctx)
 }
 

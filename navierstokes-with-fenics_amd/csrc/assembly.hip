@@ -35,6 +35,8 @@ struct CellGeo {
 };
 
 __device__ __forceinline__ CellGeo load_geo(const double* __restrict__ vx, int nc, int c) {
+  // (products fuse with the sums of their own statement only: every kernel that inlines this gets the same bits)
+#pragma clang fp contract(on)
   const double x0 = vx[c], y0 = vx[(size_t)nc + c];
   const double x1 = vx[(size_t)2 * nc + c], y1 = vx[(size_t)3 * nc + c];
   const double x2 = vx[(size_t)4 * nc + c], y2 = vx[(size_t)5 * nc + c];
@@ -53,6 +55,7 @@ __device__ __forceinline__ CellGeo load_geo(const double* __restrict__ vx, int n
 // physical gradient of a reference gradient (dr0, dr1): g_a = sum_b Jinv[b][a] dr_b
 __device__ __forceinline__ void phys(const CellGeo& g, double dr0, double dr1, double& gx,
                                      double& gy) {
+#pragma clang fp contract(on)
   gx = g.ji00 * dr0 + g.ji10 * dr1;
   gy = g.ji01 * dr0 + g.ji11 * dr1;
 }
@@ -452,30 +455,15 @@ void launch_cfl(hipStream_t s, const MeshDev& m, const double* u, double scale, 
 // per quadrature point for all 6 test functions.
 //   LIN = 0  r_(i,a) = int c(u)_a phi_i ;  LIN = 1  Newton matrix times v ;  LIN = 2  Picard matrix
 //   times v.  FORM as in k_conv_jac (0 standard, 1 rotational, 2 divergence, 3 skew-symmetric).
+// element vector of one cell: u (and the direction w) at the 6 nodes in registers; shared by the one-thread-per-cell
+// kernel below and the lattice kernel k_jac_lattice (same arithmetic, bit for bit)
 template <int FORM, int LIN>
-__global__ __launch_bounds__(256) void k_conv_cell(int nc, const double* __restrict__ vx,
-                                                   const int32_t* __restrict__ p2,
-                                                   const double* __restrict__ u,
-                                                   const double* __restrict__ v, double cc,
-                                                   const int32_t* __restrict__ ndst,
-                                                   double* __restrict__ rbuf) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
-  const CellGeo g = load_geo(vx, nc, c);
-  double ux[6], uy[6], wx[LIN ? 6 : 1], wy[LIN ? 6 : 1];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int node = p2[(size_t)k * nc + c];
-    const double2 a = reinterpret_cast<const double2*>(u)[node];
-    ux[k] = a.x;
-    uy[k] = a.y;
-    if (LIN) {
-      const double2 b = reinterpret_cast<const double2*>(v)[node];
-      wx[k] = b.x;
-      wy[k] = b.y;
-    }
-  }
-  double rx[6], ry[6];
+__device__ __forceinline__ void conv_cell_eval(const CellGeo& g, const double* ux, const double* uy,
+                                               const double* wx, const double* wy, double cc,
+                                               double* rx, double* ry) {
+  // contraction inside statements only (not across them, which depends on the surrounding kernel): the two kernels
+  // that inline this function produce the same element vectors bit for bit
+#pragma clang fp contract(on)
 #pragma unroll
   for (int i = 0; i < 6; ++i) rx[i] = ry[i] = 0.0;
   for (int q = 0; q < 7; ++q) {
@@ -563,6 +551,33 @@ __global__ __launch_bounds__(256) void k_conv_cell(int nc, const double* __restr
       }
     }
   }
+}
+
+template <int FORM, int LIN>
+__global__ __launch_bounds__(256) void k_conv_cell(int nc, const double* __restrict__ vx,
+                                                   const int32_t* __restrict__ p2,
+                                                   const double* __restrict__ u,
+                                                   const double* __restrict__ v, double cc,
+                                                   const int32_t* __restrict__ ndst,
+                                                   double* __restrict__ rbuf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const CellGeo g = load_geo(vx, nc, c);
+  double ux[6], uy[6], wx[LIN ? 6 : 1], wy[LIN ? 6 : 1];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int node = p2[(size_t)k * nc + c];
+    const double2 a = reinterpret_cast<const double2*>(u)[node];
+    ux[k] = a.x;
+    uy[k] = a.y;
+    if (LIN) {
+      const double2 b = reinterpret_cast<const double2*>(v)[node];
+      wx[k] = b.x;
+      wy[k] = b.y;
+    }
+  }
+  double rx[6], ry[6];
+  conv_cell_eval<FORM, LIN>(g, ux, uy, wx, wy, cc, rx, ry);
   // node-sorted element buffer: entry (c, i) lands inside the contiguous run of its node
   double2* out = reinterpret_cast<double2*>(rbuf);
 #pragma unroll
@@ -754,6 +769,363 @@ void launch_convection_cells(hipStream_t s, const MeshDev& m, const double* u, c
   NSFEM_REQUIRE(m.dim == 2, "launch_convection_cells: triangles only");
   if (picard) launch_conv_cell<2>(s, m, u, v, cc, form);
   else launch_conv_cell<1>(s, m, u, v, cc, form);
+}
+
+
+// ---------------------------------------------------------------- lattice Jacobian action
+// y = L x + c_c [d conv(u)/du] x  (identity on the rows flagged in the mask) in ONE launch on 2D lattice meshes
+// (rectangle_mesh numbering: cell 2 (sy nx + sx) + t, P2 node j W + i): the pair of launches it replaces --
+// k_conv_cell (element vectors -> node-sorted buffer in HBM) and the dictionary product that sums the buffer --
+// moves 96 B per cell out and in again, and the element kernel's scattered 16-byte stores and dependent index
+// loads keep it at a third of its VALU bound.  Here a workgroup owns the nodes of 31 x 7 squares:
+//   phase 0  u and x on the 65 x 17 nodes the 32 x 8 squares around them touch are staged in LDS (row-contiguous
+//            global reads), together with the operator's stencil dictionary;
+//   phase 1  one thread per owned node: acc = (L x)(node) from the LDS copy of x -- the dictionary entry's
+//            products in entry order, exactly the sum of k_spmv_dict;
+//   phase 2  one thread per cell (512 cells, the one-square ring around the owned nodes is recomputed by the
+//            neighbouring workgroups): node values from LDS, conv_cell_eval in registers -- no index loads, the
+//            node positions of a cell are a template of its type;
+//   phase 3  six rounds: in round r every cell adds its element vector entry to the node it is the r-th
+//            adjacent cell of (ascending cell number: at most one writer per node and round, and the node sums
+//            come out in the order of the node-sorted buffer, bit for bit);
+//   phase 4  y written once (coalesced 16-byte stores).
+// Algorithmic bytes per launch: u, x read, y written (48 B per node), 48 B per cell of vertex coordinates, one
+// byte per node of dictionary ids and two of masks.
+// tile shapes: SX x SY squares per workgroup (powers of two; one cell per thread, 2 SX SY threads), of which the
+// workgroup owns the nodes of (SX - 1) x (SY - 1)
+
+struct JacLatArgs {
+  int nx, ny, W, H, nc;
+  int ntx, ntiles;
+  int lmax, lp, n_st;   // lp: table row stride (lmax rounded up to 4, zero padded)
+  int dbg;              // measurements only (NSFEM_JL_DBG): 1 no element kernel, 2 no L product, 4 no node sums
+  double cc;
+  // per cell type t and local node k, packed 6 x 5 bits (k-th field): the node's lattice offset from the square's corner
+  // node as dj * 3 + di, and the cell's rank among the cells around that node (ascending cell number).  Plain
+  // integers on purpose: an array indexed by the lane's cell type turns into VECTOR loads from the kernel-argument
+  // segment (38 per wave, ~14 us of the launch).
+  int noff0, noff1, rank0, rank1;
+};
+
+template <int FORM, int LIN, int SX, int SY>
+__global__ __launch_bounds__(2 * SX * SY) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __restrict__ u,
+                   const double* __restrict__ x, const uint8_t* __restrict__ sid8,
+                   const uint8_t* __restrict__ mask, const int32_t* __restrict__ slen,
+                   const int32_t* __restrict__ spack, const double* __restrict__ sval,
+                   double* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) double sh_jl[];
+  constexpr int NT = 2 * SX * SY;                                   // threads
+  constexpr int kJlNW = 2 * SX + 1, kJlNH = 2 * SY + 1;             // staged node lines
+  constexpr int kJlOX = 2 * (SX - 1), kJlOY = 2 * (SY - 1);         // owned node lines
+  constexpr int LOGSX = SX == 32 ? 5 : SX == 16 ? 4 : 3;
+  static_assert((1 << LOGSX) == SX, "SX: 8, 16 or 32");
+  constexpr int NN = kJlNW * kJlNH;
+  double2* __restrict__ su = reinterpret_cast<double2*>(sh_jl);
+  double2* __restrict__ sx = su + NN;
+  double2* __restrict__ sa = sx + NN;
+  double* __restrict__ tv = reinterpret_cast<double*>(sa + NN);       // [n_st * lp]
+  int* __restrict__ to = reinterpret_cast<int*>(tv + a.n_st * a.lp);
+  int* __restrict__ tl = to + a.n_st * a.lp;
+  // XCD x (workgroups b = x mod 8) walks a contiguous range of tiles: neighbouring tiles share their halo in L2
+  const int per = (a.ntiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tile >= a.ntiles || (a.dbg & 256)) return;
+  const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
+  const int i0 = tx * kJlOX - 2, j0 = ty * kJlOY - 2;               // lattice position of the LDS tile's corner
+  const int tid = threadIdx.x;
+  const double2* __restrict__ u2 = reinterpret_cast<const double2*>(u);
+  const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
+  // ---- phase 0: every global load of the workgroup is requested before the first one is waited for
+  constexpr int NLD = (NN + NT - 1) / NT;
+  double2 uv[NLD], xv[NLD];
+#pragma unroll
+  for (int r = 0; r < NLD; ++r) {
+    const int t = tid + r * NT;
+    const int lj = t / kJlNW, li = t - lj * kJlNW;
+    const int gi = i0 + li, gj = j0 + lj;
+    uv[r] = make_double2(0.0, 0.0);
+    xv[r] = uv[r];
+    if (t < NN && gi >= 0 && gi < a.W && gj >= 0 && gj < a.H && !(a.dbg & 8)) {
+      const size_t g = (size_t)gj * a.W + gi;
+      uv[r] = u2[g];
+      xv[r] = x2[g];
+    }
+  }
+  // (this thread's cell, its two owned nodes)
+  const int ct = tid & 1, sxl = (tid >> 1) & (SX - 1), syl = tid >> (1 + LOGSX);
+  const int sqx = (i0 >> 1) + sxl, sqy = (j0 >> 1) + syl;          // (i0, j0 even; >> is an arithmetic shift)
+  const bool cell = sqx >= 0 && sqx < a.nx && sqy >= 0 && sqy < a.ny;
+  CellGeo geo;
+  if (cell && !(a.dbg & 16)) geo = load_geo(vx, a.nc, 2 * (sqy * a.nx + sqx) + ct);
+  else geo.ji00 = geo.ji01 = geo.ji10 = geo.ji11 = geo.adet = 1.0;
+  constexpr int OWN = kJlOX * kJlOY, NOWN = (OWN + NT - 1) / NT;
+  int obase[NOWN], oent[NOWN], omask[NOWN];
+  size_t onode[NOWN];
+#pragma unroll
+  for (int r = 0; r < NOWN; ++r) {
+    const int o = tid + r * NT;
+    const int oj = o / kJlOX, oi = o - oj * kJlOX;
+    const int gi = i0 + 2 + oi, gj = j0 + 2 + oj;
+    obase[r] = -1;
+    oent[r] = 0;
+    omask[r] = 0;
+    onode[r] = 0;
+    if (o < OWN && gi < a.W && gj < a.H) {
+      obase[r] = (oj + 2) * kJlNW + oi + 2;
+      onode[r] = (size_t)gj * a.W + gi;
+      oent[r] = sid8[onode[r]];
+      omask[r] = reinterpret_cast<const uint16_t*>(mask)[onode[r]];
+    }
+  }
+  for (int t = tid; t < a.n_st * a.lp; t += NT) {
+    const int e = t / a.lp, k = t - e * a.lp;
+    const bool in = k < a.lmax;
+    tv[t] = in ? sval[e * a.lmax + k] : 0.0;
+    const int pk = in ? spack[e * a.lmax + k] : (8 * 32 + 8);
+    to[t] = ((pk >> 5) - 8) * kJlNW + ((pk & 31) - 8);
+  }
+  if (tid < a.n_st) tl[tid] = slen[tid];
+  if (a.dbg & 512) return;
+#pragma unroll
+  for (int r = 0; r < NLD; ++r) {
+    const int t = tid + r * NT;
+    if (t < NN) {
+      su[t] = uv[r];
+      sx[t] = xv[r];
+    }
+  }
+  __syncthreads();
+  if (a.dbg & 128) return;
+  // ---- phase 1: (L x) on the owned nodes; four entries of the row in flight (rows are zero padded to 4).
+  // (Measured and rejected: advancing the rows of the thread's two nodes together with the next trip's table
+  // entries prefetched -- 51.1 instead of 48.3 us per launch at n = 512.)
+#pragma unroll
+  for (int r = 0; r < NOWN; ++r) {
+    if (obase[r] < 0) continue;
+    const int base = obase[r];
+    const int L = (a.dbg & 2) ? 0 : tl[oent[r]];
+    const int* __restrict__ op = to + oent[r] * a.lp;
+    const double* __restrict__ vp = tv + oent[r] * a.lp;
+    double ax = 0.0, ay = 0.0;
+    for (int k = 0; k < L; k += 4) {
+      const int4 o4 = *reinterpret_cast<const int4*>(op + k);
+      const double2 va = *reinterpret_cast<const double2*>(vp + k), vb = *reinterpret_cast<const double2*>(vp + k + 2);
+      const double2 x0 = sx[base + o4.x], x1 = sx[base + o4.y], x2_ = sx[base + o4.z], x3 = sx[base + o4.w];
+      ax = fma(va.x, x0.x, ax); ay = fma(va.x, x0.y, ay);
+      ax = fma(va.y, x1.x, ax); ay = fma(va.y, x1.y, ay);
+      ax = fma(vb.x, x2_.x, ax); ay = fma(vb.x, x2_.y, ay);
+      ax = fma(vb.y, x3.x, ax); ay = fma(vb.y, x3.y, ay);
+    }
+    sa[base] = make_double2(ax, ay);
+  }
+  // ---- phase 2: the element vector of this thread's cell
+  int nl[6];
+  double rx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, ry[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const int corner = 2 * syl * kJlNW + 2 * sxl;
+  const int pno = a.noff0 ^ ((a.noff0 ^ a.noff1) & -ct), prk = a.rank0 ^ ((a.rank0 ^ a.rank1) & -ct);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int f = (pno >> (5 * k)) & 31;          // dj * 3 + di
+    const int dj = (f * 11) >> 5;                 // f / 3 for f < 9
+    nl[k] = corner + dj * kJlNW + (f - 3 * dj);
+  }
+  if (cell && !(a.dbg & 64)) {
+    double ux[6], uy[6], wx[6], wy[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double2 p = su[nl[k]], q = sx[nl[k]];
+      ux[k] = p.x; uy[k] = p.y;
+      wx[k] = q.x; wy[k] = q.y;
+    }
+    if (a.dbg & 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { rx[k] = ux[k] + wx[k]; ry[k] = uy[k] + wy[k]; }
+    } else {
+      conv_cell_eval<FORM, LIN>(geo, ux, uy, wx, wy, a.cc, rx, ry);
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: node sums in ascending cell order
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int rk = (prk >> (5 * k)) & 31;
+      if (cell && rk == r && !(a.dbg & 4)) {
+        double2 v = sa[nl[k]];
+        v.x += rx[k];
+        v.y += ry[k];
+        sa[nl[k]] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- phase 4
+  double2* __restrict__ y2 = reinterpret_cast<double2*>(y);
+#pragma unroll
+  for (int r = 0; r < NOWN; ++r) {
+    if (obase[r] < 0) continue;
+    double2 v = sa[obase[r]];
+    const double2 xo = sx[obase[r]];
+    if (omask[r] & 0x00ff) v.x = xo.x;
+    if (omask[r] & 0xff00) v.y = xo.y;
+    if (!(a.dbg & 32) || v.x == 1.2345) y2[onode[r]] = v;
+  }
+}
+
+bool build_cell_lattice(const int32_t* p2map, int nc, int W, int H, CellLattice& cl) {
+  cl = CellLattice();
+  cl.tried = true;
+  if (W < 7 || H < 7 || !(W & 1) || !(H & 1)) return false;
+  const int nx = (W - 1) / 2, ny = (H - 1) / 2;
+  if ((int64_t)2 * nx * ny != nc) return false;
+  // the template of the two cell types: node positions relative to the square's corner node
+  for (int t = 0; t < 2; ++t)
+    for (int k = 0; k < 6; ++k) {
+      const int node = p2map[(size_t)t * 6 + k];
+      const int j = node / W, i = node - j * W;
+      if (i > 2 || j > 2) return false;
+      cl.di[t][k] = i;
+      cl.dj[t][k] = j;
+    }
+  for (int sy = 0; sy < ny; ++sy)
+    for (int sx = 0; sx < nx; ++sx)
+      for (int t = 0; t < 2; ++t) {
+        const size_t c = 2 * ((size_t)sy * nx + sx) + t;
+        for (int k = 0; k < 6; ++k)
+          if (p2map[c * 6 + k] != (2 * sy + cl.dj[t][k]) * W + 2 * sx + cl.di[t][k]) return false;
+      }
+  // rank of (t, k) among the cells around its node, taken at the interior square (1, 1)
+  for (int t = 0; t < 2; ++t)
+    for (int k = 0; k < 6; ++k) {
+      const size_t c = 2 * ((size_t)1 * nx + 1) + t;
+      const int node = p2map[c * 6 + k];
+      int before = 0;
+      for (int sy = 0; sy < 3; ++sy)
+        for (int sx = 0; sx < 3; ++sx)
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const size_t c2 = 2 * ((size_t)sy * nx + sx) + t2;
+            if (c2 >= c) continue;
+            for (int k2 = 0; k2 < 6; ++k2) before += p2map[c2 * 6 + k2] == node;
+          }
+      if (before > 5) return false;
+      cl.rank[t][k] = before;
+    }
+  cl.nx = nx; cl.ny = ny; cl.W = W; cl.H = H;
+  cl.ok = true;
+  return true;
+}
+
+static bool g_jac_lattice_on = true;
+static int g_jac_lattice_dbg = 0;
+// tile shape in use: 0 = 32 x 8 squares (512 threads), 1 = 16 x 8 (256), 2 = 16 x 16 (512), 3 = 8 x 8 (128)
+static int g_jac_lattice_tile = 0;
+void refresh_assembly_switches() {
+  const char* e = std::getenv("NSFEM_JAC_LATTICE");
+  g_jac_lattice_on = e ? std::atoi(e) != 0 : true;
+  e = std::getenv("NSFEM_JL_DBG");
+  g_jac_lattice_dbg = e ? std::atoi(e) : 0;
+  e = std::getenv("NSFEM_JL_TILE");
+  g_jac_lattice_tile = e ? std::max(0, std::min(3, std::atoi(e))) : 0;
+}
+static void jac_lattice_shape(int& sx, int& sy) {
+  static const int shapes[4][2] = {{32, 8}, {16, 8}, {16, 16}, {8, 8}};
+  sx = shapes[g_jac_lattice_tile][0];
+  sy = shapes[g_jac_lattice_tile][1];
+}
+static size_t jac_lattice_lds(const StencilDict& d) {
+  const size_t lp = (size_t)((d.lmax + 3) & ~3);
+  int sx, sy;
+  jac_lattice_shape(sx, sy);
+  return (size_t)3 * (2 * sx + 1) * (2 * sy + 1) * sizeof(double2) + (size_t)d.n_stencils * lp * 12 +
+         (size_t)d.n_stencils * 4 + 16;
+}
+
+bool jacobian_lattice_available(const MeshDev& m, const BlockMat& L) {
+  const CellLattice& cl = m.cl;
+  if (!g_jac_lattice_on || !cl.ok || m.dim != 2 || !L.dict_ready || !L.dict) return false;
+  const StencilDict& d = *L.dict;
+  return d.lat_w == cl.W && d.lat_h == cl.H && d.lat_r <= 2 && !d.rect && L.br == 1 && L.bc == 1 &&
+         d.n_stencils <= 64 && jac_lattice_lds(d) <= (size_t)96 * 1024;
+}
+int64_t jacobian_lattice_bytes(const MeshDev& m) {
+  return (int64_t)m.n_p2 * (3 * 16 + 1 + 2) + (int64_t)m.n_cells * 48;
+}
+
+bool launch_jacobian_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u,
+                             const double* x, double cc, int form, bool picard, const uint8_t* mask,
+                             double* y) {
+  const CellLattice& cl = m.cl;
+  if (!mask || !jacobian_lattice_available(m, L)) return false;
+  const StencilDict& d = *L.dict;
+  JacLatArgs a;
+  a.nx = cl.nx; a.ny = cl.ny; a.W = cl.W; a.H = cl.H; a.nc = m.n_cells;
+  int sx, sy;
+  jac_lattice_shape(sx, sy);
+  const int ox = 2 * (sx - 1), oy = 2 * (sy - 1);
+  a.ntx = (cl.W + ox - 1) / ox;
+  a.ntiles = a.ntx * ((cl.H + oy - 1) / oy);
+  a.lmax = d.lmax; a.lp = (d.lmax + 3) & ~3; a.n_st = d.n_stencils;
+  a.dbg = g_jac_lattice_dbg;
+  a.cc = cc;
+  int pk[2][2] = {{0, 0}, {0, 0}};
+  for (int t = 0; t < 2; ++t)
+    for (int k = 0; k < 6; ++k) {
+      pk[0][t] |= (cl.dj[t][k] * 3 + cl.di[t][k]) << (5 * k);
+      pk[1][t] |= cl.rank[t][k] << (5 * k);
+    }
+  a.noff0 = pk[0][0]; a.noff1 = pk[0][1]; a.rank0 = pk[1][0]; a.rank1 = pk[1][1];
+  const size_t lds = jac_lattice_lds(d);
+  const int grid = ((a.ntiles + 7) / 8) * 8;
+#define NSFEM_JL_T(F, LIN, SX, SY)                                                                          \
+  do {                                                                                                      \
+    static bool attr = false;                                                                               \
+    if (!attr) {                                                                                            \
+      NSFEM_HIP(hipFuncSetAttribute((const void*)k_jac_lattice<F, LIN, SX, SY>,                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                \
+      attr = true;                                                                                          \
+      if (std::getenv("NSFEM_JL_OCC")) {                                                                    \
+        int nb = 0;                                                                                         \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_jac_lattice<F, LIN, SX, SY>, \
+                                                           2 * SX * SY, lds);                               \
+        std::fprintf(stderr, "k_jac_lattice<%d x %d>: %d workgroups per CU at %zu B of LDS\n", SX, SY, nb, lds); \
+      }                                                                                                     \
+    }                                                                                                       \
+    hipLaunchKernelGGL((k_jac_lattice<F, LIN, SX, SY>), dim3(grid), dim3(2 * SX * SY), lds, s, a, m.vx.p, u, x, \
+                       d.sid8.p, mask, d.len.p, d.pack.p, L.dict_vals.p, y);                                \
+  } while (0)
+#define NSFEM_JL(F, LIN)                                                                                    \
+  do {                                                                                                      \
+    switch (g_jac_lattice_tile) {                                                                           \
+      case 1: NSFEM_JL_T(F, LIN, 16, 8); break;                                                             \
+      case 2: NSFEM_JL_T(F, LIN, 16, 16); break;                                                            \
+      case 3: NSFEM_JL_T(F, LIN, 8, 8); break;                                                              \
+      default: NSFEM_JL_T(F, LIN, 32, 8); break;                                                            \
+    }                                                                                                       \
+  } while (0)
+  if (lds > 96 * 1024) return false;
+  if (picard) {
+    switch (form) {
+      case 0: NSFEM_JL(0, 2); break;
+      case 1: NSFEM_JL(1, 2); break;
+      case 2: NSFEM_JL(2, 2); break;
+      case 3: NSFEM_JL(3, 2); break;
+      default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
+    }
+  } else {
+    switch (form) {
+      case 0: NSFEM_JL(0, 1); break;
+      case 1: NSFEM_JL(1, 1); break;
+      case 2: NSFEM_JL(2, 1); break;
+      case 3: NSFEM_JL(3, 1); break;
+      default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
+    }
+  }
+#undef NSFEM_JL_T
+#undef NSFEM_JL
+  NSFEM_HIP(hipGetLastError());
+  return true;
 }
 
 }  // namespace nsfem

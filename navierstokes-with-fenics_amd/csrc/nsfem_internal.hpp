@@ -248,6 +248,7 @@ void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x,
 
 // multi-step lattice smoother (2D lexicographic lattices with a stencil dictionary; linalg.hip)
 void refresh_env_switches();            // NSFEM_LATTICE, NSFEM_LATTICE_TRANSFERS (re-read by nsfem_create)
+void refresh_assembly_switches();       // NSFEM_JAC_LATTICE
 bool lattice_transfers_enabled();
 bool lattice_smoother_available(const BlockMat& A, int nv);
 int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid);
@@ -262,6 +263,16 @@ void launch_lattice_sidm(hipStream_t s, const BlockMat& A, int nv, const uint8_t
 int64_t lattice_launch_bytes(const BlockMat& A, int nv, bool from_zero, bool d_in, bool d_out, bool r_out);
 
 // element kernels
+// 2D lattice meshes in rectangle_mesh numbering (cell 2 (sy nx + sx) + t, P2 node j W + i): the node positions of
+// a cell are a template of its type -- verified cell by cell on the host (build_cell_lattice), used by k_jac_lattice
+struct CellLattice {
+  bool ok = false, tried = false;
+  int nx = 0, ny = 0, W = 0, H = 0;
+  int di[2][6] = {{0}}, dj[2][6] = {{0}};   // lattice offset of local node k of cell type t from the square's corner
+  int rank[2][6] = {{0}};                   // position of the cell among the cells around that node (ascending)
+};
+bool build_cell_lattice(const int32_t* p2map /* [cell][6] */, int nc, int W, int H, CellLattice& cl);
+
 struct MeshDev {
   int dim = 2;              // 2: triangles (6 + 3 nodes per cell), 3: tetrahedra (10 + 4)
   int n_cells = 0, n_p2 = 0, n_p1 = 0, n_vertices = 0;
@@ -275,6 +286,7 @@ struct MeshDev {
   DevBuf<int32_t> nptr, ndst;
   DevBuf<double> ebuf;      // element Jacobian blocks [cell][6][6][4] (plain stores)
   DevBuf<double> rbuf;      // element residual [cell][6][2]
+  CellLattice cl;
 };
 void launch_assemble_p2_scalar(hipStream_t s, const MeshDev& m, const Pattern& p22,
                                double* mass, double* stiff);
@@ -329,6 +341,12 @@ void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, 
                               const uint8_t* skipmask = nullptr);
 // only the element kernel of the action: the element vectors land node-sorted in m.rbuf (runs m.nptr); the
 // caller sums them per node (launch_spmv_with_gather)
+// y = L x + c_c [d conv(u)/du] x, identity on the rows flagged in mask: ONE launch on 2D lattice meshes (m.cl.ok and a
+// lattice stencil dictionary of L); false = not available, nothing launched
+bool jacobian_lattice_available(const MeshDev& m, const BlockMat& L);
+int64_t jacobian_lattice_bytes(const MeshDev& m);   // u, x read, y written, ids + masks, vertex coordinates
+bool launch_jacobian_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u, const double* x,
+                             double cc, int form, bool picard, const uint8_t* mask, double* y);
 void launch_convection_cells(hipStream_t s, const MeshDev& m, const double* u, const double* v, double cc,
                              int form, bool picard);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
@@ -805,6 +823,7 @@ struct nsfem_ctx {
     size_t n = 0;
     ~Probe() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
   } conv_probe;
+  int64_t jac_lattice_launches = 0;   // applications of the matrix-free Jacobian through k_jac_lattice
   bool mf_active = false;           // the running step driver applies the Jacobian matrix-free
   int pressure_history = 0;         // IPCS: pressure levels shifted since the state was last set (0..2)
   struct MixedOp : nsfem::Operator {

@@ -275,3 +275,44 @@ def test_cycles_on_the_lattice_kernel_equal_the_one_step_cycles(n, monkeypatch):
     u, p = out["fused"][0], out["fused"][1]
     assert rel(u, orc.vel[1]) < 1e-8
     assert rel(p - p.mean(), orc.p_old - orc.p_old.mean()) < 1e-7
+
+
+@pytest.mark.parametrize("nx,ny,form_id,form,picard", [
+    (16, 16, 0, "standard", False), (80, 24, 0, "standard", False), (36, 52, 1, "rotational", False),
+    (40, 40, 2, "divergence", False), (64, 32, 3, "skew_symmetric", False), (48, 20, 0, "standard", True)])
+def test_lattice_jacobian_kernel_equals_the_launch_pair_bitwise_and_the_oracle(nx, ny, form_id, form, picard,
+                                                                               monkeypatch):
+    """Matrix-free action of the velocity Jacobian  y = L x + c_c [d conv(u)/du] x  (identity on Dirichlet rows) on
+    lattice meshes: the one-launch kernel k_jac_lattice against the pair it replaces (k_conv_cell + dictionary product
+    with fused node gather; NSFEM_JAC_LATTICE=0) bit for bit -- same products in the same order -- and both against
+    the oracle's exact Gateaux derivative (source/ns_solver_base.py:370-390 linearised).  Tile edges: 1 x 3 up to
+    3 x 8 workgroup tiles, partial tiles in both directions."""
+    from gpu_common import box, cavity_bc
+    mesh, dm, marks = box(nx, ny, p1=(nx / 16.0, ny / 16.0))          # binary spacing: exact dictionary
+    bd, bv = cavity_bc(dm, marks)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    rng = np.random.default_rng(100 * nx + ny)
+    u = rng.standard_normal(dm.n_velocity)
+    x = rng.standard_normal(dm.n_velocity)
+    out = {}
+    for tag, env in (("pair", "0"), ("lattice", "1")):
+        monkeypatch.setenv("NSFEM_JAC_LATTICE", env)
+        ctx = context(mesh, dm)
+        ctx.set_coeffs(0.8, 1.0, 0.02)
+        ctx.set_bdf((1.5, -2.0, 0.5), 0.05)
+        ctx.set_dirichlet(nat.VELOCITY, bd.astype(np.int32), bv)
+        ctx.set_state(nat.USTAR, u)
+        ctx.set_convective_form(form_id, picard=picard)
+        info0 = ctx.jacobian_info()
+        y = ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x)
+        info = ctx.jacobian_info()
+        assert info0["path"] == info["path"] == ("lattice-kernel" if tag == "lattice" else "fused-gather")
+        assert info["lattice_launches"] == (1 if tag == "lattice" else 0)
+        out[tag] = y
+        ctx.close()
+    assert np.array_equal(out["pair"], out["lattice"])
+    L = 1.5 / 0.05 * s.vector_mass() + 0.02 * s.vector_stiffness()
+    J = L + 0.8 * (s.picard_convection(u, form) if picard else s.convection_jacobian(u, form))
+    ref = J @ x
+    ref[bd] = x[bd]
+    assert rel(out["lattice"], ref) < 1e-13

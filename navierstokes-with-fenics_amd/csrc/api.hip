@@ -655,9 +655,17 @@ static void fill_linop(nsfem_ctx* c, LinOp& op, bool velocity) {
   op.n_global = velocity ? 2 * c->n_p2_global : c->n_p1_global;
 }
 
+static int jacobian_path(nsfem_ctx* c);
 static void momentum_residual_raw(nsfem_ctx* c, const double* u, double* out) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c);
+  // lattice meshes (same conditions as the one-launch Jacobian action): product, + g, element kernel and node sums
+  // in one launch of k_jac_lattice<FORM, 0>
+  if (jacobian_path(c) == 2 &&
+      launch_residual_lattice(s, c->mesh, c->L, u, c->gconst.p, cc_of(c), c->conv_form, out)) {
+    ++c->jac_lattice_launches;
+    return;
+  }
   launch_spmv(s, c->L, c->mesh.dim, u, out, nullptr, MASK_NONE);
   launch_axpby(s, nv, 1.0, out, 1.0, c->gconst.p, out);
   if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], u, out, nullptr);

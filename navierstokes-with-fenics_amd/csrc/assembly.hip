@@ -813,7 +813,11 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
                    const double* __restrict__ x, const uint8_t* __restrict__ sid8,
                    const uint8_t* __restrict__ mask, const int32_t* __restrict__ slen,
                    const int32_t* __restrict__ spack, const double* __restrict__ sval,
-                   double* __restrict__ y) {
+                   const double* __restrict__ gadd, double* __restrict__ y) {
+  // LIN = 0: the momentum residual  y = L u + g + c_c conv(u)  (x is not read, no mask: the Dirichlet rows are
+  // set by the caller afterwards); g joins the node's sum after the L product and before the element vectors,
+  // the order of the launches it replaces (product, axpby, k_conv_cell, k_res_gather)
+  constexpr bool RES = LIN == 0;
   extern __shared__ __attribute__((aligned(16))) double sh_jl[];
   constexpr int NT = 2 * SX * SY;                                   // threads
   constexpr int kJlNW = 2 * SX + 1, kJlNH = 2 * SY + 1;             // staged node lines
@@ -822,7 +826,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   static_assert((1 << LOGSX) == SX, "SX: 8, 16 or 32");
   constexpr int NN = kJlNW * kJlNH;
   double2* __restrict__ su = reinterpret_cast<double2*>(sh_jl);
-  double2* __restrict__ sx = su + NN;
+  double2* __restrict__ sx = RES ? su : su + NN;
   double2* __restrict__ sa = sx + NN;
   double* __restrict__ tv = reinterpret_cast<double*>(sa + NN);       // [n_st * lp]
   int* __restrict__ to = reinterpret_cast<int*>(tv + a.n_st * a.lp);
@@ -849,7 +853,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     if (t < NN && gi >= 0 && gi < a.W && gj >= 0 && gj < a.H && !(a.dbg & 8)) {
       const size_t g = (size_t)gj * a.W + gi;
       uv[r] = u2[g];
-      xv[r] = x2[g];
+      if (!RES) xv[r] = x2[g];
     }
   }
   // (this thread's cell, its two owned nodes)
@@ -862,6 +866,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   constexpr int OWN = kJlOX * kJlOY, NOWN = (OWN + NT - 1) / NT;
   int obase[NOWN], oent[NOWN], omask[NOWN];
   size_t onode[NOWN];
+  double2 og[RES ? NOWN : 1];
 #pragma unroll
   for (int r = 0; r < NOWN; ++r) {
     const int o = tid + r * NT;
@@ -875,7 +880,8 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
       obase[r] = (oj + 2) * kJlNW + oi + 2;
       onode[r] = (size_t)gj * a.W + gi;
       oent[r] = sid8[onode[r]];
-      omask[r] = reinterpret_cast<const uint16_t*>(mask)[onode[r]];
+      if (RES) og[r] = reinterpret_cast<const double2*>(gadd)[onode[r]];
+      else omask[r] = reinterpret_cast<const uint16_t*>(mask)[onode[r]];
     }
   }
   for (int t = tid; t < a.n_st * a.lp; t += NT) {
@@ -892,7 +898,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     const int t = tid + r * NT;
     if (t < NN) {
       su[t] = uv[r];
-      sx[t] = xv[r];
+      if (!RES) sx[t] = xv[r];
     }
   }
   __syncthreads();
@@ -917,6 +923,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
       ax = fma(vb.x, x2_.x, ax); ay = fma(vb.x, x2_.y, ay);
       ax = fma(vb.y, x3.x, ax); ay = fma(vb.y, x3.y, ay);
     }
+    if (RES) { ax += og[r].x; ay += og[r].y; }
     sa[base] = make_double2(ax, ay);
   }
   // ---- phase 2: the element vector of this thread's cell
@@ -931,16 +938,19 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     nl[k] = corner + dj * kJlNW + (f - 3 * dj);
   }
   if (cell && !(a.dbg & 64)) {
-    double ux[6], uy[6], wx[6], wy[6];
+    double ux[6], uy[6], wx[RES ? 1 : 6], wy[RES ? 1 : 6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double2 p = su[nl[k]], q = sx[nl[k]];
+      const double2 p = su[nl[k]];
       ux[k] = p.x; uy[k] = p.y;
-      wx[k] = q.x; wy[k] = q.y;
+      if (!RES) {
+        const double2 q = sx[nl[k]];
+        wx[k] = q.x; wy[k] = q.y;
+      }
     }
     if (a.dbg & 1) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { rx[k] = ux[k] + wx[k]; ry[k] = uy[k] + wy[k]; }
+      for (int k = 0; k < 6; ++k) { rx[k] = ux[k]; ry[k] = uy[k]; }
     } else {
       conv_cell_eval<FORM, LIN>(geo, ux, uy, wx, wy, a.cc, rx, ry);
     }
@@ -967,9 +977,11 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   for (int r = 0; r < NOWN; ++r) {
     if (obase[r] < 0) continue;
     double2 v = sa[obase[r]];
-    const double2 xo = sx[obase[r]];
-    if (omask[r] & 0x00ff) v.x = xo.x;
-    if (omask[r] & 0xff00) v.y = xo.y;
+    if (!RES) {
+      const double2 xo = sx[obase[r]];
+      if (omask[r] & 0x00ff) v.x = xo.x;
+      if (omask[r] & 0xff00) v.y = xo.y;
+    }
     if (!(a.dbg & 32) || v.x == 1.2345) y2[onode[r]] = v;
   }
 }
@@ -1019,7 +1031,9 @@ bool build_cell_lattice(const int32_t* p2map, int nc, int W, int H, CellLattice&
 
 static bool g_jac_lattice_on = true;
 static int g_jac_lattice_dbg = 0;
-// tile shape in use: 0 = 32 x 8 squares (512 threads), 1 = 16 x 8 (256), 2 = 16 x 16 (512), 3 = 8 x 8 (128)
+// tile shape in use: 0 = 32 x 8 squares (512 threads), 1 = 16 x 8 (256).  Measured at n = 512 (us per launch of the
+// Newton action): 32 x 8: 48.3, 16 x 8: 50.4, 16 x 16: 50.5, 8 x 8: 55.5 -- the launch is bound by the latency chain of
+// a wave (loads, barriers, LDS phases) at 4 waves per SIMD, not by the shape of the tile
 static int g_jac_lattice_tile = 0;
 void refresh_assembly_switches() {
   const char* e = std::getenv("NSFEM_JAC_LATTICE");
@@ -1027,10 +1041,10 @@ void refresh_assembly_switches() {
   e = std::getenv("NSFEM_JL_DBG");
   g_jac_lattice_dbg = e ? std::atoi(e) : 0;
   e = std::getenv("NSFEM_JL_TILE");
-  g_jac_lattice_tile = e ? std::max(0, std::min(3, std::atoi(e))) : 0;
+  g_jac_lattice_tile = e ? std::max(0, std::min(1, std::atoi(e))) : 0;
 }
 static void jac_lattice_shape(int& sx, int& sy) {
-  static const int shapes[4][2] = {{32, 8}, {16, 8}, {16, 16}, {8, 8}};
+  static const int shapes[2][2] = {{32, 8}, {16, 8}};
   sx = shapes[g_jac_lattice_tile][0];
   sy = shapes[g_jac_lattice_tile][1];
 }
@@ -1053,11 +1067,12 @@ int64_t jacobian_lattice_bytes(const MeshDev& m) {
   return (int64_t)m.n_p2 * (3 * 16 + 1 + 2) + (int64_t)m.n_cells * 48;
 }
 
-bool launch_jacobian_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u,
-                             const double* x, double cc, int form, bool picard, const uint8_t* mask,
-                             double* y) {
+// lin: 0 residual (x, mask unused; gadd = g), 1 Newton action, 2 Picard action
+static bool launch_lattice_cells(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u,
+                                 const double* x, double cc, int form, int lin, const uint8_t* mask,
+                                 const double* gadd, double* y) {
   const CellLattice& cl = m.cl;
-  if (!mask || !jacobian_lattice_available(m, L)) return false;
+  if (!jacobian_lattice_available(m, L)) return false;
   const StencilDict& d = *L.dict;
   JacLatArgs a;
   a.nx = cl.nx; a.ny = cl.ny; a.W = cl.W; a.H = cl.H; a.nc = m.n_cells;
@@ -1093,39 +1108,44 @@ bool launch_jacobian_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L,
       }                                                                                                     \
     }                                                                                                       \
     hipLaunchKernelGGL((k_jac_lattice<F, LIN, SX, SY>), dim3(grid), dim3(2 * SX * SY), lds, s, a, m.vx.p, u, x, \
-                       d.sid8.p, mask, d.len.p, d.pack.p, L.dict_vals.p, y);                                \
+                       d.sid8.p, mask, d.len.p, d.pack.p, L.dict_vals.p, gadd, y);                          \
   } while (0)
 #define NSFEM_JL(F, LIN)                                                                                    \
   do {                                                                                                      \
     switch (g_jac_lattice_tile) {                                                                           \
       case 1: NSFEM_JL_T(F, LIN, 16, 8); break;                                                             \
-      case 2: NSFEM_JL_T(F, LIN, 16, 16); break;                                                            \
-      case 3: NSFEM_JL_T(F, LIN, 8, 8); break;                                                              \
       default: NSFEM_JL_T(F, LIN, 32, 8); break;                                                            \
     }                                                                                                       \
   } while (0)
   if (lds > 96 * 1024) return false;
-  if (picard) {
-    switch (form) {
-      case 0: NSFEM_JL(0, 2); break;
-      case 1: NSFEM_JL(1, 2); break;
-      case 2: NSFEM_JL(2, 2); break;
-      case 3: NSFEM_JL(3, 2); break;
-      default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
-    }
-  } else {
-    switch (form) {
-      case 0: NSFEM_JL(0, 1); break;
-      case 1: NSFEM_JL(1, 1); break;
-      case 2: NSFEM_JL(2, 1); break;
-      case 3: NSFEM_JL(3, 1); break;
-      default: throw Error(NSFEM_ERR_ARG, "unknown convective form");
-    }
+#define NSFEM_JL_F(LIN)                                                                                     \
+  switch (form) {                                                                                           \
+    case 0: NSFEM_JL(0, LIN); break;                                                                        \
+    case 1: NSFEM_JL(1, LIN); break;                                                                        \
+    case 2: NSFEM_JL(2, LIN); break;                                                                        \
+    case 3: NSFEM_JL(3, LIN); break;                                                                        \
+    default: throw Error(NSFEM_ERR_ARG, "unknown convective form");                                         \
   }
+  if (lin == 0) { NSFEM_JL_F(0) } else if (lin == 2) { NSFEM_JL_F(2) } else { NSFEM_JL_F(1) }
+#undef NSFEM_JL_F
 #undef NSFEM_JL_T
 #undef NSFEM_JL
   NSFEM_HIP(hipGetLastError());
   return true;
+}
+
+bool launch_jacobian_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u,
+                             const double* x, double cc, int form, bool picard, const uint8_t* mask,
+                             double* y) {
+  if (!mask) return false;
+  return launch_lattice_cells(s, m, L, u, x, cc, form, picard ? 2 : 1, mask, nullptr, y);
+}
+// y = L u + g + c_c conv(u): the momentum residual before its Dirichlet rows are set.  Only on dictionaries that
+// equal the assembled matrix bit for bit (the residual decides the convergence of the Newton iteration)
+bool launch_residual_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u, const double* g,
+                             double cc, int form, double* y) {
+  if (!L.dict || !L.dict->exact || !g) return false;
+  return launch_lattice_cells(s, m, L, u, u, cc, form, 0, nullptr, g, y);
 }
 
 }  // namespace nsfem

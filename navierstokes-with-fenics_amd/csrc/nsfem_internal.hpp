@@ -341,6 +341,8 @@ void launch_convection_action(hipStream_t s, const MeshDev& m, const double* u, 
                               const uint8_t* skipmask = nullptr);
 // only the element kernel of the action: the element vectors land node-sorted in m.rbuf (runs m.nptr); the
 // caller sums them per node (launch_spmv_with_gather)
+bool launch_residual_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u, const double* g,
+                             double cc, int form, double* y);   // y = L u + g + c_c conv(u) (exact dictionaries)
 // y = L x + c_c [d conv(u)/du] x, identity on the rows flagged in mask: ONE launch on 2D lattice meshes (m.cl.ok and a
 // lattice stencil dictionary of L); false = not available, nothing launched
 bool jacobian_lattice_available(const MeshDev& m, const BlockMat& L);

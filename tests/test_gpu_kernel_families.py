@@ -316,3 +316,41 @@ def test_lattice_jacobian_kernel_equals_the_launch_pair_bitwise_and_the_oracle(n
     ref = J @ x
     ref[bd] = x[bd]
     assert rel(out["lattice"], ref) < 1e-13
+
+
+@pytest.mark.parametrize("nx,ny,form_id,form", [(16, 16, 0, "standard"), (80, 24, 3, "skew_symmetric"),
+                                                 (36, 52, 1, "rotational"), (40, 40, 2, "divergence")])
+def test_lattice_residual_kernel_equals_the_four_launch_path_bitwise_and_the_oracle(nx, ny, form_id, form, monkeypatch):
+    """Momentum residual  b = L u* + g + c_c conv(u*)  (Dirichlet rows u* - g_D; source/ns_ipcs_solver.py:126-135) on
+    lattice meshes: k_jac_lattice<FORM, 0> in one launch against product + axpby + k_conv_cell + k_res_gather
+    (NSFEM_JAC_LATTICE=0) bit for bit, and against the oracle's residual."""
+    from gpu_common import box, cavity_bc
+    mesh, dm, marks = box(nx, ny, p1=(nx / 16.0, ny / 16.0))
+    bd, bv = cavity_bc(dm, marks)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    rng = np.random.default_rng(7 * nx + ny)
+    u, u1, u2 = (rng.standard_normal(dm.n_velocity) for _ in range(3))
+    p = rng.standard_normal(dm.n_p1)
+    out = {}
+    for tag, env in (("four", "0"), ("lattice", "1")):
+        monkeypatch.setenv("NSFEM_JAC_LATTICE", env)
+        ctx = context(mesh, dm)
+        ctx.set_coeffs(0.8, 1.0, 0.02)
+        ctx.set_bdf((1.5, -2.0, 0.5), 0.05)
+        ctx.set_dirichlet(nat.VELOCITY, bd.astype(np.int32), bv)
+        for slot, v in ((nat.U1, u1), (nat.U2, u2), (nat.USTAR, u), (nat.P_OLD, p)):
+            ctx.set_state(slot, v)
+        ctx.set_convective_form(form_id)
+        n0 = ctx.jacobian_info()["lattice_launches"]
+        ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+        info = ctx.jacobian_info()
+        assert info["path"] == ("lattice-kernel" if tag == "lattice" else "fused-gather")
+        assert info["lattice_launches"] - n0 == (1 if tag == "lattice" else 0)
+        out[tag] = ctx.get_rhs(nat.SYS_MOMENTUM)
+        ctx.close()
+    assert np.array_equal(out["four"], out["lattice"])
+    M = s.vector_mass()
+    b = (1.5 / 0.05 * M + 0.02 * s.vector_stiffness()) @ u + M @ ((-2.0 * u1 + 0.5 * u2) / 0.05) \
+        - 1.0 * (s.divergence().T @ p) + 0.8 * s.convection_residual(u, form)      # (fem_oracle.IPCSOracle: const)
+    b[bd] = u[bd] - bv
+    assert rel(out["lattice"], b) < 1e-12

@@ -1225,92 +1225,159 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   LatticeSlots<NV, K> st;
   unsigned long long differs = 0;
   int stu = -1;
+  // Staging in three passes, so that a wave has ONE memory round trip per pass instead of one per load (loads
+  // behind lane-dependent branches are issued and waited for one by one -- 10 to 30 dependent round trips per
+  // launch, which is what a launch on the small levels of the hierarchy cost): every load is unconditional at an
+  // index clamped into the lattice, the conditions select the loaded values afterwards.
+  //   pass 1  rings, clamped node indices, the byte entry | masks of every slot
+  //   pass 2  the vector operands of every slot (b or the 7 fine values of R rf; d; x, P xc)
+  //   pass 3  masks and conditions applied, slot state filled, start iterate stored to LDS
+  int ringq[K], smq[K], gjcq[K];
+  size_t gcl[K];
+  const int gic = min(max(gi, 0), a.W - 1);
 #pragma unroll
   for (int q = 0; q < K; ++q) {
     const int pr = 2 * (2 * q + (w & 1)) + (lane >> 5);
     const int gj = oy + 2 * pr + pj;
     const bool in = in_x && gj >= 0 && gj < a.H;
     const int ey = max(max(j0 - gj, gj - (j1 - 1)), 0);
-    const int ring = in ? min(max(ex, ey), 255) : 255;
+    ringq[q] = in ? min(max(ex, ey), 255) : 255;
     if (q == 0) {
       st.self0 = cls * plane + pr * 32 + (lane & 31);
       st.grow0 = gj * a.W + gi;
       st.gstep = 8 * a.W;
     }
-    int stq = 0, mkq = 0;
+    const int gjc = min(max(gj, 0), a.H - 1);
+    gjcq[q] = gjc;
+    gcl[q] = (size_t)gjc * a.W + gic;
+    smq[q] = a.sidm[gcl[q]];
+  }
+  double braw[K][NV], draw[K][NV], xraw[K][NV];
+  // (one loop per kernel-uniform case: the loads of all slots sit in one basic block and are issued together)
+  if (a.rf) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      // b = R rf: the node's own fine value + half of its six fine neighbours (ascending fine index, the
+      // order of the CSR row of R = P^T); absent neighbours: the own value with weight 0
+      const int fi = 2 * gic, fj = 2 * gjcq[q];
+      const size_t fb = (size_t)fj * a.Wf + fi;
+      const bool l_ = fi > 0, r_ = fi < a.Wf - 1, d_ = fj > 0, u_ = fj < a.Hf - 1;
+      const size_t n0 = (d_ && l_) ? fb - a.Wf - 1 : fb, n1 = d_ ? fb - a.Wf : fb, n2 = l_ ? fb - 1 : fb;
+      const size_t n4 = r_ ? fb + 1 : fb, n5 = u_ ? fb + a.Wf : fb, n6 = (u_ && r_) ? fb + a.Wf + 1 : fb;
+      const double w0 = (d_ && l_) ? 0.5 : 0.0, w1 = d_ ? 0.5 : 0.0, w2 = l_ ? 0.5 : 0.0;
+      const double w4 = r_ ? 0.5 : 0.0, w5 = u_ ? 0.5 : 0.0, w6 = (u_ && r_) ? 0.5 : 0.0;
+      double f[7][NV];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        f[0][c] = a.rf[n0 * NV + c]; f[1][c] = a.rf[n1 * NV + c]; f[2][c] = a.rf[n2 * NV + c];
+        f[3][c] = a.rf[fb * NV + c];
+        f[4][c] = a.rf[n4 * NV + c]; f[5][c] = a.rf[n5 * NV + c]; f[6][c] = a.rf[n6 * NV + c];
+      }
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        double v = 0.0;
+        v += w0 * f[0][c];
+        v += w1 * f[1][c];
+        v += w2 * f[2][c];
+        v += f[3][c];
+        v += w4 * f[4][c];
+        v += w5 * f[5][c];
+        v += w6 * f[6][c];
+        braw[q][c] = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) braw[q][c] = a.b[gcl[q] * NV + c];
+  }
+  if (!a.from_zero && a.d_in) {
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) draw[q][c] = a.d_in[gcl[q] * NV + c];
+  } else {
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) draw[q][c] = 0.0;
+  }
+  if (!a.from_zero && a.xc) {
+    // start vector = [x_in +] P xc: even-even nodes copy their coarse node, the others average the two
+    // coarse nodes (I, J) and (I + pi, J + pj)
+    double xin[K][NV];
+    if (a.x_in) {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+#pragma unroll
+        for (int c = 0; c < NV; ++c) xin[q][c] = a.x_in[gcl[q] * NV + c];
+    }
+    const size_t cmax = (size_t)a.Wc * ((a.H + 1) >> 1) - 1;
+    const double pw0 = cls != 0 ? 0.5 : 1.0, pw1 = cls != 0 ? 0.5 : 0.0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const size_t c0 = (size_t)(gjcq[q] >> 1) * a.Wc + (gic >> 1);
+      const size_t c1 = min(c0 + pi + (size_t)pj * a.Wc, cmax);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const double v0 = a.xc[c0 * NV + c], v1 = a.xc[c1 * NV + c];
+        xraw[q][c] = pw0 * v0 + pw1 * v1;            // (1 v0 + 0 v1 on the even-even class: the copy, exactly)
+      }
+    }
+    if (a.x_in) {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+#pragma unroll
+        for (int c = 0; c < NV; ++c) xraw[q][c] = xin[q][c] + xraw[q][c];
+    }
+  } else if (!a.from_zero) {
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) xraw[q][c] = a.x_in[gcl[q] * NV + c];
+  } else {
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) xraw[q][c] = 0.0;
+  }
+  double diq[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) diq[q] = a.from_zero ? tdinv[smq[q] & 63] : 0.0;
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const int ring = ringq[q];
+    const bool counts = ring <= need;
+    const int stq = counts ? (smq[q] & 63) : 0, mkq = counts ? (smq[q] >> 6) : 0;
     double xv[NV];
 #pragma unroll
-    for (int c = 0; c < NV; ++c) st.bq[q][c] = st.dq[q][c] = xv[c] = 0.0;
-    if (ring <= need) {
-      if (a.sidm) {
-        const int sm = a.sidm[st.grow(q)];
-        stq = sm & 63;
-        mkq = sm >> 6;
-      } else {
-        stq = a.sid[st.grow(q)];
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-          if (a.mask && a.mask[(size_t)st.grow(q) * NV + c]) mkq |= 1 << c;
-      }
+    for (int c = 0; c < NV; ++c) {
+      const bool mk = (mkq >> c) & 1;
+      double bv = counts ? braw[q][c] : 0.0;
       if (a.rf) {
-        // b = R rf: the node's own fine value + half of its six fine neighbours (ascending fine index, the
-        // order of the CSR row of R = P^T); rows flagged in the mask get 0
-        const int fi = 2 * gi, fj = 2 * gj;
-        const size_t fb = (size_t)fj * a.Wf + fi;
-        const bool l_ = fi > 0, r_ = fi < a.Wf - 1, d_ = fj > 0, u_ = fj < a.Hf - 1;
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-          double v = 0.0;
-          if (d_ && l_) v += 0.5 * a.rf[(fb - a.Wf - 1) * NV + c];
-          if (d_) v += 0.5 * a.rf[(fb - a.Wf) * NV + c];
-          if (l_) v += 0.5 * a.rf[(fb - 1) * NV + c];
-          v += a.rf[fb * NV + c];
-          if (r_) v += 0.5 * a.rf[(fb + 1) * NV + c];
-          if (u_) v += 0.5 * a.rf[(fb + a.Wf) * NV + c];
-          if (u_ && r_) v += 0.5 * a.rf[(fb + a.Wf + 1) * NV + c];
-          if ((mkq >> c) & 1) v = 0.0;
-          st.bq[q][c] = v;
-          if (ring == 0) a.b_out[(size_t)st.grow(q) * NV + c] = v;
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < NV; ++c) st.bq[q][c] = a.b[(size_t)st.grow(q) * NV + c];
+        if (mk) bv = 0.0;
+        if (counts && ring == 0) a.b_out[st.grow(q) * NV + c] = bv;
       }
-#pragma unroll
-      for (int c = 0; c < NV; ++c)
-        if (!a.from_zero && a.d_in && ring <= Go) st.dq[q][c] = a.d_in[(size_t)st.grow(q) * NV + c];
-    }
-    if (!a.from_zero && ring <= a.G) {
-      if (a.xc) {
-        // start vector = [x_in +] P xc: even-even nodes copy their coarse node, the others average the two
-        // coarse nodes (I, J) and (I + pi, J + pj); rows flagged in the mask get 0
-        const size_t c0 = (size_t)(gj >> 1) * a.Wc + (gi >> 1), c1 = c0 + pi + (size_t)pj * a.Wc;
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-          double v = a.xc[c0 * NV + c];
-          if (cls != 0) v = 0.5 * v + 0.5 * a.xc[c1 * NV + c];
-          if (a.x_in) v = a.x_in[(size_t)st.grow(q) * NV + c] + v;
-          xv[c] = (mkq >> c) & 1 ? 0.0 : v;
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < NV; ++c) xv[c] = a.x_in[(size_t)st.grow(q) * NV + c];
-      }
+      st.bq[q][c] = bv;
+      st.dq[q][c] = (counts && !a.from_zero && a.d_in && ring <= Go) ? draw[q][c] : 0.0;
+      double v = 0.0;
+      if (!a.from_zero && ring <= a.G) v = (a.xc && mk) ? 0.0 : xraw[q][c];
+      xv[c] = v;
     }
     st.info[q] = (ring << 16) | (mkq << 8) | stq;
     // do the wave's nodes share their dictionary entry?
-    const bool counts = ring <= need;
     const unsigned long long who = __ballot(counts);
     if (who != 0) {
       if (stu < 0) stu = __builtin_amdgcn_readfirstlane(__shfl(stq, __ffsll((long long)who) - 1, 64));
       differs |= __ballot(counts && stq != stu);
     }
     if (a.from_zero) {                    // step 0 from a zero start: pointwise
-      const double di = ring <= need ? tdinv[stq] : 0.0;
+      const double di = counts ? diq[q] : 0.0;
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
         double v = 0.0;
-        if (ring <= need) {
+        if (counts) {
           if (!((mkq >> c) & 1)) v = a.c2[0] * di * st.bq[q][c];
           else if (a.ident && a.S == 1) v = st.bq[q][c];
         }
@@ -1438,7 +1505,20 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   a.ident = ident;
   a.x_in = x_in; a.b = b; a.d_in = d_in; a.x_out = x_out; a.d_out = d_out; a.r_out = r_out;
   a.sid = d.sid8.p; a.mask = mask;
-  a.sidm = (sidm && d.n_stencils <= 64 && nv <= 2) ? sidm : nullptr;
+  // entry | masks as ONE byte per row: callers outside the multigrid (test hook, timing) get it built here
+  NSFEM_REQUIRE(d.n_stencils <= 64 && nv <= 2, "the lattice kernel needs <= 64 dictionary entries and <= 2 components");
+  if (!sidm) {
+    static uint8_t* scratch = nullptr;         // (never freed; stream ordered: the launch below follows the fill)
+    static size_t cap = 0;
+    if (cap < (size_t)d.n_rows) {
+      if (scratch) NSFEM_HIP(hipFree(scratch));
+      cap = (size_t)d.n_rows;
+      NSFEM_HIP(hipMalloc((void**)&scratch, cap + 64));
+    }
+    launch_lattice_sidm(s, A, nv, mask, scratch);
+    sidm = scratch;
+  }
+  a.sidm = sidm;
   const int32_t* toff = lattice_offsets(s, d, 32, a.EHh);
   a.lp = (d.lmax + 3) & ~3;
   a.n_st = d.n_stencils;

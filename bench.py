@@ -1128,23 +1128,40 @@ def cavity_ipcs_bench(args):
             cells_only = nbytes_conv < 0
             nbytes_conv = abs(nbytes_conv)
             ach = nbytes_conv / (ms_conv * 1e-3) / 1e9
-            assembly = {"kernel": ("k_conv_cell<FORM,1>: element kernel of the matrix-free action of the convection blocks of "
-                                   "the velocity Jacobian (the per-Newton-iteration assembly of the fused step; one thread "
-                                   "per cell, element vectors stored node-sorted); their per-node sums run inside the "
-                                   "L-product launch k_spmv_dict_w8<2,0> (fused node gather)") if cells_only else
-                                  ("k_conv_cell<FORM,1> + k_res_gather: matrix-free action of the convection "
-                                   "blocks of the velocity Jacobian (the per-Newton-iteration assembly of the "
-                                   "fused step; one thread per cell, element vectors gathered per node in fixed order)"),
-                        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_application": nbytes_conv,
-                        "bytes_formula": ("n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x + 96 element vector "
-                                          "stored)" if cells_only else
-                                          "n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x) + n_dofs_velocity x 16 "
-                                          "(SURVEY.md 8d: vector assembly; the element buffer the two kernels hand "
-                                          "over, 2 x 96 B per cell, is implementation traffic and not counted)"),
-                        "ms_per_application": ms_conv, "applications_timed": n_conv,
-                        "timing": "HIP-event pair around each application inside the BiCGStab solves of 5 solver steps"}
-            if ms_conv_cold is not None and not cells_only:
+            one_launch = ctx.jacobian_info()["path"] == "lattice-kernel"
+            if one_launch:
+                assembly = {"kernel": ("k_jac_lattice<FORM,1>: the WHOLE matrix-free action of the velocity Jacobian  y = L x + c_c "
+                                       "[d conv(u)/du] x  in one launch (the per-Newton-iteration assembly of the fused step, "
+                                       "ns_ipcs_solver.py:136-147): u, x of a 32 x 8-square tile staged in LDS, dictionary product "
+                                       "of L from LDS, one cell per thread (7-point quadrature, node positions from the cell-type "
+                                       "template: no index loads), element vectors summed per node in LDS in ascending cell "
+                                       "order (bitwise equal to k_conv_cell + k_spmv_dict_w8 with node gather), y written once"),
+                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_application": nbytes_conv,
+                            "bytes_formula": "n_p2 (3 x 16 u, x, y + 1 dictionary id + 2 mask bytes) + n_cells x 48 vertex coordinates",
+                            "ms_per_application": ms_conv, "applications_timed": n_conv,
+                            "bound_note": ("not HBM bound: 7 x 130 fp64 operations per cell put the VALU floor at 15 us of the "
+                                           "launch; the rest is the latency chain of a wave (loads, 9 barriers, LDS phases) at "
+                                           "the 4 waves per SIMD its 126 VGPRs allow (DESIGN.md 4d)"),
+                            "timing": "HIP-event pair around each application inside the BiCGStab solves of 5 solver steps"}
+            else:
+              assembly = {"kernel": ("k_conv_cell<FORM,1>: element kernel of the matrix-free action of the convection blocks of "
+                                     "the velocity Jacobian (the per-Newton-iteration assembly of the fused step; one thread "
+                                     "per cell, element vectors stored node-sorted); their per-node sums run inside the "
+                                     "L-product launch k_spmv_dict_w8<2,0> (fused node gather)") if cells_only else
+                                    ("k_conv_cell<FORM,1> + k_res_gather: matrix-free action of the convection "
+                                     "blocks of the velocity Jacobian (the per-Newton-iteration assembly of the "
+                                     "fused step; one thread per cell, element vectors gathered per node in fixed order)"),
+                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_application": nbytes_conv,
+                          "bytes_formula": ("n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x + 96 element vector "
+                                            "stored)" if cells_only else
+                                            "n_cells (48 coords + 24 dof ids + 2 x 96 nodal values of u, x) + n_dofs_velocity x 16 "
+                                            "(SURVEY.md 8d: vector assembly; the element buffer the two kernels hand "
+                                            "over, 2 x 96 B per cell, is implementation traffic and not counted)"),
+                          "ms_per_application": ms_conv, "applications_timed": n_conv,
+                          "timing": "HIP-event pair around each application inside the BiCGStab solves of 5 solver steps"}
+            if ms_conv_cold is not None and not cells_only and not one_launch:
                 assembly["cold_cache"] = {"achieved": nbytes_conv / (ms_conv_cold * 1e-3) / 1e9,
                                           "frac": nbytes_conv / (ms_conv_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           "ms_per_application": ms_conv_cold}

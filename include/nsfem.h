@@ -448,7 +448,9 @@ int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]);
  * stops and reports the average duration [ms] of one application, the number of applications and
  * the algorithmic bytes of one application (SURVEY.md section 8d formula).  One GPU, triangles, lattice
  * mesh: the per-node sums run inside the L-product launch, the event pair then brackets the element
- * kernel alone -- flagged by a NEGATIVE byte count (minus the element kernel's own bytes) */
+ * kernel alone -- flagged by a NEGATIVE byte count (minus the element kernel's own bytes).  Lattice meshes in
+ * rectangle_mesh numbering (nsfem_jacobian_info path 2): the pair brackets k_jac_lattice, i.e. the WHOLE Jacobian
+ * action  L x + c_c [d conv(u)/du] x  in one launch; the byte count is nsfem_jacobian_info's out[2] */
 int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_ms, int64_t* applications,
                              int64_t* algorithmic_bytes);
 /* How the matrix-free action of the velocity Jacobian (NSFEM_OP_MOMENTUM_JAC_MF; the operator of the Newton-Krylov

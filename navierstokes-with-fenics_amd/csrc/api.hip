@@ -2419,7 +2419,8 @@ extern "C" int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_
   if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
   if (applications) *applications = n;
   if (algorithmic_bytes)
-    *algorithmic_bytes = convection_gather_fused(ctx) ? -convection_cells_bytes(ctx) : convection_action_bytes(ctx);
+    *algorithmic_bytes = jacobian_path(ctx) == 2 ? jacobian_lattice_bytes(ctx->mesh)
+                         : convection_gather_fused(ctx) ? -convection_cells_bytes(ctx) : convection_action_bytes(ctx);
   API_END(ctx)
 }
 

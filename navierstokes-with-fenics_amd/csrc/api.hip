@@ -891,6 +891,7 @@ static void correction_assemble(nsfem_ctx* c) {
                            hipMemcpyDeviceToDevice, s));
   launch_set_values(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, c->state[NSFEM_U0].p);
   if (!c->dinv_m_ready) {
+    ++c->mass_dinv_epoch;
     launch_inv_diag(s, c->M2, c->mesh.dim, c->mask_v.p, c->dinv_m.p);
     c->dinv_m_ready = true;
   }
@@ -921,13 +922,17 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
       mg.lv[0].has_halo = true;
     }
     mg.setup_work(s);
+    c->mass_dinv_copied_epoch = -1;            // (fresh work vectors)
     // interval [0.98 lmin, 1.02 lmax] in the parametrisation of Multigrid::cheb_coeffs
     c->mass_kappa = (1.02 * lmax) / (0.98 * lmin);
     mg.eig_ratio = c->mass_kappa;
     mg.lv[0].lmax = 1.02 * lmax / 1.05;
   }
   MGLevel& L = mg.lv[0];
-  NSFEM_HIP(hipMemcpyAsync(L.dinv.p, c->dinv_m.p, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+  if (c->mass_dinv_copied_epoch != c->mass_dinv_epoch) {       // (once per change of the Dirichlet set, not per solve)
+    NSFEM_HIP(hipMemcpyAsync(L.dinv.p, c->dinv_m.p, sizeof(double) * nv, hipMemcpyDeviceToDevice, s));
+    c->mass_dinv_copied_epoch = c->mass_dinv_epoch;
+  }
   KrylovWork& w = c->kw;
   w.ensure(nv);
   double* x = c->state[NSFEM_U0].p;

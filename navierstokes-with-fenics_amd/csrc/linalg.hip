@@ -2549,15 +2549,18 @@ enum { P_RHO = 0, P_RR = 1, P_TS = 2, P_TT = 3, P_RTV = 4, P_PQ = 5, P_RZ0 = 6, 
 enum { S_RHO_OLD = 0, S_ALPHA = 1, S_OMEGA = 2, S_RHO = 3, S_RHAT2 = 4, S_RHAT2_NEXT = 5 };
 
 // rhat = r ; parts[RHO] = parts[RR] = r.r
+// (rcopy: the residual is `r` itself still in the caller's right-hand side -- zero start vector -- and is stored
+// to the work vector here instead of by a copy launch of its own)
 __global__ __launch_bounds__(256) void k_bicg_start(int64_t n, const double* __restrict__ r,
                                                     double* __restrict__ rhat,
                                                     double* __restrict__ parts,
-                                                    double* __restrict__ scal) {
+                                                    double* __restrict__ scal, double* __restrict__ rcopy) {
   __shared__ double sh[4];
   double v = 0.0;
   GRID_STRIDE(i, n) {
     const double ri = r[i];
     rhat[i] = ri;
+    if (rcopy) rcopy[i] = ri;
     v += ri * ri;
   }
   v = block_sum(v, sh);
@@ -2722,15 +2725,14 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   };
   if (op.x_zero) {
     // zero start vector (Newton updates): r = b - A 0 = b, no operator application (A 0 = 0 on every row,
-    // identity rows included)
-    NSFEM_HIP(hipMemcpyAsync(w.r.p, b, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    // identity rows included); the start kernel below stores it
   } else if (op.custom) {
     op.custom->apply(s, x, w.r.p);
     launch_axpby(s, n, 1.0, b, -1.0, w.r.p, w.r.p);
   } else {
     launch_residual(s, *op.A, op.nv, x, b, w.r.p, op.rowmask, op.maskmode);
   }
-  LAUNCH(k_bicg_start, kParts, s, n, w.r.p, w.rhat.p, parts, scal);
+  LAUNCH(k_bicg_start, kParts, s, n, op.x_zero ? b : w.r.p, w.rhat.p, parts, scal, op.x_zero ? w.r.p : (double*)nullptr);
   // |b| for the relative criterion goes into the slot next to (rho, |r0|^2): ONE all-reduce for
   // the three start-up sums and one read-back for the two the host needs
   static_assert(P_RR == P_RHO + 1 && P_TS == P_RHO + 2, "start-up slots must be adjacent");
@@ -2801,7 +2803,7 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
         launch_residual(s, *op.A, op.nv, x, b, w.r.p, op.rowmask, op.maskmode, phase);
       });
     }
-    LAUNCH(k_bicg_start, kParts, s, n, w.r.p, w.rhat.p, parts, scal);
+    LAUNCH(k_bicg_start, kParts, s, n, w.r.p, w.rhat.p, parts, scal, (double*)nullptr);
     reduce_slots(op, s, parts, P_RHO, 2);
     const double true_r = std::sqrt(host_sum_parts(s, w, P_RR));
     if (!std::isfinite(true_r)) return NSFEM_ERR_BREAKDOWN;

@@ -729,6 +729,7 @@ struct nsfem_ctx {
   // per-system work vectors
   nsfem::DevBuf<double> rhs_v, rhs_p, dx_v, gconst, tmp_v, tmp_p, dinv_v, dinv_p, dinv_m;
   bool dinv_p_ready = false, dinv_m_ready = false;
+  int64_t mass_dinv_epoch = 0, mass_dinv_copied_epoch = -1;   // dinv_m recomputed / copied into the mass smoother
   nsfem::KrylovWork kw;
   int assembled_system = -1;
   double area = 0.0;

@@ -1175,7 +1175,8 @@ def cavity_ipcs_bench(args):
     # command and labelled so (`traffic_source`), null when no such profile exists for the size
     traffic = traffic_source = None
     lattice = mg_levels is not None and ctx.smoother_info().get("multistep_lattice_kernel")
-    for fname in ("r03_a_bench_n512_pmc_fetch_write_size.json", "r02_pmc_fetch_write_size.json"):
+    for fname in ("r03_b_bench_n512_pmc_fetch_write_size.json", "r03_a_bench_n512_pmc_fetch_write_size.json",
+                  "r02_pmc_fetch_write_size.json"):
         pmc = os.path.join(ROOT, "profiles", fname)
         if world == 1 and n == 512 and mg_levels is not None and os.path.exists(pmc):
             # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE; a kernel

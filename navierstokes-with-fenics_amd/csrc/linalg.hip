@@ -2567,6 +2567,7 @@ __global__ __launch_bounds__(256) void k_bicg_start(int64_t n, const double* __r
   if (threadIdx.x == 0) {
     parts[P_RHO * kParts + blockIdx.x] = v;
     parts[P_RR * kParts + blockIdx.x] = v;
+    if (rcopy) parts[P_TS * kParts + blockIdx.x] = v;          // zero start: |b|^2 = |r0|^2, no dot launch of its own
     if (blockIdx.x == 0) {
       scal[S_RHO_OLD] = 1.0;
       scal[S_ALPHA] = 1.0;
@@ -2736,7 +2737,7 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   // |b| for the relative criterion goes into the slot next to (rho, |r0|^2): ONE all-reduce for
   // the three start-up sums and one read-back for the two the host needs
   static_assert(P_RR == P_RHO + 1 && P_TS == P_RHO + 2, "start-up slots must be adjacent");
-  launch_dot(s, n, b, b, parts + P_TS * kParts);
+  if (!op.x_zero) launch_dot(s, n, b, b, parts + P_TS * kParts);
   reduce_slots(op, s, parts, P_RHO, 3);
   double rr, bb;
   host_sum_parts2(s, w, P_RR, P_TS, rr, bb);

@@ -354,3 +354,34 @@ def test_lattice_residual_kernel_equals_the_four_launch_path_bitwise_and_the_ora
         - 1.0 * (s.divergence().T @ p) + 0.8 * s.convection_residual(u, form)      # (fem_oracle.IPCSOracle: const)
     b[bd] = u[bd] - bv
     assert rel(out["lattice"], b) < 1e-12
+
+
+def test_lattice_jacobian_kernel_on_an_inexact_dictionary_serves_the_action_but_not_the_residual(monkeypatch):
+    """Spacing 1/48 (not a binary fraction): the stencil dictionary equals the assembled matrix only to 2^-40 of its
+    largest entry.  The Jacobian ACTION may use it (as the launch pair does: same bits from both), the Newton RESIDUAL
+    must come from the assembled values: k_jac_lattice<FORM, 0> is not launched and the right-hand side equals the
+    four-launch path bit for bit."""
+    from gpu_common import box, cavity_bc
+    mesh, dm, marks = box(48, 48)
+    bd, bv = cavity_bc(dm, marks)
+    rng = np.random.default_rng(48)
+    u, x = rng.standard_normal(dm.n_velocity), rng.standard_normal(dm.n_velocity)
+    out = {}
+    for tag, env in (("pair", "0"), ("lattice", "1")):
+        monkeypatch.setenv("NSFEM_JAC_LATTICE", env)
+        ctx = context(mesh, dm)
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_bdf((1.5, -2.0, 0.5), 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, bd.astype(np.int32), bv)
+        ctx.set_state(nat.USTAR, u)
+        ctx.set_state(nat.U1, u)
+        ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+        n_res = ctx.jacobian_info()["lattice_launches"]
+        y = ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x)
+        info = ctx.jacobian_info()
+        assert n_res == 0                                             # no residual through the dictionary
+        assert info["lattice_launches"] == (1 if tag == "lattice" else 0)
+        out[tag] = (y, ctx.get_rhs(nat.SYS_MOMENTUM))
+        ctx.close()
+    assert np.array_equal(out["pair"][0], out["lattice"][0])
+    assert np.array_equal(out["pair"][1], out["lattice"][1])

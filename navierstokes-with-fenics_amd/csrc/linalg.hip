@@ -1578,6 +1578,139 @@ void launch_lattice_sidm(hipStream_t s, const BlockMat& A, int nv, const uint8_t
   NSFEM_HIP(hipGetLastError());
 }
 
+// b_c = R r on a lattice hierarchy (coarse lattice = even-even sublattice, R = P^T of the lattice interpolation):
+// the coarse node's own fine value + half of its six fine neighbours, summed in ascending fine index (the order of
+// the CSR row of R); rows flagged in the coarse mask get 0.  One thread per coarse node, the seven NV-wide loads
+// unconditional at clamped indices (absent neighbours: the own value with weight 0).  Replaces the CSR product with
+// R on the restriction chain of a cycle without pre-smoothing: no matrix stream, no index loads.
+template <int NV>
+__global__ __launch_bounds__(256) void k_restrict_lattice(int Wc, int Hc, int Wf, int Hf,
+                                                          const double* __restrict__ rf,
+                                                          const uint8_t* __restrict__ mask,
+                                                          double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Wc * Hc) return;
+  const int J = t / Wc, I = t - J * Wc;
+  const int fi = 2 * I, fj = 2 * J;
+  const size_t fb = (size_t)fj * Wf + fi;
+  const bool l_ = fi > 0, r_ = fi < Wf - 1, d_ = fj > 0, u_ = fj < Hf - 1;
+  const size_t n0 = (d_ && l_) ? fb - Wf - 1 : fb, n1 = d_ ? fb - Wf : fb, n2 = l_ ? fb - 1 : fb;
+  const size_t n4 = r_ ? fb + 1 : fb, n5 = u_ ? fb + Wf : fb, n6 = (u_ && r_) ? fb + Wf + 1 : fb;
+  const double w0 = (d_ && l_) ? 0.5 : 0.0, w1 = d_ ? 0.5 : 0.0, w2 = l_ ? 0.5 : 0.0;
+  const double w4 = r_ ? 0.5 : 0.0, w5 = u_ ? 0.5 : 0.0, w6 = (u_ && r_) ? 0.5 : 0.0;
+  double f[7][NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    f[0][c] = rf[n0 * NV + c]; f[1][c] = rf[n1 * NV + c]; f[2][c] = rf[n2 * NV + c];
+    f[3][c] = rf[fb * NV + c];
+    f[4][c] = rf[n4 * NV + c]; f[5][c] = rf[n5 * NV + c]; f[6][c] = rf[n6 * NV + c];
+  }
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    double v = 0.0;
+    v += w0 * f[0][c];
+    v += w1 * f[1][c];
+    v += w2 * f[2][c];
+    v += f[3][c];
+    v += w4 * f[4][c];
+    v += w5 * f[5][c];
+    v += w6 * f[6][c];
+    if (mask && mask[(size_t)t * NV + c]) v = 0.0;
+    out[(size_t)t * NV + c] = v;
+  }
+}
+bool launch_restrict_lattice(hipStream_t s, int nv, int Wc, int Hc, int Wf, int Hf, const double* rf,
+                             const uint8_t* mask, double* out) {
+  if (nv < 1 || nv > 2 || Wf != 2 * Wc - 1 || Hf != 2 * Hc - 1) return false;
+  const dim3 grid((Wc * Hc + 255) / 256), block(256);
+  if (nv == 1) hipLaunchKernelGGL(k_restrict_lattice<1>, grid, block, 0, s, Wc, Hc, Wf, Hf, rf, mask, out);
+  else hipLaunchKernelGGL(k_restrict_lattice<2>, grid, block, 0, s, Wc, Hc, Wf, Hf, rf, mask, out);
+  NSFEM_HIP(hipGetLastError());
+  return true;
+}
+
+// Two restrictions of a chain in one launch:  b1 = R1 rf  and  b2 = R2 b1  (both stored: the levels' later smoothing
+// launches read them).  A workgroup owns 16 x 16 nodes of the coarsest of the three lattices: it forms the 33 x 33
+// nodes of the middle lattice around them in LDS (its own 32 x 32 are stored; the one-node ring is recomputed by the
+// neighbours), then its 256 coarse nodes from LDS.  Same sums in the same order as two launches of
+// k_restrict_lattice.
+template <int NV>
+__global__ __launch_bounds__(256) void k_restrict_lattice2(int W2, int H2, int W1, int H1, int Wf, int Hf,
+                                                           const double* __restrict__ rf,
+                                                           const uint8_t* __restrict__ mask1,
+                                                           const uint8_t* __restrict__ mask2,
+                                                           double* __restrict__ b1, double* __restrict__ b2) {
+  __shared__ double sh[33 * 33 * NV];
+  const int ntx = (W2 + 15) >> 4;
+  const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+  const int i10 = 32 * tx - 1, j10 = 32 * ty - 1;
+  for (int t = threadIdx.x; t < 33 * 33; t += 256) {
+    const int lj = t / 33, li = t - lj * 33;
+    const int i1 = i10 + li, j1 = j10 + lj;
+    const bool in = i1 >= 0 && i1 < W1 && j1 >= 0 && j1 < H1;
+    const int fi = 2 * min(max(i1, 0), W1 - 1), fj = 2 * min(max(j1, 0), H1 - 1);
+    const size_t fb = (size_t)fj * Wf + fi;
+    const bool l_ = fi > 0, r_ = fi < Wf - 1, d_ = fj > 0, u_ = fj < Hf - 1;
+    const size_t n0 = (d_ && l_) ? fb - Wf - 1 : fb, n1 = d_ ? fb - Wf : fb, n2 = l_ ? fb - 1 : fb;
+    const size_t n4 = r_ ? fb + 1 : fb, n5 = u_ ? fb + Wf : fb, n6 = (u_ && r_) ? fb + Wf + 1 : fb;
+    const double w0 = (d_ && l_) ? 0.5 : 0.0, w1 = d_ ? 0.5 : 0.0, w2 = l_ ? 0.5 : 0.0;
+    const double w4 = r_ ? 0.5 : 0.0, w5 = u_ ? 0.5 : 0.0, w6 = (u_ && r_) ? 0.5 : 0.0;
+    double f[7][NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      f[0][c] = rf[n0 * NV + c]; f[1][c] = rf[n1 * NV + c]; f[2][c] = rf[n2 * NV + c];
+      f[3][c] = rf[fb * NV + c];
+      f[4][c] = rf[n4 * NV + c]; f[5][c] = rf[n5 * NV + c]; f[6][c] = rf[n6 * NV + c];
+    }
+    const size_t g1 = (size_t)min(max(j1, 0), H1 - 1) * W1 + min(max(i1, 0), W1 - 1);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      double v = 0.0;
+      v += w0 * f[0][c];
+      v += w1 * f[1][c];
+      v += w2 * f[2][c];
+      v += f[3][c];
+      v += w4 * f[4][c];
+      v += w5 * f[5][c];
+      v += w6 * f[6][c];
+      if (!in || (mask1 && mask1[g1 * NV + c])) v = 0.0;
+      sh[t * NV + c] = v;
+      if (in && li >= 1 && lj >= 1) b1[g1 * NV + c] = v;
+    }
+  }
+  __syncthreads();
+  const int I2 = 16 * tx + (threadIdx.x & 15), J2 = 16 * ty + (threadIdx.x >> 4);
+  if (I2 >= W2 || J2 >= H2) return;
+  const int fi = 2 * I2, fj = 2 * J2;                       // position on the middle lattice
+  const bool l_ = fi > 0, r_ = fi < W1 - 1, d_ = fj > 0, u_ = fj < H1 - 1;
+  const int cb = (2 * (int)(threadIdx.x >> 4) + 1) * 33 + 2 * (int)(threadIdx.x & 15) + 1;
+  const double w0 = (d_ && l_) ? 0.5 : 0.0, w1 = d_ ? 0.5 : 0.0, w2 = l_ ? 0.5 : 0.0;
+  const double w4 = r_ ? 0.5 : 0.0, w5 = u_ ? 0.5 : 0.0, w6 = (u_ && r_) ? 0.5 : 0.0;
+  const size_t g2 = (size_t)J2 * W2 + I2;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    double v = 0.0;
+    v += w0 * sh[(cb - 33 - 1) * NV + c];
+    v += w1 * sh[(cb - 33) * NV + c];
+    v += w2 * sh[(cb - 1) * NV + c];
+    v += sh[cb * NV + c];
+    v += w4 * sh[(cb + 1) * NV + c];
+    v += w5 * sh[(cb + 33) * NV + c];
+    v += w6 * sh[(cb + 33 + 1) * NV + c];
+    if (mask2 && mask2[g2 * NV + c]) v = 0.0;
+    b2[g2 * NV + c] = v;
+  }
+}
+bool launch_restrict_lattice2(hipStream_t s, int nv, int W2, int H2, int W1, int H1, int Wf, int Hf,
+                              const double* rf, const uint8_t* mask1, const uint8_t* mask2, double* b1, double* b2) {
+  if (nv < 1 || nv > 2 || Wf != 2 * W1 - 1 || Hf != 2 * H1 - 1 || W1 != 2 * W2 - 1 || H1 != 2 * H2 - 1) return false;
+  const dim3 grid(((W2 + 15) / 16) * ((H2 + 15) / 16)), block(256);
+  if (nv == 1) hipLaunchKernelGGL(k_restrict_lattice2<1>, grid, block, 0, s, W2, H2, W1, H1, Wf, Hf, rf, mask1, mask2, b1, b2);
+  else hipLaunchKernelGGL(k_restrict_lattice2<2>, grid, block, 0, s, W2, H2, W1, H1, Wf, Hf, rf, mask1, mask2, b1, b2);
+  NSFEM_HIP(hipGetLastError());
+  return true;
+}
+
 // value table of the lattice kernel: rows of lp = lmax rounded up to a multiple of 4, zero padded
 __global__ __launch_bounds__(256) void k_dict_pad(int n_st, int lmax, int lp, const double* __restrict__ vals,
                                                   double* __restrict__ out) {

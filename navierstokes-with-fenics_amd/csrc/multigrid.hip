@@ -812,6 +812,12 @@ bool Multigrid::restrict_to(hipStream_t s, size_t l, const double* src) {
   return false;
 }
 
+// level l hands its right-hand side to level l + 1 inside that level's first smoothing launch (fused restriction)
+bool Multigrid::chain_child_forms_b(size_t l) {
+  return transfer_lattice(l) && starts_from_zero(l + 1) &&
+         !((l + 2 == lv.size()) && !(truncated() && l + 2 == active) && dense_coarse);
+}
+
 bool Multigrid::transfer_lattice(size_t l) {
   if (!lattice_transfers_enabled() || l + 1 >= lv.size()) return false;
   MGLevel& L = lv[l];
@@ -846,7 +852,24 @@ const double* Multigrid::vcycle_lattice(hipStream_t s, size_t l, const double* b
                              !((l + 2 == lv.size()) && !(truncated() && l + 2 == active) && dense_coarse);
   auto descend = [&](const double* fine) -> const double* {
     if (child_lattice) return vcycle_lattice(s, l + 1, C.b.p, C.x.p, fine);
-    launch_spmv(s, *L.R, nv, fine, C.b.p, C.mask, MASK_ZERO);
+    if (restricted_to == l + 1) {                   // (this level's b was formed together with the parent's)
+      restricted_to = 0;
+      return vcycle(s, l + 1, C.b.p, C.x.p, false);
+    }
+    // lattice transfers: the 7-point gather kernel instead of the CSR product with R -- and when the child restricts
+    // at once as well (no pre-smoothing, explicit restriction), both restrictions in one launch
+    if (tl && pre == 0 && l + 2 < lv.size() && !(truncated() && l + 2 == active) && lattice_ok(C) &&
+        transfer_lattice(l + 1) && !chain_child_forms_b(l + 1)) {
+      MGLevel& D = lv[l + 2];
+      if (launch_restrict_lattice2(s, nv, D.A->dict->lat_w, D.A->dict->lat_h, C.A->dict->lat_w, C.A->dict->lat_h,
+                                   L.A->dict->lat_w, L.A->dict->lat_h, fine, C.mask, D.mask, C.b.p, D.b.p)) {
+        restricted_to = l + 2;
+        return vcycle(s, l + 1, C.b.p, C.x.p, false);
+      }
+    }
+    if (!(tl && launch_restrict_lattice(s, nv, C.A->dict->lat_w, C.A->dict->lat_h, L.A->dict->lat_w, L.A->dict->lat_h,
+                                        fine, C.mask, C.b.p)))
+      launch_spmv(s, *L.R, nv, fine, C.b.p, C.mask, MASK_ZERO);
     return vcycle(s, l + 1, C.b.p, C.x.p, false);
   };
   if (pre > 0) {

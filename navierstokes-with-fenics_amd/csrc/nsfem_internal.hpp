@@ -259,6 +259,12 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
                          double* b_out = nullptr);
 // out[row] = dictionary entry | (mask of component c) << (6 + c): one byte per row for the lattice kernel
 void launch_lattice_sidm(hipStream_t s, const BlockMat& A, int nv, const uint8_t* mask, uint8_t* out);
+// out = R rf on a lattice hierarchy (rows flagged in the coarse mask: 0); false = shapes do not nest, nothing launched
+bool launch_restrict_lattice(hipStream_t s, int nv, int Wc, int Hc, int Wf, int Hf, const double* rf,
+                             const uint8_t* mask, double* out);
+// two levels of a restriction chain in one launch: b1 = R1 rf, b2 = R2 b1
+bool launch_restrict_lattice2(hipStream_t s, int nv, int W2, int H2, int W1, int H1, int Wf, int Hf,
+                              const double* rf, const uint8_t* mask1, const uint8_t* mask2, double* b1, double* b2);
 
 int64_t lattice_launch_bytes(const BlockMat& A, int nv, bool from_zero, bool d_in, bool d_out, bool r_out);
 
@@ -662,6 +668,8 @@ struct Multigrid : Precond {
   // multi-step lattice kernel (2D lexicographic lattices, serial levels): `steps` Chebyshev steps out of
   // place, optionally the residual of the result as well
   bool lattice_ok(const MGLevel& L) const;
+  bool chain_child_forms_b(size_t l);
+  size_t restricted_to = 0;      // level whose b the two-level restriction kernel has already formed in this leg
   // xc: the start vector is [x_in +] P xc (prolongation fused into the staging); rf: b = R rf is computed by the
   // first launch and stored to `b` (restriction fused)
   void smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,

@@ -954,9 +954,15 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
   const double sk = std::sqrt(c->mass_kappa);
   const double rate = std::log((sk + 1.0) / (sk - 1.0));
   double res = r0;
+  // The a-priori count below is a worst-case bound; the same solve one time step ago tells what was actually needed
+  // (first_check + 1 = its count, reduced by next_hint's linear-convergence estimate when it overshot): the first
+  // sequence runs that many steps, the bound takes over if the residual check then fails.
+  int k_hint = o.first_check >= 1 ? o.first_check + 1 : 0;
   while (!info.converged && info.iterations < o.max_iter) {
     // steps needed for the error bound 2 sqrt(kappa) ((sqrt(kappa)-1)/(sqrt(kappa)+1))^k <= target / res
     int k = (int)std::ceil(std::log(2.0 * sk * res / target) / rate);
+    if (k_hint > 0) k = std::min(k, k_hint);
+    k_hint = 0;
     k = std::max(1, std::min(k, o.max_iter - info.iterations));
     mg.smooth(s, L, w.r.p, nullptr, w.q.p, k);                       // e ~ M^{-1} r
     launch_axpby(s, nv, 1.0, x, 1.0, w.q.p, x);                      // x += e (e = 0 on Dirichlet dofs)
@@ -1029,6 +1035,8 @@ extern "C" int nsfem_get_rhs(nsfem_ctx* ctx, int system, double* host, int64_t n
   API_END(ctx)
 }
 
+static nsfem_krylov_opts hinted(nsfem_krylov_opts k, int hint);
+static int next_hint(const nsfem_solve_info& si, const nsfem_krylov_opts& k);
 extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* opts,
                            nsfem_solve_info* info) {
   nsfem_solve_info local;
@@ -1040,7 +1048,12 @@ extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* 
   switch (system) {
     case NSFEM_SYS_MOMENTUM: rc = momentum_solve_update(ctx, *opts, inf); break;
     case NSFEM_SYS_POISSON: rc = poisson_solve(ctx, *opts, inf); break;
-    case NSFEM_SYS_CORRECTION: rc = correction_solve(ctx, *opts, inf); break;
+    case NSFEM_SYS_CORRECTION:
+      // (the Chebyshev mass solve takes its step count from the previous solve: the same predictor as in the fused
+      // step drivers, so that the explicit seam and the fused step stay bit for bit equal)
+      rc = correction_solve(ctx, hinted(*opts, ctx->hint_cor), inf);
+      ctx->hint_cor = next_hint(inf, *opts);
+      break;
     default: throw Error(NSFEM_ERR_ARG, "nsfem_solve: system not available");
   }
   if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "Krylov breakdown");

@@ -594,12 +594,35 @@ static void coriolis_apply(nsfem_ctx* c, double g, const double* u, double* y,
   launch_spmv_axpy(s, c->M2, c->mesh.dim, 1.0, c->rot_tmp.p, y, skipmask);
 }
 
+// lattice meshes: dictionary copies of the rectangular divergence / gradient blocks (the monolithic operator uses
+// them in every Krylov iteration; the pressure-correction scheme once per step each -- there only dictionaries that
+// equal the assembled blocks bit for bit serve, see spmv_dispatch)
+static void ensure_div_dicts(nsfem_ctx* ctx) {
+  if (ctx->dictD_tried) return;
+  ctx->dictD_tried = true;
+  hipStream_t s = ctx->stream;
+  const int dim = ctx->mesh.dim;
+  if (build_stencil_dict(s, ctx->p21, ctx->DT.vals.p, nullptr, ctx->dict21, dim, true)) {
+    ctx->DT.dict = &ctx->dict21;
+    ctx->DT.sell_update(s);
+  }
+  if (build_stencil_dict(s, ctx->p12, ctx->Dv.vals.p, nullptr, ctx->dict12, dim, true)) {
+    ctx->Dv.dict = &ctx->dict12;
+    ctx->Dv.sell_update(s);
+  }
+  if (build_stencil_dict(s, ctx->p21, ctx->Gr.vals.p, nullptr, ctx->dict21g, dim, true)) {
+    ctx->Gr.dict = &ctx->dict21g;
+    ctx->Gr.sell_update(s);
+  }
+}
+
 // time-step constant part of the momentum residual:
 //   g = M (a1 u1 + a2 u2) / k - c_p (p_old, div w) - c_b M f + traction
 static void momentum_begin_step(nsfem_ctx* c, bool with_old_pressure = true) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c);
   ensure_L(c);
+  ensure_div_dicts(c);
   const double a1 = c->alpha[1] / c->k, a2 = c->alpha[2] / c->k;
   if (c->have_body_force) {
     NSFEM_REQUIRE(std::isfinite(c->coef[3]), "body force set but body_force_term coefficient is None");
@@ -1826,18 +1849,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   ctx->mixed_op.n = nv + np;
   ctx->block_prec.c = ctx;
   ctx->picard = opts->picard != 0;
-  if (!ctx->dictD_tried) {          // lattice meshes: dictionary copies of the divergence blocks
-    ctx->dictD_tried = true;
-    const int dim = ctx->mesh.dim;
-    if (build_stencil_dict(s, ctx->p21, ctx->DT.vals.p, nullptr, ctx->dict21, dim, true)) {
-      ctx->DT.dict = &ctx->dict21;
-      ctx->DT.sell_update(s);
-    }
-    if (build_stencil_dict(s, ctx->p12, ctx->Dv.vals.p, nullptr, ctx->dict12, dim, true)) {
-      ctx->Dv.dict = &ctx->dict12;
-      ctx->Dv.sell_update(s);
-    }
-  }
+  ensure_div_dicts(ctx);
   momentum_begin_step(ctx, false);
   double r = bdf_residual(ctx);
   const double r0 = r;

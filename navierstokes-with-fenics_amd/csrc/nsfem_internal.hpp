@@ -804,7 +804,7 @@ struct nsfem_ctx {
   bool dict22_tried = false;
   nsfem::StencilDict dict11;                   // rows of the scalar P1 operators of the fine mesh
   bool dict11_tried = false;
-  nsfem::StencilDict dict21, dict12;           // divergence-transpose / divergence blocks (monolithic scheme)
+  nsfem::StencilDict dict21, dict12, dict21g;  // divergence-transpose / divergence / gradient blocks
   bool dictD_tried = false;
   int bc_p_any = -1;                           // partitioned: pressure Dirichlet dofs on any rank (-1 unknown)
   bool schur_additive = false;                 // operators of nsfem_mg_set_schur_operator are rank parts

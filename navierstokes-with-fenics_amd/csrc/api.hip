@@ -968,8 +968,9 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
   residual_norm(w.r.p);
   launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, parts + (P10 + 1) * kParts);
   if (c->distributed()) c->comm->allreduce_sum(s, parts + P10 * kParts, 2 * kParts);
-  const double r0 = std::sqrt(host_sum_parts(s, w, P10));
-  const double bnorm = std::sqrt(host_sum_parts(s, w, P10 + 1));
+  double rr0, bb0;
+  host_sum_parts2(s, w, P10, P10 + 1, rr0, bb0);
+  const double r0 = std::sqrt(rr0), bnorm = std::sqrt(bb0);
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
   info.residual0 = info.residual = r0;
   info.iterations = 0;

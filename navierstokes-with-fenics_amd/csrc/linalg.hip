@@ -2659,10 +2659,15 @@ double host_sum_parts(hipStream_t s, KrylovWork& w, int which) {
 }
 
 // two slots with ONE device -> host round trip
-static void host_sum_parts2(hipStream_t s, KrylovWork& w, int a, int b, double& ra, double& rb) {
-  for (int which : {a, b})
-    NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)which * kParts, w.parts.p + (size_t)which * kParts,
-                             sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
+void host_sum_parts2(hipStream_t s, KrylovWork& w, int a, int b, double& ra, double& rb) {
+  if (b == a + 1) {            // adjacent slots: one copy
+    NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)a * kParts, w.parts.p + (size_t)a * kParts,
+                             sizeof(double) * 2 * kParts, hipMemcpyDeviceToHost, s));
+  } else {
+    for (int which : {a, b})
+      NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)which * kParts, w.parts.p + (size_t)which * kParts,
+                               sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
+  }
   NSFEM_HIP(hipStreamSynchronize(s));
   ra = rb = 0.0;
   for (int i = 0; i < kParts; ++i) {

@@ -705,6 +705,7 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
         const nsfem_krylov_opts& o, nsfem_solve_info& info, bool project_mean);
 
 double host_sum_parts(hipStream_t s, KrylovWork& w, int which);   // sync + sum
+void host_sum_parts2(hipStream_t s, KrylovWork& w, int a, int b, double& ra, double& rb);   // two slots, one round trip
 
 }  // namespace nsfem
 

@@ -385,3 +385,47 @@ def test_lattice_jacobian_kernel_on_an_inexact_dictionary_serves_the_action_but_
         ctx.close()
     assert np.array_equal(out["pair"][0], out["lattice"][0])
     assert np.array_equal(out["pair"][1], out["lattice"][1])
+
+
+def test_full_size_properties_of_the_one_launch_jacobian_and_residual(monkeypatch):
+    """BASELINE configs[1] at full size (512 x 512, 2.1 M velocity dofs), where the oracle cannot follow: the
+    one-launch kernel equals the launch pair bit for bit (action and residual), the action is linear to round-off,
+    and it is the Gateaux derivative of the residual it shares its element kernel with:
+    (F(u + eps x) - F(u)) / eps -> J(u) x."""
+    from gpu_common import box, cavity_bc
+    n = 512
+    mesh, dm, marks = box(n, n)
+    bd, bv = cavity_bc(dm, marks)
+    rng = np.random.default_rng(512)
+    X = dm.p2_coords
+    u = np.stack([np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]), np.cos(X[:, 0]) * np.sin(4 * X[:, 1])], axis=1).ravel()
+    x = rng.standard_normal(dm.n_velocity)
+    y = rng.standard_normal(dm.n_velocity)
+    free = np.ones(dm.n_velocity, dtype=bool)
+    free[bd] = False
+    res = {}
+    for tag, env in (("pair", "0"), ("lattice", "1")):
+        monkeypatch.setenv("NSFEM_JAC_LATTICE", env)
+        ctx = context(mesh, dm)
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_bdf((1.5, -2.0, 0.5), 1e-3)
+        ctx.set_dirichlet(nat.VELOCITY, bd.astype(np.int32), bv)
+        ctx.set_state(nat.USTAR, u)
+        ctx.assemble(nat.SYS_MOMENTUM, new_step=True)
+        out = [ctx.get_rhs(nat.SYS_MOMENTUM), ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, x)]
+        if tag == "lattice":
+            assert ctx.jacobian_info()["path"] == "lattice-kernel" and ctx.jacobian_info()["lattice_launches"] == 2
+            jy = ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, y)
+            jc = ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, 0.75 * x - 1.5 * y)
+            assert rel(jc, 0.75 * out[1] - 1.5 * jy) < 1e-14
+            xs = np.stack([np.cos(2 * X[:, 0] + X[:, 1]), np.sin(X[:, 0] - 3 * X[:, 1])], axis=1).ravel()   # smooth direction
+            js = ctx.operator_apply(nat.OP_MOMENTUM_JAC_MF, xs)
+            eps = 1e-6
+            ctx.set_state(nat.USTAR, u + eps * xs)
+            ctx.assemble(nat.SYS_MOMENTUM)
+            fd = (ctx.get_rhs(nat.SYS_MOMENTUM) - out[0]) / eps
+            assert rel(fd[free], js[free]) < 1e-4
+        res[tag] = out
+        ctx.close()
+    assert np.array_equal(res["pair"][0], res["lattice"][0])
+    assert np.array_equal(res["pair"][1], res["lattice"][1])

@@ -172,6 +172,54 @@ def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None, peri
     return len(levels)
 
 
+def _host_threads():
+    import os
+    env = os.environ.get("NSFEM_HOST_THREADS")
+    return max(1, int(env)) if env else max(1, min(16, os.cpu_count() or 1))
+
+
+def _matmul_rows_parallel(A, B, min_rows=20000):
+    """A @ B for CSR matrices, the rows of A split into contiguous blocks over host threads (set-up time only).
+    Same result as ``A @ B`` bit for bit: a row of the product depends on that row of A alone."""
+    import scipy.sparse as sp
+    from concurrent.futures import ThreadPoolExecutor
+    A = A.tocsr()
+    B = B.tocsr()
+    nt = min(_host_threads(), max(1, A.shape[0] // min_rows))
+    if nt <= 1:
+        C = (A @ B).tocsr()
+        C.sort_indices()
+        return C
+    # blocks of (nearly) equal work: rows weighted by their number of entries
+    work = np.concatenate([[0], np.cumsum(np.diff(A.indptr) + 1)])
+    cuts = np.searchsorted(work, np.linspace(0, work[-1], nt + 1)[1:-1])
+    bounds = np.unique(np.concatenate([[0], cuts, [A.shape[0]]]))
+    def block(k):
+        Ck = (A[bounds[k]:bounds[k + 1]] @ B).tocsr()
+        Ck.sort_indices()                                  # (inside the worker: the sort is a third of the time)
+        return Ck
+
+    with ThreadPoolExecutor(max_workers=nt) as pool:
+        parts = list(pool.map(block, range(bounds.size - 1)))
+    # (row blocks of one CSR matrix: concatenate the arrays -- scipy's vstack takes longer than the products)
+    counts = np.concatenate([np.diff(p.indptr) for p in parts])
+    total = int(counts.sum(dtype=np.int64))
+    idx_t = np.int64 if total > np.iinfo(np.int32).max else np.int32
+    indptr = np.zeros(A.shape[0] + 1, dtype=idx_t)
+    np.cumsum(counts, out=indptr[1:])
+    data = np.empty(total, dtype=parts[0].data.dtype)
+    indices = np.empty(total, dtype=idx_t)
+    o = 0
+    for p in parts:
+        data[o:o + p.nnz] = p.data
+        indices[o:o + p.nnz] = p.indices
+        o += p.nnz
+    C = sp.csr_matrix((A.shape[0], B.shape[1]), dtype=data.dtype)
+    C.data, C.indices, C.indptr = data, indices, indptr     # (assembled arrays: no re-validation pass)
+    C.has_sorted_indices = True
+    return C
+
+
 def attach_schur_laplacian(ctx, velocity_bc_dofs, part=None):
     """Algebraic pressure Laplacian of the monolithic scheme's Schur-complement preconditioner:
     A_L = D_f diag(M_v)^{-1} D_f^T on the fine P1 space (D_f = divergence block without the
@@ -189,7 +237,7 @@ def attach_schur_laplacian(ctx, velocity_bc_dofs, part=None):
     rows of every product at their owners (nsfem_mg_set_schur_mode)."""
     import scipy.sparse as sp
     import _native as nat
-    D = ctx.operator_csr(nat.OP_DIV).tocsc()                        # n_p1 x (dim n_p2)
+    D = ctx.operator_csr(nat.OP_DIV)                                # n_p1 x (dim n_p2), CSR
     m = ctx.operator_csr(nat.OP_MASS_P2).diagonal()
     width = D.shape[1] // m.size
     w = np.repeat(1.0 / m, width)                                   # node-interleaved components
@@ -208,14 +256,18 @@ def attach_schur_laplacian(ctx, velocity_bc_dofs, part=None):
         B.sort_indices()
         return B
 
-    A = (D @ sp.diags(w) @ D.T).tocsr()
+    # D W D^T with the column scaling applied to D's stored values (no diagonal-matrix product) and the sparse
+    # products split into row blocks over host threads (scipy's SpGEMM releases the GIL; every row is formed by
+    # the same code in the same order: bit for bit the serial product)
+    Dw = sp.csr_matrix((D.data * w[D.indices], D.indices, D.indptr), shape=D.shape)
+    A = _matmul_rows_parallel(Dw, D.T.tocsr())
     ones = np.ones(A.shape[0])
     local = float(np.abs(A @ ones).max() / max(np.abs(A.diagonal()).max(), 1e-300))
     singular = bool(ctx.comm_allreduce([local], "max")[0] <= 1e-10)
     ctx.mg_set_schur_operator(0, with_diagonal(A) if additive else A, singular)
     for l, (n_coarse, (rowptr, col, val)) in enumerate(ctx.mg_prolongations):
         P = sp.csr_matrix((val, col, rowptr), shape=(A.shape[0], n_coarse))
-        A = (P.T @ A @ P).tocsr()
+        A = _matmul_rows_parallel(P.T.tocsr(), _matmul_rows_parallel(A, P))
         ctx.mg_set_schur_operator(l + 1, with_diagonal(A) if additive else A, singular)
     return singular
 

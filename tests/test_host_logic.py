@@ -721,3 +721,26 @@ def test_bench_parent_only_spawns_and_supervises_its_ranks():
     assert res.returncode != 0
     assert "exited with code" in res.stderr and "no ROCm-capable device" in res.stderr
     assert res.stdout.strip() == ""
+
+
+def test_row_parallel_sparse_product_equals_the_serial_product_bitwise(monkeypatch):
+    """Set-up of the algebraic Schur Laplacian (multigrid.attach_schur_laplacian): the sparse products D W D^T and
+    P^T A P run in row blocks on host threads -- same arrays as scipy's serial product, bit for bit, sorted columns,
+    empty rows and the single-thread path included."""
+    import scipy.sparse as sp
+    from multigrid import _matmul_rows_parallel
+    rng = np.random.default_rng(11)
+    n, k = 60000, 6
+    A = sp.csr_matrix((rng.standard_normal(n * k), (np.repeat(np.arange(n), k), rng.integers(0, n // 3, n * k))),
+                      shape=(n, n // 3))
+    A.sum_duplicates()
+    A = A.tolil(); A[100:140] = 0; A = A.tocsr(); A.eliminate_zeros()          # a stretch of empty rows
+    B = A.T.tocsr()
+    ref = (A @ B).tocsr()
+    ref.sort_indices()
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("NSFEM_HOST_THREADS", threads)
+        C = _matmul_rows_parallel(A, B, min_rows=5000)
+        assert C.shape == ref.shape and C.has_sorted_indices
+        assert np.array_equal(C.indptr, ref.indptr) and np.array_equal(C.indices, ref.indices)
+        assert np.array_equal(C.data, ref.data)

@@ -8,6 +8,7 @@
 // with dolfin's NewtonSolver control (residual criterion, relaxation 1; parameters
 // from source/ns_ipcs_solver.py:143-147) and Krylov solves instead of sparse LU.
 #include "nsfem_internal.hpp"
+#include <chrono>
 #include <algorithm>
 
 using namespace nsfem;
@@ -107,6 +108,16 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   NSFEM_HIP(hipStreamCreate(&fresh->stream));
   hipStream_t s = fresh->stream;
   const int nc = m->n_cells;
+  // NSFEM_DEBUG_SETUP=1: wall-clock of the phases of this function on stderr
+  const bool dbg_setup = std::getenv("NSFEM_DEBUG_SETUP") != nullptr;
+  auto t_setup = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg_setup) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[nsfem_create] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_setup).count());
+    t_setup = now;
+  };
   // ---- mesh arrays, SoA
   const int dim = m->dim;
   NSFEM_REQUIRE(dim == 2 || dim == 3, "dim must be 2 (triangles) or 3 (tetrahedra)");
@@ -153,11 +164,14 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
     fresh->mesh.p2.upload(p2, s);
     fresh->mesh.p1.upload(p1, s);
   }
+  lap("mesh arrays");
   // ---- sparsity patterns + slot maps (host), then device copies
   {
     HostPattern h;
     build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, nl2, m->p2_dofmap, nl2, true, h, true);
+    lap("pattern p22 (host)");
     upload_pattern(s, h, fresh->p22, true);
+    lap("pattern p22 upload");
     {
       std::vector<int32_t> ptr, idx;
       build_inverse_index(m->n_p2, (int64_t)nc * nl2,
@@ -172,12 +186,16 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
       fresh->mesh.ebuf.alloc((size_t)nc * nl2 * nl2 * dim * dim);
       fresh->mesh.rbuf.alloc((size_t)nc * nl2 * dim);
     }
+    lap("node-sorted index + buffers");
     build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, nl1, m->p1_dofmap, nl1, true, h, true);
     upload_pattern(s, h, fresh->p11, true);
+    lap("pattern p11");
     build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, nl1, m->p2_dofmap, nl2, false, h, true);
     upload_pattern(s, h, fresh->p12, true);
+    lap("pattern p12");
     build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, nl2, m->p1_dofmap, nl1, false, h, true);
     upload_pattern(s, h, fresh->p21, true);
+    lap("pattern p21");
   }
   // ---- constant operators, integrated on the device
   QuadTables qt;
@@ -197,7 +215,9 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   launch_assemble_p1_scalar(s, fresh->mesh, fresh->p11, fresh->Ap.vals.p, fresh->Mp.vals.p);
   launch_assemble_div_grad(s, fresh->mesh, fresh->p12, fresh->p21, fresh->Dv.vals.p,
                            fresh->Gr.vals.p, fresh->DT.vals.p);
+  lap("operator assembly (device)");
   for (BlockMat* A : {&fresh->M2, &fresh->K2, &fresh->Ap, &fresh->Mp}) A->sell_update(s);
+  lap("SELL / dictionary copies");
   // ---- state + work vectors
   for (int i = 0; i < NSFEM_N_SLOTS; ++i) {
     fresh->state[i].alloc((size_t)slot_size(fresh, i));
@@ -219,6 +239,7 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   fresh->mask_p.zero(s);
   fresh->kw.ensure((int64_t)std::max(nv, np));
   NSFEM_HIP(hipStreamSynchronize(s));
+  lap("state + work vectors");
   *out = fresh;
   fresh = nullptr;
   }

@@ -1004,6 +1004,7 @@ const double* Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double
 
 void Multigrid::apply(hipStream_t s, const double* r, double* z) {
   NSFEM_REQUIRE(ready, "multigrid hierarchy not refreshed");
+  restricted_to = 0;
   (void)vcycle(s, 0, r, z);                         // (level 0: the result is in z)
 }
 

@@ -1032,7 +1032,8 @@ bool build_cell_lattice(const int32_t* p2map, int nc, int W, int H, CellLattice&
 static bool g_jac_lattice_on = true;
 static int g_jac_lattice_dbg = 0;
 // tile shape in use: 0 = 32 x 8 squares (512 threads), 1 = 16 x 8 (256).  Measured at n = 512 (us per launch of the
-// Newton action): 32 x 8: 48.3, 16 x 8: 50.4, 16 x 16: 50.5, 8 x 8: 55.5 -- the launch is bound by the latency chain of
+// Newton action): 32 x 8: 48.3, 16 x 8: 50.4, 16 x 16: 50.5, 8 x 8: 55.5, 32 x 16 (1024 threads, one workgroup per CU):
+// 62.7 -- the launch is bound by the latency chain of
 // a wave (loads, barriers, LDS phases) at 4 waves per SIMD, not by the shape of the tile
 static int g_jac_lattice_tile = 0;
 void refresh_assembly_switches() {

@@ -230,14 +230,28 @@ void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* row
   for (int k = 0; k < nnz; ++k) rp[col[k] + 1]++;
   for (int j = 0; j < n_coarse; ++j) rp[j + 1] += rp[j];
   std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+  // h_inj: the finer-level node that REPRESENTS a coarse node when row flags (Dirichlet sets) are handed down the
+  // hierarchy.  Nested levels: the coinciding node (a row of P with the single entry 1).  Non-nested levels
+  // (interpolation between meshes with an odd number of cells): the fine node the coarse hat function weighs most,
+  // provided the weight is at least 1/2 -- on a boundary that is a node of the same boundary line.
   h_inj.assign((size_t)n_coarse, -1);
+  std::vector<double> best((size_t)n_coarse, 0.0);
+  bool nested = true;
+  for (int i = 0; i < n_fine && nested; ++i)
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if (val[k] != 1.0 && val[k] != 0.5) { nested = false; break; }
   for (int i = 0; i < n_fine; ++i)
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
       const int j = col[k];
       rc[fill[j]] = i;
       rv[fill[j]] = val[k];
       fill[j]++;
-      if (rowptr[i + 1] - rowptr[i] == 1 && std::fabs(val[k] - 1.0) < 1e-14) h_inj[j] = i;
+      if (nested) {
+        if (rowptr[i + 1] - rowptr[i] == 1 && std::fabs(val[k] - 1.0) < 1e-14) h_inj[j] = i;
+      } else if (val[k] >= 0.5 && val[k] > best[(size_t)j]) {
+        best[(size_t)j] = val[k];
+        h_inj[j] = i;
+      }
     }
   // (on partitioned meshes the coarse ghost line above the strip has no fine counterpart:
   //  h_inj stays -1 there; such nodes are flagged as ghosts by the caller)

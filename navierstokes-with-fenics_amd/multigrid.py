@@ -44,6 +44,39 @@ def structured_prolongation(nx, ny):
     return rowptr, col, val
 
 
+def interpolation_prolongation(nx, ny, cx, cy):
+    """P1 prolongation between NON-NESTED right-diagonal meshes of the same rectangle: the value of the coarse
+    (cx, cy) hat functions at every vertex of the fine (nx, ny) mesh (barycentric weights in the coarse triangle
+    that holds it).  Lets hierarchies continue below a level with an odd number of cells (333 -> 167 -> 84 -> ...);
+    for nx = 2 cx, ny = 2 cy it equals ``structured_prolongation``.  CSR (rowptr, col, val), rows = fine vertices."""
+    ix, iy = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    ix, iy = ix.ravel(), iy.ravel()
+    # position in coarse cell units, exact rational arithmetic in integers: x = ix cx / nx
+    qx, rx = np.divmod(ix * cx, nx)
+    qy, ry = np.divmod(iy * cy, ny)
+    on_right = qx == cx
+    qx = np.where(on_right, cx - 1, qx); rx = np.where(on_right, nx, rx)        # last vertex: s = 1 in the last cell
+    on_top = qy == cy
+    qy = np.where(on_top, cy - 1, qy); ry = np.where(on_top, ny, ry)
+    s_ = rx / float(nx)
+    t_ = ry / float(ny)
+    v0 = qy * (cx + 1) + qx
+    v1, v2, v3 = v0 + 1, v0 + (cx + 1), v0 + (cx + 1) + 1
+    below = rx * ny >= ry * nx                      # s >= t: triangle (v0, v1, v3), else (v0, v2, v3)
+    w0 = np.where(below, 1.0 - s_, 1.0 - t_)
+    wm = np.where(below, s_ - t_, t_ - s_)
+    vm = np.where(below, v1, v2)
+    w3 = np.where(below, t_, s_)
+    cols = np.stack([v0, vm, v3], axis=1)
+    vals = np.stack([w0, wm, w3], axis=1)
+    keep = vals > 0.0
+    counts = keep.sum(axis=1)
+    rowptr = np.zeros(ix.size + 1, dtype=np.int32)
+    np.cumsum(counts, out=rowptr[1:])
+    # (columns ascending within a row: v0 < v1 < v3 and v0 < v2 < v3)
+    return rowptr, cols[keep].astype(np.int32), vals[keep].astype(np.float64)
+
+
 def structured_prolongation_3d(nx, ny, nz):
     """P1 prolongation between the Kuhn meshes (nx/2, ny/2, nz/2) -> (nx, ny, nz) of
     ``fem_mesh.box_mesh``: every edge of the Kuhn split points in a direction of {0,1}^3, so a fine
@@ -75,13 +108,15 @@ def structured_prolongation_3d(nx, ny, nz):
     return rowptr, col, val
 
 
-def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200):
+def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200, allow_non_nested=True):
     """[(coarse mesh, prolongation CSR to the next finer mesh), ...] finest-first for 2D
     right-diagonal rectangle meshes or (with ``nz``) 3D Kuhn box meshes.
     ``coarsest`` given: coarsen while every direction stays even and >= ``coarsest`` cells.
     ``coarsest`` None: coarsen until the level has at most ``dense_max`` nodes (the device solves
     the coarsest level with a dense inverse; one more level of ~8 small kernels costs more than a
-    1000-unknown dense mat-vec) or a direction becomes odd."""
+    1000-unknown dense mat-vec).  2D: a level with an odd number of cells in some direction is followed by the
+    NON-NESTED mesh of ceil(n / 2) cells (``interpolation_prolongation``; the coarse operators are rediscretised on
+    every level anyway); 3D or ``allow_non_nested=False``: the hierarchy ends where a direction becomes odd."""
     from fem_mesh import box_mesh
     n = [nx, ny] if nz is None else [nx, ny, nz]
     levels = []
@@ -89,14 +124,22 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200)
     def nodes(m):
         return int(np.prod([k + 1 for k in m]))
 
-    while all(k % 2 == 0 for k in n):
+    while True:
+        even = all(k % 2 == 0 for k in n)
+        if not even and (nz is not None or not allow_non_nested or min(n) < 5):
+            break                                   # (3D Kuhn meshes and periodic hierarchies: nested levels only)
+        nc = [(k + 1) // 2 for k in n]
         if coarsest is not None:
-            if min(n) // 2 < coarsest:
+            if min(nc) < coarsest:
                 break
-        elif nodes(n) <= dense_max or min(n) // 2 < 2:
+        elif nodes(n) <= dense_max or min(nc) < 2:
             break
-        P = structured_prolongation(*n) if nz is None else structured_prolongation_3d(*n)
-        n = [k // 2 for k in n]
+        if even:
+            P = structured_prolongation(*n) if nz is None else structured_prolongation_3d(*n)
+        else:
+            # an odd number of cells: the next mesh is not nested -- linear interpolation between the two meshes
+            P = interpolation_prolongation(n[0], n[1], nc[0], nc[1])
+        n = nc
         mesh = rectangle_mesh(p0, p1, *n) if nz is None else box_mesh(p0, p1, *n)
         levels.append((mesh, P))
     return levels
@@ -154,7 +197,7 @@ def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None, peri
     else:
         # coarsest None: down to the first level with <= 1200 nodes (512^2 -> 32^2 = 1089 nodes,
         # 64^3 -> 8^3 = 729), solved with a dense inverse on the device
-        levels = structured_hierarchy(*info, coarsest=coarsest) if info is not None else []
+        levels = structured_hierarchy(*info, coarsest=coarsest, allow_non_nested=periodic is None) if info is not None else []
     ctx.mg_prolongations = []                          # kept for attach_schur_laplacian
     if periodic is not None:
         # periodic = (constrained domain, P1 dof of every fine-mesh vertex): the coarse levels

@@ -114,16 +114,29 @@ class StripPartition:
         lx, ly, lown, fine_level = nx, ny, own, self.fine
         # (``min_rows``: strips thinner than that are all halo -- every product of such a level is a
         # latency-bound message -- so the partitioned levels end there and the replicated hierarchy takes over)
-        while lx % 2 == 0 and lown % 2 == 0 and lown // 2 >= max(1, min_rows) and min(lx, ly) // 2 >= coarsest:
-            cx, cy, cown = lx // 2, ly // 2, lown // 2
+        # (one rank: a level with an odd number of cells is followed by the NON-NESTED mesh of ceil(n / 2) cells,
+        # multigrid.interpolation_prolongation -- 333 -> 167 -> 84 -> 42 -> 21; strips of several ranks need nested
+        # levels for their halo lines and stop there)
+        while True:
+            even = lx % 2 == 0 and lown % 2 == 0
+            if not even and not (size == 1 and min(lx, ly) >= 5):
+                break
+            cx, cy, cown = (lx + 1) // 2, (ly + 1) // 2, (lown + 1) // 2
+            if cown < max(1, min_rows) or min(cx, cy) < coarsest:
+                break
             lev = StripLevel(p0, p1, cx, cy, rank * cown, cown, g)
-            # prolongation for the (cx, lev.rows) -> (lx, 2 * lev.rows) refinement, truncated
-            # to the vertex rows the finer local mesh actually has
-            rowptr, col, val = structured_prolongation(lx, 2 * lev.rows)
-            n_fine = (lx + 1) * (fine_level.rows + 1)
-            rowptr = rowptr[: n_fine + 1].copy()
-            nnz = rowptr[-1]
-            self.levels.append((lev, (rowptr, col[:nnz].copy(), val[:nnz].copy())))
+            if even:
+                # prolongation for the (cx, lev.rows) -> (lx, 2 * lev.rows) refinement, truncated
+                # to the vertex rows the finer local mesh actually has
+                rowptr, col, val = structured_prolongation(lx, 2 * lev.rows)
+                n_fine = (lx + 1) * (fine_level.rows + 1)
+                rowptr = rowptr[: n_fine + 1].copy()
+                nnz = rowptr[-1]
+                col, val = col[:nnz].copy(), val[:nnz].copy()
+            else:
+                from multigrid import interpolation_prolongation
+                rowptr, col, val = interpolation_prolongation(lx, ly, cx, cy)
+            self.levels.append((lev, (rowptr, col, val)))
             lx, ly, lown, fine_level = cx, cy, cown, lev
         # replicated coarsest problem: the global mesh of the last level
         last = self.levels[-1][0] if self.levels else self.fine
@@ -135,7 +148,7 @@ class StripPartition:
         if global_coarsest is not None:
             from multigrid import structured_hierarchy
             self.global_tail = structured_hierarchy(self.p0, self.p1, last.nx, ly,
-                                                    coarsest=global_coarsest)
+                                                    coarsest=global_coarsest, allow_non_nested=False)
 
     def attach(self, ctx, degree=None, eig_ratio=None):
         """Ship the partition, the local multigrid levels and the replicated global coarsest
@@ -260,7 +273,7 @@ class SlabPartition:
         self.global_tail = []
         if global_coarsest is not None:
             self.global_tail = structured_hierarchy(self.p0, self.p1, last.nx, last.ny, lz,
-                                                    coarsest=global_coarsest)
+                                                    coarsest=global_coarsest, allow_non_nested=False)
 
     def attach(self, ctx, degree=None, eig_ratio=None):
         from fem_mesh import box_mesh
@@ -408,7 +421,7 @@ class PeriodicSlabPartition:
         vdof = (((iz % cz) * cy + (iy % cy)) * cx + (ix % cx)).transpose(2, 1, 0).ravel().astype(np.int64)
         tail = []
         if self.global_coarsest is not None:
-            tail = structured_hierarchy(self.p0, self.p1, cx, cy, cz, coarsest=self.global_coarsest)
+            tail = structured_hierarchy(self.p0, self.p1, cx, cy, cz, coarsest=self.global_coarsest, allow_non_nested=False)
         return mesh, vdof, tail
 
     def attach(self, ctx, degree=None, eig_ratio=None):
@@ -529,7 +542,7 @@ class PeriodicStripPartition:
         ctx.mg_set_global_coarse(mesh.coords, mesh.cells, self.coarse_global_offset,
                                  dofmap=f_dof[mesh.cells.astype(np.int64)])
         tail = [] if self.global_coarsest is None else \
-            structured_hierarchy(self.p0, self.p1, cx, cy, coarsest=self.global_coarsest)
+            structured_hierarchy(self.p0, self.p1, cx, cy, coarsest=self.global_coarsest, allow_non_nested=False)
         import scipy.sparse as sp
         for cmesh, (rowptr, col, val) in tail:
             c_dof = vdof_of(cmesh.structured[2:])

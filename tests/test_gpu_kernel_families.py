@@ -429,3 +429,48 @@ def test_full_size_properties_of_the_one_launch_jacobian_and_residual(monkeypatc
         ctx.close()
     assert np.array_equal(res["pair"][0], res["lattice"][0])
     assert np.array_equal(res["pair"][1], res["lattice"][1])
+
+
+@pytest.mark.parametrize("n", [50, 27])
+def test_hierarchies_continue_below_odd_levels_with_non_nested_meshes(n):
+    """A structured mesh whose cell count becomes odd on the way down (50 -> 25 -> 13 -> 7 -> 4; 27 -> 14 -> 7 -> 4; BASELINE's
+    333 x 333) used to end its hierarchy there -- a two-level method with a huge smoothed coarsest level.  Now the next
+    level is the NON-NESTED mesh of ceil(n / 2) cells with linear interpolation between the meshes
+    (multigrid.interpolation_prolongation); the Dirichlet rows go down through the fine node a coarse hat function weighs
+    most.  IPCS steps with multigrid-preconditioned BiCGStab / CG: converged fields against the LU oracle and iteration
+    counts of a working multigrid."""
+    from gpu_common import box, cavity_bc
+    from multigrid import attach_hierarchy, structured_hierarchy
+    mesh, dm, marks = box(n, n)
+    mesh.structured = ((0.0, 0.0), (1.0, 1.0), n, n)
+    sizes = [m.structured[2] for m, _ in structured_hierarchy(*mesh.structured, coarsest=4)]
+    assert sizes == ([25, 13, 7, 4] if n == 50 else [14, 7, 4])
+    bd, bv = cavity_bc(dm, marks)
+    ctx = context(mesh, dm)
+    assert attach_hierarchy(ctx, mesh, coarsest=4) == len(sizes)
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    ctx.set_dirichlet(nat.VELOCITY, bd.astype(np.int32), bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.mg_set_truncation(0.0, 0.1)            # full cycles: every level, every transfer
+    opts = ctx.default_step_opts()
+    for o in (opts.momentum, opts.poisson, opts.correction):
+        o.rtol = 1e-12
+    opts.momentum.precond = opts.poisson.precond = 1
+    opts.correction.precond = 2
+    its = []
+    for step in range(3):
+        ctx.set_bdf((1.0, -1.0, 0.0) if step == 0 else (1.5, -2.0, 0.5), 0.01)
+        info = ctx.step_ipcs(opts)
+        ctx.advance(0)
+        its.append((info.newton_iterations, info.krylov_iterations_momentum, info.krylov_iterations_poisson))
+    u, p = ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)
+    ctx.close()
+    assert all(k[1] <= 12 * k[0] and k[2] <= 16 for k in its), its      # (a two-level method needs 60+ CG iterations)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.IPCSOracle(s, dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None),
+                        refactor_every_step=False)
+    for step in range(3):
+        orc.step(fo.bdf_alpha(step, 1.0), 0.01, (bd, bv))
+        orc.advance()
+    assert rel(u, orc.vel[1]) < 1e-8
+    assert rel(p - p.mean(), orc.p_old - orc.p_old.mean()) < 1e-7

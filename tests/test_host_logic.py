@@ -744,3 +744,31 @@ def test_row_parallel_sparse_product_equals_the_serial_product_bitwise(monkeypat
         assert C.shape == ref.shape and C.has_sorted_indices
         assert np.array_equal(C.indptr, ref.indptr) and np.array_equal(C.indices, ref.indices)
         assert np.array_equal(C.data, ref.data)
+
+
+def test_interpolation_prolongation_between_non_nested_meshes():
+    """multigrid.interpolation_prolongation: equals the nested prolongation for even sizes, reproduces linear functions
+    between meshes of ceil(n / 2) cells, rows sum to 1 with weights in (0, 1], at most 3 entries per row; the structured
+    hierarchy of BASELINE's 333 x 333 mesh runs down to 21 cells."""
+    import scipy.sparse as sp
+    from multigrid import interpolation_prolongation, structured_hierarchy, structured_prolongation
+    for nx, ny in ((8, 6), (16, 16)):
+        a = structured_prolongation(nx, ny)
+        b = interpolation_prolongation(nx, ny, nx // 2, ny // 2)
+        shape = ((nx + 1) * (ny + 1), (nx // 2 + 1) * (ny // 2 + 1))
+        assert abs(sp.csr_matrix((a[2], a[1], a[0]), shape=shape) - sp.csr_matrix((b[2], b[1], b[0]), shape=shape)).max() == 0.0
+    for nx, ny, cx, cy in ((333, 333, 167, 167), (25, 13, 13, 7), (9, 8, 5, 4)):
+        rp, c, v = interpolation_prolongation(nx, ny, cx, cy)
+        P = sp.csr_matrix((v, c, rp), shape=((nx + 1) * (ny + 1), (cx + 1) * (cy + 1)))
+        X, Y = np.meshgrid(np.linspace(0, 1, nx + 1), np.linspace(0, 2, ny + 1), indexing="xy")
+        Xc, Yc = np.meshgrid(np.linspace(0, 1, cx + 1), np.linspace(0, 2, cy + 1), indexing="xy")
+        f = lambda x, y: 1.5 + 2.0 * x - 3.0 * y
+        assert abs(P @ f(Xc, Yc).ravel() - f(X, Y).ravel()).max() < 1e-14
+        assert abs(np.asarray(P.sum(axis=1)).ravel() - 1.0).max() < 1e-15
+        assert v.min() > 0.0 and v.max() <= 1.0 and np.diff(rp).max() <= 3
+        assert all(np.all(np.diff(c[rp[i]:rp[i + 1]]) > 0) for i in range(0, rp.size - 1, 97))     # sorted columns
+    assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0), (1, 1), 333, 333)] == \
+        [(167, 167), (84, 84), (42, 42), (21, 21)]
+    assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0), (1, 1), 512, 512)] == \
+        [(256, 256), (128, 128), (64, 64), (32, 32)]
+    assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0), (1, 1), 333, 333, allow_non_nested=False)] == []

@@ -917,8 +917,8 @@ def _serial_coarsest(n, dim=2):
     """cells across the coarsest mesh on one GPU: the first level with <= 1200 nodes (dense
     solve): 2D 512 -> 32 (1089 nodes), 336 -> 21 (484 nodes), 333 -> 21 through non-nested levels; 3D 64 -> 8 (729),
     48 -> 6 (343)"""
-    while (n + 1) ** dim > 1200 and (n % 2 == 0 or (dim == 2 and n >= 5)):
-        n = (n + 1) // 2            # (2D: odd sizes continue with non-nested levels, 333 -> 167 -> 84 -> 42 -> 21)
+    while (n + 1) ** dim > 1200 and (n % 2 == 0 or n >= 5):
+        n = (n + 1) // 2            # (odd sizes continue with non-nested levels, 333 -> 167 -> 84 -> 42 -> 21)
     return n
 
 

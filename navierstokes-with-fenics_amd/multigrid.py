@@ -77,6 +77,45 @@ def interpolation_prolongation(nx, ny, cx, cy):
     return rowptr, cols[keep].astype(np.int32), vals[keep].astype(np.float64)
 
 
+def interpolation_prolongation_3d(nx, ny, nz, cx, cy, cz):
+    """The 3D counterpart of ``interpolation_prolongation`` for the Kuhn box meshes of ``fem_mesh.box_mesh``: a point
+    with cube-local coordinates ordered  a >= b >= c  (axes p, q, r) lies in the tetrahedron  v000, + e_p, + e_q, v111  and
+    has the barycentric weights  1 - a, a - b, b - c, c.  Integer arithmetic decides the ordering; for even sizes it equals
+    ``structured_prolongation_3d``."""
+    iz, iy, ix = np.meshgrid(np.arange(nz + 1), np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
+    idx = [ix.ravel(), iy.ravel(), iz.ravel()]
+    nf, nc = [nx, ny, nz], [cx, cy, cz]
+    q, r = [], []
+    for a in range(3):
+        qa, ra = np.divmod(idx[a] * nc[a], nf[a])
+        last = qa == nc[a]
+        q.append(np.where(last, nc[a] - 1, qa))
+        r.append(np.where(last, nf[a], ra))
+    # local coordinates as exact fractions r[a] / nf[a]: compare through the common denominator
+    den = nf[0] * nf[1] * nf[2]
+    num = np.stack([r[a] * (den // nf[a]) for a in range(3)], axis=1)            # [n, 3] integers
+    order = np.argsort(-num, axis=1, kind="stable")                              # axes by descending coordinate
+    srt = np.take_along_axis(num, order, axis=1) / float(den)
+    stride = np.array([1, cx + 1, (cx + 1) * (cy + 1)], dtype=np.int64)
+    v0 = q[0] + q[1] * stride[1] + q[2] * stride[2]
+    v1 = v0 + stride[order[:, 0]]
+    v2 = v1 + stride[order[:, 1]]
+    v3 = v0 + stride.sum()
+    cols = np.stack([v0, v1, v2, v3], axis=1)
+    vals = np.stack([1.0 - srt[:, 0], srt[:, 0] - srt[:, 1], srt[:, 1] - srt[:, 2], srt[:, 2]], axis=1)
+    keep = vals > 0.0
+    counts = keep.sum(axis=1)
+    rowptr = np.zeros(cols.shape[0] + 1, dtype=np.int32)
+    np.cumsum(counts, out=rowptr[1:])
+    # columns ascending within a row: sort the kept entries of every row
+    key = np.where(keep, cols, np.iinfo(np.int64).max)
+    perm = np.argsort(key, axis=1, kind="stable")
+    cols = np.take_along_axis(cols, perm, axis=1)
+    vals = np.take_along_axis(vals, perm, axis=1)
+    keep = np.take_along_axis(keep, perm, axis=1)
+    return rowptr, cols[keep].astype(np.int32), vals[keep].astype(np.float64)
+
+
 def structured_prolongation_3d(nx, ny, nz):
     """P1 prolongation between the Kuhn meshes (nx/2, ny/2, nz/2) -> (nx, ny, nz) of
     ``fem_mesh.box_mesh``: every edge of the Kuhn split points in a direction of {0,1}^3, so a fine
@@ -116,7 +155,8 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200,
     the coarsest level with a dense inverse; one more level of ~8 small kernels costs more than a
     1000-unknown dense mat-vec).  2D: a level with an odd number of cells in some direction is followed by the
     NON-NESTED mesh of ceil(n / 2) cells (``interpolation_prolongation``; the coarse operators are rediscretised on
-    every level anyway); 3D or ``allow_non_nested=False``: the hierarchy ends where a direction becomes odd."""
+    every level anyway; 3D: ``interpolation_prolongation_3d``); ``allow_non_nested=False``: the hierarchy ends where a
+    direction becomes odd."""
     from fem_mesh import box_mesh
     n = [nx, ny] if nz is None else [nx, ny, nz]
     levels = []
@@ -126,8 +166,8 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200,
 
     while True:
         even = all(k % 2 == 0 for k in n)
-        if not even and (nz is not None or not allow_non_nested or min(n) < 5):
-            break                                   # (3D Kuhn meshes and periodic hierarchies: nested levels only)
+        if not even and (not allow_non_nested or min(n) < 5):
+            break                                   # (periodic and multi-rank hierarchies: nested levels only)
         nc = [(k + 1) // 2 for k in n]
         if coarsest is not None:
             if min(nc) < coarsest:
@@ -138,7 +178,8 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200,
             P = structured_prolongation(*n) if nz is None else structured_prolongation_3d(*n)
         else:
             # an odd number of cells: the next mesh is not nested -- linear interpolation between the two meshes
-            P = interpolation_prolongation(n[0], n[1], nc[0], nc[1])
+            P = interpolation_prolongation(n[0], n[1], nc[0], nc[1]) if nz is None else \
+                interpolation_prolongation_3d(n[0], n[1], n[2], nc[0], nc[1], nc[2])
         n = nc
         mesh = rectangle_mesh(p0, p1, *n) if nz is None else box_mesh(p0, p1, *n)
         levels.append((mesh, P))

@@ -257,15 +257,25 @@ class SlabPartition:
         self.p1_owned = self.p1_ghost == 0
         self.levels = []
         lx, ly, lz, lown, fine_level = nx, ny, nz, own, self.fine
-        while lx % 2 == 0 and ly % 2 == 0 and lown % 2 == 0 and lown // 2 >= 1 \
-                and min(lx, ly, lz) // 2 >= coarsest:
-            cx, cy, cz, cown = lx // 2, ly // 2, lz // 2, lown // 2
+        # (one rank: odd levels continue through non-nested Kuhn meshes, multigrid.interpolation_prolongation_3d)
+        while True:
+            even = lx % 2 == 0 and ly % 2 == 0 and lown % 2 == 0
+            if not even and not (size == 1 and min(lx, ly, lz) >= 5):
+                break
+            cx, cy, cz, cown = (lx + 1) // 2, (ly + 1) // 2, (lz + 1) // 2, (lown + 1) // 2
+            if cown < 1 or min(cx, cy, cz) < coarsest:
+                break
             lev = SlabLevel(p0, p1, cx, cy, cz, rank * cown, cown, g)
-            rowptr, col, val = structured_prolongation_3d(lx, ly, 2 * lev.rows)
-            n_fine = (lx + 1) * (ly + 1) * (fine_level.rows + 1)
-            rowptr = rowptr[: n_fine + 1].copy()
-            nnz = rowptr[-1]
-            self.levels.append((lev, (rowptr, col[:nnz].copy(), val[:nnz].copy())))
+            if even:
+                rowptr, col, val = structured_prolongation_3d(lx, ly, 2 * lev.rows)
+                n_fine = (lx + 1) * (ly + 1) * (fine_level.rows + 1)
+                rowptr = rowptr[: n_fine + 1].copy()
+                nnz = rowptr[-1]
+                col, val = col[:nnz].copy(), val[:nnz].copy()
+            else:
+                from multigrid import interpolation_prolongation_3d
+                rowptr, col, val = interpolation_prolongation_3d(lx, ly, lz, cx, cy, cz)
+            self.levels.append((lev, (rowptr, col, val)))
             lx, ly, lz, lown, fine_level = cx, cy, cz, cown, lev
         last = self.levels[-1][0] if self.levels else self.fine
         self.coarse_global_shape = (last.nx, last.ny, lz)

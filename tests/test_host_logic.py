@@ -772,3 +772,18 @@ def test_interpolation_prolongation_between_non_nested_meshes():
     assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0), (1, 1), 512, 512)] == \
         [(256, 256), (128, 128), (64, 64), (32, 32)]
     assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0), (1, 1), 333, 333, allow_non_nested=False)] == []
+    # 3D Kuhn meshes: equal to the nested prolongation for even sizes, linear functions reproduced otherwise
+    from multigrid import interpolation_prolongation_3d, structured_prolongation_3d
+    from fem_mesh import box_mesh
+    a = structured_prolongation_3d(4, 6, 8)
+    b = interpolation_prolongation_3d(4, 6, 8, 2, 3, 4)
+    shape = (5 * 7 * 9, 3 * 4 * 5)
+    assert abs(sp.csr_matrix((a[2], a[1], a[0]), shape=shape) - sp.csr_matrix((b[2], b[1], b[0]), shape=shape)).max() == 0.0
+    rp, c, v = interpolation_prolongation_3d(9, 7, 5, 5, 4, 3)
+    mf, mc = box_mesh((0, 0, 0), (1, 2, 3), 9, 7, 5), box_mesh((0, 0, 0), (1, 2, 3), 5, 4, 3)
+    P = sp.csr_matrix((v, c, rp), shape=(mf.coords.shape[0], mc.coords.shape[0]))
+    g = lambda X: 0.5 + X[:, 0] - 2.0 * X[:, 1] + 3.0 * X[:, 2]
+    assert abs(P @ g(mc.coords) - g(mf.coords)).max() < 1e-13
+    assert abs(np.asarray(P.sum(axis=1)).ravel() - 1.0).max() < 1e-15 and v.min() > 0.0 and np.diff(rp).max() <= 4
+    assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0, 0), (1, 1, 1), 50, 50, 50)] == \
+        [(25, 25, 25), (13, 13, 13), (7, 7, 7)]

@@ -785,5 +785,15 @@ def test_interpolation_prolongation_between_non_nested_meshes():
     g = lambda X: 0.5 + X[:, 0] - 2.0 * X[:, 1] + 3.0 * X[:, 2]
     assert abs(P @ g(mc.coords) - g(mf.coords)).max() < 1e-13
     assert abs(np.asarray(P.sum(axis=1)).ravel() - 1.0).max() < 1e-15 and v.min() > 0.0 and np.diff(rp).max() <= 4
+    # ... and it is the interpolant of THIS triangulation: a random nodal field evaluated in the coarse mesh's own cells
+    rng = np.random.default_rng(0)
+    field = rng.standard_normal(mc.coords.shape[0])
+    T = mc.coords[mc.cells]
+    A = np.stack([T[:, 1] - T[:, 0], T[:, 2] - T[:, 0], T[:, 3] - T[:, 0]], axis=2)
+    for i in rng.integers(0, mf.coords.shape[0], 60):
+        lam = np.linalg.solve(A, (mf.coords[i] - T[:, 0])[:, :, None])[:, :, 0]
+        L = np.concatenate([1.0 - lam.sum(axis=1, keepdims=True), lam], axis=1)
+        k = int(np.argmax(L.min(axis=1)))                     # the cell that holds the point
+        assert abs((P @ field)[i] - (L[k] * field[mc.cells[k]]).sum()) < 1e-13
     assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0, 0), (1, 1, 1), 50, 50, 50)] == \
         [(25, 25, 25), (13, 13, 13), (7, 7, 7)]

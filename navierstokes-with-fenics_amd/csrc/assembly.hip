@@ -798,7 +798,7 @@ struct JacLatArgs {
   int nx, ny, W, H, nc;
   int ntx, ntiles;
   int lmax, lp, n_st;   // lp: table row stride (lmax rounded up to 4, zero padded)
-  int dbg;              // measurements only (NSFEM_JL_DBG): 1 no element kernel, 2 no L product, 4 no node sums
+  int dbg;              // knock-out build only (NSFEM_KNOCKOUTS): 1 no element kernel, 2 no L product, 4 no node sums
   double cc;
   // per cell type t and local node k, packed 6 x 5 bits (k-th field): the node's lattice offset from the square's corner
   // node as dj * 3 + di, and the cell's rank among the cells around that node (ascending cell number).  Plain
@@ -834,7 +834,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   // XCD x (workgroups b = x mod 8) walks a contiguous range of tiles: neighbouring tiles share their halo in L2
   const int per = (a.ntiles + 7) >> 3;
   const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (tile >= a.ntiles || (a.dbg & 256)) return;
+  if (tile >= a.ntiles || NSFEM_KO(a.dbg & 256)) return;
   const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
   const int i0 = tx * kJlOX - 2, j0 = ty * kJlOY - 2;               // lattice position of the LDS tile's corner
   const int tid = threadIdx.x;
@@ -850,7 +850,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     const int gi = i0 + li, gj = j0 + lj;
     uv[r] = make_double2(0.0, 0.0);
     xv[r] = uv[r];
-    if (t < NN && gi >= 0 && gi < a.W && gj >= 0 && gj < a.H && !(a.dbg & 8)) {
+    if (t < NN && gi >= 0 && gi < a.W && gj >= 0 && gj < a.H && !NSFEM_KO(a.dbg & 8)) {
       const size_t g = (size_t)gj * a.W + gi;
       uv[r] = u2[g];
       if (!RES) xv[r] = x2[g];
@@ -861,7 +861,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   const int sqx = (i0 >> 1) + sxl, sqy = (j0 >> 1) + syl;          // (i0, j0 even; >> is an arithmetic shift)
   const bool cell = sqx >= 0 && sqx < a.nx && sqy >= 0 && sqy < a.ny;
   CellGeo geo;
-  if (cell && !(a.dbg & 16)) geo = load_geo(vx, a.nc, 2 * (sqy * a.nx + sqx) + ct);
+  if (cell && !NSFEM_KO(a.dbg & 16)) geo = load_geo(vx, a.nc, 2 * (sqy * a.nx + sqx) + ct);
   else geo.ji00 = geo.ji01 = geo.ji10 = geo.ji11 = geo.adet = 1.0;
   constexpr int OWN = kJlOX * kJlOY, NOWN = (OWN + NT - 1) / NT;
   int obase[NOWN], oent[NOWN], omask[NOWN];
@@ -892,7 +892,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     to[t] = ((pk >> 5) - 8) * kJlNW + ((pk & 31) - 8);
   }
   if (tid < a.n_st) tl[tid] = slen[tid];
-  if (a.dbg & 512) return;
+  if NSFEM_KO(a.dbg & 512) return;
 #pragma unroll
   for (int r = 0; r < NLD; ++r) {
     const int t = tid + r * NT;
@@ -902,7 +902,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     }
   }
   __syncthreads();
-  if (a.dbg & 128) return;
+  if NSFEM_KO(a.dbg & 128) return;
   // ---- phase 1: (L x) on the owned nodes; four entries of the row in flight (rows are zero padded to 4).
   // (Measured and rejected: advancing the rows of the thread's two nodes together with the next trip's table
   // entries prefetched -- 51.1 instead of 48.3 us per launch at n = 512.)
@@ -910,7 +910,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   for (int r = 0; r < NOWN; ++r) {
     if (obase[r] < 0) continue;
     const int base = obase[r];
-    const int L = (a.dbg & 2) ? 0 : tl[oent[r]];
+    const int L = NSFEM_KO(a.dbg & 2) ? 0 : tl[oent[r]];
     const int* __restrict__ op = to + oent[r] * a.lp;
     const double* __restrict__ vp = tv + oent[r] * a.lp;
     double ax = 0.0, ay = 0.0;
@@ -937,7 +937,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     const int dj = (f * 11) >> 5;                 // f / 3 for f < 9
     nl[k] = corner + dj * kJlNW + (f - 3 * dj);
   }
-  if (cell && !(a.dbg & 64)) {
+  if (cell && !NSFEM_KO(a.dbg & 64)) {
     double ux[6], uy[6], wx[RES ? 1 : 6], wy[RES ? 1 : 6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -948,7 +948,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
         wx[k] = q.x; wy[k] = q.y;
       }
     }
-    if (a.dbg & 1) {
+    if NSFEM_KO(a.dbg & 1) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) { rx[k] = ux[k]; ry[k] = uy[k]; }
     } else {
@@ -962,7 +962,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int rk = (prk >> (5 * k)) & 31;
-      if (cell && rk == r && !(a.dbg & 4)) {
+      if (cell && rk == r && !NSFEM_KO(a.dbg & 4)) {
         double2 v = sa[nl[k]];
         v.x += rx[k];
         v.y += ry[k];
@@ -982,7 +982,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
       if (omask[r] & 0x00ff) v.x = xo.x;
       if (omask[r] & 0xff00) v.y = xo.y;
     }
-    if (!(a.dbg & 32) || v.x == 1.2345) y2[onode[r]] = v;
+    if (!NSFEM_KO(a.dbg & 32) || v.x == 1.2345) y2[onode[r]] = v;
   }
 }
 
@@ -1039,8 +1039,10 @@ static int g_jac_lattice_tile = 0;
 void refresh_assembly_switches() {
   const char* e = std::getenv("NSFEM_JAC_LATTICE");
   g_jac_lattice_on = e ? std::atoi(e) != 0 : true;
+#if NSFEM_KNOCKOUTS
   e = std::getenv("NSFEM_JL_DBG");
   g_jac_lattice_dbg = e ? std::atoi(e) : 0;
+#endif
   e = std::getenv("NSFEM_JL_TILE");
   g_jac_lattice_tile = e ? std::max(0, std::min(1, std::atoi(e))) : 0;
 }

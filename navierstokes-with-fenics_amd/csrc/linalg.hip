@@ -53,7 +53,7 @@ struct SpmvArgs {
                    // Newton matrix with dolfin-style Dirichlet rows) instead of 0
   int dict_ok;     // the product may use the matrix's stencil-dictionary copy (smoothing steps only:
                    // the copy equals the CSR matrix to the dedupe tolerance, not bitwise)
-  int dbg;         // NSFEM_SPMV_DEBUG (measurement experiments only; wrong results): 1 = gather from
+  int dbg;         // knock-out build only (NSFEM_KNOCKOUTS; wrong results): 1 = gather from
                    // the chunk's own rows (perfectly local x), 2 = skip the x gather altogether
   // dictionary kernel, EPI_STORE: after the product row r also adds the run gptr[r] .. gptr[r + 1] of
   // NV-wide entries of gbuf (the node-sorted element vectors of the matrix-free convection action: the node
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int4* __r
         }
     }
   }
-  if (a.dbg == 1) {
+  if (NSFEM_KO(a.dbg == 1)) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (cc_[u] >= 0) cc_[u] = r0 + (4 * tid + u) % nrows;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void k_spmv_stream(int n_rblk, const int4* __r
     if (cc_[u] >= 0) {
 #pragma unroll
       for (int t = 0; t < BC * NV; ++t)
-        xv[u][t] = a.dbg == 2 ? (double)cc_[u] : x[(size_t)cc_[u] * (BC * NV) + t];
+        xv[u][t] = NSFEM_KO(a.dbg == 2) ? (double)cc_[u] : x[(size_t)cc_[u] * (BC * NV) + t];
     }
   // products -> LDS.  Nonzero q = 4 tid + u of the aligned window is parked at slot u * 256 + tid:
   // consecutive lanes write consecutive slots (the natural slot q would put the lanes 4 NO doubles
@@ -1014,7 +1014,7 @@ struct LatticeArgs {
   int EHh;                  // rows of a class plane (= (TY + 2 Ge) / 2); a plane row has 32 words
   int from_zero, ident;
   int lp, n_st;             // table stride (longest stencil rounded up to a multiple of 4), entries
-  int dbg;                  // NSFEM_LATTICE_DBG (measurement only, wrong results): 1 no stages, 4 no row products
+  int dbg;                  // knock-out build only (NSFEM_KNOCKOUTS, wrong results): 1 no stages, 4 no row products
   const double *x_in, *b, *d_in;
   double *x_out, *d_out, *r_out;
   const uint8_t *sid, *mask;
@@ -1076,7 +1076,7 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
       double acc[NV];
 #pragma unroll
       for (int c = 0; c < NV; ++c) acc[c] = 0.0;
-      if (!(a.dbg & 4)) {
+      if (!NSFEM_KO(a.dbg & 4)) {
         if (NV == 2) {
           const vec* __restrict__ xv = reinterpret_cast<const vec*>(src) + st.self(q);
 #pragma unroll
@@ -1155,7 +1155,7 @@ __device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, Lat
       double acc[NV];
 #pragma unroll
       for (int c = 0; c < NV; ++c) acc[c] = 0.0;
-      for (int k0 = 0; k0 < L && !(a.dbg & 4); k0 += 4) {
+      for (int k0 = 0; k0 < L && !NSFEM_KO(a.dbg & 4); k0 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const double v = vp[k0 + u];
@@ -1389,7 +1389,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
     for (int c = 0; c < NV; ++c) xs0[(size_t)st.self(q) * NV + c] = xv[c];
   }
   __syncthreads();                       // E is staged
-  if (!(a.dbg & 1)) {
+  if (!NSFEM_KO(a.dbg & 1)) {
     if (differs == 0 && stu >= 0) {
       const int L = tlen[stu];
       const double* __restrict__ vp = tval + (size_t)stu * a.lp;
@@ -1404,7 +1404,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
     }
   }
   // the newest iterate sits in the buffer the last smoothing stage wrote (stage m writes buffer m & 1)
-  const int n_smooth = (a.dbg & 1) ? 0 : a.S - a.from_zero;
+  const int n_smooth = NSFEM_KO(a.dbg & 1) ? 0 : a.S - a.from_zero;
   const double* __restrict__ fin = (n_smooth & 1) ? xs1 : xs0;
 #pragma unroll
   for (int q = 0; q < K; ++q)
@@ -1523,8 +1523,12 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   a.lp = (d.lmax + 3) & ~3;
   a.n_st = d.n_stencils;
   NSFEM_REQUIRE(A.lat_vals.n == (size_t)d.n_stencils * a.lp, "lattice value table missing");
+#if NSFEM_KNOCKOUTS
   static const int dbg = [] { const char* e = std::getenv("NSFEM_LATTICE_DBG"); return e ? std::atoi(e) : 0; }();
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   for (int k = 0; k < 4; ++k) { a.c1[k] = k < steps ? c1[k] : 0.0; a.c2[k] = k < steps ? c2[k] : 0.0; }
   const size_t lds = (size_t)2 * 4 * 32 * a.EHh * nv * 8;
   const int grid = (a.ntiles + 7) & ~7;
@@ -2279,11 +2283,15 @@ static SpmvArgs make_args(const double* x, const double* b, double* y, const uin
   a.ident = 0;
   a.dict_ok = 0;
   a.y2 = nullptr;
+#if NSFEM_KNOCKOUTS
   static const int dbg = [] {
     const char* e = std::getenv("NSFEM_SPMV_DEBUG");
     return e ? std::atoi(e) : 0;
   }();
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   a.gptr = nullptr;
   a.gbuf = nullptr;
   return a;

@@ -13,6 +13,18 @@
 #include <map>
 #include "../../include/nsfem.h"
 
+// Knock-out switches of the measurement experiments (NSFEM_LATTICE_DBG, NSFEM_JL_DBG, NSFEM_SPMV_DEBUG: parts of the
+// dominant kernels switched off, WRONG results): compiled in only with -DNSFEM_KNOCKOUTS=1 (scripts/build_knockouts.sh);
+// in the product build NSFEM_KO(..) is the constant 0 and the environment variables are never read.
+#ifndef NSFEM_KNOCKOUTS
+#define NSFEM_KNOCKOUTS 0
+#endif
+#if NSFEM_KNOCKOUTS
+#define NSFEM_KO(expr) (expr)
+#else
+#define NSFEM_KO(expr) (0)
+#endif
+
 namespace nsfem {
 
 struct Error : std::runtime_error {

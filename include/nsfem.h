@@ -441,6 +441,13 @@ int nsfem_time_spmv(nsfem_ctx* ctx, int op, int reps, double* ms_per_launch,
  * Newton-Jacobian products only -- never by a residual or a linear operator whose solution is
  * returned; NSFEM_DICT=0 disables it. */
 int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]);
+/* Test hook: z = M^-1 r, one cycle of a multigrid preconditioner on host vectors (which: 0 = pressure Poisson
+   hierarchy, 1 = velocity hierarchy); nsfem_mg_info: out = {fused-leg kind (0 separate launches, 1 one launch below
+   the finest level of a truncated cycle, 2 down-legs + tail + up-legs), fused launches per cycle, levels in use,
+   fused launches so far}.  New functionality (the reference has no preconditioner: sparse LU,
+   source/ns_ipcs_solver.py:171,205). */
+int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double* z);
+int nsfem_mg_info(nsfem_ctx* ctx, int which, int64_t out[4]);
 /* in-situ HIP-event timing of the matrix-free convection action of the velocity Jacobian inside
  * the Newton-Krylov solves (element kernel k_conv_cell / k3_conv_cell + node gather = the
  * per-iteration "assembly" of the fused step drivers; replaces the dolfin assemble(J) call of

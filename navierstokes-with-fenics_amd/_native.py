@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_smoother_info", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_smoother_detail", "nsfem_profile_convection", "nsfem_jacobian_info", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local", "nsfem_comm_attach_shm",
+    "nsfem_mg_apply", "nsfem_mg_info",
 )
 
 
@@ -201,6 +202,8 @@ def load_library(path=None):
         "nsfem_mg_set_schur_mode": (C.c_int, [vp, C.c_int]),
         "nsfem_smoother_info": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "nsfem_jacobian_info": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+        "nsfem_mg_apply": (C.c_int, [vp, C.c_int, pd, pd]),
+        "nsfem_mg_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64)]),
         "nsfem_set_halo_lists": (C.c_int, [vp, C.c_int, C.POINTER(HaloLists)]),
         "nsfem_mg_set_global_index": (C.c_int, [vp, i32, pi]),
         "nsfem_comm_allreduce": (C.c_int, [vp, pd, C.c_int, C.c_int]),
@@ -460,6 +463,19 @@ class NsfemContext:
         return dict(kind=("csr-stream", "sell-64", "stencil-dictionary", "stencil-dictionary")[int(out[0])],
                     multistep_lattice_kernel=int(out[0]) == 3, stencils=int(out[1]),
                     longest_row=abs(int(out[2])), bitwise_exact=int(out[2]) < 0, csr_bytes=int(out[3]))
+
+    def mg_apply(self, which, r):
+        """one cycle z = M^-1 r of the pressure (which=0) or velocity (which=1) multigrid preconditioner"""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        self._check(self._lib.nsfem_mg_apply(self._h, int(which), _dp(r), _dp(z)))
+        return z
+
+    def mg_info(self, which):
+        """dict(legs, launches_per_cycle, levels, leg_launches): how the cycles of a hierarchy run"""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.nsfem_mg_info(self._h, int(which), out))
+        return dict(legs=int(out[0]), launches_per_cycle=int(out[1]), levels=int(out[2]), leg_launches=int(out[3]))
 
     def mg_set_schur_mode(self, additive):
         """partitioned meshes: the Schur operators set afterwards are this rank's additive parts"""

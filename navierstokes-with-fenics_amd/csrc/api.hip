@@ -95,6 +95,7 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   NSFEM_REQUIRE(m && out, "null argument");
   refresh_env_switches();
   refresh_assembly_switches();
+  refresh_leg_switches();
   *out = nullptr;
   NSFEM_REQUIRE(m->dim == 2 || m->dim == 3, "dim must be 2 (triangles) or 3 (tetrahedra)");
   NSFEM_REQUIRE(m->n_cells > 0 && m->n_vertices > 0 && m->n_p2 > 0 && m->n_p1 > 0, "empty mesh");
@@ -1145,7 +1146,8 @@ static void fill_p1_level(nsfem_ctx* ctx, nsfem_ctx::P1Level* lv, int n_vertices
   launch_assemble_p1_scalar(s, lv->mesh, lv->pat, lv->K.vals.p, lv->M.vals.p);
   // lattice levels: stencil dictionary of the level's operators (smoothing steps of both hierarchies;
   // the multi-step lattice kernel needs it)
-  if (build_stencil_dict(s, lv->pat, lv->M.vals.p, lv->K.vals.p, lv->dict))
+  // (2D: down to 3 x 3 nodes -- the fused legs of mglegs.hip run the whole bottom of a cycle from these tables)
+  if (build_stencil_dict(s, lv->pat, lv->M.vals.p, lv->K.vals.p, lv->dict, 1, false, dim == 2 ? 9 : 0))
     lv->K.dict = lv->M.dict = lv->Lc.dict = &lv->dict;
   lv->K.sell_update(s);
   lv->M.sell_update(s);
@@ -2324,6 +2326,46 @@ extern "C" int nsfem_kernel_apply(nsfem_ctx* ctx, nsfem_kernel_test* t) {
   t->dict_entries = have_dict ? dict.n_stencils : 0;
   t->dict_exact = have_dict && dict.exact ? 1 : 0;
   t->lattice_w = have_dict ? dict.lat_w : 0;
+  API_END(ctx)
+}
+
+// Test hook: one application z = M^-1 r of a multigrid preconditioner on host vectors -- which = 0 pressure Poisson
+// hierarchy (mg_p), 1 velocity hierarchy (mg_v, the identity rows of the Newton preconditioner included).  Lets the
+// parity tests compare the fused multi-level launches (mglegs.hip) with the separate launches cycle by cycle.
+extern "C" int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double* z) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && r && z && (which == 0 || which == 1), "bad argument");
+  NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
+  hipStream_t s = ctx->stream;
+  ensure_L(ctx);                       // (builds the dictionaries of the fine P1 operators as well)
+  if (which == 0 && ctx->mg_p.legs_kind == 0) ctx->mg_p_dirty = true;   // planned before the dictionaries existed
+  mg_refresh(ctx, which == 1);
+  const int64_t n = which == 1 ? nvel(ctx) : npre(ctx);
+  DevBuf<double> dr, dz;
+  dr.upload(r, (size_t)n, s);
+  dz.alloc((size_t)n);
+  dz.zero(s);
+  (which == 1 ? ctx->mg_v : ctx->mg_p).apply(s, dr.p, dz.p);
+  NSFEM_HIP(hipMemcpyAsync(z, dz.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  API_END(ctx)
+}
+
+// How a multigrid cycle runs: out = {kind of the fused legs (0 separate launches, 1 one launch below the finest level
+// of a truncated cycle, 2 down-legs + single-workgroup tail + up-legs), launches of k_mg_leg per cycle, levels in use,
+// launches of k_mg_leg so far}
+extern "C" int nsfem_mg_info(nsfem_ctx* ctx, int which, int64_t out[4]) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out && (which == 0 || which == 1), "bad argument");
+  NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
+  ensure_L(ctx);
+  mg_refresh(ctx, which == 1);
+  Multigrid& mg = which == 1 ? ctx->mg_v : ctx->mg_p;
+  if (mg.legs_kind < 0) mg.build_legs(ctx->stream);
+  out[0] = mg.legs_kind;
+  out[1] = mg.legs_kind == 1 ? 1 : (mg.legs_kind == 2 ? (int64_t)(mg.legs_down.size() + mg.legs_up.size() + 1) : 0);
+  out[2] = (int64_t)(mg.truncated() ? mg.active : mg.lv.size());
+  out[3] = mg.leg_launches;
   API_END(ctx)
 }
 

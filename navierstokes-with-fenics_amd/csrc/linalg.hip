@@ -1432,7 +1432,12 @@ void refresh_env_switches() {
 bool lattice_transfers_enabled() { return g_lattice_transfers_on; }
 bool lattice_smoother_available(const BlockMat& A, int nv) {
   const bool on = g_lattice_on;
-  return on && A.dict_ready && A.dict && A.dict->lat_w > 0 && A.br == 1 && A.bc == 1 && (nv == 1 || nv == 2);
+  return on && A.dict_ready && A.dict && A.dict->lat_w >= 8 && A.br == 1 && A.bc == 1 && (nv == 1 || nv == 2);
+}
+bool lattice_tables_available(const BlockMat& A, int nv) {
+  return g_lattice_on && A.dict && A.dict->n_stencils > 0 && A.dict->n_stencils <= 64 && A.dict->lat_w > 0 &&
+         A.br == 1 && A.bc == 1 && (nv == 1 || nv == 2) && A.lat_vals.p != nullptr && A.dict_dinv.p != nullptr &&
+         (A.dict_ready || A.dict->tables_only);
 }
 int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid) {
   // operator applications per launch: at most 3 (reach 2: halo 6) / 4 (reach 1)
@@ -1744,14 +1749,18 @@ __global__ __launch_bounds__(256) void k_dict_fill(int64_t len, int bsz, const i
 }
 
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
-                        StencilDict& d, int bsz, bool rect) {
+                        StencilDict& d, int bsz, bool rect, int min_rows_lattice) {
   d.n_stencils = 0;
   d.max_local = 0;
+  d.tables_only = false;
   const char* env = std::getenv("NSFEM_DICT");        // (read per context: tests switch it)
   const bool enabled = env ? std::atoi(env) != 0 : true;
   // (>= 1024 rows: lattice levels down to 33 x 33 nodes get a dictionary; NSFEM_DICT_MIN_ROWS overrides)
   const char* env_min = std::getenv("NSFEM_DICT_MIN_ROWS");
-  const int min_rows = env_min ? std::atoi(env_min) : 1024;
+  const int min_rows_full = env_min ? std::atoi(env_min) : 1024;
+  // (smaller patterns: accepted only as 2D lattices, for the fused multigrid legs -- see the end)
+  const bool small = p.n_rows < min_rows_full;
+  const int min_rows = (min_rows_lattice > 0 && !rect && bsz == 1) ? std::min(min_rows_lattice, min_rows_full) : min_rows_full;
   if (!enabled || p.n_rows < min_rows || p.h_rowptr.empty() || (!rect && p.n_rows != p.n_cols)) return false;
   const int n = p.n_rows;
   const size_t nval = (size_t)p.nnz * bsz;
@@ -1882,7 +1891,7 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
         if (o > 2 && (omin == 0 || o < omin)) omin = o;
       }
     for (int Wc = omin; omin > 0 && Wc <= omin + 2 && d.lat_w == 0; ++Wc) {
-      if (Wc < 8 || n % Wc != 0 || n / Wc < 3) continue;
+      if (Wc < 3 || n % Wc != 0 || n / Wc < 3) continue;
       const int Hc = n / Wc;
       std::vector<int32_t> pk((size_t)ns * lmax, 8 * 32 + 8);
       bool ok = true;
@@ -1915,6 +1924,13 @@ bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, co
     }
   }
   NSFEM_HIP(hipStreamSynchronize(s));
+  if (small) {
+    if (d.lat_w == 0) {            // a small pattern that is no lattice: no dictionary (as before)
+      d.n_stencils = 0;
+      return false;
+    }
+    d.tables_only = true;
+  }
   return true;
 }
 
@@ -1939,7 +1955,7 @@ void BlockMat::sell_update(hipStream_t s) {
         NSFEM_HIP(hipGetLastError());
       }
     }
-    dict_ready = true;
+    dict_ready = !dict->tables_only;
   }
   sell_ready = false;
   if (!pat || pat->n_slices == 0 || br != 1 || bc != 1) return;

@@ -387,6 +387,7 @@ void Multigrid::setup_work(hipStream_t s) {
 
 // masks (host, level 0) -> coarse levels by injection; dinv, lambda_max, coarse inverse
 void Multigrid::refresh(hipStream_t s, const std::vector<uint8_t>& mask0, bool singular) {
+  legs_kind = -1;                  // fused launches are planned again from the new masks / coefficients
   std::vector<uint8_t> cur = mask0, nxt;
   std::vector<double> hp(kParts);
   const size_t n_used = truncated() ? active : lv.size();
@@ -1019,6 +1020,7 @@ const double* Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double
 void Multigrid::apply(hipStream_t s, const double* r, double* z) {
   NSFEM_REQUIRE(ready, "multigrid hierarchy not refreshed");
   restricted_to = 0;
+  if (vcycle_legs(s, r, z)) return;                 // fused multi-level launches (mglegs.hip)
   (void)vcycle(s, 0, r, z);                         // (level 0: the result is in z)
 }
 

@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <functional>
 #include <map>
+#include <memory>
 #include "../../include/nsfem.h"
 
 // Knock-out switches of the measurement experiments (NSFEM_LATTICE_DBG, NSFEM_JL_DBG, NSFEM_SPMV_DEBUG: parts of the
@@ -150,6 +151,8 @@ struct StencilDict {
   int n_rows = 0, n_stencils = 0, lmax = 0;
   bool exact = false;      // every row equals its representative BITWISE (meshes with a binary spacing): the
                            // dictionary copy is the matrix itself and every product may use it
+  bool tables_only = false; // small lattice levels (< 1024 rows): the tables exist for the fused multigrid legs
+                           // (mglegs.hip) only -- products and single-level smoothing keep the CSR kernels
   int bsz = 1;             // doubles per entry (block matrices: br * bc)
   bool rect = false;       // offsets are relative to the row's FIRST column (rectangular P2 x P1 blocks:
                            // the two numberings differ), kept per row in cbase; square: relative to the row
@@ -178,8 +181,9 @@ struct StencilDict {
   mutable std::vector<LatticeOffsets> loff_cache;   // one table per tile shape in use (built on first use)
 };
 // false: the rows do not repeat (unstructured mesh) -- no dictionary
+// min_rows > 0: patterns down to that many rows are accepted when they turn out to be 2D lattices (tables_only)
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
-                        StencilDict& d, int bsz = 1, bool rect = false);
+                        StencilDict& d, int bsz = 1, bool rect = false, int min_rows = 0);
 
 struct BlockMat {
   const Pattern* pat = nullptr;
@@ -261,8 +265,10 @@ void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x,
 // multi-step lattice smoother (2D lexicographic lattices with a stencil dictionary; linalg.hip)
 void refresh_env_switches();            // NSFEM_LATTICE, NSFEM_LATTICE_TRANSFERS (re-read by nsfem_create)
 void refresh_assembly_switches();       // NSFEM_JAC_LATTICE
+void refresh_leg_switches();            // NSFEM_MG_LEGS, NSFEM_LEG_GROUP, NSFEM_LEG_T (mglegs.hip)
 bool lattice_transfers_enabled();
 bool lattice_smoother_available(const BlockMat& A, int nv);
+bool lattice_tables_available(const BlockMat& A, int nv);   // dictionary tables of a 2D lattice operator are in place
 int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid);
 void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
                          const double* d_in, double* x_out, double* d_out, double* r_out,
@@ -611,6 +617,72 @@ struct MGLevel {
   DevBuf<double> t;              // additive levels: the product before the smoother update
 };
 
+
+// ---- fused multi-level launches on 2D lattice hierarchies (mglegs.hip) ---------------------------
+// A "leg" is a short program of level operations (load, restrict, Chebyshev step, residual, prolong, store, dense
+// coarse solve) that ONE launch of k_mg_leg runs from LDS: a workgroup owns a tile of the coarsest level of the leg
+// (the anchor) and the matching nodes of the finer levels; every operation works on the tile widened by the halo the
+// later operations need (planned backwards on the host), halo nodes are computed redundantly by the neighbours.
+// Replaces the 7 - 13 us launches of the small multigrid levels (one per smoothing sequence, transfer and coarse
+// solve) by one launch per cycle leg.
+enum LegOpType { LEG_LOADB = 0, LEG_LOADX, LEG_RESTRICT_G, LEG_RESTRICT_L, LEG_CHEB0, LEG_CHEB, LEG_RESID,
+                 LEG_PROLONG, LEG_STORE, LEG_DENSE };
+enum LegFlags { LEGF_OLD_ZERO = 1, LEGF_IDENT = 2, LEGF_ADD = 4, LEGF_EXT_IN = 8, LEGF_EXT_OUT = 16, LEGF_SYNC = 32 };
+constexpr int kLegMaxLevels = 8, kLegMaxOps = 96;
+// builder record of one operation (host): level / array numbers, resolved by LegPlan::finalize
+struct LegOpDev {
+  int type, lev, dst, src, halo, flags, n_dense, pad_;
+  double c1, c2;
+  const double* gin;       // LOADB / LOADX / RESTRICT_G source, DENSE: the inverse [nv][n][n]
+  double* gout;            // STORE / RESTRICT_L target (own nodes only)
+};
+// what the kernel reads per operation: everything resolved to plain numbers, one contiguous (scalar) load.
+// LDS arrays: node (i, j) of a level sits at off + ((j - ly + g) * pitch + (i - lx + g)) * NV, (lx, ly) = first own
+// node of the workgroup's tile on that level, g = halo + reach (zeroed guard ring)
+struct LegOpRec {
+  int type, flags, halo, shift;
+  int W, H, np, n_dense;
+  int d_off, d_pitch, d_g, s_off, s_pitch, s_g;       // destination / source array
+  int b_off, b_pitch, b_g, e_off, e_pitch, e_g;       // right-hand side array; entry | mask bytes (offset in bytes)
+  int t_off, o_shift, o_W, o_H;                       // value table; the other level of a transfer ...
+  int o_off, o_pitch, o_g, R;                         // ... and its array
+  double c1, c2;
+  const double* gin;
+  double* gout;
+};
+struct LegLevelDev {
+  int W, H, shift, R;
+  int n_st, lmax, lp, np;          // dictionary entries, longest row, value-table stride, (2 R + 1)^2
+  int t_off, e_off, e_pitch, e_g;  // dense value table (offset in doubles), entry | mask bytes (offset in bytes)
+  const uint8_t* sidm;
+  const double* tval;              // [n_st][lp]
+  const int32_t* pack;             // [n_st][lmax]  (dj + 8) * 32 + (di + 8)
+  const int32_t* len;
+  const double* dinv;
+};
+struct LegPlanDev {
+  int n_levels, n_ops, T, ntx, nty, Wa, Ha, lds_doubles;
+  LegLevelDev lv[kLegMaxLevels];
+  LegOpRec op[kLegMaxOps];
+};
+struct MGLevel;
+struct LegPlan {
+  int nv = 1, threads = 1024;
+  std::vector<MGLevel*> lv;        // finest first; the last one is the anchor (tiles are cut on it)
+  std::vector<LegOpDev> ops;
+  LegPlanDev h;                    // host copy of what the kernel reads
+  DevBuf<LegPlanDev> dev;
+  size_t lds_bytes = 0;
+  double redundancy = 1.0;         // node operations of the launch / the same without halos
+  int64_t launches = 0;
+  // ops appended by the builders; `lev` indexes lv
+  void add(int type, int lev, int dst, int src, int flags = 0, double c1 = 0.0, double c2 = 0.0,
+           const double* gin = nullptr, double* gout = nullptr, int n_dense = 0);
+  // plan the halos backwards, lay the LDS out for tiles of T anchor nodes; false: does not fit `lds_limit`
+  bool finalize(hipStream_t s, int T, size_t lds_limit);
+  void launch(hipStream_t s, const double* ext_in, double* ext_out);
+};
+
 struct Multigrid : Precond {
   int nv = 1;
   std::vector<MGLevel> lv;
@@ -682,6 +754,17 @@ struct Multigrid : Precond {
   bool lattice_ok(const MGLevel& L) const;
   bool chain_child_forms_b(size_t l);
   size_t restricted_to = 0;      // level whose b the two-level restriction kernel has already formed in this leg
+  // fused legs (mglegs.hip): built on first use after a refresh; legs_kind 0 = none (separate launches),
+  // 1 = truncated cycle without pre-smoothing: ONE launch for everything below the finest level,
+  // 2 = V(pre, post) cycle with a dense coarsest level: down-legs, one single-workgroup tail, up-legs
+  int legs_kind = -1;            // -1: not tried since the last refresh
+  std::vector<std::unique_ptr<LegPlan>> legs_down, legs_up;
+  std::unique_ptr<LegPlan> leg_tail, leg_coarse;
+  int64_t leg_launches = 0;
+  void ensure_sidm(hipStream_t s, MGLevel& L);
+  bool leg_level_ok(size_t l) const;
+  void build_legs(hipStream_t s);
+  bool vcycle_legs(hipStream_t s, const double* b, double* x);
   // xc: the start vector is [x_in +] P xc (prolongation fused into the staging); rf: b = R rf is computed by the
   // first launch and stored to `b` (restriction fused)
   void smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const double* x_in, double* x_out,

@@ -147,7 +147,7 @@ def structured_prolongation_3d(nx, ny, nz):
     return rowptr, col, val
 
 
-def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200, allow_non_nested=True):
+def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200, allow_non_nested=True, tail_nodes=0):
     """[(coarse mesh, prolongation CSR to the next finer mesh), ...] finest-first for 2D
     right-diagonal rectangle meshes or (with ``nz``) 3D Kuhn box meshes.
     ``coarsest`` given: coarsen while every direction stays even and >= ``coarsest`` cells.
@@ -156,10 +156,15 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200,
     1000-unknown dense mat-vec).  2D: a level with an odd number of cells in some direction is followed by the
     NON-NESTED mesh of ceil(n / 2) cells (``interpolation_prolongation``; the coarse operators are rediscretised on
     every level anyway; 3D: ``interpolation_prolongation_3d``); ``allow_non_nested=False``: the hierarchy ends where a
-    direction becomes odd."""
+    direction becomes odd.
+    ``tail_nodes`` > 0 (2D, ``coarsest`` None): where the rule above would stop, NESTED coarsening goes on while every
+    direction stays even and the level has more than ``tail_nodes`` nodes -- the device runs the levels of <= 65 x 65
+    nodes, the dense coarsest solve included, in ONE single-workgroup launch (csrc/mglegs.hip: the tail), where a
+    further level costs a microsecond and a 1089-unknown dense product does not fit."""
     from fem_mesh import box_mesh
     n = [nx, ny] if nz is None else [nx, ny, nz]
     levels = []
+    nested = True
 
     def nodes(m):
         return int(np.prod([k + 1 for k in m]))
@@ -173,7 +178,8 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200,
             if min(nc) < coarsest:
                 break
         elif nodes(n) <= dense_max or min(nc) < 2:
-            break
+            if not (tail_nodes > 0 and nz is None and even and nested and nodes(n) > tail_nodes and min(nc) >= 2):
+                break
         if even:
             P = structured_prolongation(*n) if nz is None else structured_prolongation_3d(*n)
         else:
@@ -181,6 +187,7 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200,
             P = interpolation_prolongation(n[0], n[1], nc[0], nc[1]) if nz is None else \
                 interpolation_prolongation_3d(n[0], n[1], n[2], nc[0], nc[1], nc[2])
         n = nc
+        nested = nested and even
         mesh = rectangle_mesh(p0, p1, *n) if nz is None else box_mesh(p0, p1, *n)
         levels.append((mesh, P))
     return levels
@@ -238,7 +245,12 @@ def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None, peri
     else:
         # coarsest None: down to the first level with <= 1200 nodes (512^2 -> 32^2 = 1089 nodes,
         # 64^3 -> 8^3 = 729), solved with a dense inverse on the device
-        levels = structured_hierarchy(*info, coarsest=coarsest, allow_non_nested=periodic is None) if info is not None else []
+        # (experimental fused legs, NSFEM_MG_LEGS=1: nested 2D hierarchies continue down to <= 100 nodes for the
+        #  single-workgroup tail of csrc/mglegs.hip)
+        import os
+        tail = 100 if (periodic is None and os.environ.get("NSFEM_MG_LEGS", "0") not in ("", "0")) else 0
+        levels = structured_hierarchy(*info, coarsest=coarsest, allow_non_nested=periodic is None,
+                                      tail_nodes=tail) if info is not None else []
     ctx.mg_prolongations = []                          # kept for attach_schur_laplacian
     if periodic is not None:
         # periodic = (constrained domain, P1 dof of every fine-mesh vertex): the coarse levels

@@ -288,6 +288,7 @@ extern "C" int nsfem_set_coeffs(nsfem_ctx* ctx, const double c[6]) {
   NSFEM_REQUIRE(std::isfinite(c[1]) && std::isfinite(c[2]), "pressure and viscous coefficients are required");
   for (int i = 0; i < 6; ++i) ctx->coef[i] = c[i];
   ctx->L_dirty = true;
+  ctx->graph_epoch++;                  // (coefficients are baked into captured kernel arguments)
   API_END(ctx)
 }
 
@@ -297,6 +298,7 @@ extern "C" int nsfem_set_bdf(nsfem_ctx* ctx, const double alpha[3], double k) {
   // alpha = (0, 0, 0) selects the stationary equations (monolithic step only)
   NSFEM_REQUIRE(k > 0.0 && std::isfinite(k) && std::isfinite(alpha[0]), "bad BDF coefficients");
   if (alpha[0] != ctx->alpha[0] || k != ctx->k) ctx->L_dirty = true;
+  if (alpha[0] != ctx->alpha[0] || alpha[1] != ctx->alpha[1] || alpha[2] != ctx->alpha[2] || k != ctx->k) ctx->graph_epoch++;
   for (int i = 0; i < 3; ++i) ctx->alpha[i] = alpha[i];
   ctx->k = k;
   API_END(ctx)
@@ -306,6 +308,7 @@ extern "C" int nsfem_set_convective_form(nsfem_ctx* ctx, int form, int picard) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
   NSFEM_REQUIRE(form >= 0 && form <= 3, "unknown convective form");
+  if (ctx->conv_form != form || ctx->picard != (picard != 0)) ctx->graph_epoch++;
   ctx->conv_form = form;
   ctx->picard = picard != 0;
   API_END(ctx)
@@ -315,6 +318,7 @@ extern "C" int nsfem_set_viscous_form(nsfem_ctx* ctx, int traction_form) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
   ctx->traction_form = traction_form ? 1 : 0;
+  ctx->graph_epoch++;
   if (ctx->traction_form && !ctx->have_E) {
     ctx->E.init(&ctx->p22, ctx->mesh.dim, ctx->mesh.dim, ctx->stream);
     launch_assemble_viscous_extra(ctx->stream, ctx->mesh, ctx->p22, ctx->E.vals.p);
@@ -835,7 +839,10 @@ static bool use_matrix_free(const nsfem_ctx* c, const nsfem_step_opts* o) {
 }
 
 // J dx = b ; u* -= dx
-static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+// known_rhs_norm >= 0: |rhs_v|_2 as the caller has just evaluated it (the Newton residual norm): the solve starts
+// without reading its start-up sums back
+static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info,
+                                 double known_rhs_norm = -1.0) {
   hipStream_t s = c->stream;
   c->dx_v.zero(s);
   LinOp op;
@@ -859,6 +866,7 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
   }
   op.graph_epoch = c->graph_epoch;
   op.x_zero = true;                 // dx_v was just zeroed
+  op.known_bnorm = known_rhs_norm;
   int rc = bicgstab(s, c->kw, op, c->rhs_v.p, c->dx_v.p, o, info);
   if (rc != NSFEM_OK) return rc;
   double* u = c->state[NSFEM_USTAR].p;
@@ -982,31 +990,40 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
   w.ensure(nv);
   double* x = c->state[NSFEM_U0].p;
   double* parts = w.parts.p;
-  auto residual_norm = [&](double* r) {
+  auto residual_norm = [&](double* r, int slot = P10) {
     if (c->distributed()) c->comm->exchange(s, c->halo_p2, x, c->mesh.dim);
     launch_residual(s, c->M2, c->mesh.dim, x, c->rhs_v.p, r, c->mask_v.p, MASK_ZERO);
-    launch_dot(s, nv, r, r, parts + P10 * kParts);
+    launch_dot(s, nv, r, r, parts + slot * kParts);
   };
-  residual_norm(w.r.p);
-  launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, parts + (P10 + 1) * kParts);
+  // The a-priori step count is a worst-case bound; the same solve one time step ago tells what was actually needed
+  // (first_check = its count, reduced by next_hint's linear-convergence estimate when it overshot): the first
+  // sequence runs that many steps, the bound takes over if the residual check then fails.  With such a prediction
+  // (one rank) the start-up sums |r0|^2, |b|^2 are not read back before the sequence: they wait in their own slots
+  // and come with the residual check after it -- one device -> host round trip per solve instead of two.
+  int k_hint = o.first_check >= 1 ? o.first_check : 0;
+  const bool deferred = k_hint > 0 && !c->distributed();
+  constexpr int PR0 = 12, PB0 = 13;
+  residual_norm(w.r.p, deferred ? PR0 : P10);
+  launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, parts + (deferred ? PB0 : P10 + 1) * kParts);
   if (c->distributed()) c->comm->allreduce_sum(s, parts + P10 * kParts, 2 * kParts);
-  double rr0, bb0;
-  host_sum_parts2(s, w, P10, P10 + 1, rr0, bb0);
-  const double r0 = std::sqrt(rr0), bnorm = std::sqrt(bb0);
-  const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+  double rr0 = 0.0, bb0 = 0.0, r0 = 0.0, bnorm = 0.0, target = 0.0;
+  if (!deferred) {
+    host_sum_parts2(s, w, P10, P10 + 1, rr0, bb0);
+    r0 = std::sqrt(rr0);
+    bnorm = std::sqrt(bb0);
+    target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+    w.last_target = target;
+  }
   info.residual0 = info.residual = r0;
   info.iterations = 0;
-  info.converged = r0 <= target;
+  info.converged = deferred ? false : r0 <= target;
   const double sk = std::sqrt(c->mass_kappa);
   const double rate = std::log((sk + 1.0) / (sk - 1.0));
   double res = r0;
-  // The a-priori count below is a worst-case bound; the same solve one time step ago tells what was actually needed
-  // (first_check + 1 = its count, reduced by next_hint's linear-convergence estimate when it overshot): the first
-  // sequence runs that many steps, the bound takes over if the residual check then fails.
-  int k_hint = o.first_check >= 1 ? o.first_check + 1 : 0;
+  bool first_pass = true;
   while (!info.converged && info.iterations < o.max_iter) {
     // steps needed for the error bound 2 sqrt(kappa) ((sqrt(kappa)-1)/(sqrt(kappa)+1))^k <= target / res
-    int k = (int)std::ceil(std::log(2.0 * sk * res / target) / rate);
+    int k = (deferred && first_pass) ? k_hint : (int)std::ceil(std::log(2.0 * sk * res / target) / rate);
     if (k_hint > 0) k = std::min(k, k_hint);
     k_hint = 0;
     k = std::max(1, std::min(k, o.max_iter - info.iterations));
@@ -1015,7 +1032,19 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
     info.iterations += k;
     residual_norm(w.r.p);
     if (c->distributed()) c->comm->allreduce_sum(s, parts + P10 * kParts, kParts);
-    res = std::sqrt(host_sum_parts(s, w, P10));
+    if (deferred && first_pass) {
+      double rr;
+      host_sum_parts3(s, w, P10, PR0, PB0, rr, rr0, bb0);
+      r0 = std::sqrt(rr0);
+      bnorm = std::sqrt(bb0);
+      target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+      w.last_target = target;
+      info.residual0 = r0;
+      res = std::sqrt(rr);
+    } else {
+      res = std::sqrt(host_sum_parts(s, w, P10));
+    }
+    first_pass = false;
     if (!std::isfinite(res)) return NSFEM_ERR_BREAKDOWN;
     info.residual = res;
     info.converged = res <= target;
@@ -1082,7 +1111,7 @@ extern "C" int nsfem_get_rhs(nsfem_ctx* ctx, int system, double* host, int64_t n
 }
 
 static nsfem_krylov_opts hinted(nsfem_krylov_opts k, int hint);
-static int next_hint(const nsfem_solve_info& si, const nsfem_krylov_opts& k);
+static int next_hint(const nsfem_solve_info& si, const nsfem_krylov_opts& k, double target);
 extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* opts,
                            nsfem_solve_info* info) {
   nsfem_solve_info local;
@@ -1098,7 +1127,7 @@ extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* 
       // (the Chebyshev mass solve takes its step count from the previous solve: the same predictor as in the fused
       // step drivers, so that the explicit seam and the fused step stay bit for bit equal)
       rc = correction_solve(ctx, hinted(*opts, ctx->hint_cor), inf);
-      ctx->hint_cor = next_hint(inf, *opts);
+      ctx->hint_cor = next_hint(inf, *opts, ctx->kw.last_target);
       break;
     default: throw Error(NSFEM_ERR_ARG, "nsfem_solve: system not available");
   }
@@ -1672,6 +1701,7 @@ extern "C" int nsfem_mg_set_truncation(nsfem_ctx* ctx, double max_ratio, double 
   ctx->mg_trunc_ratio = max_ratio;
   ctx->mg_trunc_tol = coarse_tol;
   ctx->L_dirty = true;
+  ctx->graph_epoch++;
   API_END(ctx)
 }
 
@@ -1700,16 +1730,19 @@ static nsfem_krylov_opts forced_opts(const nsfem_step_opts* o, const nsfem_krylo
 // GPU runs dry.  The same solve of the previous time step is an excellent predictor of the
 // iteration count: the first check is postponed to one iteration before that count.
 static nsfem_krylov_opts hinted(nsfem_krylov_opts k, int hint) {
-  k.first_check = std::max(k.first_check, hint - 1);
+  // (round 4: AT the predicted count, not one iteration before it -- a check costs ~15 - 20 us of idle GPU, and
+  // next_hint lowers the prediction when the residual at the check is far below the target)
+  k.first_check = std::max(k.first_check, hint);
   return k;
 }
 // The predictor for the next solve: the iteration count of this one, reduced when the postponed
 // first check found the residual far below the target (linear-convergence estimate of the count
 // that would have sufficed) -- otherwise a single long solve would keep all later ones long.
-static int next_hint(const nsfem_solve_info& si, const nsfem_krylov_opts& k) {
+static int next_hint(const nsfem_solve_info& si, const nsfem_krylov_opts& k, double target) {
+  (void)k;
   if (!si.converged) return 0;                     // a failed solve predicts nothing
   if (si.iterations <= 1 || !(si.residual > 0.0) || !(si.residual0 > si.residual)) return si.iterations;
-  const double target = std::max(k.atol, k.rtol * si.residual0);
+  // (target: the solve's own absolute target max(atol, rtol |b|) -- with a good start vector |r0| << |b|)
   if (!(si.residual < target) || !(si.residual0 > target)) return si.iterations;
   const double need = si.iterations * std::log(si.residual0 / target) / std::log(si.residual0 / si.residual);
   return std::max(1, std::min(si.iterations, (int)std::ceil(need)));
@@ -1723,6 +1756,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
   NSFEM_REQUIRE(ctx->alpha[0] != 0.0, "the pressure-correction scheme needs alpha0 != 0");
+  if (ctx->conv_form != opts->convective_form || ctx->picard) ctx->graph_epoch++;
   ctx->conv_form = opts->convective_form;
   ctx->picard = false;
   nsfem_step_info& inf = info ? *info : local;
@@ -1740,8 +1774,8 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     nsfem_solve_info si;
     int& hint = ctx->hint_mom[std::min(it, 3)];
     const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
-    int rc = momentum_solve_update(ctx, hinted(ko, hint), si);
-    hint = next_hint(si, ko);
+    int rc = momentum_solve_update(ctx, hinted(ko, hint), si, r);
+    hint = next_hint(si, ko, ctx->kw.last_target);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the diffusion step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)
@@ -1761,7 +1795,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     poisson_assemble(ctx, opts->pressure_extrapolation != 0);
     nsfem_solve_info si;
     int rc = poisson_solve(ctx, hinted(opts->poisson, ctx->hint_poi), si);
-    ctx->hint_poi = next_hint(si, opts->poisson);
+    ctx->hint_poi = next_hint(si, opts->poisson, ctx->kw.last_target);
     inf.krylov_iterations_poisson = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the projection step");
   }
@@ -1770,7 +1804,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     correction_assemble(ctx);
     nsfem_solve_info si;
     int rc = correction_solve(ctx, hinted(opts->correction, ctx->hint_cor), si);
-    ctx->hint_cor = next_hint(si, opts->correction);
+    ctx->hint_cor = next_hint(si, opts->correction, ctx->kw.last_target);
     inf.krylov_iterations_correction = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the velocity correction step");
   }
@@ -1855,6 +1889,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
   NSFEM_REQUIRE(opts->convective_form >= 0 && opts->convective_form <= 3, "unknown convective form");
   NSFEM_REQUIRE(opts->newton_max_iter > 0 && opts->newton_max_iter < NSFEM_MAX_NEWTON,
                 "newton_max_iter out of range");
+  if (ctx->conv_form != opts->convective_form || ctx->picard != (opts->picard != 0)) ctx->graph_epoch++;
   ctx->conv_form = opts->convective_form;
   NSFEM_REQUIRE(!ctx->distributed() || ctx->schur_singular < 0 || ctx->schur_additive,
                 "partitioned meshes take the algebraic Schur Laplacian as additive rank parts "
@@ -1899,7 +1934,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
     op.x_zero = true;               // dx_m was just zeroed
     int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, hinted(ko, hint), si);
-    hint = next_hint(si, ko);
+    hint = next_hint(si, ko, ctx->kw.last_target);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the monolithic step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)
@@ -2058,7 +2093,7 @@ extern "C" int nsfem_set_preconditioner_shift(nsfem_ctx* ctx, double shift) {
   API_BEGIN
   NSFEM_REQUIRE(ctx, "null context");
   NSFEM_REQUIRE(shift >= 0.0 && std::isfinite(shift), "the preconditioner shift must be >= 0");
-  if (shift != ctx->prec_shift) ctx->L_dirty = true;
+  if (shift != ctx->prec_shift) { ctx->L_dirty = true; ctx->graph_epoch++; }
   ctx->prec_shift = shift;
   API_END(ctx)
 }
@@ -2069,6 +2104,7 @@ extern "C" int nsfem_set_angular_velocity(nsfem_ctx* ctx, double omega, double o
   NSFEM_REQUIRE(ctx, "null context");
   NSFEM_REQUIRE(ctx->mesh.dim == 2, "scalar angular velocity: 2D meshes (use nsfem_set_angular_velocity_3d)");
   NSFEM_REQUIRE(std::isfinite(omega) && std::isfinite(omega_dot), "non-finite angular velocity");
+  if (ctx->omega != omega || ctx->omega_dot != omega_dot) ctx->graph_epoch++;
   ctx->omega = omega;
   ctx->omega_dot = omega_dot;
   API_END(ctx)
@@ -2081,6 +2117,7 @@ extern "C" int nsfem_set_angular_velocity_3d(nsfem_ctx* ctx, const double omega[
   NSFEM_REQUIRE(ctx->mesh.dim == 3, "vector angular velocity: 3D meshes only");
   for (int a = 0; a < 3; ++a) {
     NSFEM_REQUIRE(std::isfinite(omega[a]) && std::isfinite(omega_dot[a]), "non-finite angular velocity");
+    if (ctx->omega3[a] != omega[a] || ctx->omega_dot3[a] != omega_dot[a]) ctx->graph_epoch++;
     ctx->omega3[a] = omega[a];
     ctx->omega_dot3[a] = omega_dot[a];
   }
@@ -2402,9 +2439,12 @@ extern "C" int nsfem_profile_smoother(nsfem_ctx* ctx, int enable, double* avg_ms
     mg.prof_steps = 0;
     mg.prof_bytes = 0;
     mg.prof = true;
+    ctx->kw.graphs_suspended = true;     // (HIP events are recorded inside the iteration bodies)
+    ctx->kw.clear_graphs();
     return NSFEM_OK;
   }
   mg.prof = false;
+  ctx->kw.graphs_suspended = ctx->conv_probe.on;
   NSFEM_HIP(hipStreamSynchronize(ctx->stream));
   double total = 0.0;
   for (size_t i = 0; i + 1 < mg.prof_n; i += 2) {
@@ -2499,9 +2539,12 @@ extern "C" int nsfem_profile_convection(nsfem_ctx* ctx, int enable, double* avg_
     }
     pr.n = 0;
     pr.on = true;
+    ctx->kw.graphs_suspended = true;     // (HIP events are recorded inside the iteration bodies)
+    ctx->kw.clear_graphs();
     return NSFEM_OK;
   }
   pr.on = false;
+  ctx->kw.graphs_suspended = ctx->mg_v.prof;
   NSFEM_HIP(hipStreamSynchronize(ctx->stream));
   double total = 0.0;
   for (size_t i = 0; i + 1 < pr.n; i += 2) {

@@ -2622,38 +2622,58 @@ void KrylovWork::ensure(int64_t n_) {
     parts.alloc((size_t)kPartSlots * kParts);
     scal.alloc(16);
     NSFEM_HIP(hipHostMalloc((void**)&h_parts, sizeof(double) * kPartSlots * kParts));
+    NSFEM_HIP(hipHostMalloc((void**)&h_res, sizeof(HostResult), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h_res, 0, sizeof(HostResult));
   }
 }
 KrylovWork::~KrylovWork() {
   if (h_parts) (void)hipHostFree(h_parts);
+  if (h_res) (void)hipHostFree(h_res);
   clear_graphs();
 }
 
 void KrylovWork::clear_graphs() {
   for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
   graphs.clear();
+  seen.clear();
 }
 
 bool KrylovWork::graphs_enabled(const LinOp& op) const {
   static const bool on = [] {
-    // measured on MI355X (n = 512 IPCS step): 16.97 ms eager vs 17.01 ms with graph replay --
-    // the step is bound by the GPU-side cost of the small multigrid kernels, not by host
-    // launches, so replay is opt-in
+    // Measured on the MI355X (scripts/micro/launchgap.hip): a dependent kernel boundary costs 2.7 - 2.8 us between
+    // eager launches and 1.75 us inside a replayed graph -- but every Krylov iteration ends in a host check, and a
+    // replay starts 10 - 16 us after the host calls it where the first eager launch starts after ~3: n = 512 IPCS
+    // steps 2.54 ms with every iteration body replayed vs 2.50 ms eager (round 4, same box; round 1: 17.01 vs 16.97).
+    // Replay stays opt-in (NSFEM_GRAPHS=1).
     const char* e = std::getenv("NSFEM_GRAPHS");
     return e ? std::atoi(e) != 0 : false;
   }();
-  return on && op.comm == nullptr;      // (RCCL calls are not captured)
+  return on && !graphs_off && !graphs_suspended && op.comm == nullptr;      // (RCCL calls are not captured)
 }
 
 void KrylovWork::replay(hipStream_t s, const GraphKey& key, const std::function<void()>& body) {
   if (key.epoch != epoch) {             // operators / smoother data changed: baked arguments stale
+    if (!graphs.empty()) {
+      short_epochs = replays_in_epoch < 64 ? short_epochs + 1 : 0;
+      if (short_epochs >= 3) graphs_off = true;     // captures do not pay: eager launches from now on
+    }
     clear_graphs();
     epoch = key.epoch;
+    replays_in_epoch = 0;
+    if (graphs_off) { body(); return; }
   }
+  ++replays_in_epoch;
   hipGraphExec_t exec = nullptr;
   for (auto& g : graphs)
     if (g.first == key) { exec = g.second; break; }
   if (!exec) {
+    bool known = false;
+    for (const GraphKey& k : seen) known = known || k == key;
+    if (!known) {                       // first run of this body: eager (first-use set-up inside it may synchronise)
+      seen.push_back(key);
+      body();
+      return;
+    }
     hipGraph_t graph = nullptr;
     NSFEM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     try {
@@ -2672,32 +2692,82 @@ void KrylovWork::replay(hipStream_t s, const GraphKey& key, const std::function<
   NSFEM_HIP(hipGraphLaunch(exec, s));
 }
 
-double host_sum_parts(hipStream_t s, KrylovWork& w, int which) {
-  NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)which * kParts, w.parts.p + (size_t)which * kParts,
-                           sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
-  NSFEM_HIP(hipStreamSynchronize(s));
-  const double* p = w.h_parts + (size_t)which * kParts;
-  double acc = 0.0;
-  for (int i = 0; i < kParts; ++i) acc += p[i];
-  return acc;
+// sums of up to four partial-sum slots -> coherent host memory, then the sequence number (system-scope release)
+__global__ __launch_bounds__(256) void k_publish(const double* __restrict__ parts, int n, int s0, int s1, int s2, int s3,
+                                                 KrylovWork::HostResult* __restrict__ out, uint64_t seq) {
+  __shared__ double sh[4];
+  const int slot[4] = {s0, s1, s2, s3};
+  double r[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < n; ++k) r[k] = sum_parts(parts + (size_t)slot[k] * kParts, sh);
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < n; ++k) out->v[k] = r[k];
+    __threadfence_system();
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
-// two slots with ONE device -> host round trip
+// the host side: launch, spin on the sequence number (the stream is in order: everything queued before has finished
+// when it arrives); a stream error ends the wait
+static void publish_and_wait(hipStream_t s, KrylovWork& w, int n, const int slot[4], double out[4]) {
+  static const bool copy_path = std::getenv("NSFEM_SYNC_COPY") != nullptr;      // (the round-3 path, for A/B timing)
+  if (copy_path || !w.h_res) {
+    int lo = slot[0], hi = slot[0];
+    for (int k = 1; k < n; ++k) { lo = std::min(lo, slot[k]); hi = std::max(hi, slot[k]); }
+    NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)lo * kParts, w.parts.p + (size_t)lo * kParts,
+                             sizeof(double) * (size_t)(hi - lo + 1) * kParts, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < n; ++k) {
+      double acc = 0.0;
+      for (int i = 0; i < kParts; ++i) acc += w.h_parts[(size_t)slot[k] * kParts + i];
+      out[k] = acc;
+    }
+    return;
+  }
+  const uint64_t seq = ++w.seq_no;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(kBlock), 0, s, (const double*)w.parts.p, n, slot[0], slot[1], slot[2],
+                     slot[3], w.h_res, seq);
+  NSFEM_HIP(hipGetLastError());
+  volatile uint64_t* flag = &w.h_res->seq;
+  for (uint64_t spins = 0;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+    if ((spins & 0xffff) == 0xffff) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e != hipSuccess && e != hipErrorNotReady)
+        throw Error(NSFEM_ERR_HIP, std::string("stream error while waiting for a reduction: ") + hipGetErrorString(e));
+      if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        // (the stream drained but the flag store is not visible yet: one more look after a full synchronisation)
+        NSFEM_HIP(hipStreamSynchronize(s));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+          throw Error(NSFEM_ERR_HIP, "reduction result never reached the host");
+        break;
+      }
+    }
+  }
+  for (int k = 0; k < n; ++k) out[k] = w.h_res->v[k];
+}
+
+double host_sum_parts(hipStream_t s, KrylovWork& w, int which) {
+  const int slot[4] = {which, which, which, which};
+  double out[4];
+  publish_and_wait(s, w, 1, slot, out);
+  return out[0];
+}
+
+// two / three slots with ONE device -> host round trip
 void host_sum_parts2(hipStream_t s, KrylovWork& w, int a, int b, double& ra, double& rb) {
-  if (b == a + 1) {            // adjacent slots: one copy
-    NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)a * kParts, w.parts.p + (size_t)a * kParts,
-                             sizeof(double) * 2 * kParts, hipMemcpyDeviceToHost, s));
-  } else {
-    for (int which : {a, b})
-      NSFEM_HIP(hipMemcpyAsync(w.h_parts + (size_t)which * kParts, w.parts.p + (size_t)which * kParts,
-                               sizeof(double) * kParts, hipMemcpyDeviceToHost, s));
-  }
-  NSFEM_HIP(hipStreamSynchronize(s));
-  ra = rb = 0.0;
-  for (int i = 0; i < kParts; ++i) {
-    ra += w.h_parts[(size_t)a * kParts + i];
-    rb += w.h_parts[(size_t)b * kParts + i];
-  }
+  const int slot[4] = {a, b, a, a};
+  double out[4];
+  publish_and_wait(s, w, 2, slot, out);
+  ra = out[0];
+  rb = out[1];
+}
+void host_sum_parts3(hipStream_t s, KrylovWork& w, int a, int b, int c, double& ra, double& rb, double& rc) {
+  const int slot[4] = {a, b, c, a};
+  double out[4];
+  publish_and_wait(s, w, 3, slot, out);
+  ra = out[0];
+  rb = out[1];
+  rc = out[2];
 }
 
 // solves with rtol at or below this confirm the true residual on convergence (see bicgstab)
@@ -2706,7 +2776,9 @@ constexpr double kConfirmRtol = 1e-10;
 // --------------------------------------------------------------- BiCGStab
 // partial-sum slots
 // (RHO, RR), (TS, TT) and the CG pairs (RZ, RR') are adjacent: one all-reduce per kernel
-enum { P_RHO = 0, P_RR = 1, P_TS = 2, P_TT = 3, P_RTV = 4, P_PQ = 5, P_RZ0 = 6, P_RZ1 = 8 };
+enum { P_RHO = 0, P_RR = 1, P_TS = 2, P_TT = 3, P_RTV = 4, P_PQ = 5, P_RZ0 = 6, P_RZ1 = 8, P_R0 = 12, P_B0 = 13 };
+// (P_R0, P_B0: |r0|^2 and |b|^2 of the running solve, kept until the first convergence check reads them together
+// with the current residual -- a solve without communicator starts without a device -> host round trip)
 // device scalars
 enum { S_RHO_OLD = 0, S_ALPHA = 1, S_OMEGA = 2, S_RHO = 3, S_RHAT2 = 4, S_RHAT2_NEXT = 5 };
 
@@ -2729,7 +2801,11 @@ __global__ __launch_bounds__(256) void k_bicg_start(int64_t n, const double* __r
   if (threadIdx.x == 0) {
     parts[P_RHO * kParts + blockIdx.x] = v;
     parts[P_RR * kParts + blockIdx.x] = v;
-    if (rcopy) parts[P_TS * kParts + blockIdx.x] = v;          // zero start: |b|^2 = |r0|^2, no dot launch of its own
+    parts[P_R0 * kParts + blockIdx.x] = v;
+    if (rcopy) {                                               // zero start: |b|^2 = |r0|^2, no dot launch of its own
+      parts[P_TS * kParts + blockIdx.x] = v;
+      parts[P_B0 * kParts + blockIdx.x] = v;
+    }
     if (blockIdx.x == 0) {
       scal[S_RHO_OLD] = 1.0;
       scal[S_ALPHA] = 1.0;
@@ -2899,17 +2975,28 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   // |b| for the relative criterion goes into the slot next to (rho, |r0|^2): ONE all-reduce for
   // the three start-up sums and one read-back for the two the host needs
   static_assert(P_RR == P_RHO + 1 && P_TS == P_RHO + 2, "start-up slots must be adjacent");
-  if (!op.x_zero) launch_dot(s, n, b, b, parts + P_TS * kParts);
+  if (!op.x_zero) launch_dot(s, n, b, b, parts + (op.comm ? P_TS : P_B0) * kParts);
   reduce_slots(op, s, parts, P_RHO, 3);
-  double rr, bb;
-  host_sum_parts2(s, w, P_RR, P_TS, rr, bb);
-  const double r0 = std::sqrt(rr);
-  const double bnorm = std::sqrt(bb);
-  const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+  // The host needs |r0| and |b| only to form the target of the convergence checks.  Known to the caller (Newton:
+  // |b| = the nonlinear residual norm just evaluated, zero start): no round trip.  Otherwise (one rank) the two
+  // sums wait in their own slots and the FIRST check reads them together with the residual of that iteration.
+  double rr = 0.0, bb = 0.0, r0 = 0.0, bnorm = 0.0, target = 0.0;
+  bool deferred = false;
+  if (op.x_zero && op.known_bnorm >= 0.0) {
+    r0 = bnorm = op.known_bnorm;
+  } else if (!op.comm && o.max_iter > 0) {
+    deferred = true;
+  } else {
+    host_sum_parts2(s, w, P_RR, P_TS, rr, bb);
+    r0 = std::sqrt(rr);
+    bnorm = std::sqrt(bb);
+  }
+  auto set_target = [&] { target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0)); w.last_target = target; };
+  set_target();
   info.residual0 = r0;
   info.residual = r0;
   info.iterations = 0;
-  info.converged = (r0 <= target);
+  info.converged = deferred ? false : (r0 <= target);
   const int check = o.check_every > 0 ? o.check_every : 1;
   int it = 0;
   auto body = [&](int first) {
@@ -2939,12 +3026,27 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   bool restart = false;
   for (;;) {
     while (!info.converged && it < o.max_iter) {
-      if (it == 0 || restart || !w.graphs_enabled(op)) body((it == 0 || restart) ? 1 : 0);
-      else w.replay(s, key, [&] { body(0); });
+      const int first = (it == 0 || restart) ? 1 : 0;
+      if (!w.graphs_enabled(op)) body(first);
+      else {
+        GraphKey k2 = key;
+        k2.parity = first;
+        w.replay(s, k2, [&] { body(first); });
+      }
       restart = false;
       ++it;
       if ((it >= o.first_check && it % check == 0) || it == o.max_iter) {
-        rr = host_sum_parts(s, w, P_RR);
+        if (deferred) {
+          double rr0;
+          host_sum_parts3(s, w, P_RR, P_R0, P_B0, rr, rr0, bb);
+          r0 = std::sqrt(rr0);
+          bnorm = std::sqrt(bb);
+          set_target();
+          info.residual0 = r0;
+          deferred = false;
+        } else {
+          rr = host_sum_parts(s, w, P_RR);
+        }
         if (!std::isfinite(rr) || rr > 1e20 * std::max(r0 * r0, bnorm * bnorm)) {   // NaN / diverging
           info.iterations = it;
           info.residual = rr;
@@ -3059,7 +3161,7 @@ __global__ __launch_bounds__(256) void k_cg_p(int64_t n, const double* __restric
 __global__ __launch_bounds__(256) void k_cgcg_dots(int64_t n, const double* __restrict__ r,
                                                    const double* __restrict__ u,
                                                    const double* __restrict__ wv,
-                                                   double* __restrict__ parts, int slot) {
+                                                   double* __restrict__ parts, int slot, int keep_slot) {
   __shared__ double sh[4];
   double a = 0.0, b = 0.0, c = 0.0;
   GRID_STRIDE(i, n) {
@@ -3075,6 +3177,7 @@ __global__ __launch_bounds__(256) void k_cgcg_dots(int64_t n, const double* __re
     parts[(slot + 0) * kParts + blockIdx.x] = a;
     parts[(slot + 1) * kParts + blockIdx.x] = b;
     parts[(slot + 2) * kParts + blockIdx.x] = c;
+    if (keep_slot >= 0) parts[keep_slot * kParts + blockIdx.x] = c;      // |r0|^2 of the solve (first check)
   }
 }
 
@@ -3114,25 +3217,30 @@ static int pcg_single_reduction(hipStream_t s, KrylovWork& w, const LinOp& op, c
   double* parts = w.parts.p;
   double* scal = w.scal.p;
   const int slot = P_RZ0;                       // gamma, delta, |r|^2 in slots 6, 7, 8 ; |b|^2 in 9
-  auto precond_and_dots = [&] {
+  auto precond_and_dots = [&](int keep = -1) {
     op.prec->apply(s, w.r.p, w.z.p);                                    // u
     product_with_halo(op.comm, op.halo, op.halo_width, s, w.z.p, op.A->pat, [&](int phase) {
       launch_spmv(s, *op.A, op.nv, w.z.p, w.q.p, op.rowmask, op.maskmode, 0, phase);   // w = A u
     });
-    LAUNCH(k_cgcg_dots, kParts, s, n, w.r.p, w.z.p, w.q.p, parts, slot);
+    LAUNCH(k_cgcg_dots, kParts, s, n, w.r.p, w.z.p, w.q.p, parts, slot, keep);
   };
   launch_residual(s, *op.A, op.nv, x, rhs, w.r.p, op.rowmask, op.maskmode);
-  precond_and_dots();
-  launch_dot(s, n, rhs, rhs, parts + (slot + 3) * kParts);
+  // one rank: |r0|^2 and |b|^2 wait in their own slots for the first convergence check (see bicgstab)
+  bool deferred = !op.comm && o.max_iter > 0;
+  precond_and_dots(deferred ? P_R0 : -1);
+  launch_dot(s, n, rhs, rhs, parts + (deferred ? P_B0 : slot + 3) * kParts);
   reduce_slots(op, s, parts, slot, 4);
-  double rr, bb;
-  host_sum_parts2(s, w, slot + 2, slot + 3, rr, bb);
-  const double r0 = std::sqrt(rr);
-  const double bnorm = std::sqrt(bb);
-  const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+  double rr = 0.0, bb = 0.0, r0 = 0.0, bnorm = 0.0, target = 0.0;
+  if (!deferred) {
+    host_sum_parts2(s, w, slot + 2, slot + 3, rr, bb);
+    r0 = std::sqrt(rr);
+    bnorm = std::sqrt(bb);
+  }
+  auto set_target = [&] { target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0)); w.last_target = target; };
+  set_target();
   info.residual0 = info.residual = r0;
   info.iterations = 0;
-  info.converged = (r0 <= target);
+  info.converged = deferred ? false : (r0 <= target);
   const int check = o.check_every > 0 ? o.check_every : 1;
   int it = 0;
   // (the recurrence residual r -= alpha s drifts from b - A x; tight solves confirm the true
@@ -3141,14 +3249,32 @@ static int pcg_single_reduction(hipStream_t s, KrylovWork& w, const LinOp& op, c
   bool restart = false;
   for (;;) {
     while (!info.converged && it < o.max_iter) {
-      LAUNCH(k_cgcg_update, kParts, s, n, (it == 0 || restart) ? 1 : 0, it & 1, w.z.p, w.q.p, w.p.p, w.s.p, x,
-             w.r.p, parts, slot, scal);
+      const int first = (it == 0 || restart) ? 1 : 0, par = it & 1;
+      auto body = [&] {
+        LAUNCH(k_cgcg_update, kParts, s, n, first, par, w.z.p, w.q.p, w.p.p, w.s.p, x, w.r.p, parts, slot, scal);
+        precond_and_dots();
+      };
+      if (!w.graphs_enabled(op)) body();
+      else {
+        const GraphKey key{(const void*)op.A, (const void*)op.prec, (const void*)x, (const void*)rhs, n,
+                           16 + 2 * first + par, op.graph_epoch};
+        w.replay(s, key, body);
+      }
       restart = false;
-      precond_and_dots();
       reduce_slots(op, s, parts, slot, 3);
       ++it;
       if ((it >= o.first_check && it % check == 0) || it == o.max_iter) {
-        rr = host_sum_parts(s, w, slot + 2);
+        if (deferred) {
+          double rr0;
+          host_sum_parts3(s, w, slot + 2, P_R0, P_B0, rr, rr0, bb);
+          r0 = std::sqrt(rr0);
+          bnorm = std::sqrt(bb);
+          set_target();
+          info.residual0 = r0;
+          deferred = false;
+        } else {
+          rr = host_sum_parts(s, w, slot + 2);
+        }
         if (!std::isfinite(rr)) {
           info.iterations = it;
           info.residual = rr;
@@ -3211,6 +3337,7 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   const double r0 = std::sqrt(rr);
   const double bnorm = std::sqrt(bb);
   const double target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+  w.last_target = target;
   info.residual0 = r0;
   info.residual = r0;
   info.iterations = 0;

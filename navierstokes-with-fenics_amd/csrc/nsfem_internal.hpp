@@ -49,7 +49,7 @@ struct Error : std::runtime_error {
 // number of partial sums every reduction kernel emits (= its grid size); the
 // consumer kernels re-reduce them in a fixed order => bitwise reproducible dots.
 constexpr int kParts = 512;
-constexpr int kPartSlots = 12;   // partial-sum slots of the Krylov work space (slots 10, 11: drivers)
+constexpr int kPartSlots = 14;   // partial-sum slots of the Krylov work space (slots 10, 11: drivers; 12, 13: start sums |r0|^2, |b|^2)
 constexpr int kBlock = 256;
 
 template <class T>
@@ -425,9 +425,24 @@ struct KrylovWork {
   DevBuf<double> parts;     // [kPartSlots][kParts]
   DevBuf<double> scal;      // device scalars
   double* h_parts = nullptr;   // pinned host [kPartSlots][kParts]
+  // reduced sums for the host (convergence checks): a one-workgroup kernel re-reduces the partial sums of up to four
+  // slots in the order the device kernels use (sum_parts) and stores them, then a sequence number, into coherent
+  // pinned host memory; the host spins on the number.  Replaces hipMemcpyAsync + hipStreamSynchronize: on the
+  // MI355X the copy path leaves the GPU idle ~20 us before and ~25 us after the copy (rocprofv3 trace, round 4)
+  struct HostResult { double v[4]; uint64_t seq; };
+  HostResult* h_res = nullptr;
+  uint64_t seq_no = 0;
   // captured HIP graphs of the iteration bodies
   std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+  std::vector<GraphKey> seen;   // bodies that ran eagerly once (lazy table builds synchronise): captured at their second run
   uint64_t epoch = 0;
+  // replay is worth its capture only while the baked arguments stay put: contexts whose operators change every few
+  // iterations (variable time steps) fall back to eager launches (graphs_off); profiling windows that record HIP
+  // events inside the bodies suspend it
+  double last_target = 0.0;     // absolute residual target of the last solve (max(atol, rtol |b|)): the drivers' iteration predictor
+  bool graphs_off = false, graphs_suspended = false;
+  int64_t replays_in_epoch = 0;
+  int short_epochs = 0;
   bool graphs_enabled(const LinOp& op) const;
   void replay(hipStream_t s, const GraphKey& key, const std::function<void()>& body);
   void clear_graphs();
@@ -574,6 +589,8 @@ struct LinOp {
   uint64_t graph_epoch = 0;         // bumped whenever baked kernel arguments may have changed
   bool x_zero = false;              // the caller's start vector is all zeros: the start residual is b itself
                                     // (BiCGStab skips the operator application that would compute b - A 0)
+  double known_bnorm = -1.0;        // >= 0: |b|_2 (all ranks), already on the host -- with x_zero it is the start
+                                    // residual too and the solve begins without a device -> host round trip
 };
 
 // ---- multigrid ------------------------------------------------------------------
@@ -801,6 +818,7 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
 
 double host_sum_parts(hipStream_t s, KrylovWork& w, int which);   // sync + sum
 void host_sum_parts2(hipStream_t s, KrylovWork& w, int a, int b, double& ra, double& rb);   // two slots, one round trip
+void host_sum_parts3(hipStream_t s, KrylovWork& w, int a, int b, int c, double& ra, double& rb, double& rc);
 
 }  // namespace nsfem
 

@@ -1025,7 +1025,7 @@ struct LatticeArgs {
   const double* rf;         // right-hand side = R rf  (restriction of the finer level's vector, lattice 2 W - 1 wide),
   double* b_out;            //   stored to b_out on the output tile for the later launches of the level
   int Wc, Wf, Hf;
-  double c1[4], c2[4];
+  double c1[8], c2[8];     // (up to 7 steps on reach-1 operators: 6 applications after the pointwise first step)
 };
 
 // per-slot state of a thread: LDS word, lattice row, packed {ring : 8 | mask bits : 8 | entry : 8}
@@ -1440,9 +1440,10 @@ bool lattice_tables_available(const BlockMat& A, int nv) {
          (A.dict_ready || A.dict->tables_only);
 }
 int lattice_smoother_max_steps(const BlockMat& A, bool from_zero, bool with_resid) {
-  // operator applications per launch: at most 3 (reach 2: halo 6) / 4 (reach 1)
-  const int mv_max = A.dict->lat_r >= 2 ? 3 : 4;
-  return std::min(4, mv_max + (from_zero ? 1 : 0) - (with_resid ? 1 : 0));
+  // operator applications per launch: at most 3 (reach 2: halo 6) / 6 (reach 1: the same halo) -- the truncated
+  // velocity cycle's coarse solve (7 steps from zero on a P1 level) is ONE launch
+  const int mv_max = A.dict->lat_r >= 2 ? 3 : 6;
+  return std::min(A.dict->lat_r >= 2 ? 4 : 7, mv_max + (from_zero ? 1 : 0) - (with_resid ? 1 : 0));
 }
 
 // LDS offsets of the dictionary's neighbours in the class-split tile of plane dimensions (ewh, ehh):
@@ -1478,7 +1479,7 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
                          const uint8_t* mask, int steps, const double* c1, const double* c2, int ident,
                          const uint8_t* sidm, const double* xc, const double* rf, double* b_out) {
   const StencilDict& d = *A.dict;
-  NSFEM_REQUIRE(steps >= 1 && steps <= 4, "lattice smoother: 1..4 steps per launch");
+  NSFEM_REQUIRE(steps >= 1 && steps <= 8, "lattice smoother: 1..8 steps per launch");
   NSFEM_REQUIRE(x_out != x_in, "lattice smoother works out of place");
   NSFEM_REQUIRE(!rf || b_out, "fused restriction needs a place to keep the right-hand side");
   LatticeArgs a;
@@ -1534,7 +1535,7 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
 #else
   a.dbg = 0;
 #endif
-  for (int k = 0; k < 4; ++k) { a.c1[k] = k < steps ? c1[k] : 0.0; a.c2[k] = k < steps ? c2[k] : 0.0; }
+  for (int k = 0; k < 8; ++k) { a.c1[k] = k < steps ? c1[k] : 0.0; a.c2[k] = k < steps ? c2[k] : 0.0; }
   const size_t lds = (size_t)2 * 4 * 32 * a.EHh * nv * 8;
   const int grid = (a.ntiles + 7) & ~7;
   // launch shape (tuning switch NSFEM_LATTICE_SHAPE): 0 = 4 waves per SIMD (<= 128 VGPRs: two workgroups per

@@ -58,6 +58,50 @@ class ProblemBase:
     def set_equation_coefficients(self):  # pragma: no cover
         raise NotImplementedError("You are calling a purely virtual method.")
 
+    # -- the protocol between a problem and its solver, as two tables ----------------------------
+    # Both drivers of the reference (source/ns_problem.py:623-700 instationary, :394-431 stationary) first call the
+    # user's hooks and then hand what the hooks left behind to the solver; only the ORDER differs between the two,
+    # so the order is the argument and the steps live here once.
+    _HOOKS = {"periodic": "set_periodic_boundary_conditions", "constraints": "set_internal_constraints",
+              "rotation": "set_angular_velocity", "bcs": "set_boundary_conditions", "force": "set_body_force",
+              "coefficients": "set_equation_coefficients", "initial": "set_initial_conditions"}
+
+    def _call_hooks(self, order):
+        """mesh, then the hooks named in ``order``; afterwards the consistency checks of the reference"""
+        self.setup_mesh()
+        assert self._mesh is not None
+        self._space_dim = self._mesh.geometry().dim()
+        self._n_cells = self._mesh.num_cells()
+        for key in order:
+            getattr(self, self._HOOKS[key])()
+            if key == "coefficients":
+                assert isinstance(getattr(self, "_coefficient_handler", None), EquationCoefficientHandler)
+                self._coefficient_handler.close()
+        if not hasattr(self, "_bcs"):
+            assert hasattr(self, "_periodic_bcs")
+        if hasattr(self, "_internal_constraints"):
+            assert hasattr(self, "_bcs")
+        if "initial" in order:
+            assert hasattr(self, "_initial_conditions")
+
+    def _hand_over_to_solver(self, solver, order):
+        """solver.set_*(...) for everything the hooks have set, in ``order``"""
+        for key in order:
+            if key == "coefficients":
+                solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
+            elif key == "force" and hasattr(self, "_body_force"):
+                solver.set_body_force(self._body_force)
+            elif key == "periodic" and hasattr(self, "_periodic_bcs"):
+                assert hasattr(self, "_periodic_boundary_ids")
+                solver.set_periodic_boundary_conditions(self._periodic_bcs, self._periodic_boundary_ids)
+            elif key == "rotation" and hasattr(self, "_angular_velocity"):
+                solver.set_angular_velocity(self._angular_velocity)
+            elif key == "bcs" and hasattr(self, "_bcs"):
+                constraints = (self._internal_constraints,) if hasattr(self, "_internal_constraints") else ()
+                solver.set_boundary_conditions(self._bcs, *constraints)
+            elif key == "initial":
+                solver.set_initial_conditions(self._initial_conditions)
+
     # -- field access ------------------------------------------------------------------
     def _get_solver(self):  # pragma: no cover
         raise NotImplementedError("You are calling a purely virtual method.")
@@ -306,25 +350,7 @@ class InstationaryProblem(ProblemBase):
 
     def solve_problem(self):
         assert hasattr(self, "_InstationarySolverClass")
-        self.setup_mesh()
-        assert self._mesh is not None
-        self._space_dim = self._mesh.geometry().dim()
-        self._n_cells = self._mesh.num_cells()
-        self.set_periodic_boundary_conditions()
-        self.set_internal_constraints()
-        self.set_angular_velocity()
-        self.set_boundary_conditions()
-        self.set_body_force()
-        self.set_equation_coefficients()
-        assert isinstance(getattr(self, "_coefficient_handler", None), EquationCoefficientHandler)
-        self._coefficient_handler.close()
-        self.set_initial_conditions()
-        if not hasattr(self, "_bcs"):
-            assert hasattr(self, "_periodic_bcs")
-        if hasattr(self, "_internal_constraints"):
-            assert hasattr(self, "_bcs")
-        assert hasattr(self, "_initial_conditions")
-
+        self._call_hooks(("periodic", "constraints", "rotation", "bcs", "force", "coefficients", "initial"))
         self._time_stepping = BDFTimeStepping(self._start_time, self._end_time,
                                               desired_start_time_step=self._desired_start_time_step)
         if not hasattr(self, "_navier_stokes_solver"):
@@ -345,20 +371,7 @@ class InstationaryProblem(ProblemBase):
             for key, value in dict(settings).items():
                 assert hasattr(solver, key), "unknown solver setting %r" % (key,)
                 setattr(solver, key, value)
-        solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
-        if hasattr(self, "_body_force"):
-            solver.set_body_force(self._body_force)
-        if hasattr(self, "_periodic_bcs"):
-            assert hasattr(self, "_periodic_boundary_ids")
-            solver.set_periodic_boundary_conditions(self._periodic_bcs, self._periodic_boundary_ids)
-        if hasattr(self, "_angular_velocity"):
-            solver.set_angular_velocity(self._angular_velocity)
-        if hasattr(self, "_bcs"):
-            if hasattr(self, "_internal_constraints"):
-                solver.set_boundary_conditions(self._bcs, self._internal_constraints)
-            else:
-                solver.set_boundary_conditions(self._bcs)
-        solver.set_initial_conditions(self._initial_conditions)
+        self._hand_over_to_solver(solver, ("coefficients", "force", "periodic", "rotation", "bcs", "initial"))
         self._write_xdmf_file(current_time=0.0)
         print("Solving problem until time = {:0.2f}".format(self._time_stepping.end_time))
 

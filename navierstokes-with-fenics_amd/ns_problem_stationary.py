@@ -7,7 +7,6 @@ import math
 import numpy as np
 
 import dlfn_compat as dlfn
-from auxiliary_classes import EquationCoefficientHandler
 from ns_problem import ProblemBase
 from ns_solver_base import StationarySolverBase as StationarySolver
 
@@ -27,37 +26,13 @@ class StationaryProblem(ProblemBase):
         return self._navier_stokes_solver
 
     def solve_problem(self):
-        self.setup_mesh()
-        assert self._mesh is not None
-        self._space_dim = self._mesh.geometry().dim()
-        self._n_cells = self._mesh.num_cells()
-        self.set_periodic_boundary_conditions()
-        self.set_internal_constraints()
-        self.set_boundary_conditions()
-        self.set_body_force()
-        self.set_angular_velocity()
-        self.set_equation_coefficients()
-        assert isinstance(getattr(self, "_coefficient_handler", None), EquationCoefficientHandler)
-        self._coefficient_handler.close()
-        if not hasattr(self, "_bcs"):
-            assert hasattr(self, "_periodic_bcs")
+        self._call_hooks(("periodic", "constraints", "bcs", "force", "rotation", "coefficients"))
         if not hasattr(self, "_navier_stokes_solver"):
             self._navier_stokes_solver = StationarySolver(
                 self._mesh, self._boundary_markers, self._form_convective_term, self._tol,
                 self._maxiter, self._tol_picard, self._maxiter_picard)
         solver = self._navier_stokes_solver
-        solver.set_equation_coefficients(self._coefficient_handler.equation_coefficients)
-        if hasattr(self, "_body_force"):
-            solver.set_body_force(self._body_force)
-        if hasattr(self, "_angular_velocity"):
-            solver.set_angular_velocity(self._angular_velocity)
-        if hasattr(self, "_periodic_bcs"):
-            solver.set_periodic_boundary_conditions(self._periodic_bcs, self._periodic_boundary_ids)
-        if hasattr(self, "_bcs"):
-            if hasattr(self, "_internal_constraints"):
-                solver.set_boundary_conditions(self._bcs, self._internal_constraints)
-            else:
-                solver.set_boundary_conditions(self._bcs)
+        self._hand_over_to_solver(solver, ("coefficients", "force", "rotation", "periodic", "bcs"))
         try:
             Re = self._coefficient_handler.Re
             dlfn.info("Solving problem with Re = {0:.2f}".format(Re if Re is not None else float("nan")))

@@ -660,6 +660,53 @@ def test_inexact_newton_reaches_the_reference_criterion_and_the_same_fields(sche
     ctx.close()
 
 
+def test_timed_settings_on_the_lattice_kernels_match_the_oracle_at_config0_size():
+    """What bench.py times -- ALL five throughput knobs together (Krylov rtol 1e-8, Newton forcing 1e-4, truncated
+    velocity cycle, Chebyshev mass solve, extrapolated pressure start) on the one-launch lattice kernels
+    (k_cheb_lattice with fused transfers, k_jac_lattice) -- against the LU oracle at BASELINE configs[0]'s size,
+    64 x 64 cells (129 x 129 P2 lattice: 3 x 11 tiles of the lattice smoother), 4 steps of the Re = 100 cavity.
+    Velocity and pressure agree to north_star's 1e-6 and every step ends on the reference's Newton criterion
+    evaluated on the true nonlinear residual (source/ns_ipcs_solver.py:144-147, 198-208)."""
+    from multigrid import attach_hierarchy
+    n = 64
+    mesh, dm, marks = box(n, n)
+    mesh.structured = ((0.0, 0.0), (1.0, 1.0), n, n)
+    ctx = context(mesh, dm)
+    attach_hierarchy(ctx, mesh)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    bd, bv = cavity_bc(dm, marks)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+    ctx.mg_set_truncation(4.0, 0.1)
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    o = ctx.default_step_opts()
+    for k in (o.momentum, o.poisson, o.correction):
+        k.rtol = 1e-8
+    o.momentum.precond = o.poisson.precond = 1
+    o.correction.precond = 2                         # Chebyshev mass solve with a-priori bounds
+    o.newton_forcing = 1e-4
+    o.pressure_extrapolation = 1
+    dt = 8.0e-3                                      # the step size of the n = 512 run scaled with h (same CFL)
+    for step in range(4):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, dt)
+        info = ctx.step_ipcs(o)
+        ctx.advance(0)
+        orc.step(alpha, dt, (bd, bv))
+        orc.advance()
+        res = [info.newton_residuals[i] for i in range(info.newton_iterations + 1)]
+        assert info.converged and (res[-1] < 1e-10 or res[-1] / res[0] < 1e-9), res
+    assert ctx.smoother_info()["multistep_lattice_kernel"]
+    ji = ctx.jacobian_info()
+    assert ji["path"] == "lattice-kernel" and ji["lattice_launches"] > 0
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-6
+    p = ctx.get_state(nat.P_OLD)
+    assert rel(p - p.mean(), orc.p_old - orc.p_old.mean()) < 1e-6
+    ctx.close()
+
+
 def test_truncated_velocity_cycle_is_only_a_preconditioner_change():
     """nsfem_mg_set_truncation: at a small time step the velocity operator alpha0/k M + c_v K is
     mass dominated on the coarser levels; the cycle stops at the first such level and solves it by

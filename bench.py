@@ -1005,6 +1005,15 @@ def cavity_ipcs_bench(args):
 
     _apply_truncation(ctx, args)
     ctx.set_overlap(args.overlap == "on")
+    # projection step by fast diagonalisation (one rank: the P1 space is the whole rectangle lattice)
+    fast_diag = False
+    if world == 1 and args.poisson_solver == "fd":
+        import poisson_fd
+        lines = poisson_fd.lattice_lines(part.mesh)
+        factors = poisson_fd.factors(lines[0], lines[1], np.zeros(0, np.int64)) if lines is not None else None
+        if factors is not None:
+            ctx.poisson_set_fast_diag(factors)
+            fast_diag = True
 
     def throughput_opts():
         o = ctx.default_step_opts()
@@ -1012,6 +1021,8 @@ def cavity_ipcs_bench(args):
             k.rtol = args.krylov_rtol
         if mg_levels is not None:
             o.momentum.precond = o.poisson.precond = 1
+        if fast_diag:
+            o.poisson.precond = 3
         o.correction.precond = 2 if args.mass_solver == "chebyshev" else 0
         o.newton_forcing = args.newton_forcing
         o.matrix_free = args.matrix_free
@@ -1081,7 +1092,7 @@ def cavity_ipcs_bench(args):
                 "scaling": "strong" if strong else "weak", "dtype": "f64", "data": "synthetic",
                 "time_steps_per_sec": steps_per_s,
                 "config": {"workload": "cavity-ipcs %dx%d, timed steps only" % (n, ny_global),
-                           "cells": n, "n_dofs": n_dofs,
+                           "cells": n, "n_dofs": n_dofs, "poisson_solver": "fd" if fast_diag else "mg",
                            "newton_its_per_step": float(its[0]), "bicgstab_its_per_step": float(its[1]),
                            "poisson_cg_its_per_step": float(its[2]), "comm_per_step_rank0": comm_per_step},
                 "roofline": {"frac": None, "ms_per_launch": None}}
@@ -1225,6 +1236,9 @@ def cavity_ipcs_bench(args):
                                   "max_rel_diff_pressure_vs_exact": dp_l2,
                                   "tolerance": tol_fields,
                                   "newton_bicgstab_poisson_its_per_step_exact": [float(v) for v in its_exact]},
+                   "poisson_solver": ("fast diagonalisation: x += V_y ((V_y^T R V_x) .* inv) V_x^T, four fp64 MFMA products "
+                                      "(csrc/fastdiag.hip), one pass + residual check" if fast_diag else
+                                      "CG preconditioned by the pressure V(2,2) cycle"),
                    "preconditioner": "jacobi" if mg_levels is None else
                    "geometric multigrid, Chebyshev-Jacobi smoothing: V(0,3) momentum, V(2,2) Poisson; %d coarse P1 levels" % mg_levels,
                    "parallelism": "1 GPU" if world == 1 else
@@ -1295,6 +1309,7 @@ def solver_surface_run(args, n, u_abi, p_abi):
                 krylov_rtol=args.krylov_rtol, newton_forcing=args.newton_forcing,
                 pressure_start=args.pressure_start if args.pressure_start == "extrapolated" else "previous",
                 mass_solver=args.mass_solver, mg_truncation=(parts[0], parts[1] if len(parts) > 1 else 0.1),
+                poisson_solver="fast_diagonalization" if args.poisson_solver == "fd" else "multigrid",
                 matrix_free={0: None, 1: False, 2: True}[args.matrix_free])
 
         def setup_mesh(self):
@@ -1393,6 +1408,9 @@ def main():
                     help="velocity Jacobian in the step driver: 0 auto, 1 assembled, 2 matrix-free")
     ap.add_argument("--mass-solver", choices=("chebyshev", "cg"), default="chebyshev",
                     help="velocity-correction mass solve: Chebyshev with a-priori bounds (no dots) or Jacobi-CG")
+    ap.add_argument("--poisson-solver", choices=("fd", "mg"), default="fd",
+                    help="projection step (one GPU, rectangle lattices): fd = direct solve by fast diagonalisation (four "
+                         "dense products on the matrix cores, csrc/fastdiag.hip), mg = multigrid-preconditioned CG")
     ap.add_argument("--pressure-start", choices=("extrapolated", "previous"), default="extrapolated",
                     help="start vector of the projection-step CG: 2 p_n - p_(n-1) or p_n")
     ap.add_argument("--halo-mode", choices=("relaxed", "exact"), default="relaxed",

@@ -111,7 +111,9 @@ typedef struct {
   int32_t max_iter;
   int32_t precond;      /* 0 = Jacobi, 1 = multigrid (where available), 2 = (velocity mass
                            solve only) Chebyshev iteration with a-priori element bounds:
-                           no dot products, no all-reduce inside the iteration      */
+                           no dot products, no all-reduce inside the iteration;
+                           3 = (projection step only) direct solve by fast diagonalisation on
+                           tensor-product lattices, see nsfem_poisson_set_fast_diag            */
   int32_t check_every;  /* host convergence check interval (>=1)               */
   int32_t first_check;  /* iterations before the first host convergence check (every check is a
                            device -> host round trip; the step drivers set it from the iteration
@@ -446,7 +448,16 @@ int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]);
    the finest level of a truncated cycle, 2 down-legs + tail + up-legs), fused launches per cycle, levels in use,
    fused launches so far}.  New functionality (the reference has no preconditioner: sparse LU,
    source/ns_ipcs_solver.py:171,205). */
-int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double* z);
+int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double* z);   /* which = 2: fast diagonalisation */
+/* Direct solver of the projection step on tensor-product lattices (replaces the sparse LU of
+   source/ns_ipcs_solver.py:160-171 where it applies): Vx [W x W], Vy [H x H] generalised eigenvectors of the 1D
+   stiffness / lumped-mass pairs of the two directions (row-major, V^T W V = I, zero rows on Dirichlet sides),
+   inv [H x W] = 1 / (lambda_y,j + lambda_x,i) (0: singular mode, Dirichlet slots).  The P1 space must be the W x H
+   lattice in lexicographic numbering.  nsfem_krylov_opts.precond = 3 of the projection step then runs
+   x += A^+ (b - A x) (four dense products on the matrix cores) and checks the residual.  Host side:
+   poisson_fd.factors(). */
+int nsfem_poisson_set_fast_diag(nsfem_ctx* ctx, int32_t W, int32_t H, const double* Vx, const double* Vy,
+                                const double* inv);
 int nsfem_mg_info(nsfem_ctx* ctx, int which, int64_t out[4]);
 /* in-situ HIP-event timing of the matrix-free convection action of the velocity Jacobian inside
  * the Newton-Krylov solves (element kernel k_conv_cell / k3_conv_cell + node gather = the

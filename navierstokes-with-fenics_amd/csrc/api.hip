@@ -914,7 +914,54 @@ static bool pressure_pinned_anywhere(nsfem_ctx* c) {
   return c->bc_p_any > 0;
 }
 
+// Projection step by fast diagonalisation (precond = 3; tensor-product lattices, Dirichlet conditions on whole sides):
+// x += A^+ (b - A x), then the residual is checked -- the direct solve is exact up to round-off, so ONE pass and one
+// device -> host round trip; further passes (iterative refinement) only if the check fails.
+static int poisson_solve_fast_diag(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  hipStream_t s = c->stream;
+  const int64_t np = npre(c);
+  NSFEM_REQUIRE(c->fd_p.ready() && (int64_t)c->fd_p.W * c->fd_p.H == np,
+                "fast diagonalisation requested but no factors were set (nsfem_poisson_set_fast_diag)");
+  NSFEM_REQUIRE(!c->distributed(), "fast diagonalisation: one rank only");
+  KrylovWork& w = c->kw;
+  w.ensure(std::max<int64_t>(np, nvel(c)));
+  double* parts = w.parts.p;
+  double* x = c->state[NSFEM_P].p;
+  const double* rhs = c->rhs_p.p;
+  if (!pressure_pinned_anywhere(c)) {
+    // singular (all-Neumann) operator: make the right-hand side compatible, as the CG path does
+    NSFEM_HIP(hipMemcpyAsync(w.t.p, rhs, sizeof(double) * np, hipMemcpyDeviceToDevice, s));
+    launch_sum_sub_mean(s, np, w.t.p, parts + 10 * kParts);
+    rhs = w.t.p;
+  }
+  constexpr int PR = 10, PB0 = 13;
+  launch_dot(s, np, rhs, rhs, parts + PB0 * kParts);
+  info.iterations = 0;
+  info.converged = 0;
+  double bnorm = 0.0, target = 0.0;
+  launch_residual(s, c->Ap, 1, x, rhs, w.r.p, c->mask_p.p, MASK_ZERO);
+  for (int pass = 0; pass < std::max(1, std::min(o.max_iter, 8)); ++pass) {
+    c->fd_p.apply(s, w.r.p, w.z.p);
+    launch_axpby(s, np, 1.0, x, 1.0, w.z.p, x);
+    ++info.iterations;
+    // the residual of the corrected iterate (the next pass's right-hand side)
+    launch_residual(s, c->Ap, 1, x, rhs, w.r.p, c->mask_p.p, MASK_ZERO);
+    launch_dot(s, np, w.r.p, w.r.p, parts + PR * kParts);
+    double rr, bb;
+    host_sum_parts2(s, w, PR, PB0, rr, bb);
+    bnorm = std::sqrt(bb);
+    target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+    w.last_target = target;
+    if (!std::isfinite(rr)) return NSFEM_ERR_BREAKDOWN;
+    info.residual = std::sqrt(rr);
+    if (pass == 0) info.residual0 = info.residual;
+    if (info.residual <= target) { info.converged = 1; break; }
+  }
+  return info.converged ? NSFEM_OK : NSFEM_ERR_NOT_CONVERGED;
+}
+
 static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  if (o.precond == 3) return poisson_solve_fast_diag(c, o, info);
   LinOp op;
   op.A = &c->Ap;
   op.nv = 1;
@@ -1110,7 +1157,8 @@ extern "C" int nsfem_get_rhs(nsfem_ctx* ctx, int system, double* host, int64_t n
   API_END(ctx)
 }
 
-static nsfem_krylov_opts hinted(nsfem_krylov_opts k, int hint);
+static nsfem_krylov_opts hinted(nsfem_krylov_opts k, const nsfem_ctx::SolveHint& h, bool exact = false);
+static void note_solve(nsfem_ctx::SolveHint& h, const nsfem_solve_info& si, const nsfem_krylov_opts& k, double target);
 static int next_hint(const nsfem_solve_info& si, const nsfem_krylov_opts& k, double target);
 extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* opts,
                            nsfem_solve_info* info) {
@@ -1126,8 +1174,8 @@ extern "C" int nsfem_solve(nsfem_ctx* ctx, int system, const nsfem_krylov_opts* 
     case NSFEM_SYS_CORRECTION:
       // (the Chebyshev mass solve takes its step count from the previous solve: the same predictor as in the fused
       // step drivers, so that the explicit seam and the fused step stay bit for bit equal)
-      rc = correction_solve(ctx, hinted(*opts, ctx->hint_cor), inf);
-      ctx->hint_cor = next_hint(inf, *opts, ctx->kw.last_target);
+      rc = correction_solve(ctx, hinted(*opts, ctx->hint_cor, opts->precond == 2), inf);
+      note_solve(ctx->hint_cor, inf, *opts, ctx->kw.last_target);
       break;
     default: throw Error(NSFEM_ERR_ARG, "nsfem_solve: system not available");
   }
@@ -1729,11 +1777,20 @@ static nsfem_krylov_opts forced_opts(const nsfem_step_opts* o, const nsfem_krylo
 // Every host convergence check of a Krylov solve is a device -> host round trip during which the
 // GPU runs dry.  The same solve of the previous time step is an excellent predictor of the
 // iteration count: the first check is postponed to one iteration before that count.
-static nsfem_krylov_opts hinted(nsfem_krylov_opts k, int hint) {
-  // (round 4: AT the predicted count, not one iteration before it -- a check costs ~15 - 20 us of idle GPU, and
-  // next_hint lowers the prediction when the residual at the check is far below the target)
-  k.first_check = std::max(k.first_check, hint);
+// Round 4: a check costs ~15 - 20 us of idle GPU, an iteration too many costs the iteration.  While the count is
+// steady (the last two solves needed exactly the prediction) the first check sits AT the predicted count -- one round
+// trip per solve --, otherwise and at every 8th solve (the probe that notices a falling count) one iteration before
+// it.  exact: the prediction itself (the Chebyshev mass solve runs exactly that many steps before its only check).
+static nsfem_krylov_opts hinted(nsfem_krylov_opts k, const nsfem_ctx::SolveHint& h, bool exact) {
+  const bool steady = h.same >= 2 && (h.count & 7) != 7;
+  k.first_check = std::max(k.first_check, (exact || steady) ? h.its : h.its - 1);
   return k;
+}
+static void note_solve(nsfem_ctx::SolveHint& h, const nsfem_solve_info& si, const nsfem_krylov_opts& k, double target) {
+  const int next = next_hint(si, k, target);
+  h.same = (si.converged && next == h.its && si.iterations == h.its) ? h.same + 1 : 0;
+  h.its = next;
+  ++h.count;
 }
 // The predictor for the next solve: the iteration count of this one, reduced when the postponed
 // first check found the residual far below the target (linear-convergence estimate of the count
@@ -1772,10 +1829,10 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   while (!converged && it < opts->newton_max_iter) {
     if (!ctx->mf_active) momentum_jacobian(ctx);
     nsfem_solve_info si;
-    int& hint = ctx->hint_mom[std::min(it, 3)];
+    nsfem_ctx::SolveHint& hint = ctx->hint_mom[std::min(it, 3)];
     const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
     int rc = momentum_solve_update(ctx, hinted(ko, hint), si, r);
-    hint = next_hint(si, ko, ctx->kw.last_target);
+    note_solve(hint, si, ko, ctx->kw.last_target);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the diffusion step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)
@@ -1795,7 +1852,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
     poisson_assemble(ctx, opts->pressure_extrapolation != 0);
     nsfem_solve_info si;
     int rc = poisson_solve(ctx, hinted(opts->poisson, ctx->hint_poi), si);
-    ctx->hint_poi = next_hint(si, opts->poisson, ctx->kw.last_target);
+    note_solve(ctx->hint_poi, si, opts->poisson, ctx->kw.last_target);
     inf.krylov_iterations_poisson = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the projection step");
   }
@@ -1803,8 +1860,8 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   {
     correction_assemble(ctx);
     nsfem_solve_info si;
-    int rc = correction_solve(ctx, hinted(opts->correction, ctx->hint_cor), si);
-    ctx->hint_cor = next_hint(si, opts->correction, ctx->kw.last_target);
+    int rc = correction_solve(ctx, hinted(opts->correction, ctx->hint_cor, opts->correction.precond == 2), si);
+    note_solve(ctx->hint_cor, si, opts->correction, ctx->kw.last_target);
     inf.krylov_iterations_correction = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the velocity correction step");
   }
@@ -1930,11 +1987,12 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     if (ctx->distributed()) op.comm = ctx->comm;        // all-reduce of the partial dot products
     op.graph_epoch = ctx->graph_epoch;
     nsfem_solve_info si;
-    int& hint = ctx->hint_mom[std::min(it, 3)];
+    nsfem_ctx::SolveHint& hint = ctx->hint_mom[std::min(it, 3)];
     const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
     op.x_zero = true;               // dx_m was just zeroed
+    op.known_bnorm = r;             // |rhs_m| = the Newton residual norm just evaluated (bdf_residual)
     int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, hinted(ko, hint), si);
-    hint = next_hint(si, ko, ctx->kw.last_target);
+    note_solve(hint, si, ko, ctx->kw.last_target);
     inf.krylov_iterations_momentum += si.iterations;
     if (rc == NSFEM_ERR_BREAKDOWN) throw Error(rc, "BiCGStab breakdown in the monolithic step");
     if (rc == NSFEM_ERR_NOT_CONVERGED)
@@ -2366,14 +2424,36 @@ extern "C" int nsfem_kernel_apply(nsfem_ctx* ctx, nsfem_kernel_test* t) {
   API_END(ctx)
 }
 
+// Factors of the fast diagonalisation of the pressure Poisson operator (poisson_fd.factors): the P1 space must be
+// the W x H lattice in lexicographic numbering, the pressure Dirichlet set a union of whole sides (or empty).
+// Krylov option precond = 3 of the projection step then solves it directly (four dense products on the matrix cores).
+extern "C" int nsfem_poisson_set_fast_diag(nsfem_ctx* ctx, int32_t W, int32_t H, const double* Vx, const double* Vy,
+                                           const double* inv) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && Vx && Vy && inv, "null argument");
+  NSFEM_REQUIRE((int64_t)W * H == npre(ctx), "fast diagonalisation: W x H must be the number of pressure dofs");
+  ctx->fd_p.set(ctx->stream, W, H, Vx, Vy, inv);
+  API_END(ctx)
+}
+
 // Test hook: one application z = M^-1 r of a multigrid preconditioner on host vectors -- which = 0 pressure Poisson
 // hierarchy (mg_p), 1 velocity hierarchy (mg_v, the identity rows of the Newton preconditioner included).  Lets the
 // parity tests compare the fused multi-level launches (mglegs.hip) with the separate launches cycle by cycle.
 extern "C" int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double* z) {
   API_BEGIN
-  NSFEM_REQUIRE(ctx && r && z && (which == 0 || which == 1), "bad argument");
-  NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
+  NSFEM_REQUIRE(ctx && r && z && (which == 0 || which == 1 || which == 2), "bad argument");
   hipStream_t s = ctx->stream;
+  if (which == 2) {                    // the fast-diagonalisation Poisson solve z = A^+ r
+    const int64_t n = npre(ctx);
+    DevBuf<double> dr, dz;
+    dr.upload(r, (size_t)n, s);
+    dz.alloc((size_t)n);
+    ctx->fd_p.apply(s, dr.p, dz.p);
+    NSFEM_HIP(hipMemcpyAsync(z, dz.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    NSFEM_HIP(hipStreamSynchronize(s));
+    return NSFEM_OK;
+  }
+  NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
   ensure_L(ctx);                       // (builds the dictionaries of the fine P1 operators as well)
   if (which == 0 && ctx->mg_p.legs_kind == 0) ctx->mg_p_dirty = true;   // planned before the dictionaries existed
   mg_refresh(ctx, which == 1);

@@ -1,0 +1,122 @@
+// Fast diagonalisation of the pressure Poisson operator on tensor-product lattices (poisson_fd.py builds the
+// factors on the host).  The reference solves the projection step with a sparse LU every step
+// (source/ns_ipcs_solver.py:160-171); on the right-diagonal triangulation of a rectangle the P1 stiffness matrix is the
+// tensor sum  A = K_y (x) W_x + W_y (x) K_x  of 1D stiffness and lumped mass matrices, so with the generalised
+// eigenvectors V_x, V_y of the two directions
+//
+//     z = A^+ r = V_y ( (V_y^T R V_x) .* inv ) V_x^T ,      R = r as an H x W array,  inv_ji = 1 / (lam_y,j + lam_x,i)
+//
+// -- four dense products with (n + 1)-sized matrices, the one GEMM-shaped operation of the hot path.  They run on the
+// matrix cores: v_mfma_f64_16x16x4_f64, one 16 x 16 accumulator tile per wavefront, operands staged through LDS
+// (rows padded to 48 doubles: the four k-lines a wave reads land on disjoint halves of the 64 banks), the next
+// k-block's global loads in flight under the current block's MFMAs.  (On the MI355X the fp64 matrix rate equals the
+// vector rate; what the matrix instruction buys here is 16 x fewer issued instructions and 8 x fewer LDS reads per
+// FMA than a register-tiled VALU kernel: these 513-sized products are latency bound, not flop bound.)
+#include "nsfem_internal.hpp"
+
+namespace nsfem {
+
+typedef double fd_acc4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFdBM = 32, kFdBN = 32, kFdBK = 32, kFdLd = 48;
+
+// C[M x N] = op(A)[M x K] * op(B)[K x N] (.* scale[M x N]); row-major storage.  TA: A(m, k) = A[k * lda + m];
+// TB: B(k, n) = B[n * ldb + k].  256 threads = 4 waves, wave w owns the 16 x 16 tile (w >> 1, w & 1) of a 32 x 32
+// block of C.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_fd_gemm(int M, int N, int K, const double* __restrict__ A, int lda,
+                                                 const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
+                                                 const double* __restrict__ scale) {
+  __shared__ double As[kFdBK * kFdLd];      // As[k][m]
+  __shared__ double Bs[kFdBK * kFdLd];      // Bs[k][n]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * kFdBM, n0 = blockIdx.x * kFdBN;
+  const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
+  // this thread's four elements of the A and B blocks of a k-block: element e = tid + 256 q, walked along the
+  // operand's contiguous direction
+  double ra[4], rb[4];
+  auto load_block = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      {
+        const int m = TA ? (e & 31) : (e >> 5), k = TA ? (e >> 5) : (e & 31);
+        const int gm = m0 + m, gk = k0 + k;
+        ra[q] = (gm < M && gk < K) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.0;
+      }
+      {
+        const int n = TB ? (e >> 5) : (e & 31), k = TB ? (e & 31) : (e >> 5);
+        const int gn = n0 + n, gk = k0 + k;
+        rb[q] = (gn < N && gk < K) ? (TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.0;
+      }
+    }
+  };
+  auto store_block = [&] {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      const int ma = TA ? (e & 31) : (e >> 5), ka = TA ? (e >> 5) : (e & 31);
+      As[ka * kFdLd + ma] = ra[q];
+      const int nb = TB ? (e >> 5) : (e & 31), kb = TB ? (e & 31) : (e >> 5);
+      Bs[kb * kFdLd + nb] = rb[q];
+    }
+  };
+  fd_acc4 acc = {0.0, 0.0, 0.0, 0.0};
+  load_block(0);
+  for (int k0 = 0; k0 < K; k0 += kFdBK) {
+    __syncthreads();                         // (the previous block's fragments have been read)
+    store_block();
+    __syncthreads();
+    if (k0 + kFdBK < K) load_block(k0 + kFdBK);
+#pragma unroll
+    for (int kk = 0; kk < kFdBK; kk += 4) {
+      const int kr = kk + (lane >> 4);
+      const double a = As[kr * kFdLd + wm + (lane & 15)];       // A[m = lane & 15][k = lane >> 4]
+      const double b = Bs[kr * kFdLd + wn + (lane & 15)];       // B[k = lane >> 4][n = lane & 15]
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int col = n0 + wn + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + wm + (lane >> 4) + 4 * r;
+    if (row < M && col < N) {
+      double v = acc[r];
+      if (scale) v *= scale[(size_t)row * N + col];
+      C[(size_t)row * ldc + col] = v;
+    }
+  }
+}
+
+template <bool TA, bool TB>
+static void fd_gemm(hipStream_t s, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
+                    int ldc, const double* scale) {
+  const dim3 grid((N + kFdBN - 1) / kFdBN, (M + kFdBM - 1) / kFdBM), block(256);
+  hipLaunchKernelGGL((k_fd_gemm<TA, TB>), grid, block, 0, s, M, N, K, A, lda, B, ldb, C, ldc, scale);
+  NSFEM_HIP(hipGetLastError());
+}
+
+void FastDiag::set(hipStream_t s, int W_, int H_, const double* vx, const double* vy, const double* inv_) {
+  NSFEM_REQUIRE(W_ >= 2 && H_ >= 2 && vx && vy && inv_, "fast diagonalisation: bad factors");
+  W = W_;
+  H = H_;
+  Vx.upload(vx, (size_t)W * W, s);
+  Vy.upload(vy, (size_t)H * H, s);
+  inv.upload(inv_, (size_t)H * W, s);
+  t1.alloc((size_t)H * W);
+  t2.alloc((size_t)H * W);
+  NSFEM_HIP(hipStreamSynchronize(s));
+}
+
+// z = V_y ((V_y^T (R V_x)) .* inv) V_x^T
+void FastDiag::apply(hipStream_t s, const double* r, double* z) {
+  NSFEM_REQUIRE(ready(), "fast diagonalisation: factors not set");
+  fd_gemm<false, false>(s, H, W, W, r, W, Vx.p, W, t1.p, W, nullptr);            // T1 = R V_x
+  fd_gemm<true, false>(s, H, W, H, Vy.p, H, t1.p, W, t2.p, W, inv.p);            // T2 = (V_y^T T1) .* inv
+  fd_gemm<false, true>(s, H, W, W, t2.p, W, Vx.p, W, t1.p, W, nullptr);          // T1 = T2 V_x^T
+  fd_gemm<false, false>(s, H, W, H, Vy.p, H, t1.p, W, z, W, nullptr);            // Z  = V_y T1
+  ++applications;
+}
+
+}  // namespace nsfem

@@ -2561,6 +2561,11 @@ void launch_scale_combine(hipStream_t s, int nnz, double a, const double* A, dou
                           const double* B, double* C) {
   LAUNCH(k_axpby, vgrid(nnz), s, (int64_t)nnz, a, A, b, B, C);
 }
+// x -= mean(x) (the compatible right-hand side of a singular Neumann problem); `parts`: one partial-sum slot
+void launch_sum_sub_mean(hipStream_t s, int64_t n, double* x, double* parts) {
+  LAUNCH(k_sum, kParts, s, n, x, parts);
+  LAUNCH(k_sub_mean, vgrid(n), s, n, n, parts, x);
+}
 void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, double* parts) {
   LAUNCH(k_dot, kParts, s, n, x, y, parts);
 }

@@ -399,6 +399,7 @@ void launch_lincomb3(hipStream_t s, int64_t n, double a, const double* x, double
 void launch_scale_combine(hipStream_t s, int nnz, double a, const double* A, double b,
                           const double* B, double* C);            // C = a A + b B (values)
 void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, double* parts);
+void launch_sum_sub_mean(hipStream_t s, int64_t n, double* x, double* parts);
 void launch_set_bc_residual(hipStream_t s, int nbc, const int32_t* dofs, const double* g,
                             const double* x, double* b);          // b[d] = x[d] - g[d]
 void launch_set_values(hipStream_t s, int nbc, const int32_t* dofs, const double* g, double* x);
@@ -799,6 +800,17 @@ struct Multigrid : Precond {
                    double& rho) const;
 };
 
+// Fast diagonalisation of the P1 stiffness matrix of a tensor-product lattice (fastdiag.hip, poisson_fd.py):
+// z = A^+ r by four dense products on the matrix cores
+struct FastDiag : Precond {
+  int W = 0, H = 0;
+  DevBuf<double> Vx, Vy, inv, t1, t2;
+  int64_t applications = 0;
+  bool ready() const { return W > 0 && Vx.p && Vy.p && inv.p; }
+  void set(hipStream_t s, int W_, int H_, const double* vx, const double* vy, const double* inv_);
+  void apply(hipStream_t s, const double* r, double* z) override;
+};
+
 // z[dofs] = r[dofs]
 void launch_copy_at(hipStream_t s, int n, const int32_t* dofs, const double* r, double* z);
 // mask[i] = 2 where ghost[i] != 0
@@ -901,6 +913,8 @@ struct nsfem_ctx {
   nsfem::Transfer t_p2p1;                      // P2 (fine mesh) <- P1 (fine mesh)
   nsfem::BlockMat Lc0;                         // alpha0/k M_p + c_v A_p on the fine P1 space
   nsfem::Multigrid mg_p, mg_v;
+  nsfem::FastDiag fd_p;                        // direct projection-step solver on tensor-product lattices
+  bool fd_p_singular = false;
   bool mg_built = false, mg_p_dirty = true, mg_v_dirty = true;
   std::vector<int32_t> h_bc_v, h_bc_p;         // host copies of the Dirichlet dof sets
   struct MomentumPrec : nsfem::Precond {
@@ -939,7 +953,10 @@ struct nsfem_ctx {
   nsfem::DevBuf<uint8_t> mask_m;     // ghost flags of the pressure mass smoother (partitioned)
   double prec_shift = 0.0;          // mass shift of the velocity / Schur preconditioners
   nsfem::BlockMat Lprec;            // (alpha0/k + shift) M + c_v K when shift != 0
-  int hint_mom[4] = {0, 0, 0, 0}, hint_poi = 0, hint_cor = 0;   // Krylov iteration counts of the last step
+  // iteration predictor of a recurring solve (see hinted / next_hint in api.hip): the count the same solve needed
+  // in the previous step, how many solves in a row needed exactly that count, and the number of solves so far
+  struct SolveHint { int its = 0, same = 0; int64_t count = 0; };
+  SolveHint hint_mom[4], hint_poi, hint_cor;
   // in-situ timing of the matrix-free convection action (k_conv_cell + k_res_gather): one HIP-event
   // pair per application while enabled (nsfem_profile_convection; bench.py's assembly roofline)
   struct Probe {

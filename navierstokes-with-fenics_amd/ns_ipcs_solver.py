@@ -82,6 +82,9 @@ class IPCSSolver(InstationarySolverBase):
             k.max_iter = self.krylov_max_iter
         if self._mg_levels is not None:
             o.momentum.precond = o.poisson.precond = 1
+        assert self.poisson_solver in ("multigrid", "fast_diagonalization")
+        if self.poisson_solver == "fast_diagonalization" and self._fast_diagonalization_ready():
+            o.poisson.precond = 3
         # velocity correction: Chebyshev iteration with a-priori element bounds (no dot products)
         # unless the Jacobi-CG is asked for
         assert self.mass_solver in ("chebyshev", "cg")
@@ -112,7 +115,8 @@ class IPCSSolver(InstationarySolverBase):
         if not converged:
             raise RuntimeError("Newton solver did not converge")
         self.last_newton_residuals = residuals
-        self._projection_solver.solve(**mg)
+        direct = self.poisson_solver == "fast_diagonalization" and self._fast_diagonalization_ready()
+        self._projection_solver.solve(**(dict(kw, precond=3) if direct else mg))
         cheb = self.mass_solver == "chebyshev"
         self._velocity_correction_solver.solve(**dict(kw, precond=2 if cheb else 0))
 

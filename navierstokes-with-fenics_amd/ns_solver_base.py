@@ -391,8 +391,28 @@ class SolverBase:
         self._dirichlet_bcs = {"velocity": (vd, vv), "pressure": (pd, pv)}
         self._ctx.set_dirichlet(nat.VELOCITY, vd, vv)
         self._ctx.set_dirichlet(nat.PRESSURE, pd, pv)
+        self._fast_diag_for = None           # (factors belong to a Dirichlet set: rebuilt on demand)
         self._ctx.set_viscous_form(self._form_viscous_term is WeakFormViscousTerm.traction_form)
         self._push_natural_terms()
+
+    def _fast_diagonalization_ready(self):
+        """ships the factors of the direct projection-step solver for the current pressure Dirichlet set; False where
+        it does not apply (no rectangle lattice, periodic or partitioned space, conditions on parts of a side)"""
+        import poisson_fd
+        pd = self._dirichlet_bcs["pressure"][0]
+        key = pd.tobytes()
+        if getattr(self, "_fast_diag_for", None) == key:
+            return self._fast_diag_ok
+        self._fast_diag_for, self._fast_diag_ok = key, False
+        lines = poisson_fd.lattice_lines(self._mesh)
+        if lines is None or hasattr(self, "_constrained_domain") or self._dofmap.n_p1 != lines[0].size * lines[1].size:
+            return False
+        f = poisson_fd.factors(lines[0], lines[1], pd)
+        if f is None:
+            return False
+        self._ctx.poisson_set_fast_diag(f)
+        self._fast_diag_ok = True
+        return True
 
     def _push_natural_terms(self):
         """Body force (nodal P2 interpolant) and boundary tractions -> device vectors
@@ -472,6 +492,10 @@ class InstationarySolverBase(SolverBase):
         self.pressure_start = "previous"
         #: velocity mass solve of the IPCS correction step: "chebyshev" (a-priori bounds, no dots) or "cg"
         self.mass_solver = "chebyshev"
+        #: IPCS projection step: "multigrid" (CG preconditioned by the pressure V-cycle) or
+        #: "fast_diagonalization" -- the direct solve of poisson_fd.py / csrc/fastdiag.hip where it applies
+        #: (rectangle lattices, pressure Dirichlet conditions on whole sides; elsewhere multigrid runs)
+        self.poisson_solver = "multigrid"
         #: truncated velocity multigrid cycle: None = library default (ratio 4, tolerance 0.1),
         #: 0 / False = full cycle, R or (R, tol) = truncate where c_v K_ii <= R alpha0/k M_ii
         self.mg_truncation = None
@@ -484,6 +508,7 @@ class InstationarySolverBase(SolverBase):
         self.newton_forcing = newton_forcing
         self.pressure_start = "extrapolated"
         self.mass_solver = "chebyshev"
+        self.poisson_solver = "fast_diagonalization"
         self.mg_truncation = (4.0, 0.1)
         return self
 

@@ -707,6 +707,58 @@ def test_timed_settings_on_the_lattice_kernels_match_the_oracle_at_config0_size(
     ctx.close()
 
 
+@pytest.mark.parametrize("nx,ny,outlet", [(32, 32, False), (40, 24, True), (64, 64, False)])
+def test_fast_diagonalisation_projection_step_matches_the_oracle(nx, ny, outlet):
+    """Projection step by fast diagonalisation (nsfem_krylov_opts.precond = 3: four dense products on the matrix cores,
+    csrc/fastdiag.hip) in place of the multigrid-CG solve: the device product z = A^+ r equals the numpy evaluation of
+    the same factors, and IPCS steps of the cavity (closed: singular Neumann problem; with an outflow side: pressure
+    Dirichlet on a whole side) match the LU oracle (source/ns_ipcs_solver.py:160-171) as tightly as the CG path run
+    with rtol 1e-12 does -- in ONE pass of the direct solve."""
+    import poisson_fd as pf
+    from multigrid import attach_hierarchy
+    ext = (nx / float(max(nx, ny)), ny / float(max(nx, ny)))
+    mesh, dm, marks = box(nx, ny, p1=ext)
+    mesh.structured = ((0.0, 0.0), ext, nx, ny)
+    bd, bv = cavity_bc(dm, marks)
+    nodes = np.zeros(0, np.int32)
+    if outlet:
+        nodes = np.where(np.abs(mesh.coords[:, 0] - ext[0]) < 1e-12)[0].astype(np.int32)
+    ctx = context(mesh, dm)
+    attach_hierarchy(ctx, mesh)
+    ctx.set_coeffs(1.0, 1.0, 0.01)
+    ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+    ctx.set_dirichlet(nat.PRESSURE, nodes, np.zeros(nodes.size))
+    f = pf.factors(*pf.lattice_lines(mesh), nodes)
+    ctx.poisson_set_fast_diag(f)
+    r = np.random.default_rng(nx).standard_normal(dm.n_p1)
+    r[nodes] = 0.0
+    if not outlet:
+        r -= r.mean()
+    assert rel(ctx.mg_apply(2, r), pf.apply_reference(f, r)) < 1e-13
+    s = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap)
+    coef = dict(convective_term=1.0, pressure_term=1.0, viscous_term=0.01, body_force_term=None)
+    orc = fo.IPCSOracle(s, coef, refactor_every_step=False)
+    o = ctx.default_step_opts()
+    o.momentum.precond = 1
+    o.poisson.precond = 3
+    pbc = (nodes.astype(np.int64), np.zeros(nodes.size)) if outlet else None
+    for step in range(3):
+        alpha = fo.bdf_alpha(step, 1.0)
+        ctx.set_bdf(alpha, 0.01)
+        info = ctx.step_ipcs(o)
+        ctx.advance(0)
+        orc.step(alpha, 0.01, (bd, bv), pbc) if outlet else orc.step(alpha, 0.01, (bd, bv))
+        orc.advance()
+        assert info.krylov_iterations_poisson == 1
+    assert rel(ctx.get_state(nat.U1), orc.vel[1]) < 1e-9
+    p = ctx.get_state(nat.P_OLD)
+    if outlet:
+        assert rel(p, orc.p_old) < 1e-8
+    else:
+        assert rel(p - p.mean(), orc.p_old - orc.p_old.mean()) < 1e-8
+    ctx.close()
+
+
 def test_truncated_velocity_cycle_is_only_a_preconditioner_change():
     """nsfem_mg_set_truncation: at a small time step the velocity operator alpha0/k M + c_v K is
     mass dominated on the coarser levels; the cycle stops at the first such level and solves it by

@@ -797,3 +797,44 @@ def test_interpolation_prolongation_between_non_nested_meshes():
         assert abs((P @ field)[i] - (L[k] * field[mc.cells[k]]).sum()) < 1e-13
     assert [m.structured[2:] for m, _ in structured_hierarchy((0, 0, 0), (1, 1, 1), 50, 50, 50)] == \
         [(25, 25, 25), (13, 13, 13), (7, 7, 7)]
+
+
+def test_fast_diagonalisation_factors_invert_the_oracle_stiffness_matrix():
+    """poisson_fd: on the right-diagonal triangulation of a rectangle the P1 stiffness matrix of the ORACLE is the
+    tensor sum K_y (x) W_x + W_y (x) K_x to round-off, and  V_y ((V_y^T R V_x) .* inv) V_x^T  solves with it -- all
+    Neumann (singular, compatible right-hand side), Dirichlet on one or two whole sides, non-square lattices.  A
+    Dirichlet set that is not a union of whole sides is refused."""
+    import scipy.sparse as sp
+    import fem_oracle as fo
+    import poisson_fd as pf
+    from fem_mesh import TaylorHoodDofMap, rectangle_mesh
+    rng = np.random.default_rng(5)
+    for nx, ny, sides in ((12, 7, ()), (16, 16, ("x1",)), (9, 20, ("y0", "x0")), (24, 24, ())):
+        mesh = rectangle_mesh((0.0, 0.0), (1.5, 0.7), nx, ny)
+        dm = TaylorHoodDofMap(mesh)
+        A = fo.Space(mesh.coords, mesh.cells, dm.p2_dofmap, dm.p1_dofmap).stiffness_p1().tocsr()
+        W, H = nx + 1, ny + 1
+        xs, ys = pf.lattice_lines(mesh)
+        Kx, wx = pf.line_matrices(xs)
+        Ky, wy = pf.line_matrices(ys)
+        T = sp.kron(Ky, sp.diags(wx)) + sp.kron(sp.diags(wy), Kx)
+        assert abs(A - T).max() < 1e-13 * abs(A).max()
+        ids = np.arange(W * H).reshape(H, W)
+        pick = {"x0": ids[:, 0], "x1": ids[:, -1], "y0": ids[0, :], "y1": ids[-1, :]}
+        dn = np.unique(np.concatenate([pick[k] for k in sides])) if sides else np.zeros(0, np.int64)
+        f = pf.factors(xs, ys, dn)
+        assert f is not None and f["singular"] == (len(sides) == 0)
+        r = rng.standard_normal(W * H)
+        free = np.ones(W * H, bool)
+        free[dn] = False
+        r[~free] = 0.0
+        if not sides:
+            r -= r.mean()
+        z = pf.apply_reference(f, r)
+        assert np.abs((r - A @ z)[free]).max() < 1e-11 * np.abs(r).max()
+        assert not sides or np.abs(z[~free]).max() == 0.0
+    assert pf.side_pattern(5, 4, [0, 1]) is None
+    assert pf.factors(np.linspace(0, 1, 5), np.linspace(0, 1, 4), [0, 1]) is None
+    unstructured = rectangle_mesh((0.0, 0.0), (1.0, 1.0), 4, 4)
+    unstructured.coords = unstructured.coords + 1e-3 * rng.standard_normal(unstructured.coords.shape)
+    assert pf.lattice_lines(unstructured) is None

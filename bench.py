@@ -907,6 +907,70 @@ def _smoother_roofline_extras(ctx, nv, ms_in_situ, ms_cold=None):
     return label, extra
 
 
+def _issue_floor(n):
+    """VALU floor of the dominant kernel from the committed SQ counter passes (profiles/r04_cheb_lattice_sq_counters_n512.json:
+    SQ_INSTS_VALU per launch x 4 cycles / 1024 SIMDs / 2.4 GHz); {} when no such file exists for the size"""
+    f = os.path.join(ROOT, "profiles", "r04_cheb_lattice_sq_counters_n%d.json" % n)
+    if not os.path.exists(f):
+        return {}
+    c = json.load(open(f))
+    valu = c.get("SQ_INSTS_VALU")
+    if not valu:
+        return {}
+    return {"valu_floor_us": valu * 4.0 / 1024.0 / 2.4e9 * 1e6,
+            "valu_floor_source": "SQ_INSTS_VALU per finest-level launch (%s) x 4 cycles / 1024 SIMDs / 2.4 GHz; waves %s, "
+                                 "VALU instructions per wave %s" % (os.path.basename(f), c.get("SQ_WAVES"),
+                                                                   round(valu / c["SQ_WAVES"], 1) if c.get("SQ_WAVES") else None)}
+
+
+def _trace_numbers(n, world):
+    """launches / kernel time per step of THIS command from the committed rocprofv3 kernel trace of its timed steps
+    (scripts/collect_profiles_r04.sh: bench.py --timed-only --trace-markers under rocprofv3 --kernel-trace, cut to the
+    timed region by scripts/trace_gaps.py); not measurable inside the process"""
+    f = os.path.join(ROOT, "profiles", "r04_bench_n%d_timed_steps_trace_summary.json" % n)
+    if world != 1 or not os.path.exists(f):
+        return {}
+    t = json.load(open(f))
+    return {"launches_per_step": t["launches_per_step"], "kernel_ms_per_step": t["kernel_ms_per_step"],
+            "small_launch_ms_per_step": t["small_launch_ms_per_step"],
+            "small_launches_per_step": t["small_launches_per_step"],
+            "host_round_trips_per_step": t.get("host_round_trips_per_step"),
+            "trace_source": "profiles/%s (committed kernel trace of the timed steps of this command; small = launches "
+                            "under 15 us)" % os.path.basename(f)}
+
+
+def _other_configs(args):
+    """BASELINE configs[2..4] at their bench sizes in the default job, a few timed steps each, every one in a process
+    of its own (fresh context, its own device memory): the driver's run then times them as well"""
+    import subprocess
+    out = []
+    jobs = [("dfg-bdf", ["--workload", "dfg-bdf"]),
+            ("tgv3d-ipcs", ["--workload", "tgv3d-ipcs", "--cells", "64"]),
+            ("channel3d-bdf", ["--workload", "channel3d-bdf", "--cells", "48"])]
+    for name, extra in jobs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            d = json.loads(line[-1]) if line else None
+        except Exception as exc:                       # a failed side job must not take the headline down
+            d, r = None, None
+            err = repr(exc)
+        if d is None:
+            out.append({"workload": name, "error": (r.stderr[-300:] if r is not None else err)})
+            continue
+        cfg = d.get("config", {})
+        out.append({"workload": cfg.get("workload", name), "ms_per_step": d.get("ms_per_step"), "value": d.get("value"),
+                    "unit": d.get("unit"), "steps": d.get("steps"), "warmup": d.get("warmup"),
+                    "n_dofs": cfg.get("n_dofs"),
+                    "newton_its_per_step": cfg.get("newton_its_per_step"),
+                    "bicgstab_its_per_step": cfg.get("bicgstab_its_per_step"),
+                    "roofline_frac": (d.get("roofline") or {}).get("frac"),
+                    "wall_s_incl_setup": time.perf_counter() - t0})
+    return out
+
+
 def _apply_truncation(ctx, args):
     parts = [float(v) for v in str(args.mg_truncation).split(",")]
     ctx.mg_set_truncation(parts[0], parts[1] if len(parts) > 1 else 0.1)
@@ -1058,6 +1122,8 @@ def cavity_ipcs_bench(args):
         for i in range(args.warmup):
             one_step(i, opts)
         ctx.synchronize()
+        if args.trace_markers:                 # (a k_cfl launch on either side of the timed region: scripts/trace_gaps.py)
+            ctx.cfl_number(nat.U0, args.dt)
         if dist is not None:
             dist.barrier()
         ctx.comm_stats(reset=True)
@@ -1070,6 +1136,8 @@ def cavity_ipcs_bench(args):
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if args.trace_markers:
+            ctx.cfl_number(nat.U0, args.dt)
         comm = {k: v / args.steps for k, v in ctx.comm_stats().items()}
         if dist is not None:
             import torch
@@ -1187,8 +1255,24 @@ def cavity_ipcs_bench(args):
     # command and labelled so (`traffic_source`), null when no such profile exists for the size
     traffic = traffic_source = None
     lattice = mg_levels is not None and ctx.smoother_info().get("multistep_lattice_kernel")
+    pmc4 = os.path.join(ROOT, "profiles", "r04_bench_n512_pmc_fetch_write_size.json")
+    if world == 1 and n == 512 and lattice and os.path.exists(pmc4):
+        # round 4: the MEAN over the finest-level launches (largest grid of the kernel symbol) of 2 x FETCH_SIZE +
+        # WRITE_SIZE -- the figure that pairs with the average `algorithmic_bytes_per_launch` over the same launch shapes
+        c = json.load(open(pmc4)).get("by_grid", {})
+        keys = [k for k in c.get("fetch", {}) if k.startswith("void nsfem::k_cheb_lattice<2, 3, 4> @ grid")]
+        if keys:
+            key = max(keys, key=lambda k: int(k.rsplit(" ", 1)[1]))
+            if key in c.get("write", {}):
+                traffic = (2.0 * c["fetch"][key]["mean_KB"] + c["write"][key]["mean_KB"]) * 1024.0
+                traffic_source = ("committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/"
+                                  "r04_bench_n512_pmc_fetch_write_size.json, by_grid): MEAN over the %d finest-level launches "
+                                  "of 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE; not measured by this run; "
+                                  "counts Infinity-Cache hits as well" % c["fetch"][key]["n"])
     for fname in ("r03_b_bench_n512_pmc_fetch_write_size.json", "r03_a_bench_n512_pmc_fetch_write_size.json",
                   "r02_pmc_fetch_write_size.json"):
+        if traffic is not None:
+            break
         pmc = os.path.join(ROOT, "profiles", fname)
         if world == 1 and n == 512 and mg_levels is not None and os.path.exists(pmc):
             # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE; a kernel
@@ -1247,7 +1331,7 @@ def cavity_ipcs_bench(args):
                    "newton_its_per_step": float(its[0]),
                    "bicgstab_its_per_step": float(its[1]), "poisson_cg_its_per_step": float(its[2]),
                    "comm_per_step_rank0": comm_per_step},
-        "roofline": {"bound": "hbm",
+        "roofline": {"bound": "latency/issue" if lattice else "hbm",
                      "kernel": smoother_label if mg_levels is not None else "k_spmv_stream_v1<2,2,1,0> (momentum Jacobian)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -1267,6 +1351,9 @@ def cavity_ipcs_bench(args):
                           "algorithmic_bytes_per_launch": nbytes_jac, "ms_per_launch": ms_jac},
     }
     out["roofline"].update(smoother_extra)
+    if lattice:
+        out["roofline"].update(_issue_floor(n))
+    out.update(_trace_numbers(n, world))
     ctx.close()
     _finish_dist(dist)
     if world == 1 and not args.no_solver_classes:
@@ -1275,6 +1362,8 @@ def cavity_ipcs_bench(args):
         out["config"].update(solver_surface_run(args, n, u_fast, p_fast))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(_parse_cpu_samples(args.cpu_samples), args.dt, n_dofs)
+    if rank == 0 and world == 1 and args.other_configs and getattr(args, "thread_ranks", None) is None:
+        out["other_configs"] = _other_configs(args)
     if max(du_l2, dp_l2) > tol_fields:
         raise SystemExit("bench: the timed fields differ from the exact-solver run by %.2e (velocity) / %.2e "
                          "(pressure) > %.0e" % (du_l2, dp_l2, tol_fields))
@@ -1399,6 +1488,12 @@ def main():
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling aid: only the warm-up and timed steps (no validation rerun, no in-situ / "
                          "cold-cache kernel timing, no CPU baseline); the JSON line lacks those entries")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="skip the short runs of BASELINE configs[2..4] (dfg-bdf, tgv3d-ipcs 64, channel3d-bdf 48) that the "
+                         "default job appends as `other_configs`")
+    ap.add_argument("--trace-markers", action="store_true",
+                    help="profiling aid: one k_cfl launch right before and right after the timed steps, so that a kernel "
+                         "trace can be cut to the timed region (scripts/trace_gaps.py --between k_cfl)")
     ap.add_argument("--no-multigrid", action="store_true")
     ap.add_argument("--mg-degree", type=int, default=None,
                     help="Chebyshev smoother degree (default: 2 on structured meshes, 3 on the DFG mesh)")
@@ -1488,25 +1583,48 @@ def _run_workload(args):
         return channel3d_bdf_bench(args)
     import copy
     rank = args.thread_rank if getattr(args, "thread_ranks", None) is not None else int(os.environ.get("RANK", "0"))
+    default_job = args.n is None and not args.timed_only
     both = args.gpus > 1 and args.scaling == "weak" and not args.timed_only and not args.no_strong
     if args.strong_cells is None:
         args.strong_cells = 960 if args.n in (None, 512) else args.n
-    args.n = args.n or (960 if args.scaling == "strong" else 512)
-    out = cavity_ipcs_bench(args)
+
+    def strong_block(st, a2):
+        return {"cells": a2.n, "n_dofs": st["config"]["n_dofs"], "ms_per_step": st["ms_per_step"],
+                "value": st["value"], "unit": st["unit"], "time_steps_per_sec": st["time_steps_per_sec"],
+                "steps": st["steps"], "warmup": st["warmup"],
+                "its_per_step_newton_bicgstab_poisson": [st["config"]["newton_its_per_step"],
+                                                         st["config"]["bicgstab_its_per_step"],
+                                                         st["config"]["poisson_cg_its_per_step"]],
+                "comm_per_step": st["config"]["comm_per_step_rank0"]}
+
     if both:
-        # N > 1: `value` stays the weak-scaling figure (512 x 512 cells per rank, so N = 1 equals the
-        # single-GPU line); north_star's strong-scaling quantity -- ONE 960 x 960 mesh (8.3 M dofs) cut
-        # into N strips -- is measured in the same job and reported beside it
+        # N > 1 (round 4): the HEADLINE of the line is north_star's strong-scaling quantity -- ONE 960 x 960 mesh
+        # (8.3 M dofs) cut into N strips, `"scaling": "strong"` --, the weak-scaling figure (512 x 512 cells per rank,
+        # so N = 1 equals the single-GPU line) rides along as the `weak` block.  The one-GPU point of the strong
+        # curve is the `strong_n1` block of the N = 1 line (same mesh on one GPU).
         a2 = copy.copy(args)
-        a2.scaling, a2.n, a2.timed_only = "strong", args.strong_cells, True
-        st = cavity_ipcs_bench(a2)
-        out["strong"] = {"cells": a2.n, "n_dofs": st["config"]["n_dofs"], "ms_per_step": st["ms_per_step"],
-                         "value": st["value"], "unit": st["unit"], "time_steps_per_sec": st["time_steps_per_sec"],
-                         "steps": st["steps"], "warmup": st["warmup"],
-                         "its_per_step_newton_bicgstab_poisson": [st["config"]["newton_its_per_step"],
-                                                                  st["config"]["bicgstab_its_per_step"],
-                                                                  st["config"]["poisson_cg_its_per_step"]],
-                         "comm_per_step": st["config"]["comm_per_step_rank0"]}
+        a2.scaling, a2.n = "strong", args.strong_cells
+        a2.no_cpu_baseline = a2.no_solver_classes = True
+        a2.other_configs = False
+        out = cavity_ipcs_bench(a2)
+        a1 = copy.copy(args)
+        a1.n, a1.timed_only = args.n or 512, True
+        wk = cavity_ipcs_bench(a1)
+        if out is not None and wk is not None:
+            out["weak"] = strong_block(wk, a1)
+            out["weak"]["note"] = "512 x 512 cells PER RANK (fixed work per GPU); value = all ranks' DoF-updates per second"
+    else:
+        args.n = args.n or (960 if args.scaling == "strong" else 512)
+        out = cavity_ipcs_bench(args)
+        if default_job and args.gpus == 1 and out is not None and args.scaling == "weak" and not args.no_strong:
+            # the one-GPU point of the strong-scaling curve the N > 1 lines report: the 960 x 960 mesh on one GPU
+            a2 = copy.copy(args)
+            a2.scaling, a2.n, a2.timed_only = "strong", args.strong_cells, True
+            a2.steps, a2.warmup = min(args.steps, 10), min(args.warmup, 3)
+            st = cavity_ipcs_bench(a2)
+            out["strong_n1"] = strong_block(st, a2)
+            out["strong_n1"]["note"] = ("the mesh of the strong-scaling curve (--gpus N > 1 reports it as its headline) on "
+                                        "ONE GPU: divide the N-GPU `value` by this one for the speed-up")
     if rank == 0:
         print(json.dumps(out))
     return None

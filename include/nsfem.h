@@ -262,6 +262,10 @@ typedef struct {
    * from coords[cells].  NULL / 0: dof = vertex id.  P then has n_dofs columns. */
   const int32_t* dofmap;
   int32_t n_dofs;
+  int32_t transfer_kind;     /* how Dirichlet / ghost flags travel down this transfer: 1 = nested levels (a coarse node
+                                takes the flag of the finer node it coincides with: the row of P with the single entry
+                                1), 2 = non-nested interpolation (the finer node its hat function weighs most, weight
+                                >= 1/2), 0 = decide from the values of P (every entry 1 or 1/2 -> nested) */
 } nsfem_mg_level_desc;
 typedef struct {
   int32_t smoother_degree;   /* Chebyshev steps per pre/post smoothing (default 2) */

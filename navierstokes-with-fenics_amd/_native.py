@@ -111,7 +111,7 @@ class MgLevelDesc(C.Structure):
                 ("n_fine", C.c_int32), ("p_rowptr", C.POINTER(C.c_int32)),
                 ("p_col", C.POINTER(C.c_int32)), ("p_val", C.POINTER(C.c_double)),
                 ("ghost", C.POINTER(C.c_uint8)), ("halo", Halo),
-                ("dofmap", C.POINTER(C.c_int32)), ("n_dofs", C.c_int32)]
+                ("dofmap", C.POINTER(C.c_int32)), ("n_dofs", C.c_int32), ("transfer_kind", C.c_int32)]
 
 
 class PartitionDesc(C.Structure):
@@ -430,7 +430,7 @@ class NsfemContext:
                                                   C.byref(info)))
         return x
 
-    def mg_add_level(self, coords, cells, p_rowptr, p_col, p_val, ghost=None, halo=None, dofmap=None):
+    def mg_add_level(self, coords, cells, p_rowptr, p_col, p_val, ghost=None, halo=None, dofmap=None, nested=None):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         rp = np.ascontiguousarray(p_rowptr, dtype=np.int32)
@@ -442,7 +442,8 @@ class NsfemContext:
         assert dm is None or dm.shape == cells.shape
         d = MgLevelDesc(coords.shape[0], cells.shape[0], _dp(coords), _ip(cells), rp.size - 1,
                         _ip(rp), _ip(pc), _dp(pv), gp, Halo.from_dict(halo),
-                        _ip(dm) if dm is not None else None, int(dm.max()) + 1 if dm is not None else 0)
+                        _ip(dm) if dm is not None else None, int(dm.max()) + 1 if dm is not None else 0,
+                        0 if nested is None else (1 if nested else 2))
         self._check(self._lib.nsfem_mg_add_level(self._h, C.byref(d)))
 
     def mg_set_schur_operator(self, level, csr, singular):

@@ -1242,7 +1242,8 @@ extern "C" int nsfem_mg_add_level(nsfem_ctx* ctx, const nsfem_mg_level_desc* d) 
   nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
   ctx->coarse.push_back(lv);
   fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells, d->dofmap, d->n_dofs);
-  lv->to_finer.build(s, n_fine, lv->n, d->p_rowptr, d->p_col, d->p_val);
+  NSFEM_REQUIRE(d->transfer_kind >= 0 && d->transfer_kind <= 2, "transfer_kind: 0 (from the values), 1 nested, 2 interpolation");
+  lv->to_finer.build(s, n_fine, lv->n, d->p_rowptr, d->p_col, d->p_val, d->transfer_kind);
   if (d->ghost) {                       // one flag per dof of the level (= per vertex without a dof map)
     lv->h_ghost.assign(d->ghost, d->ghost + lv->n);
     lv->halo = to_halo(d->halo);
@@ -1361,7 +1362,7 @@ extern "C" int nsfem_mg_add_global_level(nsfem_ctx* ctx, const nsfem_mg_level_de
   nsfem_ctx::P1Level* lv = new nsfem_ctx::P1Level();
   ctx->global_tail.push_back(lv);
   fill_p1_level(ctx, lv, d->n_vertices, d->n_cells, d->coords, d->cells, d->dofmap, d->n_dofs);
-  lv->to_finer.build(s, n_fine, lv->n, d->p_rowptr, d->p_col, d->p_val);
+  lv->to_finer.build(s, n_fine, lv->n, d->p_rowptr, d->p_col, d->p_val, d->transfer_kind);
   NSFEM_HIP(hipStreamSynchronize(s));
   API_END(ctx)
 }
@@ -1598,7 +1599,7 @@ extern "C" int nsfem_mg_finalize(nsfem_ctx* ctx, const nsfem_mg_opts* o) {
       else { col.push_back(a[i]); val.push_back(0.5); col.push_back(b[i]); val.push_back(0.5); }
       rp[i + 1] = (int32_t)col.size();
     }
-    ctx->t_p2p1.build(s, n2, ctx->mesh.n_p1, rp.data(), col.data(), val.data());
+    ctx->t_p2p1.build(s, n2, ctx->mesh.n_p1, rp.data(), col.data(), val.data(), 1 /* nested: P1 in P2 */);
   }
   ctx->Lc0.init(&ctx->p11, 1, 1, s);
   const int degree = (o && o->smoother_degree > 0) ? o->smoother_degree : 2;

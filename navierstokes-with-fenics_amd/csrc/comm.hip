@@ -598,6 +598,15 @@ Comm* make_shm_comm(const char* name, int rank, int size, int64_t slot_bytes) {
       throw Error(NSFEM_ERR_COMM, "shared-memory communicator: not all ranks attached within 120 s");
     }
   }
+  // every rank checks the geometry rank 0 wrote against its own arguments: a mismatch would make the slots overlap
+  if (c->hd->size != size || c->hd->slot_bytes != slot_bytes) {
+    const std::string msg = "shared-memory communicator: rank " + std::to_string(rank) + " was given size " +
+                            std::to_string(size) + " / slot " + std::to_string((long long)slot_bytes) +
+                            " B, rank 0 created size " + std::to_string(c->hd->size) + " / slot " +
+                            std::to_string((long long)c->hd->slot_bytes) + " B";
+    delete c;
+    throw Error(NSFEM_ERR_COMM, msg);
+  }
   return c;
 }
 

@@ -18,63 +18,72 @@ namespace nsfem {
 
 typedef double fd_acc4 __attribute__((ext_vector_type(4)));
 
-constexpr int kFdBM = 32, kFdBN = 32, kFdBK = 32, kFdLd = 48;
+constexpr int kFdBM = 32, kFdBN = 32, kFdBK = 96, kFdLd = kFdBK + 2, kFdNQ = kFdBM * kFdBK / 256;
 
 // C[M x N] = op(A)[M x K] * op(B)[K x N] (.* scale[M x N]); row-major storage.  TA: A(m, k) = A[k * lda + m];
 // TB: B(k, n) = B[n * ldb + k].  256 threads = 4 waves, wave w owns the 16 x 16 tile (w >> 1, w & 1) of a 32 x 32
-// block of C.
+// block of C.  The products are latency bound (K = 513: six k-blocks of 96, every one a global round trip): a thread
+// keeps the 2 x 12 loads of the NEXT TWO blocks in flight (register double buffer) under the 24 MFMAs of a block.  LDS: As[m][k], Bs[n][k]
+// with lines of 98 doubles -- the fragment reads (16 lines x 4 consecutive k per wave) and the stores along k are
+// conflict free.
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_fd_gemm(int M, int N, int K, const double* __restrict__ A, int lda,
                                                  const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
                                                  const double* __restrict__ scale) {
-  __shared__ double As[kFdBK * kFdLd];      // As[k][m]
-  __shared__ double Bs[kFdBK * kFdLd];      // Bs[k][n]
+  __shared__ double As[kFdBM * kFdLd];      // As[m][k]
+  __shared__ double Bs[kFdBN * kFdLd];      // Bs[n][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * kFdBM, n0 = blockIdx.x * kFdBN;
   const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
-  // this thread's four elements of the A and B blocks of a k-block: element e = tid + 256 q, walked along the
-  // operand's contiguous direction
-  double ra[4], rb[4];
-  auto load_block = [&](int k0) {
+  // element e = tid + 256 q of a 32 x 96 block, walked along the operand's contiguous direction:
+  //   contiguous along k (A row-major, B transposed): k = e % 96, line = e / 96
+  //   contiguous along m / n (A transposed, B row-major): line = e % 32, k = e / 32
+  double ra0[kFdNQ], rb0[kFdNQ], ra1[kFdNQ], rb1[kFdNQ];      // two k-blocks in flight (register double buffer)
+  auto load_block = [&](int k0, double (&ra)[kFdNQ], double (&rb)[kFdNQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kFdNQ; ++q) {
       const int e = tid + 256 * q;
       {
-        const int m = TA ? (e & 31) : (e >> 5), k = TA ? (e >> 5) : (e & 31);
+        const int m = TA ? (e & 31) : (e / kFdBK), k = TA ? (e >> 5) : (e % kFdBK);
         const int gm = m0 + m, gk = k0 + k;
         ra[q] = (gm < M && gk < K) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.0;
       }
       {
-        const int n = TB ? (e >> 5) : (e & 31), k = TB ? (e & 31) : (e >> 5);
+        const int n = TB ? (e / kFdBK) : (e & 31), k = TB ? (e % kFdBK) : (e >> 5);
         const int gn = n0 + n, gk = k0 + k;
         rb[q] = (gn < N && gk < K) ? (TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.0;
       }
     }
   };
-  auto store_block = [&] {
+  auto store_block = [&](const double (&ra)[kFdNQ], const double (&rb)[kFdNQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kFdNQ; ++q) {
       const int e = tid + 256 * q;
-      const int ma = TA ? (e & 31) : (e >> 5), ka = TA ? (e >> 5) : (e & 31);
-      As[ka * kFdLd + ma] = ra[q];
-      const int nb = TB ? (e >> 5) : (e & 31), kb = TB ? (e & 31) : (e >> 5);
-      Bs[kb * kFdLd + nb] = rb[q];
+      const int ma = TA ? (e & 31) : (e / kFdBK), ka = TA ? (e >> 5) : (e % kFdBK);
+      As[ma * kFdLd + ka] = ra[q];
+      const int nb = TB ? (e / kFdBK) : (e & 31), kb = TB ? (e % kFdBK) : (e >> 5);
+      Bs[nb * kFdLd + kb] = rb[q];
     }
   };
   fd_acc4 acc = {0.0, 0.0, 0.0, 0.0};
-  load_block(0);
-  for (int k0 = 0; k0 < K; k0 += kFdBK) {
+  const double* __restrict__ ap = As + (wm + (lane & 15)) * kFdLd + (lane >> 4);       // A[m = lane & 15][k = lane >> 4]
+  const double* __restrict__ bp = Bs + (wn + (lane & 15)) * kFdLd + (lane >> 4);       // B[k = lane >> 4][n = lane & 15]
+  load_block(0, ra0, rb0);
+  if (kFdBK < K) load_block(kFdBK, ra1, rb1);
+  for (int k0 = 0; k0 < K; k0 += 2 * kFdBK) {
     __syncthreads();                         // (the previous block's fragments have been read)
-    store_block();
+    store_block(ra0, rb0);
     __syncthreads();
-    if (k0 + kFdBK < K) load_block(k0 + kFdBK);
+    if (k0 + 2 * kFdBK < K) load_block(k0 + 2 * kFdBK, ra0, rb0);
 #pragma unroll
-    for (int kk = 0; kk < kFdBK; kk += 4) {
-      const int kr = kk + (lane >> 4);
-      const double a = As[kr * kFdLd + wm + (lane & 15)];       // A[m = lane & 15][k = lane >> 4]
-      const double b = Bs[kr * kFdLd + wn + (lane & 15)];       // B[k = lane >> 4][n = lane & 15]
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
+    for (int kk = 0; kk < kFdBK; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc, 0, 0, 0);
+    if (k0 + kFdBK >= K) break;
+    __syncthreads();
+    store_block(ra1, rb1);
+    __syncthreads();
+    if (k0 + 3 * kFdBK < K) load_block(k0 + 3 * kFdBK, ra1, rb1);
+#pragma unroll
+    for (int kk = 0; kk < kFdBK; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc, 0, 0, 0);
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   const int col = n0 + wn + (lane & 15);

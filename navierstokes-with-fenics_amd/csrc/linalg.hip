@@ -1514,15 +1514,10 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   // entry | masks as ONE byte per row: callers outside the multigrid (test hook, timing) get it built here
   NSFEM_REQUIRE(d.n_stencils <= 64 && nv <= 2, "the lattice kernel needs <= 64 dictionary entries and <= 2 components");
   if (!sidm) {
-    static uint8_t* scratch = nullptr;         // (never freed; stream ordered: the launch below follows the fill)
-    static size_t cap = 0;
-    if (cap < (size_t)d.n_rows) {
-      if (scratch) NSFEM_HIP(hipFree(scratch));
-      cap = (size_t)d.n_rows;
-      NSFEM_HIP(hipMalloc((void**)&scratch, cap + 64));
-    }
-    launch_lattice_sidm(s, A, nv, mask, scratch);
-    sidm = scratch;
+    // (per dictionary: contexts on other devices or streams bring their own operator, hence their own buffer)
+    if (d.sidm_scratch.n != (size_t)d.n_rows) d.sidm_scratch.alloc((size_t)d.n_rows);
+    launch_lattice_sidm(s, A, nv, mask, d.sidm_scratch.p);
+    sidm = d.sidm_scratch.p;
   }
   a.sidm = sidm;
   const int32_t* toff = lattice_offsets(s, d, 32, a.EHh);
@@ -1543,7 +1538,10 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   static const int shape = [] { const char* e = std::getenv("NSFEM_LATTICE_SHAPE"); return e ? std::atoi(e) : 0; }();
 #define NSFEM_LAT(NV, KK, WPE)                                                                         \
   do {                                                                                                 \
-    static bool attr_set = false;                                                                      \
+    static bool attr_dev[64];                                                                          \
+    int dev_ = 0;                                                                                      \
+    NSFEM_HIP(hipGetDevice(&dev_));                                                                    \
+    bool& attr_set = attr_dev[dev_ & 63];                                                              \
     if (!attr_set) {                                                                                   \
       NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, KK, WPE>),       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));         \

@@ -210,7 +210,7 @@ double diag_ratio_max(hipStream_t s, const Pattern& pat, const double* M, const 
 // --------------------------------------------------------------- host helpers
 // transfer matrix from CSR triplets (rows = finer level, cols = coarser level) + R = P^T
 void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* rowptr,
-                     const int32_t* col, const double* val) {
+                     const int32_t* col, const double* val, int kind) {
   const int nnz = rowptr[n_fine];
   patP.n_rows = n_fine; patP.n_cols = n_coarse; patP.nnz = nnz;
   patP.h_rowptr.assign(rowptr, rowptr + n_fine + 1);
@@ -236,8 +236,9 @@ void Transfer::build(hipStream_t s, int n_fine, int n_coarse, const int32_t* row
   // provided the weight is at least 1/2 -- on a boundary that is a node of the same boundary line.
   h_inj.assign((size_t)n_coarse, -1);
   std::vector<double> best((size_t)n_coarse, 0.0);
-  bool nested = true;
-  for (int i = 0; i < n_fine && nested; ++i)
+  // (the caller knows how it built the levels; only without that knowledge the values decide)
+  bool nested = kind != 2;
+  for (int i = 0; kind == 0 && i < n_fine && nested; ++i)
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
       if (val[k] != 1.0 && val[k] != 0.5) { nested = false; break; }
   for (int i = 0; i < n_fine; ++i)

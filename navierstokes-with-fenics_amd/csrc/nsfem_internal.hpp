@@ -179,6 +179,7 @@ struct StencilDict {
     DevBuf<int32_t> buf;   // [n_stencils][4 classes][lmax]
   };
   mutable std::vector<LatticeOffsets> loff_cache;   // one table per tile shape in use (built on first use)
+  mutable DevBuf<uint8_t> sidm_scratch;             // entry | mask bytes for callers that bring none (test hook, timing)
 };
 // false: the rows do not repeat (unstructured mesh) -- no dictionary
 // min_rows > 0: patterns down to that many rows are accepted when they turn out to be 2D lattices (tables_only)
@@ -603,8 +604,9 @@ struct Transfer {
   std::vector<double> h_val;    // host copy of P's values (lattice check)
   int lattice = -1;             // P is the lattice interpolation of a (2 Wc - 1)-wide fine lattice: -1 unknown, 0 no, 1 yes
   bool is_lattice(int wf, int hf);
+  // kind: 1 nested, 2 non-nested interpolation, 0 decide from the values (nsfem_mg_level_desc::transfer_kind)
   void build(hipStream_t s, int n_fine, int n_coarse, const int32_t* rowptr, const int32_t* col,
-             const double* val);
+             const double* val, int kind = 0);
 };
 
 struct MGLevel {

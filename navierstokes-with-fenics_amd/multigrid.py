@@ -189,6 +189,7 @@ def structured_hierarchy(p0, p1, nx, ny, nz=None, coarsest=None, dense_max=1200,
         n = nc
         nested = nested and even
         mesh = rectangle_mesh(p0, p1, *n) if nz is None else box_mesh(p0, p1, *n)
+        mesh.nested_in_finer = bool(even)          # (how row flags travel down this transfer: nsfem_mg_level_desc)
         levels.append((mesh, P))
     return levels
 
@@ -262,7 +263,8 @@ def attach_hierarchy(ctx, mesh, degree=None, eig_ratio=None, coarsest=None, peri
         ctx.mg_finalize(degree, eig_ratio)
         return len(levels)
     for coarse_mesh, (rowptr, col, val) in levels:
-        ctx.mg_add_level(coarse_mesh.coords, coarse_mesh.cells, rowptr, col, val)
+        ctx.mg_add_level(coarse_mesh.coords, coarse_mesh.cells, rowptr, col, val,
+                         nested=getattr(coarse_mesh, "nested_in_finer", None))
         ctx.mg_prolongations.append((coarse_mesh.coords.shape[0], (rowptr, col, val)))
     ctx.mg_finalize(degree, eig_ratio)
     return len(levels)

@@ -1071,7 +1071,7 @@ def cavity_ipcs_bench(args):
     ctx.set_overlap(args.overlap == "on")
     # projection step by fast diagonalisation (one rank: the P1 space is the whole rectangle lattice)
     fast_diag = False
-    if world == 1 and args.poisson_solver == "fd":
+    if world == 1 and dist is None and args.poisson_solver == "fd":
         import poisson_fd
         lines = poisson_fd.lattice_lines(part.mesh)
         factors = poisson_fd.factors(lines[0], lines[1], np.zeros(0, np.int64)) if lines is not None else None

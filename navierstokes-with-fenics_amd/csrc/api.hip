@@ -925,6 +925,7 @@ static int poisson_solve_fast_diag(nsfem_ctx* c, const nsfem_krylov_opts& o, nsf
   NSFEM_REQUIRE(!c->distributed(), "fast diagonalisation: one rank only");
   KrylovWork& w = c->kw;
   w.ensure(std::max<int64_t>(np, nvel(c)));
+  ++w.touch;
   double* parts = w.parts.p;
   double* x = c->state[NSFEM_P].p;
   const double* rhs = c->rhs_p.p;
@@ -960,6 +961,47 @@ static int poisson_solve_fast_diag(nsfem_ctx* c, const nsfem_krylov_opts& o, nsf
   return info.converged ? NSFEM_OK : NSFEM_ERR_NOT_CONVERGED;
 }
 
+// The whole projection step of the fused driver by fast diagonalisation, for the pure Neumann problem (no pressure
+// Dirichlet dofs, one rank): with the start vector p_old the residual of  A p = A p_old - (alpha0 / k) D u*  is
+// -(alpha0 / k) D u*  itself -- no product with A to form a right-hand side, none for a start residual:
+//   r = -(alpha0 / k) D u* - mean ;  z = A^+ r ;  p = p_old + z ;  check |r - A z| <= max(atol, rtol |r|)
+// (the same p as the assembled system gives, up to the constant and round-off; |r| <= |rhs| makes the check the
+// stricter one).  Further passes refine (never needed so far: the direct solve leaves ~1e-14 |r|).
+static int poisson_direct_step(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
+  hipStream_t s = c->stream;
+  const int64_t np = npre(c);
+  KrylovWork& w = c->kw;
+  w.ensure(std::max<int64_t>(np, nvel(c)));
+  ++w.touch;
+  double* parts = w.parts.p;
+  constexpr int PR = 10, PB0 = 13;
+  launch_spmv_scaled(s, c->Dv, 1, -c->alpha[0] / c->k, c->state[NSFEM_USTAR].p, w.r.p);
+  launch_sum_sub_mean(s, np, w.r.p, parts + PR * kParts);
+  launch_dot(s, np, w.r.p, w.r.p, parts + PB0 * kParts);
+  const double* base = c->state[NSFEM_P_OLD].p;
+  info.iterations = 0;
+  info.converged = 0;
+  for (int pass = 0; pass < std::max(1, std::min(o.max_iter, 8)); ++pass) {
+    c->fd_p.apply(s, w.r.p, w.z.p);
+    launch_axpby(s, np, 1.0, base, 1.0, w.z.p, c->state[NSFEM_P].p);          // p = p_old + z (later passes: p += z)
+    base = c->state[NSFEM_P].p;
+    ++info.iterations;
+    launch_residual(s, c->Ap, 1, w.z.p, w.r.p, w.q.p, nullptr, MASK_NONE);    // q = r - A z
+    launch_dot(s, np, w.q.p, w.q.p, parts + PR * kParts);
+    double qq, rr;
+    host_sum_parts2(s, w, PR, PB0, qq, rr);
+    if (!std::isfinite(qq)) return NSFEM_ERR_BREAKDOWN;
+    const double rnorm = std::sqrt(rr);
+    const double target = std::max(o.atol, o.rtol * (rnorm > 0.0 ? rnorm : 1.0));
+    w.last_target = target;
+    info.residual = std::sqrt(qq);
+    if (pass == 0) info.residual0 = rnorm;
+    if (info.residual <= target) { info.converged = 1; break; }
+    std::swap(w.r.p, w.q.p);                                                   // refine: the residual is the next right-hand side
+  }
+  return info.converged ? NSFEM_OK : NSFEM_ERR_NOT_CONVERGED;
+}
+
 static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info) {
   if (o.precond == 3) return poisson_solve_fast_diag(c, o, info);
   LinOp op;
@@ -979,13 +1021,25 @@ static int poisson_solve(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_i
 }
 
 // rhs = M u* - k/alpha0 G (p - p_old) ; start vector u0 = u* with Dirichlet values
-static void correction_assemble(nsfem_ctx* c) {
+// with_start_residual (fused step, one rank, Chebyshev mass solve): the start residual of the solve and the two sums
+// its convergence check needs come out of the same pass as the right-hand side (k_correction_setup): r0 in kw.r,
+// |r0|^2 and |rhs|^2 in the partial-sum slots 12, 13
+static void correction_assemble(nsfem_ctx* c, bool with_start_residual = false) {
   hipStream_t s = c->stream;
   const int64_t nv = nvel(c), np = npre(c);
   launch_spmv(s, c->M2, c->mesh.dim, c->state[NSFEM_USTAR].p, c->rhs_v.p, nullptr, MASK_NONE);
   launch_axpby(s, np, 1.0, c->state[NSFEM_P].p, -1.0, c->state[NSFEM_P_OLD].p, c->tmp_p.p);
   launch_spmv(s, c->Gr, 1, c->tmp_p.p, c->tmp_v.p, nullptr, MASK_NONE);
-  launch_axpby(s, nv, 1.0, c->rhs_v.p, -c->k / c->alpha[0], c->tmp_v.p, c->rhs_v.p);
+  c->cor_start_ready = false;
+  if (with_start_residual && !c->distributed() && c->mask_v.p) {
+    c->kw.ensure(nv);
+    launch_correction_setup(s, nv, -c->k / c->alpha[0], c->rhs_v.p, c->tmp_v.p, c->mask_v.p, c->kw.r.p,
+                            c->kw.parts.p + 12 * kParts, c->kw.parts.p + 13 * kParts);
+    c->cor_start_ready = true;
+    c->cor_start_touch = ++c->kw.touch;
+  } else {
+    launch_axpby(s, nv, 1.0, c->rhs_v.p, -c->k / c->alpha[0], c->tmp_v.p, c->rhs_v.p);
+  }
   if (c->ghost_v.p) launch_zero_ghost(s, nv, c->mask_v.p, c->rhs_v.p);
   NSFEM_HIP(hipMemcpyAsync(c->state[NSFEM_U0].p, c->state[NSFEM_USTAR].p, sizeof(double) * nv,
                            hipMemcpyDeviceToDevice, s));
@@ -1048,10 +1102,16 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
   // (one rank) the start-up sums |r0|^2, |b|^2 are not read back before the sequence: they wait in their own slots
   // and come with the residual check after it -- one device -> host round trip per solve instead of two.
   int k_hint = o.first_check >= 1 ? o.first_check : 0;
-  const bool deferred = k_hint > 0 && !c->distributed();
+  // (correction_assemble left r0 in w.r and the sums in slots 12, 13 -- and no other solver has run since)
+  const bool start_ready = c->cor_start_ready && c->cor_start_touch == w.touch;
+  c->cor_start_ready = false;
+  ++w.touch;
+  const bool deferred = (k_hint > 0 || start_ready) && !c->distributed();
   constexpr int PR0 = 12, PB0 = 13;
-  residual_norm(w.r.p, deferred ? PR0 : P10);
-  launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, parts + (deferred ? PB0 : P10 + 1) * kParts);
+  if (!start_ready) {
+    residual_norm(w.r.p, deferred ? PR0 : P10);
+    launch_dot(s, nv, c->rhs_v.p, c->rhs_v.p, parts + (deferred ? PB0 : P10 + 1) * kParts);
+  }
   if (c->distributed()) c->comm->allreduce_sum(s, parts + P10 * kParts, 2 * kParts);
   double rr0 = 0.0, bb0 = 0.0, r0 = 0.0, bnorm = 0.0, target = 0.0;
   if (!deferred) {
@@ -1070,7 +1130,19 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
   bool first_pass = true;
   while (!info.converged && info.iterations < o.max_iter) {
     // steps needed for the error bound 2 sqrt(kappa) ((sqrt(kappa)-1)/(sqrt(kappa)+1))^k <= target / res
-    int k = (deferred && first_pass) ? k_hint : (int)std::ceil(std::log(2.0 * sk * res / target) / rate);
+    int k = (deferred && first_pass && k_hint > 0) ? k_hint : 0;
+    if (k == 0 && deferred && first_pass) {
+      // no prediction yet (first step): the start sums are read now after all
+      double rr_, bb_;
+      host_sum_parts2(s, w, PR0, PB0, rr_, bb_);
+      r0 = res = std::sqrt(rr_);
+      bnorm = std::sqrt(bb_);
+      target = std::max(o.atol, o.rtol * (bnorm > 0.0 ? bnorm : 1.0));
+      w.last_target = target;
+      info.residual0 = info.residual = r0;
+      if (r0 <= target) { info.converged = 1; break; }
+    }
+    if (k == 0) k = (int)std::ceil(std::log(2.0 * sk * res / target) / rate);
     if (k_hint > 0) k = std::min(k, k_hint);
     k_hint = 0;
     k = std::max(1, std::min(k, o.max_iter - info.iterations));
@@ -1125,7 +1197,7 @@ extern "C" int nsfem_assemble(nsfem_ctx* ctx, int system, uint32_t flags) {
       poisson_assemble(ctx);
       break;
     case NSFEM_SYS_CORRECTION:
-      correction_assemble(ctx);
+      correction_assemble(ctx, true);      // (the same pass as the fused driver: its Chebyshev solve may start from it)
       break;
     default:
       throw Error(NSFEM_ERR_ARG, "nsfem_assemble: system not available");
@@ -1850,16 +1922,21 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   if (!converged) throw Error(NSFEM_ERR_NOT_CONVERGED, "Newton solver did not converge");
   // ---- projection step
   {
-    poisson_assemble(ctx, opts->pressure_extrapolation != 0);
     nsfem_solve_info si;
-    int rc = poisson_solve(ctx, hinted(opts->poisson, ctx->hint_poi), si);
+    int rc;
+    if (opts->poisson.precond == 3 && ctx->nbc_p == 0 && !ctx->distributed() && ctx->fd_p.ready()) {
+      rc = poisson_direct_step(ctx, opts->poisson, si);
+    } else {
+      poisson_assemble(ctx, opts->pressure_extrapolation != 0);
+      rc = poisson_solve(ctx, hinted(opts->poisson, ctx->hint_poi), si);
+    }
     note_solve(ctx->hint_poi, si, opts->poisson, ctx->kw.last_target);
     inf.krylov_iterations_poisson = si.iterations;
     if (rc != NSFEM_OK) throw Error(rc, "CG failed in the projection step");
   }
   // ---- velocity correction step
   {
-    correction_assemble(ctx);
+    correction_assemble(ctx, opts->correction.precond == 2);
     nsfem_solve_info si;
     int rc = correction_solve(ctx, hinted(opts->correction, ctx->hint_cor, opts->correction.precond == 2), si);
     note_solve(ctx->hint_cor, si, opts->correction, ctx->kw.last_target);
@@ -2037,7 +2114,8 @@ extern "C" int nsfem_advance(nsfem_ctx* ctx, int scheme) {
     NSFEM_HIP(hipMemcpyAsync(ctx->state[NSFEM_P_OLD].p, ctx->state[NSFEM_P].p,
                              sizeof(double) * npre(ctx), hipMemcpyDeviceToDevice, s));
   }
-  NSFEM_HIP(hipStreamSynchronize(s));
+  // (no synchronisation: everything that reads the state is ordered on the context's stream, nsfem_get_state and
+  // nsfem_synchronize wait for it -- a host wait here left the GPU idle ~20 us in every time step)
   API_END(ctx)
 }
 

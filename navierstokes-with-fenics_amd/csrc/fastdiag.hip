@@ -65,7 +65,22 @@ __global__ __launch_bounds__(256) void k_fd_gemm(int M, int N, int K, const doub
       Bs[nb * kFdLd + kb] = rb[q];
     }
   };
-  fd_acc4 acc = {0.0, 0.0, 0.0, 0.0};
+  // (two accumulator chains and the block's 2 x 24 fragments read before its first MFMA: one chain waits for every
+  // product and, just in time, for its LDS read)
+  fd_acc4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  auto block_products = [&](const double* __restrict__ ap, const double* __restrict__ bp) {
+    double af[kFdBK / 4], bf[kFdBK / 4];
+#pragma unroll
+    for (int i = 0; i < kFdBK / 4; ++i) {
+      af[i] = ap[4 * i];
+      bf[i] = bp[4 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < kFdBK / 4; i += 2) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[i], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i + 1], bf[i + 1], acc2, 0, 0, 0);
+    }
+  };
   const double* __restrict__ ap = As + (wm + (lane & 15)) * kFdLd + (lane >> 4);       // A[m = lane & 15][k = lane >> 4]
   const double* __restrict__ bp = Bs + (wn + (lane & 15)) * kFdLd + (lane >> 4);       // B[k = lane >> 4][n = lane & 15]
   load_block(0, ra0, rb0);
@@ -75,16 +90,15 @@ __global__ __launch_bounds__(256) void k_fd_gemm(int M, int N, int K, const doub
     store_block(ra0, rb0);
     __syncthreads();
     if (k0 + 2 * kFdBK < K) load_block(k0 + 2 * kFdBK, ra0, rb0);
-#pragma unroll
-    for (int kk = 0; kk < kFdBK; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc, 0, 0, 0);
+    block_products(ap, bp);
     if (k0 + kFdBK >= K) break;
     __syncthreads();
     store_block(ra1, rb1);
     __syncthreads();
     if (k0 + 3 * kFdBK < K) load_block(k0 + 3 * kFdBK, ra1, rb1);
-#pragma unroll
-    for (int kk = 0; kk < kFdBK; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc, 0, 0, 0);
+    block_products(ap, bp);
   }
+  acc += acc2;
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   const int col = n0 + wn + (lane & 15);
 #pragma unroll

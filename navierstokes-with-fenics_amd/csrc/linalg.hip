@@ -2429,6 +2429,32 @@ __global__ __launch_bounds__(256) void k_dot(int64_t n, const double* __restrict
   v = block_sum(v, sh);
   if (threadIdx.x == 0) parts[blockIdx.x] = v;
 }
+// Right-hand side and start residual of the velocity-correction mass solve in one pass (one rank, fused step):
+//   rhs = M u* + a t  (rhs holds M u* on entry, t = G (p - p_old), a = -k / alpha0)
+//   r0  = a t on free rows, 0 on Dirichlet rows  (= rhs - M u0 for the start vector u0 = u*: the M u* parts cancel)
+// and the partial sums of |rhs|^2 and |r0|^2 -- instead of an axpby, a residual product with M and two dot launches
+__global__ __launch_bounds__(256) void k_correction_setup(int64_t n, double a, double* __restrict__ rhs,
+                                                          const double* __restrict__ t,
+                                                          const uint8_t* __restrict__ mask, double* __restrict__ r0,
+                                                          double* __restrict__ parts_r, double* __restrict__ parts_b) {
+  __shared__ double sh[4];
+  double sr = 0.0, sb = 0.0;
+  GRID_STRIDE(i, n) {
+    const double at = a * t[i];
+    const double b = rhs[i] + at;
+    const double r = mask[i] ? 0.0 : at;
+    rhs[i] = b;
+    r0[i] = r;
+    sb += b * b;
+    sr += r * r;
+  }
+  sr = block_sum(sr, sh);
+  sb = block_sum(sb, sh);
+  if (threadIdx.x == 0) {
+    parts_r[blockIdx.x] = sr;
+    parts_b[blockIdx.x] = sb;
+  }
+}
 __global__ __launch_bounds__(256) void k_set_bc_residual(int nbc, const int32_t* __restrict__ dofs,
                                                          const double* __restrict__ g,
                                                          const double* __restrict__ x,
@@ -2558,6 +2584,10 @@ void launch_lincomb3(hipStream_t s, int64_t n, double a, const double* x, double
 void launch_scale_combine(hipStream_t s, int nnz, double a, const double* A, double b,
                           const double* B, double* C) {
   LAUNCH(k_axpby, vgrid(nnz), s, (int64_t)nnz, a, A, b, B, C);
+}
+void launch_correction_setup(hipStream_t s, int64_t n, double a, double* rhs, const double* t, const uint8_t* mask,
+                             double* r0, double* parts_r, double* parts_b) {
+  LAUNCH(k_correction_setup, kParts, s, n, a, rhs, t, mask, r0, parts_r, parts_b);
 }
 // x -= mean(x) (the compatible right-hand side of a singular Neumann problem); `parts`: one partial-sum slot
 void launch_sum_sub_mean(hipStream_t s, int64_t n, double* x, double* parts) {
@@ -2955,6 +2985,7 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   const int64_t n = op.custom ? op.custom->n
                               : (int64_t)op.A->pat->n_rows * op.A->br * op.nv;
   w.ensure(n);
+  ++w.touch;
   double* parts = w.parts.p;
   double* scal = w.scal.p;
   auto apply = [&](const double* in, double* out) {
@@ -3314,6 +3345,7 @@ int pcg(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, double* 
   const Pattern& pat = *op.A->pat;
   const int64_t n = (int64_t)pat.n_rows * op.A->br * op.nv;
   w.ensure(n);
+  ++w.touch;
   double* parts = w.parts.p;
   const double* rhs = b;
   if (project_mean) {

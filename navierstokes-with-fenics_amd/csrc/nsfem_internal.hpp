@@ -401,6 +401,8 @@ void launch_scale_combine(hipStream_t s, int nnz, double a, const double* A, dou
                           const double* B, double* C);            // C = a A + b B (values)
 void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, double* parts);
 void launch_sum_sub_mean(hipStream_t s, int64_t n, double* x, double* parts);
+void launch_correction_setup(hipStream_t s, int64_t n, double a, double* rhs, const double* t, const uint8_t* mask,
+                             double* r0, double* parts_r, double* parts_b);
 void launch_set_bc_residual(hipStream_t s, int nbc, const int32_t* dofs, const double* g,
                             const double* x, double* b);          // b[d] = x[d] - g[d]
 void launch_set_values(hipStream_t s, int nbc, const int32_t* dofs, const double* g, double* x);
@@ -441,6 +443,7 @@ struct KrylovWork {
   // replay is worth its capture only while the baked arguments stay put: contexts whose operators change every few
   // iterations (variable time steps) fall back to eager launches (graphs_off); profiling windows that record HIP
   // events inside the bodies suspend it
+  uint64_t touch = 0;           // bumped by every solver that uses the work vectors (who may rely on what another left in them)
   double last_target = 0.0;     // absolute residual target of the last solve (max(atol, rtol |b|)): the drivers' iteration predictor
   bool graphs_off = false, graphs_suspended = false;
   int64_t replays_in_epoch = 0;
@@ -915,6 +918,8 @@ struct nsfem_ctx {
   nsfem::Transfer t_p2p1;                      // P2 (fine mesh) <- P1 (fine mesh)
   nsfem::BlockMat Lc0;                         // alpha0/k M_p + c_v A_p on the fine P1 space
   nsfem::Multigrid mg_p, mg_v;
+  bool cor_start_ready = false;                // correction_assemble produced the mass solve's start residual and sums
+  uint64_t cor_start_touch = 0;                //   ... and nobody has used the Krylov work vectors since (kw.touch)
   nsfem::FastDiag fd_p;                        // direct projection-step solver on tensor-product lattices
   bool fd_p_singular = false;
   bool mg_built = false, mg_p_dirty = true, mg_v_dirty = true;

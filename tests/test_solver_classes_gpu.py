@@ -242,7 +242,8 @@ def test_transient_cavity_fused_and_explicit_seam_agree():
 
 def test_throughput_settings_through_the_solver_surface_reproduce_the_c_abi_run_bitwise():
     """The settings bench.py times -- Krylov rtol 1e-8, inexact Newton (forcing 1e-4), extrapolated pressure
-    start vector, Chebyshev mass solve, truncated velocity cycle -- are attributes of the solver classes
+    start vector, Chebyshev mass solve, truncated velocity cycle, projection step by fast diagonalisation -- are
+    attributes of the solver classes
     (`problem.solver_settings`, `InstationarySolverBase.throughput_settings`).  A cavity run through
     InstationaryProblem / IPCSSolver.solve() / advance_time() with them must equal, BIT FOR BIT, the same steps
     driven through the raw C ABI (nsfem_step_ipcs with the same nsfem_step_opts and the (alpha, k) sequence the
@@ -262,6 +263,7 @@ def test_throughput_settings_through_the_solver_surface_reproduce_the_c_abi_run_
     assert solver.newton_forcing == 1e-4 and solver.pressure_start == "extrapolated" and solver.krylov_rtol == 1e-8
     opts = solver._step_options()
     assert opts.newton_forcing == 1e-4 and opts.pressure_extrapolation == 1 and opts.correction.precond == 2
+    assert solver.poisson_solver == "fast_diagonalization" and opts.poisson.precond == 3
     u_cls, p_cls = solver._ctx.get_state(nat.U1), solver._ctx.get_state(nat.P_OLD)
     # ---- the same steps through the C ABI on a fresh context
     dm, mesh = solver._dofmap, solver._mesh
@@ -273,11 +275,14 @@ def test_throughput_settings_through_the_solver_surface_reproduce_the_c_abi_run_
     ctx.set_dirichlet(nat.VELOCITY, np.asarray(bd, np.int32), np.asarray(bv, float))
     ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
     ctx.mg_set_truncation(4.0, 0.1)
+    import poisson_fd
+    ctx.poisson_set_fast_diag(poisson_fd.factors(*poisson_fd.lattice_lines(mesh), np.zeros(0, np.int64)))
     ts = BDFTimeStepping(0.0, 1.0, desired_start_time_step=dt)
     o = ctx.default_step_opts()
     for k in (o.momentum, o.poisson, o.correction):
         k.rtol, k.max_iter = 1e-8, solver.krylov_max_iter
-    o.momentum.precond = o.poisson.precond = 1
+    o.momentum.precond = 1
+    o.poisson.precond = 3
     o.correction.precond = 2
     o.newton_forcing, o.pressure_extrapolation = 1e-4, 1
     for _ in range(steps):

@@ -660,9 +660,12 @@ def test_inexact_newton_reaches_the_reference_criterion_and_the_same_fields(sche
     ctx.close()
 
 
-def test_timed_settings_on_the_lattice_kernels_match_the_oracle_at_config0_size():
-    """What bench.py times -- ALL five throughput knobs together (Krylov rtol 1e-8, Newton forcing 1e-4, truncated
-    velocity cycle, Chebyshev mass solve, extrapolated pressure start) on the one-launch lattice kernels
+@pytest.mark.parametrize("poisson", ["fast_diagonalization", "multigrid"])
+def test_timed_settings_on_the_lattice_kernels_match_the_oracle_at_config0_size(poisson):
+    """What bench.py times -- ALL throughput knobs together (Krylov rtol 1e-8, Newton forcing 1e-4, truncated
+    velocity cycle, Chebyshev mass solve, and the projection step either by fast diagonalisation on the matrix cores
+    = the bench default, or by multigrid-CG with the extrapolated pressure start = `--poisson-solver mg` and every
+    partitioned run) on the one-launch lattice kernels
     (k_cheb_lattice with fused transfers, k_jac_lattice) -- against the LU oracle at BASELINE configs[0]'s size,
     64 x 64 cells (129 x 129 P2 lattice: 3 x 11 tiles of the lattice smoother), 4 steps of the Re = 100 cavity.
     Velocity and pressure agree to north_star's 1e-6 and every step ends on the reference's Newton criterion
@@ -685,6 +688,10 @@ def test_timed_settings_on_the_lattice_kernels_match_the_oracle_at_config0_size(
     for k in (o.momentum, o.poisson, o.correction):
         k.rtol = 1e-8
     o.momentum.precond = o.poisson.precond = 1
+    if poisson == "fast_diagonalization":
+        import poisson_fd as pf
+        ctx.poisson_set_fast_diag(pf.factors(*pf.lattice_lines(mesh), np.zeros(0, np.int32)))
+        o.poisson.precond = 3
     o.correction.precond = 2                         # Chebyshev mass solve with a-priori bounds
     o.newton_forcing = 1e-4
     o.pressure_extrapolation = 1

@@ -450,7 +450,9 @@ int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]);
 /* Test hook: z = M^-1 r, one cycle of a multigrid preconditioner on host vectors (which: 0 = pressure Poisson
    hierarchy, 1 = velocity hierarchy); nsfem_mg_info: out = {fused-leg kind (0 separate launches, 1 one launch below
    the finest level of a truncated cycle, 2 down-legs + tail + up-legs), fused launches per cycle, levels in use,
-   fused launches so far}.  New functionality (the reference has no preconditioner: sparse LU,
+   fused launches so far}; which = 2 / 3: the multi-step lattice kernel on the Poisson / velocity hierarchy: out =
+   {levels whose smoothing sequences run in it (partitioned strips: relaxed halo mode only), its launches so far,
+   levels in use, ghost lattice lines of the finest level as bottom * 256 + top}.  New functionality (the reference has no preconditioner: sparse LU,
    source/ns_ipcs_solver.py:171,205). */
 int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double* z);   /* which = 2: fast diagonalisation */
 /* Direct solver of the projection step on tensor-product lattices (replaces the sparse LU of

@@ -488,6 +488,14 @@ class NsfemContext:
         self._check(self._lib.nsfem_mg_info(self._h, int(which), out))
         return dict(legs=int(out[0]), launches_per_cycle=int(out[1]), levels=int(out[2]), leg_launches=int(out[3]))
 
+    def mg_lattice_info(self, which):
+        """dict(lattice_levels, lattice_launches, levels, ghost_lines): the multi-step lattice kernel on the Poisson
+        (which = 0) / velocity (1) hierarchy; on partitioned strips it runs in relaxed halo mode only"""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.nsfem_mg_info(self._h, 2 + int(which), out))
+        return dict(lattice_levels=int(out[0]), lattice_launches=int(out[1]), levels=int(out[2]),
+                    ghost_lines=(int(out[3]) // 256, int(out[3]) % 256))
+
     def mg_set_schur_mode(self, additive):
         """partitioned meshes: the Schur operators set afterwards are this rank's additive parts"""
         self._check(self._lib.nsfem_mg_set_schur_mode(self._h, 1 if additive else 0))

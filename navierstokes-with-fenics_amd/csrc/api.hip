@@ -758,13 +758,17 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
 // how the matrix-free Jacobian action runs: 0 = L product, element kernel, node gather; 1 = element kernel, then
 // the L product sums its node-sorted vectors (one GPU, triangles, stencil dictionary); 2 = k_jac_lattice, everything
 // in one launch (lattice mesh in rectangle_mesh numbering, gradient-form viscosity, no rotating frame)
+// Partitioned strips (round 4): the local mesh of a rank is a lattice of its own (own cell rows + the ghost row), so
+// path 2 runs there as well -- after ONE halo exchange of the input; rows of ghost nodes come out as zeros (mask
+// value 2).  Path 1 stays single-context (its node-sorted buffer has no interior / halo split).
 static int jacobian_path(nsfem_ctx* c) {
-  if (c->distributed() || c->mesh.dim != 2 || cc_of(c) == 0.0 || !c->L.dict_ready) return 0;
+  if (c->mesh.dim != 2 || cc_of(c) == 0.0 || !c->L.dict_ready) return 0;
+  if (c->distributed() && !partitioned_lattice_kernels()) return 0;
   if (!c->mesh.cl.tried && c->L.dict && c->L.dict->lat_w > 0)
     build_cell_lattice(c->h_p2map.data(), c->mesh.n_cells, c->L.dict->lat_w, c->L.dict->lat_h, c->mesh.cl);
   if (!c->traction_form && coriolis_gamma(c) == 0.0 && c->mask_v.p && jacobian_lattice_available(c->mesh, c->L))
     return 2;
-  return 1;
+  return c->distributed() ? 0 : 1;
 }
 
 void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
@@ -779,11 +783,34 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
   // one GPU, triangles, lattice mesh: the element kernel of the convection action first, then ONE launch of the
   // dictionary kernel forms L x AND sums the node-sorted element vectors (no separate node gather, y is written
   // once instead of written, read and written again)
-  if (!c->distributed() && dim == 2 && cc != 0.0 && c->L.dict_ready) {
+  const int path = (dim == 2 && cc != 0.0 && c->L.dict_ready) ? jacobian_path(c) : 0;
+  if (path != 0) {
     nsfem_ctx::Probe& pr = c->conv_probe;
     const bool timed = pr.on && pr.n + 2 <= pr.ev.size();
     // lattice meshes: element kernel, node sums and L product in one launch (k_jac_lattice)
-    if (jacobian_path(c) == 2) {
+    if (path == 2) {
+      // strips: the ghost lines of the input first -- under the tile rows that read none of them when the overlap
+      // mode is on and the strip is high enough; the kernel writes zeros to the ghost rows
+      if (c->distributed()) {
+        if (c->p2_gh_lo == -2) {
+          int lo, hi;
+          const bool lines = c->L.dict && ghost_lattice_lines(c->h_ghost_p2, c->L.dict->lat_w, c->L.dict->lat_h, lo, hi);
+          c->p2_gh_lo = lines ? lo : -1;
+          c->p2_gh_hi = lines ? hi : -1;
+        }
+        if (c->comm->overlap && c->p2_gh_lo >= 0 && jacobian_lattice_split(c->mesh, c->p2_gh_lo, c->p2_gh_hi)) {
+          c->comm->exchange_begin(s, c->halo_p2, const_cast<double*>(x), dim);
+          bool ok = launch_jacobian_lattice(s, c->mesh, c->L, c->state[vel_slot].p, x, cc, c->conv_form, c->picard,
+                                            c->mask_v.p, y, 1, c->p2_gh_lo, c->p2_gh_hi);
+          c->comm->exchange_end(s);
+          ok = ok && launch_jacobian_lattice(s, c->mesh, c->L, c->state[vel_slot].p, x, cc, c->conv_form, c->picard,
+                                             c->mask_v.p, y, 2, c->p2_gh_lo, c->p2_gh_hi);
+          NSFEM_REQUIRE(ok, "one-launch Jacobian action: tile-row split failed");
+          ++c->jac_lattice_launches;
+          return;
+        }
+        c->comm->exchange(s, c->halo_p2, const_cast<double*>(x), dim);
+      }
       if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
       if (launch_jacobian_lattice(s, c->mesh, c->L, c->state[vel_slot].p, x, cc, c->conv_form, c->picard,
                                   c->mask_v.p, y)) {
@@ -795,19 +822,21 @@ void nsfem_ctx::MomentumMF::apply(hipStream_t s, const double* x, double* y) {
         return;
       }
     }
-    if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
-    launch_convection_cells(s, c->mesh, c->state[vel_slot].p, x, cc, c->conv_form, c->picard);
-    if (timed) {
-      NSFEM_HIP(hipEventRecord(pr.ev[pr.n + 1], s));
-      pr.n += 2;
+    if (!c->distributed()) {
+      if (timed) NSFEM_HIP(hipEventRecord(pr.ev[pr.n], s));
+      launch_convection_cells(s, c->mesh, c->state[vel_slot].p, x, cc, c->conv_form, c->picard);
+      if (timed) {
+        NSFEM_HIP(hipEventRecord(pr.ev[pr.n + 1], s));
+        pr.n += 2;
+      }
+      if (launch_spmv_with_gather(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, c->mesh.nptr.p, c->mesh.rbuf.p)) {
+        if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, c->mask_v.p);
+        const double g = coriolis_gamma(c);
+        if (g != 0.0) coriolis_apply(c, g, x, y, c->mask_v.p);
+        return;
+      }
+      // (no dictionary kernel: product, then the gather below re-runs the cheap element kernel)
     }
-    if (launch_spmv_with_gather(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, c->mesh.nptr.p, c->mesh.rbuf.p)) {
-      if (c->traction_form) launch_spmv_axpy(s, c->E, 1, c->coef[2], x, y, c->mask_v.p);
-      const double g = coriolis_gamma(c);
-      if (g != 0.0) coriolis_apply(c, g, x, y, c->mask_v.p);
-      return;
-    }
-    // (no dictionary kernel: product, then the gather below re-runs the cheap element kernel)
   }
   product_with_halo(c->distributed() ? c->comm : nullptr, &c->halo_p2, dim, s, x, c->L.pat,
                     [&](int phase) { launch_spmv(s, c->L, dim, x, y, c->mask_v.p, MASK_IDENTITY, 0, phase, 1); });
@@ -2552,11 +2581,21 @@ extern "C" int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double
 // launches of k_mg_leg so far}
 extern "C" int nsfem_mg_info(nsfem_ctx* ctx, int which, int64_t out[4]) {
   API_BEGIN
-  NSFEM_REQUIRE(ctx && out && (which == 0 || which == 1), "bad argument");
+  NSFEM_REQUIRE(ctx && out && which >= 0 && which <= 3, "bad argument");
   NSFEM_REQUIRE(ctx->mg_built, "no multigrid hierarchy (nsfem_mg_finalize)");
   ensure_L(ctx);
-  mg_refresh(ctx, which == 1);
-  Multigrid& mg = which == 1 ? ctx->mg_v : ctx->mg_p;
+  mg_refresh(ctx, (which & 1) == 1);
+  Multigrid& mg = (which & 1) ? ctx->mg_v : ctx->mg_p;
+  if (which & 2) {                     // the multi-step lattice kernel on this hierarchy (strips: relaxed halo mode)
+    const size_t n_used = mg.truncated() ? mg.active : mg.lv.size();
+    int64_t levels = 0;
+    for (size_t l = 0; l < n_used; ++l) levels += (mg.lattice_ok(mg.lv[l]) || mg.lattice_ok_relaxed(mg.lv[l])) ? 1 : 0;
+    out[0] = levels;
+    out[1] = mg.lattice_launches;
+    out[2] = (int64_t)n_used;
+    out[3] = mg.lv[0].ghost_lo >= 0 ? mg.lv[0].ghost_lo * 256 + mg.lv[0].ghost_hi : 0;
+    return NSFEM_OK;
+  }
   if (mg.legs_kind < 0) mg.build_legs(ctx->stream);
   out[0] = mg.legs_kind;
   out[1] = mg.legs_kind == 1 ? 1 : (mg.legs_kind == 2 ? (int64_t)(mg.legs_down.size() + mg.legs_up.size() + 1) : 0);
@@ -2647,7 +2686,8 @@ extern "C" int nsfem_smoother_info(nsfem_ctx* ctx, int64_t out[4]) {
   ensure_L(ctx);
   const Multigrid& mg = ctx->mg_v;
   const BlockMat& A = *mg.lv[0].A;
-  out[0] = A.dict_ready ? (mg.lattice_ok(mg.lv[0]) ? 3 : 2) : (A.sell_ready ? 1 : 0);
+  Multigrid& mgw = ctx->mg_v;
+  out[0] = A.dict_ready ? ((mg.lattice_ok(mg.lv[0]) || mgw.lattice_ok_relaxed(mgw.lv[0])) ? 3 : 2) : (A.sell_ready ? 1 : 0);
   out[1] = A.dict_ready ? A.dict->n_stencils : 0;
   out[2] = A.dict_ready ? (A.dict->exact ? -A.dict->lmax : A.dict->lmax) : 0;
   out[3] = smoother_launch_bytes(A, mg.nv, true);

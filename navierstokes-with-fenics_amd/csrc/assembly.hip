@@ -797,6 +797,9 @@ void launch_convection_cells(hipStream_t s, const MeshDev& m, const double* u, c
 struct JacLatArgs {
   int nx, ny, W, H, nc;
   int ntx, ntiles;
+  int tbase, tsplit, tskip;   // tile = tbase + (t < tsplit ? t : t + tskip), t < ntiles: the whole lattice, or the tile
+                              // rows away from / next to the ghost lines of a partitioned strip (two launches around
+                              // the halo exchange)
   int lmax, lp, n_st;   // lp: table row stride (lmax rounded up to 4, zero padded)
   int dbg;              // knock-out build only (NSFEM_KNOCKOUTS): 1 no element kernel, 2 no L product, 4 no node sums
   double cc;
@@ -833,8 +836,9 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   int* __restrict__ tl = to + a.n_st * a.lp;
   // XCD x (workgroups b = x mod 8) walks a contiguous range of tiles: neighbouring tiles share their halo in L2
   const int per = (a.ntiles + 7) >> 3;
-  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (tile >= a.ntiles || NSFEM_KO(a.dbg & 256)) return;
+  const int tlin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tlin >= a.ntiles || NSFEM_KO(a.dbg & 256)) return;
+  const int tile = a.tbase + (tlin < a.tsplit ? tlin : tlin + a.tskip);
   const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
   const int i0 = tx * kJlOX - 2, j0 = ty * kJlOY - 2;               // lattice position of the LDS tile's corner
   const int tid = threadIdx.x;
@@ -979,8 +983,9 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
     double2 v = sa[obase[r]];
     if (!RES) {
       const double2 xo = sx[obase[r]];
-      if (omask[r] & 0x00ff) v.x = xo.x;
-      if (omask[r] & 0xff00) v.y = xo.y;
+      // (flag 1: identity row; flag 2: ghost row of a partitioned strip -> 0, as the SpMV kernels write it)
+      if (omask[r] & 0x00ff) v.x = (omask[r] & 0x0002) ? 0.0 : xo.x;
+      if (omask[r] & 0xff00) v.y = (omask[r] & 0x0200) ? 0.0 : xo.y;
     }
     if (!NSFEM_KO(a.dbg & 32) || v.x == 1.2345) y2[onode[r]] = v;
   }
@@ -1036,9 +1041,13 @@ static int g_jac_lattice_dbg = 0;
 // 62.7 -- the launch is bound by the latency chain of
 // a wave (loads, barriers, LDS phases) at 4 waves per SIMD, not by the shape of the tile
 static int g_jac_lattice_tile = 0;
+static bool g_partitioned_lattice = true;
+bool partitioned_lattice_kernels() { return g_partitioned_lattice; }
 void refresh_assembly_switches() {
   const char* e = std::getenv("NSFEM_JAC_LATTICE");
   g_jac_lattice_on = e ? std::atoi(e) != 0 : true;
+  e = std::getenv("NSFEM_PARTITIONED_LATTICE");       // 0: partitioned strips keep the one-step / multi-launch kernels
+  g_partitioned_lattice = e ? std::atoi(e) != 0 : true;
 #if NSFEM_KNOCKOUTS
   e = std::getenv("NSFEM_JL_DBG");
   g_jac_lattice_dbg = e ? std::atoi(e) : 0;
@@ -1071,9 +1080,28 @@ int64_t jacobian_lattice_bytes(const MeshDev& m) {
 }
 
 // lin: 0 residual (x, mask unused; gadd = g), 1 Newton action, 2 Picard action
+// phase 0: every tile; 1: the tile rows that read no lattice line below `safe_lo` or from `safe_hi` on (the interior of
+// a partitioned strip, launched under the halo exchange); 2: the other tile rows.  jacobian_lattice_split tells
+// whether phases 1 / 2 exist for the given ghost lines
+static bool lattice_tile_rows(const CellLattice& cl, int gh_lo, int gh_hi, int& nty, int& r0, int& r1) {
+  int sx, sy;
+  jac_lattice_shape(sx, sy);
+  const int oy = 2 * (sy - 1);
+  nty = (cl.H + oy - 1) / oy;
+  // tile row ty reads the lattice lines ty * oy - 2 ... (ty + 1) * oy
+  r0 = 0;
+  while (r0 < nty && r0 * oy - 2 < gh_lo) ++r0;
+  r1 = nty;
+  while (r1 > r0 && r1 * oy >= cl.H - gh_hi) --r1;
+  return r1 > r0 && (r0 > 0 || r1 < nty);
+}
+bool jacobian_lattice_split(const MeshDev& m, int gh_lo, int gh_hi) {
+  int nty, r0, r1;
+  return m.cl.ok && lattice_tile_rows(m.cl, gh_lo, gh_hi, nty, r0, r1);
+}
 static bool launch_lattice_cells(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u,
                                  const double* x, double cc, int form, int lin, const uint8_t* mask,
-                                 const double* gadd, double* y) {
+                                 const double* gadd, double* y, int phase = 0, int gh_lo = 0, int gh_hi = 0) {
   const CellLattice& cl = m.cl;
   if (!jacobian_lattice_available(m, L)) return false;
   const StencilDict& d = *L.dict;
@@ -1084,6 +1112,21 @@ static bool launch_lattice_cells(hipStream_t s, const MeshDev& m, const BlockMat
   const int ox = 2 * (sx - 1), oy = 2 * (sy - 1);
   a.ntx = (cl.W + ox - 1) / ox;
   a.ntiles = a.ntx * ((cl.H + oy - 1) / oy);
+  a.tbase = 0; a.tsplit = a.ntiles; a.tskip = 0;
+  if (phase != 0) {
+    int nty, r0, r1;
+    if (!lattice_tile_rows(cl, gh_lo, gh_hi, nty, r0, r1)) return false;
+    if (phase == 1) {
+      a.tbase = r0 * a.ntx;
+      a.ntiles = (r1 - r0) * a.ntx;
+      a.tsplit = a.ntiles;
+    } else {
+      a.ntiles = (r0 + nty - r1) * a.ntx;
+      a.tsplit = r0 * a.ntx;
+      a.tskip = (r1 - r0) * a.ntx;
+    }
+    if (a.ntiles == 0) return true;
+  }
   a.lmax = d.lmax; a.lp = (d.lmax + 3) & ~3; a.n_st = d.n_stencils;
   a.dbg = g_jac_lattice_dbg;
   a.cc = cc;
@@ -1139,9 +1182,9 @@ static bool launch_lattice_cells(hipStream_t s, const MeshDev& m, const BlockMat
 
 bool launch_jacobian_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u,
                              const double* x, double cc, int form, bool picard, const uint8_t* mask,
-                             double* y) {
+                             double* y, int phase, int gh_lo, int gh_hi) {
   if (!mask) return false;
-  return launch_lattice_cells(s, m, L, u, x, cc, form, picard ? 2 : 1, mask, nullptr, y);
+  return launch_lattice_cells(s, m, L, u, x, cc, form, picard ? 2 : 1, mask, nullptr, y, phase, gh_lo, gh_hi);
 }
 // y = L u + g + c_c conv(u): the momentum residual before its Dirichlet rows are set.  Only on dictionaries that
 // equal the assembled matrix bit for bit (the residual decides the convergence of the Newton iteration)

@@ -1025,6 +1025,10 @@ struct LatticeArgs {
   const double* rf;         // right-hand side = R rf  (restriction of the finer level's vector, lattice 2 W - 1 wide),
   double* b_out;            //   stored to b_out on the output tile for the later launches of the level
   int Wc, Wf, Hf;
+  // partitioned strips, relaxed halo mode: the first gh_lo and the last gh_hi lattice lines are ghost rows -- their
+  // iterate is FROZEN through the stages of the launch (block-Jacobi across the ranks, as the one-step kernels do
+  // with SpmvArgs::ghost = 1); gh_zero: the launch ends a smoothing sequence, the ghost rows are stored as zeros
+  int gh_lo, gh_hi, gh_zero;
   double c1[8], c2[8];     // (up to 7 steps on reach-1 operators: 6 applications after the pointwise first step)
 };
 
@@ -1110,6 +1114,8 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
             dn = c2 * di * (st.bq[q][c] - acc[c]);
             if (c1 != 0.0) dn += c1 * st.dq[q][c];
             xn = src[(size_t)st.self(q) * NV + c] + dn;
+          } else if (LAT_MK(q) & 4) {          // ghost row of a strip: frozen
+            xn = src[(size_t)st.self(q) * NV + c];
           } else if (a.ident && last) {
             xn = st.bq[q][c];
           }
@@ -1177,6 +1183,8 @@ __device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, Lat
             dn = c2 * di * (st.bq[q][c] - acc[c]);
             if (c1 != 0.0) dn += c1 * st.dq[q][c];
             xn = src[(size_t)st.self(q) * NV + c] + dn;
+          } else if (LAT_MK(q) & 4) {          // ghost row of a strip: frozen
+            xn = src[(size_t)st.self(q) * NV + c];
           } else if (a.ident && last) {
             xn = st.bq[q][c];
           }
@@ -1232,7 +1240,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   //   pass 1  rings, clamped node indices, the byte entry | masks of every slot
   //   pass 2  the vector operands of every slot (b or the 7 fine values of R rf; d; x, P xc)
   //   pass 3  masks and conditions applied, slot state filled, start iterate stored to LDS
-  int ringq[K], smq[K], gjcq[K];
+  int ringq[K], smq[K], gjcq[K], ghq[K];
   size_t gcl[K];
   const int gic = min(max(gi, 0), a.W - 1);
 #pragma unroll
@@ -1242,6 +1250,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
     const bool in = in_x && gj >= 0 && gj < a.H;
     const int ey = max(max(j0 - gj, gj - (j1 - 1)), 0);
     ringq[q] = in ? min(max(ex, ey), 255) : 255;
+    ghq[q] = (gj < a.gh_lo || gj >= a.H - a.gh_hi) ? 4 : 0;
     if (q == 0) {
       st.self0 = cls * plane + pr * 32 + (lane & 31);
       st.grow0 = gj * a.W + gi;
@@ -1349,7 +1358,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   for (int q = 0; q < K; ++q) {
     const int ring = ringq[q];
     const bool counts = ring <= need;
-    const int stq = counts ? (smq[q] & 63) : 0, mkq = counts ? (smq[q] >> 6) : 0;
+    const int stq = counts ? (smq[q] & 63) : 0, mkq = counts ? ((smq[q] >> 6) | (((smq[q] >> 6) & 1) ? ghq[q] : 0)) : 0;
     double xv[NV];
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -1379,7 +1388,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
         double v = 0.0;
         if (counts) {
           if (!((mkq >> c) & 1)) v = a.c2[0] * di * st.bq[q][c];
-          else if (a.ident && a.S == 1) v = st.bq[q][c];
+          else if (a.ident && a.S == 1 && !(mkq & 4)) v = st.bq[q][c];
         }
         xv[c] = v;
         st.dq[q][c] = (mkq >> c) & 1 ? 0.0 : v;
@@ -1411,7 +1420,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
     if (LAT_RING(q) == 0) {
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
-        a.x_out[st.grow(q) * NV + c] = fin[(size_t)st.self(q) * NV + c];
+        a.x_out[st.grow(q) * NV + c] = (a.gh_zero && (LAT_MK(q) & 4)) ? 0.0 : fin[(size_t)st.self(q) * NV + c];
         if (a.d_out) a.d_out[st.grow(q) * NV + c] = st.dq[q][c];
       }
     }
@@ -1477,15 +1486,19 @@ static const int32_t* lattice_offsets(hipStream_t s, const StencilDict& d, int e
 void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
                          const double* d_in, double* x_out, double* d_out, double* r_out,
                          const uint8_t* mask, int steps, const double* c1, const double* c2, int ident,
-                         const uint8_t* sidm, const double* xc, const double* rf, double* b_out) {
+                         const uint8_t* sidm, const double* xc, const double* rf, double* b_out, int gh_lo, int gh_hi,
+                         int gh_zero) {
   const StencilDict& d = *A.dict;
   NSFEM_REQUIRE(steps >= 1 && steps <= 8, "lattice smoother: 1..8 steps per launch");
+  NSFEM_REQUIRE(gh_lo >= 0 && gh_hi >= 0 && gh_lo + gh_hi < d.lat_h && !((gh_lo || gh_hi) && (xc || rf)),
+                "lattice smoother: bad ghost lines (strips run without fused transfers)");
   NSFEM_REQUIRE(x_out != x_in, "lattice smoother works out of place");
   NSFEM_REQUIRE(!rf || b_out, "fused restriction needs a place to keep the right-hand side");
   LatticeArgs a;
   a.W = d.lat_w; a.H = d.lat_h; a.R = d.lat_r; a.S = steps;
   a.from_zero = (x_in || xc) ? 0 : 1;
   a.xc = xc; a.rf = rf; a.b_out = b_out;
+  a.gh_lo = gh_lo; a.gh_hi = gh_hi; a.gh_zero = gh_zero;
   a.Wc = (d.lat_w + 1) / 2; a.Wf = 2 * d.lat_w - 1; a.Hf = 2 * d.lat_h - 1;
   a.Mv = steps - a.from_zero + (r_out ? 1 : 0);
   NSFEM_REQUIRE(a.Mv >= 0 && a.Mv * a.R <= 8, "lattice smoother: halo too wide");

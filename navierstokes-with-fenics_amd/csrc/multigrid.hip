@@ -613,6 +613,43 @@ bool Multigrid::lattice_ok(const MGLevel& L) const {
   return !L.additive && !(comm_active() && L.has_halo) && lattice_smoother_available(*L.A, nv);
 }
 
+bool ghost_lattice_lines(const std::vector<uint8_t>& g, int W, int H, int& lo, int& hi) {
+  lo = hi = -1;
+  if (W <= 0 || H <= 0 || (size_t)W * H != g.size()) return false;
+  std::vector<int> line(H);
+  for (int j = 0; j < H; ++j) {
+    int cnt = 0;
+    for (int i = 0; i < W; ++i) cnt += g[(size_t)j * W + i] != 0;
+    if (cnt != 0 && cnt != W) return false;
+    line[j] = cnt == W;
+  }
+  int a = 0, b = 0;
+  while (a < H && line[a]) ++a;
+  while (b < H - a && line[H - 1 - b]) ++b;
+  for (int j = a; j < H - b; ++j)
+    if (line[j]) return false;
+  if (a + b >= H) return false;
+  lo = a;
+  hi = b;
+  return true;
+}
+
+bool Multigrid::lattice_ok_relaxed(MGLevel& L) {
+  if (L.additive || !(comm_active() && L.has_halo) || !relaxed_halo || !partitioned_lattice_kernels() ||
+      !lattice_smoother_available(*L.A, nv) || !L.h_ghost)
+    return false;
+  if (L.ghost_lo == -2) {
+    int lo, hi;
+    if ((int)L.h_ghost->size() == L.n && ghost_lattice_lines(*L.h_ghost, L.A->dict->lat_w, L.A->dict->lat_h, lo, hi)) {
+      L.ghost_lo = lo;
+      L.ghost_hi = hi;
+    } else {
+      L.ghost_lo = L.ghost_hi = -1;
+    }
+  }
+  return L.ghost_lo >= 0;
+}
+
 // algorithmic bytes of one launch of the lattice kernel: one byte per row (dictionary entry), the
 // mask, the dictionary once, and the vectors the launch reads / writes
 int64_t lattice_launch_bytes(const BlockMat& A, int nv, bool from_zero, bool d_in, bool d_out,
@@ -665,8 +702,11 @@ void Multigrid::smooth_lattice(hipStream_t s, MGLevel& L, const double* b, const
     double* out = last ? x_out : (cur == L.xa.p ? L.xb.p : L.xa.p);
     double* d_out = last ? nullptr : (d_cur == L.d.p ? L.d2.p : L.d.p);
     NSFEM_REQUIRE(out != cur, "lattice smoother: the caller must smooth out of place");
+    const bool strip = comm_active() && L.has_halo;        // (only reached when lattice_ok_relaxed(L))
+    ++lattice_launches;
     launch_cheb_lattice(s, *L.A, nv, cur, b, d_cur, out, d_out, rr, L.mask, ns, c1 + k, c2 + k,
-                        ident_last && last ? 1 : 0, sidm, xc_k, rf_k, rf_k ? const_cast<double*>(b) : nullptr);
+                        ident_last && last ? 1 : 0, sidm, xc_k, rf_k, rf_k ? const_cast<double*>(b) : nullptr,
+                        strip ? L.ghost_lo : 0, strip ? L.ghost_hi : 0, strip && last ? 1 : 0);
     if (timed) {
       ++prof_launches;
       prof_steps += ns;
@@ -697,6 +737,19 @@ void Multigrid::smooth(hipStream_t s, MGLevel& L, const double* b, const double*
   }
   if (!first_done && x_out != x_in && steps >= 1 && lattice_ok(L)) {
     smooth_lattice(s, L, b, x_in, x_out, steps, ident_last, nullptr);
+    return;
+  }
+  // partitioned strip, relaxed halo mode: ONE exchange of the start vector's ghost lines (none from zero, none when
+  // the caller filled them), then the whole sequence in the lattice kernel with the ghost lines frozen; the ghost
+  // rows of the result are zeros, as the last one-step launch of a sequence leaves them
+  if (!first_done && steps >= 1 && lattice_ok_relaxed(L)) {
+    const double* in = x_in;
+    if (in && !ghosts_valid) comm->exchange(s, L.halo, const_cast<double*>(in), nv);
+    if (in && in == x_out) {               // the kernel works out of place
+      NSFEM_HIP(hipMemcpyAsync(L.xc.p, in, sizeof(double) * (size_t)L.n * nv, hipMemcpyDeviceToDevice, s));
+      in = L.xc.p;
+    }
+    smooth_lattice(s, L, b, in, x_out, steps, ident_last, nullptr);
     return;
   }
   const int64_t n = (int64_t)L.n * nv;
@@ -818,7 +871,7 @@ bool Multigrid::restrict_to(hipStream_t s, size_t l, const double* src) {
   MGLevel& C = lv[l + 1];
   static const bool fuse = std::getenv("NSFEM_NO_FUSED_FIRST") == nullptr;
   // (levels smoothed by the lattice kernel run their first step themselves)
-  if (fuse && starts_from_zero(l + 1) && !lattice_ok(C)) {
+  if (fuse && starts_from_zero(l + 1) && !lattice_ok(C) && !lattice_ok_relaxed(C)) {
     double c1, c2, rho;
     cheb_coeffs(C, 0, 0.0, c1, c2, rho);
     launch_spmv_cheb_first(s, *L.R, nv, src, C.b.p, C.mask, C.dinv.p, c2, C.d.p, C.xa.p);
@@ -1012,6 +1065,11 @@ const double* Multigrid::vcycle(hipStream_t s, size_t l, const double* b, double
   // (exchanged) coarse ghosts, added to ghost values that were valid before (filled for the
   // residual), this is exactly what the owner computes for them -> no exchange before smoothing
   if (pre > 0) launch_spmv_accumulate(s, *L.P, nv, C.x.p, x, L.mask, relaxed ? 2 : 0);
+  else if (relaxed && lattice_ok_relaxed(L)) {      // (the lattice kernel smooths out of place: prolong into its input)
+    launch_spmv(s, *L.P, nv, C.x.p, L.xc.p, L.mask, MASK_ZERO, 2);
+    smooth(s, L, b, L.xc.p, x, degree, true, identity_rows && l == 0);
+    return x;
+  }
   else launch_spmv(s, *L.P, nv, C.x.p, x, L.mask, MASK_ZERO, relaxed ? 2 : 0);   // x = P x_c (every row stored)
   smooth(s, L, b, x, x, degree, relaxed, identity_rows && l == 0);
   (void)n;

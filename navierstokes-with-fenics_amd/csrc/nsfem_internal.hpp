@@ -266,6 +266,7 @@ void launch_cheb_step(hipStream_t s, const BlockMat& A, int nv, const double* x,
 // multi-step lattice smoother (2D lexicographic lattices with a stencil dictionary; linalg.hip)
 void refresh_env_switches();            // NSFEM_LATTICE, NSFEM_LATTICE_TRANSFERS (re-read by nsfem_create)
 void refresh_assembly_switches();       // NSFEM_JAC_LATTICE
+bool partitioned_lattice_kernels();      // NSFEM_PARTITIONED_LATTICE (default on): k_jac_lattice / k_cheb_lattice on strips
 void refresh_leg_switches();            // NSFEM_MG_LEGS, NSFEM_LEG_GROUP, NSFEM_LEG_T (mglegs.hip)
 bool lattice_transfers_enabled();
 bool lattice_smoother_available(const BlockMat& A, int nv);
@@ -275,7 +276,7 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
                          const double* d_in, double* x_out, double* d_out, double* r_out,
                          const uint8_t* mask, int steps, const double* c1, const double* c2, int ident,
                          const uint8_t* sidm = nullptr, const double* xc = nullptr, const double* rf = nullptr,
-                         double* b_out = nullptr);
+                         double* b_out = nullptr, int gh_lo = 0, int gh_hi = 0, int gh_zero = 0);
 // out[row] = dictionary entry | (mask of component c) << (6 + c): one byte per row for the lattice kernel
 void launch_lattice_sidm(hipStream_t s, const BlockMat& A, int nv, const uint8_t* mask, uint8_t* out);
 // out = R rf on a lattice hierarchy (rows flagged in the coarse mask: 0); false = shapes do not nest, nothing launched
@@ -373,7 +374,13 @@ bool launch_residual_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L,
 bool jacobian_lattice_available(const MeshDev& m, const BlockMat& L);
 int64_t jacobian_lattice_bytes(const MeshDev& m);   // u, x read, y written, ids + masks, vertex coordinates
 bool launch_jacobian_lattice(hipStream_t s, const MeshDev& m, const BlockMat& L, const double* u, const double* x,
-                             double cc, int form, bool picard, const uint8_t* mask, double* y);
+                             double cc, int form, bool picard, const uint8_t* mask, double* y, int phase = 0,
+                             int gh_lo = 0, int gh_hi = 0);
+// partitioned strips: can the launch be cut into tile rows that read no ghost line (phase 1, under the halo
+// exchange) and the rest (phase 2)?
+bool jacobian_lattice_split(const MeshDev& m, int gh_lo, int gh_hi);
+// are the ghost nodes of a W x H lattice whole lines at its bottom (lo of them) and top (hi)?
+bool ghost_lattice_lines(const std::vector<uint8_t>& ghost, int W, int H, int& lo, int& hi);
 void launch_convection_cells(hipStream_t s, const MeshDev& m, const double* u, const double* v, double cc,
                              int form, bool picard);
 void launch_convection_residual(hipStream_t s, const MeshDev& m, const double* u, double cc,
@@ -630,6 +637,8 @@ struct MGLevel {
   const std::vector<int32_t>* h_inj = nullptr;
   // partitioned meshes
   const std::vector<uint8_t>* h_ghost = nullptr;   // per node: nonzero = ghost
+  int ghost_lo = -2, ghost_hi = -2;                // ghost lattice lines at the bottom / top of a strip (-2: not looked
+                                                   // at yet, -1: the ghost nodes are not whole lines)
   HaloRange halo;
   bool has_halo = false;
   // partitioned meshes, operators without an element-local form (the algebraic Schur Laplacian
@@ -741,6 +750,7 @@ struct Multigrid : Precond {
   size_t prof_n = 0;
   bool prof_open = false;        // an event pair is open inside the current smooth() call
   int64_t prof_launches = 0;     // launches covered by the recorded pairs
+  int64_t lattice_launches = 0;  // launches of the multi-step lattice kernel by this hierarchy (nsfem_mg_info)
   int64_t prof_steps = 0;        // smoothing steps covered (the lattice kernel runs several per launch)
   int64_t prof_bytes = 0;        // algorithmic bytes of the covered launches (lattice kernel: per launch shape)
   bool own_mask0 = false;        // level 0 keeps its own mask buffer (tails)
@@ -775,6 +785,9 @@ struct Multigrid : Precond {
   // multi-step lattice kernel (2D lexicographic lattices, serial levels): `steps` Chebyshev steps out of
   // place, optionally the residual of the result as well
   bool lattice_ok(const MGLevel& L) const;
+  // partitioned level in relaxed halo mode whose ghost nodes are whole lattice lines: smoothing sequences run in
+  // the multi-step lattice kernel with the ghost lines frozen (transfers stay explicit products)
+  bool lattice_ok_relaxed(MGLevel& L);
   bool chain_child_forms_b(size_t l);
   size_t restricted_to = 0;      // level whose b the two-level restriction kernel has already formed in this leg
   // fused legs (mglegs.hip): built on first use after a refresh; legs_kind 0 = none (separate launches),
@@ -891,6 +904,7 @@ struct nsfem_ctx {
   nsfem::Comm* comm = nullptr;                 // owned
   nsfem::HaloRange halo_p2, halo_p1;
   std::vector<uint8_t> h_ghost_p2, h_ghost_p1; // per node: nonzero = ghost
+  int p2_gh_lo = -2, p2_gh_hi = -2;            // ghost lattice lines of the P2 lattice of a strip (-2: not looked at, -1: none such)
   nsfem::DevBuf<uint8_t> ghost_v, ghost_p;     // per vector entry: 0 / 2
   int64_t n_p2_global = 0, n_p1_global = 0;
   P1Level* global_coarse = nullptr;            // replicated global coarsest mesh (owned)

@@ -107,6 +107,8 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, rel
                                       part.p1_halo, (2 * n + 1) ** 2, (n + 1) ** 2)
             _run(ctxs[r], part.dofmap, nsteps, k, use_mg, out, r, cheb)
             out[("overlapped", r)] = ctxs[r].comm_overlapped()
+            if use_mg:
+                out[("kernels", r)] = (ctxs[r].jacobian_info(), ctxs[r].mg_lattice_info(1), ctxs[r].mg_lattice_info(0))
         except BaseException as exc:                     # a dead rank would deadlock the others
             errors.append((r, repr(exc)))
             os._exit(17)
@@ -153,6 +155,20 @@ def test_partitioned_ipcs_equals_single_context(n, size, use_mg, tail, cheb, rel
             assert 0.3 * st[r]["exchanges"] < out[("overlapped", r)] <= st[r]["exchanges"]
         else:
             assert out[("overlapped", r)] == 0
+    # every rank runs the single-GPU kernel set: the whole Jacobian action / momentum residual in
+    # ONE launch of k_jac_lattice on its strip (exact: one halo exchange of the input first), and -- in relaxed halo
+    # mode, bench.py's N > 1 default -- every smoothing sequence of the partitioned lattice levels in the multi-step
+    # kernel k_cheb_lattice with the ghost lines frozen; exact halo mode keeps the one-step kernels
+    if use_mg and n >= 32:
+        for r in range(size):
+            ji, lat_v, lat_p = out[("kernels", r)]
+            assert ji["path"] == "lattice-kernel" and ji["lattice_launches"] > 0, (r, ji)
+            if relaxed:
+                assert lat_v["lattice_levels"] >= 1 and lat_v["lattice_launches"] > 0, (r, lat_v)
+                assert lat_p["lattice_levels"] >= 1 and lat_p["lattice_launches"] > 0, (r, lat_p)
+                assert lat_v["ghost_lines"] == ((0 if r == 0 else 1), (0 if r == size - 1 else 2)), (r, lat_v)
+            else:
+                assert lat_v["lattice_launches"] == 0 and lat_p["lattice_launches"] == 0
     for c in ctxs:
         c.close()
     nat.local_group_destroy(group)

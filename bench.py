@@ -1069,15 +1069,27 @@ def cavity_ipcs_bench(args):
 
     _apply_truncation(ctx, args)
     ctx.set_overlap(args.overlap == "on")
-    # projection step by fast diagonalisation (one rank: the P1 space is the whole rectangle lattice)
+    # projection step by fast diagonalisation.  One context: the P1 space is the whole rectangle lattice.  Strips: the
+    # factors of the GLOBAL lattice, every rank keeps the rows of V_y of its own lattice lines (ghost lines included);
+    # the solve then costs one all-reduce of (ny + 1) x (n + 1) doubles and no halo exchange (csrc/fastdiag.hip)
     fast_diag = False
-    if world == 1 and dist is None and args.poisson_solver == "fd":
+    if args.poisson_solver == "fd" and not args.no_multigrid:
         import poisson_fd
-        lines = poisson_fd.lattice_lines(part.mesh)
-        factors = poisson_fd.factors(lines[0], lines[1], np.zeros(0, np.int64)) if lines is not None else None
-        if factors is not None:
-            ctx.poisson_set_fast_diag(factors)
-            fast_diag = True
+        if dist is None:
+            lines = poisson_fd.lattice_lines(part.mesh)
+            factors = poisson_fd.factors(lines[0], lines[1], np.zeros(0, np.int64)) if lines is not None else None
+            if factors is not None:
+                ctx.poisson_set_fast_diag(factors)
+                fast_diag = True
+        elif ny_global <= 8192 and dm.n_p1 % (n + 1) == 0:
+            # (the strip's vertices are the lattice lines first ... of the global lattice, vertex id = j (n + 1) + i)
+            xs, ys = np.linspace(0.0, 1.0, n + 1), np.linspace(0.0, height, ny_global + 1)
+            first = int(part.p1_global[0]) // (n + 1)
+            G = np.asarray(dm.p1_coords, dtype=np.float64).reshape(-1, n + 1, 2)
+            if (G.shape[0] == dm.n_p1 // (n + 1) and np.abs(G[:, :, 0] - xs[None, :]).max() < 1e-12 and
+                    np.abs(G[:, :, 1] - ys[first:first + G.shape[0], None]).max() < 1e-12 * max(1.0, height)):
+                ctx.poisson_set_fast_diag(poisson_fd.factors(xs, ys, np.zeros(0, np.int64)), first_line=first)
+                fast_diag = True
 
     def throughput_opts():
         o = ctx.default_step_opts()
@@ -1321,7 +1333,10 @@ def cavity_ipcs_bench(args):
                                   "tolerance": tol_fields,
                                   "newton_bicgstab_poisson_its_per_step_exact": [float(v) for v in its_exact]},
                    "poisson_solver": ("fast diagonalisation: x += V_y ((V_y^T R V_x) .* inv) V_x^T, four fp64 MFMA products "
-                                      "(csrc/fastdiag.hip), one pass + residual check" if fast_diag else
+                                      "(csrc/fastdiag.hip), one pass + residual check" +
+                                      ("; strips: every rank contracts its own lattice lines, ONE all-reduce of the "
+                                       "%d x %d transformed array per solve, no halo exchange" % (ny_global + 1, n + 1)
+                                       if dist is not None else "") if fast_diag else
                                       "CG preconditioned by the pressure V(2,2) cycle"),
                    "preconditioner": "jacobi" if mg_levels is None else
                    "geometric multigrid, Chebyshev-Jacobi smoothing: V(0,3) momentum, V(2,2) Poisson; %d coarse P1 levels" % mg_levels,

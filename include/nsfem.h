@@ -464,6 +464,12 @@ int nsfem_mg_apply(nsfem_ctx* ctx, int which, const double* r, double* z);   /* 
    poisson_fd.factors(). */
 int nsfem_poisson_set_fast_diag(nsfem_ctx* ctx, int32_t W, int32_t H, const double* Vx, const double* Vy,
                                 const double* inv);
+/* The same on a partitioned strip (nsfem_set_partition): the factors of the GLOBAL W x H lattice; the context's P1
+   space is the lattice lines first_line ... first_line + n_p1 / W - 1, ghost lines included.  The projection step of
+   nsfem_step_ipcs (precond = 3, no pressure Dirichlet dofs) then costs ONE all-reduce of W x H doubles instead of the
+   halo exchanges and dot-product reductions of a multigrid-CG solve, and returns the pressure with valid ghost rows. */
+int nsfem_poisson_set_fast_diag_rows(nsfem_ctx* ctx, int32_t W, int32_t H, int32_t first_line, const double* Vx,
+                                     const double* Vy, const double* inv);
 int nsfem_mg_info(nsfem_ctx* ctx, int which, int64_t out[4]);
 /* in-situ HIP-event timing of the matrix-free convection action of the velocity Jacobian inside
  * the Newton-Krylov solves (element kernel k_conv_cell / k3_conv_cell + node gather = the

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_mg_set_schur_operator", "nsfem_mg_set_schur_mode", "nsfem_set_halo_lists", "nsfem_smoother_info", "nsfem_mg_set_global_index", "nsfem_comm_allreduce", "nsfem_mg_add_global_level", "nsfem_cfl_number", "nsfem_set_angular_velocity", "nsfem_set_angular_velocity_3d", "nsfem_profile_smoother", "nsfem_profile_smoother_detail", "nsfem_profile_convection", "nsfem_jacobian_info", "nsfem_set_preconditioner_shift", "nsfem_poisson_solve", "nsfem_p2_mass_bounds", "nsfem_mg_set_truncation", "nsfem_comm_stats", "nsfem_mg_set_halo_mode", "nsfem_set_overlap", "nsfem_comm_overlapped", "nsfem_boundary_force",
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local", "nsfem_comm_attach_shm",
-    "nsfem_mg_apply", "nsfem_mg_info", "nsfem_poisson_set_fast_diag",
+    "nsfem_mg_apply", "nsfem_mg_info", "nsfem_poisson_set_fast_diag", "nsfem_poisson_set_fast_diag_rows",
 )
 
 
@@ -205,6 +205,7 @@ def load_library(path=None):
         "nsfem_mg_apply": (C.c_int, [vp, C.c_int, pd, pd]),
         "nsfem_mg_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64)]),
         "nsfem_poisson_set_fast_diag": (C.c_int, [vp, i32, i32, pd, pd, pd]),
+        "nsfem_poisson_set_fast_diag_rows": (C.c_int, [vp, i32, i32, i32, pd, pd, pd]),
         "nsfem_set_halo_lists": (C.c_int, [vp, C.c_int, C.POINTER(HaloLists)]),
         "nsfem_mg_set_global_index": (C.c_int, [vp, i32, pi]),
         "nsfem_comm_allreduce": (C.c_int, [vp, pd, C.c_int, C.c_int]),
@@ -473,14 +474,20 @@ class NsfemContext:
         self._check(self._lib.nsfem_mg_apply(self._h, int(which), _dp(r), _dp(z)))
         return z
 
-    def poisson_set_fast_diag(self, factors):
-        """factors of poisson_fd.factors(): the projection step may then run with Krylov option precond = 3"""
+    def poisson_set_fast_diag(self, factors, first_line=None):
+        """factors of poisson_fd.factors(): the projection step may then run with Krylov option precond = 3.
+        first_line (partitioned strips): the factors belong to the GLOBAL lattice, this context's pressure space is
+        its lines first_line, first_line + 1, ... (ghost lines included)"""
         inv = np.ascontiguousarray(factors["inv"], dtype=np.float64)
         vx = np.ascontiguousarray(factors["Vx"], dtype=np.float64)
         vy = np.ascontiguousarray(factors["Vy"], dtype=np.float64)
         H, W = inv.shape
         assert vx.shape == (W, W) and vy.shape == (H, H)
-        self._check(self._lib.nsfem_poisson_set_fast_diag(self._h, W, H, _dp(vx), _dp(vy), _dp(inv)))
+        if first_line is None:
+            self._check(self._lib.nsfem_poisson_set_fast_diag(self._h, W, H, _dp(vx), _dp(vy), _dp(inv)))
+        else:
+            self._check(self._lib.nsfem_poisson_set_fast_diag_rows(self._h, W, H, int(first_line), _dp(vx), _dp(vy),
+                                                                   _dp(inv)))
 
     def mg_info(self, which):
         """dict(legs, launches_per_cycle, levels, leg_launches): how the cycles of a hierarchy run"""

@@ -1004,19 +1004,36 @@ static int poisson_direct_step(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_s
   ++w.touch;
   double* parts = w.parts.p;
   constexpr int PR = 10, PB0 = 13;
+  // Partitioned strips: the same solve with ONE collective (FastDiag::apply_strip).  u* carries valid ghost values
+  // (every Krylov solve fills the ghosts of its solution), so D u* is complete on the owned rows; ghost rows are
+  // zeroed (every node counts once in the sums over the ranks); z comes back on every local row, ghost lines
+  // included, so p = p_old + z needs no halo exchange and the check r - A z none either.
+  const bool dist = c->distributed();
+  const uint8_t* gm = dist ? c->mask_p.p : nullptr;                            // (flag 2 on ghost rows)
+  NSFEM_REQUIRE(!dist || (c->fd_p.strip() && gm), "fast diagonalisation on a partitioned mesh: strip factors not set");
   launch_spmv_scaled(s, c->Dv, 1, -c->alpha[0] / c->k, c->state[NSFEM_USTAR].p, w.r.p);
-  launch_sum_sub_mean(s, np, w.r.p, parts + PR * kParts);
+  if (dist) {
+    launch_zero_ghost(s, np, gm, w.r.p);
+    launch_sum(s, np, w.r.p, parts + PR * kParts);
+    c->comm->allreduce_sum(s, parts + PR * kParts, kParts);
+    launch_sub_mean(s, np, c->n_p1_global, parts + PR * kParts, w.r.p);
+    launch_zero_ghost(s, np, gm, w.r.p);
+  } else {
+    launch_sum_sub_mean(s, np, w.r.p, parts + PR * kParts);
+  }
   launch_dot(s, np, w.r.p, w.r.p, parts + PB0 * kParts);
   const double* base = c->state[NSFEM_P_OLD].p;
   info.iterations = 0;
   info.converged = 0;
   for (int pass = 0; pass < std::max(1, std::min(o.max_iter, 8)); ++pass) {
-    c->fd_p.apply(s, w.r.p, w.z.p);
+    if (dist) c->fd_p.apply_strip(s, c->comm, w.r.p, w.z.p);
+    else c->fd_p.apply(s, w.r.p, w.z.p);
     launch_axpby(s, np, 1.0, base, 1.0, w.z.p, c->state[NSFEM_P].p);          // p = p_old + z (later passes: p += z)
     base = c->state[NSFEM_P].p;
     ++info.iterations;
-    launch_residual(s, c->Ap, 1, w.z.p, w.r.p, w.q.p, nullptr, MASK_NONE);    // q = r - A z
+    launch_residual(s, c->Ap, 1, w.z.p, w.r.p, w.q.p, gm, gm ? MASK_ZERO : MASK_NONE);    // q = r - A z
     launch_dot(s, np, w.q.p, w.q.p, parts + PR * kParts);
+    if (dist) c->comm->allreduce_sum(s, parts + PR * kParts, (PB0 - PR + 1) * kParts);    // (slots 10 ... 13)
     double qq, rr;
     host_sum_parts2(s, w, PR, PB0, qq, rr);
     if (!std::isfinite(qq)) return NSFEM_ERR_BREAKDOWN;
@@ -1953,7 +1970,7 @@ extern "C" int nsfem_step_ipcs(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfe
   {
     nsfem_solve_info si;
     int rc;
-    if (opts->poisson.precond == 3 && ctx->nbc_p == 0 && !ctx->distributed() && ctx->fd_p.ready()) {
+    if (opts->poisson.precond == 3 && ctx->nbc_p == 0 && ctx->fd_p.ready() && ctx->distributed() == ctx->fd_p.strip()) {
       rc = poisson_direct_step(ctx, opts->poisson, si);
     } else {
       poisson_assemble(ctx, opts->pressure_extrapolation != 0);
@@ -2540,7 +2557,24 @@ extern "C" int nsfem_poisson_set_fast_diag(nsfem_ctx* ctx, int32_t W, int32_t H,
   API_BEGIN
   NSFEM_REQUIRE(ctx && Vx && Vy && inv, "null argument");
   NSFEM_REQUIRE((int64_t)W * H == npre(ctx), "fast diagonalisation: W x H must be the number of pressure dofs");
+  NSFEM_REQUIRE(!ctx->distributed(), "partitioned context: nsfem_poisson_set_fast_diag_rows");
   ctx->fd_p.set(ctx->stream, W, H, Vx, Vy, inv);
+  API_END(ctx)
+}
+
+// Partitioned strips: the factors of the GLOBAL W x H lattice; this rank's P1 space is the lattice lines
+// first_line ... first_line + n_p1 / W - 1 (ghost lines included).  The fused step driver then solves the projection
+// step with one all-reduce of H x W doubles (FastDiag::apply_strip).
+extern "C" int nsfem_poisson_set_fast_diag_rows(nsfem_ctx* ctx, int32_t W, int32_t H, int32_t first_line,
+                                                const double* Vx, const double* Vy, const double* inv) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && Vx && Vy && inv && W >= 2, "null argument");
+  NSFEM_REQUIRE(ctx->distributed(), "strip factors need a partitioned context (nsfem_set_partition)");
+  const int64_t np = npre(ctx);
+  NSFEM_REQUIRE(np % W == 0 && first_line >= 0 && first_line + np / W <= H,
+                "fast diagonalisation: the local pressure space is not a run of whole lattice lines");
+  NSFEM_REQUIRE((int64_t)W * H == ctx->n_p1_global, "fast diagonalisation: W x H must be the global number of pressure dofs");
+  ctx->fd_p.set_rows(ctx->stream, W, H, first_line, (int)(np / W), Vx, Vy, inv);
   API_END(ctx)
 }
 

@@ -124,6 +124,7 @@ void FastDiag::set(hipStream_t s, int W_, int H_, const double* vx, const double
   NSFEM_REQUIRE(W_ >= 2 && H_ >= 2 && vx && vy && inv_, "fast diagonalisation: bad factors");
   W = W_;
   H = H_;
+  j0 = h_loc = 0;
   Vx.upload(vx, (size_t)W * W, s);
   Vy.upload(vy, (size_t)H * H, s);
   inv.upload(inv_, (size_t)H * W, s);
@@ -132,9 +133,52 @@ void FastDiag::set(hipStream_t s, int W_, int H_, const double* vx, const double
   NSFEM_HIP(hipStreamSynchronize(s));
 }
 
+// Strips of a partitioned mesh (rank r holds the lattice lines j0 ... j0 + h_loc - 1, ghost lines included; every
+// node is OWNED by one rank and r vanishes on the ghost rows): the contraction over y is a sum over the ranks,
+//
+//     T2 = sum_ranks V_y[lines of the rank, :]^T (R_loc V_x)          one all-reduce of H x W doubles
+//     Z_loc = (V_y[lines of the rank, :] (T2 .* inv)) V_x^T           every local line, ghost lines included
+//
+// -- the whole projection solve of an N-rank run costs ONE collective (the multigrid-CG solve it replaces: ~10 halo
+// exchanges + 2 small all-reduces per iteration), the four products shrink to 1 / N of their size, and the result
+// comes with valid ghost rows (no exchange afterwards).
+void FastDiag::set_rows(hipStream_t s, int W_, int H_, int j0_, int h_loc_, const double* vx, const double* vy,
+                        const double* inv_) {
+  NSFEM_REQUIRE(W_ >= 2 && H_ >= 2 && vx && vy && inv_ && j0_ >= 0 && h_loc_ >= 1 && j0_ + h_loc_ <= H_,
+                "fast diagonalisation: bad factors / lines");
+  W = W_;
+  H = H_;
+  j0 = j0_;
+  h_loc = h_loc_;
+  Vx.upload(vx, (size_t)W * W, s);
+  Vy.upload(vy + (size_t)j0 * H, (size_t)h_loc * H, s);          // rows j0 ... of the row-major H x H matrix
+  inv.upload(inv_, (size_t)H * W, s);
+  t1.alloc((size_t)h_loc * W);
+  t2.alloc((size_t)H * W);
+  NSFEM_HIP(hipStreamSynchronize(s));
+}
+
+__global__ __launch_bounds__(256) void k_fd_scale(int64_t n, const double* __restrict__ a, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= a[i];
+}
+
+void FastDiag::apply_strip(hipStream_t s, Comm* comm, const double* r, double* z) {
+  NSFEM_REQUIRE(ready() && strip() && comm, "fast diagonalisation: strip factors / communicator not set");
+  fd_gemm<false, false>(s, h_loc, W, W, r, W, Vx.p, W, t1.p, W, nullptr);          // T1 = R_loc V_x
+  fd_gemm<true, false>(s, H, W, h_loc, Vy.p, H, t1.p, W, t2.p, W, nullptr);         // T2 = V_y[loc, :]^T T1  (partial)
+  comm->allreduce_sum(s, t2.p, (int64_t)H * W);
+  const int64_t n = (int64_t)H * W;
+  hipLaunchKernelGGL(k_fd_scale, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, n,
+                     (const double*)inv.p, t2.p);
+  NSFEM_HIP(hipGetLastError());
+  fd_gemm<false, false>(s, h_loc, W, H, Vy.p, H, t2.p, W, t1.p, W, nullptr);        // U = V_y[loc, :] (T2 .* inv)
+  fd_gemm<false, true>(s, h_loc, W, W, t1.p, W, Vx.p, W, z, W, nullptr);            // Z_loc = U V_x^T
+  ++applications;
+}
+
 // z = V_y ((V_y^T (R V_x)) .* inv) V_x^T
 void FastDiag::apply(hipStream_t s, const double* r, double* z) {
-  NSFEM_REQUIRE(ready(), "fast diagonalisation: factors not set");
+  NSFEM_REQUIRE(ready() && !strip(), "fast diagonalisation: factors not set (or set for a strip)");
   fd_gemm<false, false>(s, H, W, W, r, W, Vx.p, W, t1.p, W, nullptr);            // T1 = R V_x
   fd_gemm<true, false>(s, H, W, H, Vy.p, H, t1.p, W, t2.p, W, inv.p);            // T2 = (V_y^T T1) .* inv
   fd_gemm<false, true>(s, H, W, W, t2.p, W, Vx.p, W, t1.p, W, nullptr);          // T1 = T2 V_x^T

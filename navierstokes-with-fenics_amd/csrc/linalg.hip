@@ -2607,6 +2607,10 @@ void launch_sum_sub_mean(hipStream_t s, int64_t n, double* x, double* parts) {
   LAUNCH(k_sum, kParts, s, n, x, parts);
   LAUNCH(k_sub_mean, vgrid(n), s, n, n, parts, x);
 }
+void launch_sum(hipStream_t s, int64_t n, const double* x, double* parts) { LAUNCH(k_sum, kParts, s, n, x, parts); }
+void launch_sub_mean(hipStream_t s, int64_t n, int64_t count, const double* parts, double* x) {
+  LAUNCH(k_sub_mean, vgrid(n), s, n, count, parts, x);
+}
 void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, double* parts) {
   LAUNCH(k_dot, kParts, s, n, x, y, parts);
 }

@@ -822,12 +822,24 @@ struct Multigrid : Precond {
 // z = A^+ r by four dense products on the matrix cores
 struct FastDiag : Precond {
   int W = 0, H = 0;
+  // partitioned strips: this rank holds the lattice lines j0 ... j0 + h_loc - 1 (ghost lines included) of the GLOBAL
+  // W x H lattice; Vy then keeps those rows of V_y only.  h_loc == 0: the whole lattice (one rank)
+  int j0 = 0, h_loc = 0;
   DevBuf<double> Vx, Vy, inv, t1, t2;
   int64_t applications = 0;
   bool ready() const { return W > 0 && Vx.p && Vy.p && inv.p; }
+  bool strip() const { return h_loc > 0; }
   void set(hipStream_t s, int W_, int H_, const double* vx, const double* vy, const double* inv_);
+  void set_rows(hipStream_t s, int W_, int H_, int j0_, int h_loc_, const double* vx, const double* vy,
+                const double* inv_);
   void apply(hipStream_t s, const double* r, double* z) override;
+  // strips: r with zero ghost rows in, z on EVERY local row (ghost lines included) out; one all-reduce of the
+  // H x W transformed array in between
+  void apply_strip(hipStream_t s, Comm* comm, const double* r, double* z);
 };
+// x -= sum(parts) / count on n entries (k_sum fills the slot: launch_sum)
+void launch_sum(hipStream_t s, int64_t n, const double* x, double* parts);
+void launch_sub_mean(hipStream_t s, int64_t n, int64_t count, const double* parts, double* x);
 
 // z[dofs] = r[dofs]
 void launch_copy_at(hipStream_t s, int n, const int32_t* dofs, const double* r, double* z);

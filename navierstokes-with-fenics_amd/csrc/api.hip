@@ -729,6 +729,11 @@ static double momentum_residual(nsfem_ctx* c) {
   const int64_t nv = nvel(c);
   double* u = c->state[NSFEM_USTAR].p;
   momentum_residual_raw(c, u, c->rhs_v.p);
+  if (!c->distributed() && c->mask_v.p) {      // Dirichlet rows and the norm in one launch (mask != 0 <=> bc dof)
+    double* parts = c->kw.parts.p + (size_t)10 * kParts;
+    launch_bc_residual_norm(s, nv, c->rhs_v.p, c->mask_v.p, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, parts);
+    return std::sqrt(host_sum_parts(s, c->kw, 10));
+  }
   launch_set_bc_residual(s, c->nbc_v, c->bc_v_dofs.p, c->bc_v_vals.p, u, c->rhs_v.p);
   return global_norm(c, nv, c->rhs_v.p, c->ghost_v.p ? c->mask_v.p : nullptr);
 }
@@ -764,8 +769,10 @@ static void momentum_jacobian(nsfem_ctx* c, int vel_slot = NSFEM_USTAR) {
 static int jacobian_path(nsfem_ctx* c) {
   if (c->mesh.dim != 2 || cc_of(c) == 0.0 || !c->L.dict_ready) return 0;
   if (c->distributed() && !partitioned_lattice_kernels()) return 0;
-  if (!c->mesh.cl.tried && c->L.dict && c->L.dict->lat_w > 0)
+  if (!c->mesh.cl.tried && c->L.dict && c->L.dict->lat_w > 0) {
     build_cell_lattice(c->h_p2map.data(), c->mesh.n_cells, c->L.dict->lat_w, c->L.dict->lat_h, c->mesh.cl);
+    check_uniform_geometry(c->stream, c->mesh);
+  }
   if (!c->traction_form && coriolis_gamma(c) == 0.0 && c->mask_v.p && jacobian_lattice_available(c->mesh, c->L))
     return 2;
   return c->distributed() ? 0 : 1;
@@ -873,7 +880,6 @@ static bool use_matrix_free(const nsfem_ctx* c, const nsfem_step_opts* o) {
 static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem_solve_info& info,
                                  double known_rhs_norm = -1.0) {
   hipStream_t s = c->stream;
-  c->dx_v.zero(s);
   LinOp op;
   op.A = &c->J;
   op.nv = 1;
@@ -894,7 +900,7 @@ static int momentum_solve_update(nsfem_ctx* c, const nsfem_krylov_opts& o, nsfem
     op.prec = &c->mom_prec;
   }
   op.graph_epoch = c->graph_epoch;
-  op.x_zero = true;                 // dx_v was just zeroed
+  op.x_zero = true;                 // (dx_v is not read: the first update of the solve writes it)
   op.known_bnorm = known_rhs_norm;
   int rc = bicgstab(s, c->kw, op, c->rhs_v.p, c->dx_v.p, o, info);
   if (rc != NSFEM_OK) return rc;
@@ -1192,10 +1198,20 @@ static int correction_solve_chebyshev(nsfem_ctx* c, const nsfem_krylov_opts& o, 
     if (k_hint > 0) k = std::min(k, k_hint);
     k_hint = 0;
     k = std::max(1, std::min(k, o.max_iter - info.iterations));
-    mg.smooth(s, L, w.r.p, nullptr, w.q.p, k);                       // e ~ M^{-1} r
-    launch_axpby(s, nv, 1.0, x, 1.0, w.q.p, x);                      // x += e (e = 0 on Dirichlet dofs)
-    info.iterations += k;
-    residual_norm(w.r.p);
+    if (!c->distributed() && mg.lattice_ok(L)) {
+      // lattice kernel: the residual of the correction equation r - M e (= rhs - M (x + e)) rides along in the last
+      // launch of the sequence -- no separate product with M for the check
+      mg.smooth_lattice(s, L, w.r.p, nullptr, w.q.p, k, false, w.t.p);
+      launch_axpby(s, nv, 1.0, x, 1.0, w.q.p, x);
+      info.iterations += k;
+      std::swap(w.r.p, w.t.p);
+      launch_dot(s, nv, w.r.p, w.r.p, parts + P10 * kParts);
+    } else {
+      mg.smooth(s, L, w.r.p, nullptr, w.q.p, k);                       // e ~ M^{-1} r
+      launch_axpby(s, nv, 1.0, x, 1.0, w.q.p, x);                      // x += e (e = 0 on Dirichlet dofs)
+      info.iterations += k;
+      residual_norm(w.r.p);
+    }
     if (c->distributed()) c->comm->allreduce_sum(s, parts + P10 * kParts, kParts);
     if (deferred && first_pass) {
       double rr;
@@ -2104,7 +2120,6 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     if (!ctx->mf_active) momentum_jacobian(ctx, NSFEM_U0);
     mg_refresh(ctx, true);
     mg_refresh_schur(ctx);
-    ctx->dx_m.zero(s);
     LinOp op;
     op.custom = &ctx->mixed_op;
     op.prec = &ctx->block_prec;
@@ -2113,7 +2128,7 @@ extern "C" int nsfem_step_bdf(nsfem_ctx* ctx, const nsfem_step_opts* opts, nsfem
     nsfem_solve_info si;
     nsfem_ctx::SolveHint& hint = ctx->hint_mom[std::min(it, 3)];
     const nsfem_krylov_opts ko = forced_opts(opts, opts->momentum, r0);
-    op.x_zero = true;               // dx_m was just zeroed
+    op.x_zero = true;               // (dx_m is not read: the first update of the solve writes it)
     op.known_bnorm = r;             // |rhs_m| = the Newton residual norm just evaluated (bdf_residual)
     int rc = bicgstab(s, ctx->kw, op, ctx->rhs_m.p, ctx->dx_m.p, hinted(ko, hint), si);
     note_solve(hint, si, ko, ctx->kw.last_target);

@@ -816,7 +816,7 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
                    const double* __restrict__ x, const uint8_t* __restrict__ sid8,
                    const uint8_t* __restrict__ mask, const int32_t* __restrict__ slen,
                    const int32_t* __restrict__ spack, const double* __restrict__ sval,
-                   const double* __restrict__ gadd, double* __restrict__ y) {
+                   const double* __restrict__ gadd, double* __restrict__ y, const double* __restrict__ ugeo) {
   // LIN = 0: the momentum residual  y = L u + g + c_c conv(u)  (x is not read, no mask: the Dirichlet rows are
   // set by the caller afterwards); g joins the node's sum after the L product and before the element vectors,
   // the order of the launches it replaces (product, axpby, k_conv_cell, k_res_gather)
@@ -865,7 +865,16 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
   const int sqx = (i0 >> 1) + sxl, sqy = (j0 >> 1) + syl;          // (i0, j0 even; >> is an arithmetic shift)
   const bool cell = sqx >= 0 && sqx < a.nx && sqy >= 0 && sqy < a.ny;
   CellGeo geo;
-  if (cell && !NSFEM_KO(a.dbg & 16)) geo = load_geo(vx, a.nc, 2 * (sqy * a.nx + sqx) + ct);
+  if (ugeo) {
+    // uniform lattice: the two cell types' geometry through the scalar cache (wave-uniform addresses), picked per lane
+    const double g0[5] = {ugeo[0], ugeo[1], ugeo[2], ugeo[3], ugeo[4]};
+    const double g1[5] = {ugeo[5], ugeo[6], ugeo[7], ugeo[8], ugeo[9]};
+    geo.ji00 = cell ? (ct ? g1[0] : g0[0]) : 1.0;
+    geo.ji01 = cell ? (ct ? g1[1] : g0[1]) : 1.0;
+    geo.ji10 = cell ? (ct ? g1[2] : g0[2]) : 1.0;
+    geo.ji11 = cell ? (ct ? g1[3] : g0[3]) : 1.0;
+    geo.adet = cell ? (ct ? g1[4] : g0[4]) : 1.0;
+  } else if (cell && !NSFEM_KO(a.dbg & 16)) geo = load_geo(vx, a.nc, 2 * (sqy * a.nx + sqx) + ct);
   else geo.ji00 = geo.ji01 = geo.ji10 = geo.ji11 = geo.adet = 1.0;
   constexpr int OWN = kJlOX * kJlOY, NOWN = (OWN + NT - 1) / NT;
   int obase[NOWN], oent[NOWN], omask[NOWN];
@@ -992,7 +1001,9 @@ void k_jac_lattice(JacLatArgs a, const double* __restrict__ vx, const double* __
 }
 
 bool build_cell_lattice(const int32_t* p2map, int nc, int W, int H, CellLattice& cl) {
-  cl = CellLattice();
+  cl.ok = false;
+  cl.geo_uniform = false;
+  cl.nx = cl.ny = cl.W = cl.H = 0;
   cl.tried = true;
   if (W < 7 || H < 7 || !(W & 1) || !(H & 1)) return false;
   const int nx = (W - 1) / 2, ny = (H - 1) / 2;
@@ -1034,6 +1045,37 @@ bool build_cell_lattice(const int32_t* p2map, int nc, int W, int H, CellLattice&
   return true;
 }
 
+// is the geometry of every cell that of the first cell of its type, bit for bit?  (load_geo itself: what the kernels
+// would compute.)  flag[0] != 0: not uniform; ref[2][5]: the two types' geometry
+__global__ __launch_bounds__(256) void k_geo_uniform(int nc, const double* __restrict__ vx, double* __restrict__ ref,
+                                                     int* __restrict__ flag) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const CellGeo g = load_geo(vx, nc, c), r = load_geo(vx, nc, c & 1);
+  const bool same = g.ji00 == r.ji00 && g.ji01 == r.ji01 && g.ji10 == r.ji10 && g.ji11 == r.ji11 && g.adet == r.adet;
+  if (!same) flag[0] = 1;
+  if (c < 2) {
+    double* o = ref + 5 * c;
+    o[0] = g.ji00; o[1] = g.ji01; o[2] = g.ji10; o[3] = g.ji11; o[4] = g.adet;
+  }
+}
+void check_uniform_geometry(hipStream_t s, MeshDev& m) {
+  CellLattice& cl = m.cl;
+  cl.geo_uniform = false;
+  if (!cl.ok || m.dim != 2 || m.n_cells < 2) return;
+  cl.ugeo.alloc(10);
+  DevBuf<int> flag;
+  flag.alloc(1);
+  flag.zero(s);
+  hipLaunchKernelGGL(k_geo_uniform, dim3((m.n_cells + 255) / 256), dim3(256), 0, s, m.n_cells, (const double*)m.vx.p,
+                     cl.ugeo.p, flag.p);
+  NSFEM_HIP(hipGetLastError());
+  int h = 1;
+  NSFEM_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  NSFEM_HIP(hipStreamSynchronize(s));
+  cl.geo_uniform = h == 0;
+}
+
 static bool g_jac_lattice_on = true;
 static int g_jac_lattice_dbg = 0;
 // tile shape in use: 0 = 32 x 8 squares (512 threads), 1 = 16 x 8 (256).  Measured at n = 512 (us per launch of the
@@ -1042,10 +1084,13 @@ static int g_jac_lattice_dbg = 0;
 // a wave (loads, barriers, LDS phases) at 4 waves per SIMD, not by the shape of the tile
 static int g_jac_lattice_tile = 0;
 static bool g_partitioned_lattice = true;
+static bool g_jac_uniform_geo = true;                 // NSFEM_JL_UNIFORM_GEO=0: always load the cell coordinates
 bool partitioned_lattice_kernels() { return g_partitioned_lattice; }
 void refresh_assembly_switches() {
   const char* e = std::getenv("NSFEM_JAC_LATTICE");
   g_jac_lattice_on = e ? std::atoi(e) != 0 : true;
+  e = std::getenv("NSFEM_JL_UNIFORM_GEO");
+  g_jac_uniform_geo = e ? std::atoi(e) != 0 : true;
   e = std::getenv("NSFEM_PARTITIONED_LATTICE");       // 0: partitioned strips keep the one-step / multi-launch kernels
   g_partitioned_lattice = e ? std::atoi(e) != 0 : true;
 #if NSFEM_KNOCKOUTS
@@ -1154,7 +1199,8 @@ static bool launch_lattice_cells(hipStream_t s, const MeshDev& m, const BlockMat
       }                                                                                                     \
     }                                                                                                       \
     hipLaunchKernelGGL((k_jac_lattice<F, LIN, SX, SY>), dim3(grid), dim3(2 * SX * SY), lds, s, a, m.vx.p, u, x, \
-                       d.sid8.p, mask, d.len.p, d.pack.p, L.dict_vals.p, gadd, y);                          \
+                       d.sid8.p, mask, d.len.p, d.pack.p, L.dict_vals.p, gadd, y,                           \
+                       (const double*)(g_jac_uniform_geo && cl.geo_uniform ? cl.ugeo.p : nullptr));         \
   } while (0)
 #define NSFEM_JL(F, LIN)                                                                                    \
   do {                                                                                                      \

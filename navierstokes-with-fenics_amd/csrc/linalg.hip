@@ -2468,6 +2468,28 @@ __global__ __launch_bounds__(256) void k_correction_setup(int64_t n, double a, d
     parts_b[blockIdx.x] = sb;
   }
 }
+// Dirichlet rows of a Newton residual AND its squared norm in one launch (one rank): b[dof_j] = x[dof_j] - g_j on the
+// nbc constrained dofs (their rows carry mask != 0 and are skipped by the sum over the free rows, so the two parts
+// of the kernel touch disjoint entries), parts = sum over all rows of b^2
+__global__ __launch_bounds__(256) void k_bc_residual_norm(int64_t n, double* __restrict__ b, const uint8_t* __restrict__ mask,
+                                                          int nbc, const int32_t* __restrict__ dofs,
+                                                          const double* __restrict__ g, const double* __restrict__ x,
+                                                          double* __restrict__ parts) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  GRID_STRIDE(i, n) {
+    const double bi = mask[i] ? 0.0 : b[i];
+    v += bi * bi;
+  }
+  GRID_STRIDE(j, nbc) {
+    const int d = dofs[j];
+    const double r = x[d] - g[j];
+    b[d] = r;
+    v += r * r;
+  }
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) parts[blockIdx.x] = v;
+}
 __global__ __launch_bounds__(256) void k_set_bc_residual(int nbc, const int32_t* __restrict__ dofs,
                                                          const double* __restrict__ g,
                                                          const double* __restrict__ x,
@@ -2613,6 +2635,10 @@ void launch_sub_mean(hipStream_t s, int64_t n, int64_t count, const double* part
 }
 void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, double* parts) {
   LAUNCH(k_dot, kParts, s, n, x, y, parts);
+}
+void launch_bc_residual_norm(hipStream_t s, int64_t n, double* b, const uint8_t* mask, int nbc, const int32_t* dofs,
+                             const double* g, const double* x, double* parts) {
+  LAUNCH(k_bc_residual_norm, kParts, s, n, b, mask, nbc, dofs, g, x, parts);
 }
 void launch_set_bc_residual(hipStream_t s, int nbc, const int32_t* dofs, const double* g,
                             const double* x, double* b) {
@@ -2966,7 +2992,7 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __rest
                                                  const double* __restrict__ t,
                                                  double* __restrict__ x, double* __restrict__ r,
                                                  double* __restrict__ parts,
-                                                 double* __restrict__ scal) {
+                                                 double* __restrict__ scal, int x_is_zero) {
   __shared__ double sh[4];
   const double ts = sum_parts(parts + P_TS * kParts, sh);
   const double tt = sum_parts(parts + P_TT * kParts, sh);
@@ -2976,9 +3002,16 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* __rest
   const double omega = (tt > 0.0) ? ts / tt : 0.0;
   const double alpha = scal[S_ALPHA];
   const double rho = scal[S_RHO];
-  GRID_STRIDE(i, n) {
-    x[i] += alpha * phat[i] + omega * shat[i];
-    r[i] = sv[i] - omega * t[i];
+  if (x_is_zero) {                       // (first iteration from a zero start vector: x is not read -- the caller
+    GRID_STRIDE(i, n) {                  // did not have to clear it; 0 + v == v, the same bits)
+      x[i] = alpha * phat[i] + omega * shat[i];
+      r[i] = sv[i] - omega * t[i];
+    }
+  } else {
+    GRID_STRIDE(i, n) {
+      x[i] += alpha * phat[i] + omega * shat[i];
+      r[i] = sv[i] - omega * t[i];
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -3051,6 +3084,9 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
   info.converged = deferred ? false : (r0 <= target);
   const int check = o.check_every > 0 ? o.check_every : 1;
   int it = 0;
+  // (op.x_zero: the start vector is zero BY CONTRACT and need not be stored: the first update writes x, and a solve
+  // that ends without an iteration clears it)
+  bool x_unwritten = op.x_zero;
   auto body = [&](int first) {
     LAUNCH(k_bicg_p, kParts, s, n, first, w.r.p, w.v.p, op.prec ? nullptr : op.dinv,
            w.p.p, w.phat.p, w.rhat.p, parts, scal);
@@ -3064,7 +3100,7 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     apply(w.shat.p, w.t.p);
     LAUNCH(k_dot_ts_tt, kParts, s, n, w.t.p, w.s.p, w.rhat.p, parts);
     reduce_slots(op, s, parts, P_TS, 5);
-    LAUNCH(k_bicg_xr, kParts, s, n, w.phat.p, w.shat.p, w.s.p, w.t.p, x, w.r.p, parts, scal);
+    LAUNCH(k_bicg_xr, kParts, s, n, w.phat.p, w.shat.p, w.s.p, w.t.p, x, w.r.p, parts, scal, x_unwritten ? 1 : 0);
   };
   // iterations >= 1 replay one captured HIP graph (same kernels, same arguments): removes the
   // host launch cost of the ~100 small multigrid kernels per iteration
@@ -3082,9 +3118,10 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
       if (!w.graphs_enabled(op)) body(first);
       else {
         GraphKey k2 = key;
-        k2.parity = first;
+        k2.parity = first | (x_unwritten ? 2 : 0);
         w.replay(s, k2, [&] { body(first); });
       }
+      x_unwritten = false;
       restart = false;
       ++it;
       if ((it >= o.first_check && it % check == 0) || it == o.max_iter) {
@@ -3132,6 +3169,7 @@ int bicgstab(hipStream_t s, KrylovWork& w, const LinOp& op, const double* b, dou
     info.converged = false;                          // continue from the true residual
     restart = true;
   }
+  if (x_unwritten) NSFEM_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));     // (no iteration ran)
   info.iterations = it;
   return info.converged ? NSFEM_OK : NSFEM_ERR_NOT_CONVERGED;
 }

@@ -296,8 +296,15 @@ struct CellLattice {
   int nx = 0, ny = 0, W = 0, H = 0;
   int di[2][6] = {{0}}, dj[2][6] = {{0}};   // lattice offset of local node k of cell type t from the square's corner
   int rank[2][6] = {{0}};                   // position of the cell among the cells around that node (ascending)
+  // uniform lattices (every cell of a type has the geometry of the first one BIT FOR BIT -- checked on the device
+  // with the kernels' own load_geo): {J^-1, |det|} of the two cell types; the one-launch kernel then takes the
+  // geometry from 10 scalar loads instead of six strided coordinate loads per cell (48 B per cell of the launch)
+  bool geo_uniform = false;
+  DevBuf<double> ugeo;                      // [2][5]
 };
 bool build_cell_lattice(const int32_t* p2map /* [cell][6] */, int nc, int W, int H, CellLattice& cl);
+struct MeshDev;
+void check_uniform_geometry(hipStream_t s, MeshDev& m);   // fills m.cl.geo_uniform / ugeo (after build_cell_lattice)
 
 struct MeshDev {
   int dim = 2;              // 2: triangles (6 + 3 nodes per cell), 3: tetrahedra (10 + 4)
@@ -410,6 +417,9 @@ void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, doub
 void launch_sum_sub_mean(hipStream_t s, int64_t n, double* x, double* parts);
 void launch_correction_setup(hipStream_t s, int64_t n, double a, double* rhs, const double* t, const uint8_t* mask,
                              double* r0, double* parts_r, double* parts_b);
+// the same together with |b|^2 (512 partial sums) in one launch; rows with mask != 0 must be exactly the nbc dofs
+void launch_bc_residual_norm(hipStream_t s, int64_t n, double* b, const uint8_t* mask, int nbc, const int32_t* dofs,
+                             const double* g, const double* x, double* parts);
 void launch_set_bc_residual(hipStream_t s, int nbc, const int32_t* dofs, const double* g,
                             const double* x, double* b);          // b[d] = x[d] - g[d]
 void launch_set_values(hipStream_t s, int nbc, const int32_t* dofs, const double* g, double* x);

@@ -1036,12 +1036,12 @@ struct LatticeArgs {
 // (ring = distance to the output tile, 255: no node), b, d and the newest iterate
 // (slot q of a thread sits 128 LDS words and 8 lattice lines after slot 0; the newest iterate is not kept
 // in registers -- every smoothing stage writes it to LDS, the final store reads it back)
-template <int NV, int K>
+template <int NV, int K, int WPC>
 struct LatticeSlots {
   int self0, grow0, gstep;       // LDS word / lattice row of slot 0, lattice-row stride between slots (8 W)
   int info[K];
   double bq[K][NV], dq[K][NV];
-  __device__ __forceinline__ int self(int q) const { return self0 + 128 * q; }
+  __device__ __forceinline__ int self(int q) const { return self0 + 64 * WPC * q; }
   __device__ __forceinline__ size_t grow(int q) const { return (size_t)(grow0 + q * gstep); }
 };
 #define LAT_RING(q) ((st.info[q] >> 16) & 255)
@@ -1050,8 +1050,8 @@ struct LatticeSlots {
 
 // stages of a wave whose nodes share ONE dictionary entry: its LP values and LDS offsets (zero padded
 // tables, LP >= the entry's length) are scalar loads issued once, before the first stage
-template <int NV, int K, int LP>
-__device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, LatticeSlots<NV, K>& st,
+template <int NV, int K, int LP, int WPC>
+__device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, LatticeSlots<NV, K, WPC>& st,
                                                        double* __restrict__ xs0, double* __restrict__ xs1,
                                                        const double* __restrict__ vp,
                                                        const int32_t* __restrict__ op, double di) {
@@ -1114,10 +1114,8 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
             dn = c2 * di * (st.bq[q][c] - acc[c]);
             if (c1 != 0.0) dn += c1 * st.dq[q][c];
             xn = src[(size_t)st.self(q) * NV + c] + dn;
-          } else if (LAT_MK(q) & 4) {          // ghost row of a strip: frozen
-            xn = src[(size_t)st.self(q) * NV + c];
-          } else if (a.ident && last) {
-            xn = st.bq[q][c];
+          } else if ((a.ident && last) || (LAT_MK(q) & 4)) {    // identity row on the last step; ghost row of a
+            xn = st.bq[q][c];                                     // strip: frozen (its start value sits in bq)
           }
           st.dq[q][c] = dn;
           dst[(size_t)st.self(q) * NV + c] = xn;
@@ -1133,8 +1131,8 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
 }
 
 // the same for a wave whose nodes use several entries (tiles at the domain boundary): per-lane loads
-template <int NV, int K>
-__device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, LatticeSlots<NV, K>& st,
+template <int NV, int K, int WPC>
+__device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, LatticeSlots<NV, K, WPC>& st,
                                                        double* __restrict__ xs0, double* __restrict__ xs1,
                                                        const double* __restrict__ tval,
                                                        const int32_t* __restrict__ toff,
@@ -1183,10 +1181,8 @@ __device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, Lat
             dn = c2 * di * (st.bq[q][c] - acc[c]);
             if (c1 != 0.0) dn += c1 * st.dq[q][c];
             xn = src[(size_t)st.self(q) * NV + c] + dn;
-          } else if (LAT_MK(q) & 4) {          // ghost row of a strip: frozen
-            xn = src[(size_t)st.self(q) * NV + c];
-          } else if (a.ident && last) {
-            xn = st.bq[q][c];
+          } else if ((a.ident && last) || (LAT_MK(q) & 4)) {    // identity row on the last step; ghost row of a
+            xn = st.bq[q][c];                                     // strip: frozen (its start value sits in bq)
           }
           st.dq[q][c] = dn;
           dst[(size_t)st.self(q) * NV + c] = xn;
@@ -1206,8 +1202,8 @@ __device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, Lat
 // the stencil's end), toff[(st * 4 + class) * lp + k] LDS offset of the k-th neighbour, tlen[st],
 // tdinv[st] = 1 / diagonal.  512 threads: waves 2c, 2c + 1 own class c; slot q of wave w covers the plane
 // rows 2 (2 q + (w & 1)) and the next.
-template <int NV, int K, int WPE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+template <int NV, int K, int WPE, int WPC>
+__global__ __launch_bounds__(256 * WPC) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_t* __restrict__ toff,
                     const int32_t* __restrict__ tlen, const double* __restrict__ tdinv) {
   extern __shared__ double sh_lat[];
@@ -1224,13 +1220,13 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   const int plane = 32 * a.EHh;
   double* __restrict__ xs0 = sh_lat;                              // [4 planes][EHh][32][NV], two buffers
   double* __restrict__ xs1 = sh_lat + (size_t)4 * plane * NV;
-  const int cls = w >> 1, pi = cls & 1, pj = cls >> 1;
+  const int cls = w / WPC, pi = cls & 1, pj = cls >> 1;      // (WPC waves per parity class: 2 or 4)
   const int gi = ox + 2 * (lane & 31) + pi;
   const bool in_x = gi >= 0 && gi < a.W;
   const int ex = max(max(i0 - gi, gi - (i1 - 1)), 0);
   const int Go = a.R * max(a.Mv - 1, 0);
   const int need = (a.from_zero || a.xc) ? a.G : Go;              // nodes whose b / entry / mask are used
-  LatticeSlots<NV, K> st;
+  LatticeSlots<NV, K, WPC> st;
   unsigned long long differs = 0;
   int stu = -1;
   // Staging in three passes, so that a wave has ONE memory round trip per pass instead of one per load (loads
@@ -1240,21 +1236,20 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   //   pass 1  rings, clamped node indices, the byte entry | masks of every slot
   //   pass 2  the vector operands of every slot (b or the 7 fine values of R rf; d; x, P xc)
   //   pass 3  masks and conditions applied, slot state filled, start iterate stored to LDS
-  int ringq[K], smq[K], gjcq[K], ghq[K];
+  int ringq[K], smq[K], gjcq[K];
   size_t gcl[K];
   const int gic = min(max(gi, 0), a.W - 1);
 #pragma unroll
   for (int q = 0; q < K; ++q) {
-    const int pr = 2 * (2 * q + (w & 1)) + (lane >> 5);
+    const int pr = 2 * (WPC * q + (w & (WPC - 1))) + (lane >> 5);
     const int gj = oy + 2 * pr + pj;
     const bool in = in_x && gj >= 0 && gj < a.H;
     const int ey = max(max(j0 - gj, gj - (j1 - 1)), 0);
     ringq[q] = in ? min(max(ex, ey), 255) : 255;
-    ghq[q] = (gj < a.gh_lo || gj >= a.H - a.gh_hi) ? 4 : 0;
     if (q == 0) {
       st.self0 = cls * plane + pr * 32 + (lane & 31);
       st.grow0 = gj * a.W + gi;
-      st.gstep = 8 * a.W;
+      st.gstep = 4 * WPC * a.W;
     }
     const int gjc = min(max(gj, 0), a.H - 1);
     gjcq[q] = gjc;
@@ -1358,7 +1353,8 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   for (int q = 0; q < K; ++q) {
     const int ring = ringq[q];
     const bool counts = ring <= need;
-    const int stq = counts ? (smq[q] & 63) : 0, mkq = counts ? ((smq[q] >> 6) | (((smq[q] >> 6) & 1) ? ghq[q] : 0)) : 0;
+    const int stq = counts ? (smq[q] & 63) : 0, mkq = counts ? ((smq[q] >> 6) | ((((smq[q] >> 6) & 1) && (gjcq[q] < a.gh_lo || gjcq[q] >= a.H - a.gh_hi)) ? 4 : 0)) : 0;
+    // (bit 2: ghost row of a partitioned strip -- whole lattice lines at the bottom / top, flagged in the mask as well)
     double xv[NV];
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -1368,11 +1364,11 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
         if (mk) bv = 0.0;
         if (counts && ring == 0) a.b_out[st.grow(q) * NV + c] = bv;
       }
-      st.bq[q][c] = bv;
       st.dq[q][c] = (counts && !a.from_zero && a.d_in && ring <= Go) ? draw[q][c] : 0.0;
       double v = 0.0;
       if (!a.from_zero && ring <= a.G) v = (a.xc && mk) ? 0.0 : xraw[q][c];
       xv[c] = v;
+      st.bq[q][c] = (mkq & 4) ? v : bv;        // (ghost rows carry their frozen iterate in place of b)
     }
     st.info[q] = (ring << 16) | (mkq << 8) | stq;
     // do the wave's nodes share their dictionary entry?
@@ -1404,12 +1400,12 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
       const double* __restrict__ vp = tval + (size_t)stu * a.lp;
       const int32_t* __restrict__ op = toff + ((size_t)stu * 4 + cls) * a.lp;
       const double di = tdinv[stu];
-      if (L <= 8 && a.lp >= 8) lattice_stages_uniform<NV, K, 8>(a, st, xs0, xs1, vp, op, di);
-      else if (L <= 12 && a.lp >= 12) lattice_stages_uniform<NV, K, 12>(a, st, xs0, xs1, vp, op, di);
-      else if (L <= 20 && a.lp >= 20) lattice_stages_uniform<NV, K, 20>(a, st, xs0, xs1, vp, op, di);
-      else lattice_stages_general<NV, K>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
+      if (L <= 8 && a.lp >= 8) lattice_stages_uniform<NV, K, 8, WPC>(a, st, xs0, xs1, vp, op, di);
+      else if (L <= 12 && a.lp >= 12) lattice_stages_uniform<NV, K, 12, WPC>(a, st, xs0, xs1, vp, op, di);
+      else if (L <= 20 && a.lp >= 20) lattice_stages_uniform<NV, K, 20, WPC>(a, st, xs0, xs1, vp, op, di);
+      else lattice_stages_general<NV, K, WPC>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
     } else {
-      lattice_stages_general<NV, K>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
+      lattice_stages_general<NV, K, WPC>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
     }
   }
   // the newest iterate sits in the buffer the last smoothing stage wrote (stage m writes buffer m & 1)
@@ -1511,7 +1507,15 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   // 48 / 56 us -- 21 spilled registers under the 128-VGPR cap and 1040 tiles on 512 workgroup slots)
   int eh = nn >= 20000 ? 24 : 16;
   static const int force_eh = [] { const char* e = std::getenv("NSFEM_LATTICE_EH"); return e ? std::atoi(e) : 0; }();
-  if (force_eh == 16 || force_eh == 24 || force_eh == 32) eh = force_eh;
+  // 48 lines: ONE workgroup of 1024 threads per CU (four waves per parity class, the same three slots per thread and
+  // the same 4 waves per SIMD as two 24-line workgroups): the halo is shared by twice the output lines -- 1.64
+  // instead of 2.46 staged nodes per output node at a 6-line halo, 1.20 instead of 1.45 row-steps per useful one.
+  // Measured (round 4): n = 512 (1.05 M nodes) 1.94 vs 1.925 ms/step with 24 lines, n = 1024 (4.2 M nodes) 7.21 vs
+  // 7.29 -- the launch is bound by the latency chain of a workgroup, not by the halo; 16-wave barriers cost what the
+  // halo saves.  On from 2 M lattice nodes.
+  static const int tall_from = [] { const char* e = std::getenv("NSFEM_LATTICE_TALL_FROM"); return e ? std::atoi(e) : 2000000; }();
+  if (nn >= tall_from && a.H >= 96) eh = 48;
+  if (force_eh == 16 || force_eh == 24 || force_eh == 32 || force_eh == 48) eh = force_eh;
   while (eh < 32 && eh - 2 * a.Ge < 8) eh += 8;
   const int tmx = 64 - 2 * a.Ge, tmy = eh - 2 * a.Ge;
   NSFEM_REQUIRE(tmx >= 2 && tmy >= 2, "lattice smoother: halo too wide for the tile");
@@ -1549,26 +1553,27 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   // launch shape (tuning switch NSFEM_LATTICE_SHAPE): 0 = 4 waves per SIMD (<= 128 VGPRs: two workgroups per
   // CU), 1 = 2 waves per SIMD (no register cap: one workgroup per CU)
   static const int shape = [] { const char* e = std::getenv("NSFEM_LATTICE_SHAPE"); return e ? std::atoi(e) : 0; }();
-#define NSFEM_LAT(NV, KK, WPE)                                                                         \
+#define NSFEM_LAT(NV, KK, WPE, WPC)                                                                    \
   do {                                                                                                 \
     static bool attr_dev[64];                                                                          \
     int dev_ = 0;                                                                                      \
     NSFEM_HIP(hipGetDevice(&dev_));                                                                    \
     bool& attr_set = attr_dev[dev_ & 63];                                                              \
     if (!attr_set) {                                                                                   \
-      NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, KK, WPE>),       \
+      NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, KK, WPE, WPC>),  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));         \
       attr_set = true;                                                                                 \
     }                                                                                                  \
-    hipLaunchKernelGGL((k_cheb_lattice<NV, KK, WPE>), dim3(grid), dim3(512), lds, s, a,                \
+    hipLaunchKernelGGL((k_cheb_lattice<NV, KK, WPE, WPC>), dim3(grid), dim3(256 * WPC), lds, s, a,     \
                        (const double*)A.lat_vals.p, toff, (const int32_t*)d.len.p,                     \
                        (const double*)A.dict_dinv.p);                                                  \
   } while (0)
 #define NSFEM_LAT_K(NV, WPE)                        \
   do {                                              \
-    if (eh == 32) NSFEM_LAT(NV, 4, WPE);            \
-    else if (eh == 24) NSFEM_LAT(NV, 3, WPE);       \
-    else NSFEM_LAT(NV, 2, WPE);                     \
+    if (eh == 48) NSFEM_LAT(NV, 3, 4, 4);           \
+    else if (eh == 32) NSFEM_LAT(NV, 4, WPE, 2);    \
+    else if (eh == 24) NSFEM_LAT(NV, 3, WPE, 2);    \
+    else NSFEM_LAT(NV, 2, WPE, 2);                  \
   } while (0)
   if (nv == 2 && shape == 1) NSFEM_LAT_K(2, 2);
   else if (nv == 2 && shape == 2) NSFEM_LAT_K(2, 6);

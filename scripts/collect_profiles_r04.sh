@@ -60,8 +60,12 @@ if has configs; then
   timeout -k 10 600 python3 bench.py --cells 333 --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs > $O/r04_bench_n333.json 2> $O/bench_333.err
   timeout -k 10 600 python3 bench.py --workload tgv3d-ipcs --cells 64 --steps 20 --warmup 3 > $O/r04_bench_tgv3d_n64.json 2> $O/bench_tgv.err
   timeout -k 10 600 python3 bench.py --workload channel3d-bdf --cells 48 --steps 10 --warmup 3 > $O/r04_bench_channel3d_n48.json 2> $O/bench_ch48.err
-  timeout -k 10 900 python3 bench.py --workload channel3d-bdf --cells 64 --steps 5 --warmup 2 > $O/r04_bench_channel3d_n64.json 2> $O/bench_ch64.err
+  timeout -k 10 900 python3 bench.py --workload channel3d-bdf --cells 64 --steps 10 --warmup 3 > $O/r04_bench_channel3d_n64.json 2> $O/bench_ch64.err
   timeout -k 10 600 python3 bench.py --workload dfg-bdf --steps 20 --warmup 3 > $O/r04_bench_dfg.json 2> $O/bench_dfg.err
-  for f in n1024 n333 tgv3d_n64 channel3d_n48 channel3d_n64 dfg; do python3 scripts/show_bench.py $O/r04_bench_$f.json; done
+  # functional rehearsal of the N-rank paths on ONE GPU (thread ranks, in-process communicator): message counts and the
+  # kernel set of a strong-scaling step on 8 strips -- NOT a performance figure
+  timeout -k 10 600 python3 bench.py --local-ranks 8 --scaling strong --cells 960 --steps 4 --warmup 2 --timed-only > $O/r04_bench_strong_960_thread_ranks_8.json 2> $O/bench_lr8.err
+  NSFEM_SETUP_PROFILE=1 NSFEM_DEBUG_SETUP=1 timeout -k 10 600 python3 scripts/r03_setup_profile.py 64 > $O/r04_setup.txt 2>&1
+  for f in n1024 n333 tgv3d_n64 channel3d_n48 channel3d_n64 dfg strong_960_thread_ranks_8; do python3 scripts/show_bench.py $O/r04_bench_$f.json; done
 fi
 ls $O

@@ -210,6 +210,8 @@ int nsfem_operator_shape(nsfem_ctx* ctx, int op, int64_t* n_rows, int64_t* n_col
                          int64_t* nnz_scalar);
 /* scalar CSR copy (blocks expanded); arrays sized from nsfem_operator_shape */
 int nsfem_operator_export(nsfem_ctx* ctx, int op, int32_t* rowptr, int32_t* col, double* val);
+/* diagonal of a square scalar operator (n_rows doubles) without exporting the matrix */
+int nsfem_operator_diagonal(nsfem_ctx* ctx, int op, double* out);
 /* y = op * x on the device through the production SpMV kernel (host in/out) */
 int nsfem_operator_apply(nsfem_ctx* ctx, int op, const double* x, double* y);
 /* Test hook (parity tests): ONE product / residual / Chebyshev-Jacobi smoothing sequence of the scalar

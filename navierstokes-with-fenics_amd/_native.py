@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "nsfem_set_partition", "nsfem_comm_unique_id", "nsfem_comm_attach_rccl",
     "nsfem_comm_local_create", "nsfem_comm_local_destroy", "nsfem_comm_attach_local", "nsfem_comm_attach_shm",
     "nsfem_mg_apply", "nsfem_mg_info", "nsfem_poisson_set_fast_diag", "nsfem_poisson_set_fast_diag_rows",
+    "nsfem_operator_diagonal",
 )
 
 
@@ -205,6 +206,7 @@ def load_library(path=None):
         "nsfem_mg_apply": (C.c_int, [vp, C.c_int, pd, pd]),
         "nsfem_mg_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64)]),
         "nsfem_poisson_set_fast_diag": (C.c_int, [vp, i32, i32, pd, pd, pd]),
+        "nsfem_operator_diagonal": (C.c_int, [vp, C.c_int, pd]),
         "nsfem_poisson_set_fast_diag_rows": (C.c_int, [vp, i32, i32, i32, pd, pd, pd]),
         "nsfem_set_halo_lists": (C.c_int, [vp, C.c_int, C.POINTER(HaloLists)]),
         "nsfem_mg_set_global_index": (C.c_int, [vp, i32, pi]),
@@ -599,6 +601,14 @@ class NsfemContext:
         val = np.empty(nnz.value, dtype=np.float64)
         self._check(self._lib.nsfem_operator_export(self._h, op, _ip(rowptr), _ip(col), _dp(val)))
         return sp.csr_matrix((val, col, rowptr), shape=(nr.value, ncol.value))
+
+    def operator_diagonal(self, op):
+        """diagonal of a square scalar device operator (no matrix export)"""
+        nr, ncol, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.nsfem_operator_shape(self._h, op, C.byref(nr), C.byref(ncol), C.byref(nnz)))
+        out = np.empty(nr.value, dtype=np.float64)
+        self._check(self._lib.nsfem_operator_diagonal(self._h, op, _dp(out)))
+        return out
 
     def operator_nnz(self, op):
         """block-nonzeros x block size of a device operator"""

@@ -8,6 +8,7 @@
 // with dolfin's NewtonSolver control (residual criterion, relaxation 1; parameters
 // from source/ns_ipcs_solver.py:143-147) and Krylov solves instead of sparse LU.
 #include "nsfem_internal.hpp"
+#include <thread>
 #include <chrono>
 #include <algorithm>
 
@@ -126,12 +127,16 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   {
     std::vector<double> vx((size_t)nl1 * dim * nc);
     std::vector<int32_t> p2((size_t)nl2 * nc), p1((size_t)nl1 * nc);
-    double area = 0.0;
-    for (int c = 0; c < nc; ++c) {
+    // (cell ranges on host threads; the cell volumes are summed afterwards in cell order: the same total on any
+    // number of threads)
+    std::vector<double> vol((size_t)nc);
+    std::vector<int> bad((size_t)std::max(1, host_threads()), 0);
+    auto fill_cells = [&](int c0, int c1, int tix) {
+    for (int c = c0; c < c1; ++c) {
       double x[4][3] = {{0}};
       for (int v = 0; v < nl1; ++v) {
         const int vid = m->cells[(size_t)c * nl1 + v];
-        NSFEM_REQUIRE(vid >= 0 && vid < m->n_vertices, "cell vertex id out of range");
+        if (vid < 0 || vid >= m->n_vertices) { bad[tix] = 1; return; }
         for (int d = 0; d < dim; ++d) {
           x[v][d] = m->coords[(size_t)vid * dim + d];
           vx[(size_t)(dim * v + d) * nc + c] = x[v][d];
@@ -140,18 +145,33 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
       double det;
       if (dim == 2) {
         det = (x[1][0] - x[0][0]) * (x[2][1] - x[0][1]) - (x[2][0] - x[0][0]) * (x[1][1] - x[0][1]);
-        area += 0.5 * std::fabs(det);
+        vol[c] = 0.5 * std::fabs(det);
       } else {
         double a[3], b[3], e[3];
         for (int d = 0; d < 3; ++d) { a[d] = x[1][d] - x[0][d]; b[d] = x[2][d] - x[0][d]; e[d] = x[3][d] - x[0][d]; }
         det = a[0] * (b[1] * e[2] - b[2] * e[1]) - a[1] * (b[0] * e[2] - b[2] * e[0]) +
               a[2] * (b[0] * e[1] - b[1] * e[0]);
-        area += std::fabs(det) / 6.0;
+        vol[c] = std::fabs(det) / 6.0;
       }
-      NSFEM_REQUIRE(det != 0.0, "degenerate cell");
+      if (det == 0.0) { bad[tix] = 2; return; }
       for (int k = 0; k < nl2; ++k) p2[(size_t)k * nc + c] = m->p2_dofmap[(size_t)c * nl2 + k];
       for (int k = 0; k < nl1; ++k) p1[(size_t)k * nc + c] = m->p1_dofmap[(size_t)c * nl1 + k];
     }
+    };
+    {
+      const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), nc / 65536));
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; ++t)
+        th.emplace_back(fill_cells, (int)((int64_t)nc * t / nt), (int)((int64_t)nc * (t + 1) / nt), t);
+      fill_cells(0, (int)((int64_t)nc / nt), 0);
+      for (auto& x : th) x.join();
+      for (int t = 0; t < nt; ++t) {
+        NSFEM_REQUIRE(bad[t] != 1, "cell vertex id out of range");
+        NSFEM_REQUIRE(bad[t] != 2, "degenerate cell");
+      }
+    }
+    double area = 0.0;
+    for (int c = 0; c < nc; ++c) area += vol[c];
     fresh->area = area;
     fresh->h_p2map.assign(m->p2_dofmap, m->p2_dofmap + (size_t)nl2 * nc);
     fresh->h_p1map.assign(m->p1_dofmap, m->p1_dofmap + (size_t)nl1 * nc);
@@ -167,13 +187,27 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
   }
   lap("mesh arrays");
   // ---- sparsity patterns + slot maps (host), then device copies
+  // (round 4: built on the device by one radix sort per pattern, pattern_device.hip; NSFEM_PATTERN_HOST=1 keeps the
+  // threaded host construction of pattern.cpp -- the two produce the same arrays)
+  const bool pattern_on_host = std::getenv("NSFEM_PATTERN_HOST") != nullptr;
+  if (!pattern_on_host) {
+    for (int64_t q = 0; q < (int64_t)nc * nl2; ++q)
+      NSFEM_REQUIRE(m->p2_dofmap[q] >= 0 && m->p2_dofmap[q] < m->n_p2, "dof map entry out of range (P2)");
+    for (int64_t q = 0; q < (int64_t)nc * nl1; ++q)
+      NSFEM_REQUIRE(m->p1_dofmap[q] >= 0 && m->p1_dofmap[q] < m->n_p1, "dof map entry out of range (P1)");
+  }
   {
     HostPattern h;
-    build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, nl2, m->p2_dofmap, nl2, true, h, true);
-    lap("pattern p22 (host)");
-    upload_pattern(s, h, fresh->p22, true);
-    lap("pattern p22 upload");
-    {
+    if (pattern_on_host) {
+      build_pattern(m->n_p2, m->n_p2, nc, m->p2_dofmap, nl2, m->p2_dofmap, nl2, true, h, true);
+      lap("pattern p22 (host)");
+      upload_pattern(s, h, fresh->p22, true);
+      lap("pattern p22 upload");
+    } else {
+      build_pattern_device(s, m->n_p2, m->n_p2, nc, fresh->mesh.p2.p, nl2, fresh->mesh.p2.p, nl2, true, fresh->p22);
+      lap("pattern p22 (device)");
+    }
+    if (pattern_on_host) {
       std::vector<int32_t> ptr, idx;
       build_inverse_index(m->n_p2, (int64_t)nc * nl2,
                           [&](int64_t src) { return m->p2_dofmap[src]; }, ptr, idx);
@@ -184,19 +218,30 @@ extern "C" int nsfem_create(const nsfem_mesh_desc* m, int device, nsfem_ctx** ou
         dst[(size_t)(src % nl2) * nc + (size_t)(src / nl2)] = (int32_t)pos;
       }
       fresh->mesh.ndst.upload(dst, s);
-      fresh->mesh.ebuf.alloc((size_t)nc * nl2 * nl2 * dim * dim);
-      fresh->mesh.rbuf.alloc((size_t)nc * nl2 * dim);
+    } else {
+      build_node_index_device(s, m->n_p2, nc, nl2, fresh->mesh.p2.p, fresh->mesh.nptr, fresh->mesh.ndst);
     }
+    fresh->mesh.ebuf.alloc((size_t)nc * nl2 * nl2 * dim * dim);
+    fresh->mesh.rbuf.alloc((size_t)nc * nl2 * dim);
     lap("node-sorted index + buffers");
-    build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, nl1, m->p1_dofmap, nl1, true, h, true);
-    upload_pattern(s, h, fresh->p11, true);
-    lap("pattern p11");
-    build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, nl1, m->p2_dofmap, nl2, false, h, true);
-    upload_pattern(s, h, fresh->p12, true);
-    lap("pattern p12");
-    build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, nl2, m->p1_dofmap, nl1, false, h, true);
-    upload_pattern(s, h, fresh->p21, true);
-    lap("pattern p21");
+    if (pattern_on_host) {
+      build_pattern(m->n_p1, m->n_p1, nc, m->p1_dofmap, nl1, m->p1_dofmap, nl1, true, h, true);
+      upload_pattern(s, h, fresh->p11, true);
+      lap("pattern p11");
+      build_pattern(m->n_p1, m->n_p2, nc, m->p1_dofmap, nl1, m->p2_dofmap, nl2, false, h, true);
+      upload_pattern(s, h, fresh->p12, true);
+      lap("pattern p12");
+      build_pattern(m->n_p2, m->n_p1, nc, m->p2_dofmap, nl2, m->p1_dofmap, nl1, false, h, true);
+      upload_pattern(s, h, fresh->p21, true);
+      lap("pattern p21");
+    } else {
+      build_pattern_device(s, m->n_p1, m->n_p1, nc, fresh->mesh.p1.p, nl1, fresh->mesh.p1.p, nl1, true, fresh->p11);
+      lap("pattern p11");
+      build_pattern_device(s, m->n_p1, m->n_p2, nc, fresh->mesh.p1.p, nl1, fresh->mesh.p2.p, nl2, false, fresh->p12);
+      lap("pattern p12");
+      build_pattern_device(s, m->n_p2, m->n_p1, nc, fresh->mesh.p2.p, nl2, fresh->mesh.p1.p, nl1, false, fresh->p21);
+      lap("pattern p21");
+    }
   }
   // ---- constant operators, integrated on the device
   QuadTables qt;
@@ -2434,6 +2479,23 @@ extern "C" int nsfem_operator_export(nsfem_ctx* ctx, int op, int32_t* rowptr, in
         }
     }
   rowptr[(size_t)p.n_rows * br] = (int32_t)pos;
+  API_END(ctx)
+}
+
+// diagonal of a square scalar operator (one value per block row: 1 x 1 blocks) without exporting the matrix -- the
+// algebraic Schur Laplacian needs diag(M_v) of a 1.3e8-entry mass matrix
+extern "C" int nsfem_operator_diagonal(nsfem_ctx* ctx, int op, double* out) {
+  API_BEGIN
+  NSFEM_REQUIRE(ctx && out, "null argument");
+  int nv;
+  const BlockMat* A = get_op(ctx, op, &nv);
+  const Pattern& p = *A->pat;
+  NSFEM_REQUIRE(A->br == 1 && A->bc == 1 && p.n_rows == p.n_cols && p.diag.p, "diagonal: square scalar operators only");
+  DevBuf<double> d;
+  d.alloc((size_t)p.n_rows);
+  launch_gather_diag(ctx->stream, p.n_rows, p.diag.p, A->vals.p, d.p);
+  NSFEM_HIP(hipMemcpyAsync(out, d.p, sizeof(double) * (size_t)p.n_rows, hipMemcpyDeviceToHost, ctx->stream));
+  NSFEM_HIP(hipStreamSynchronize(ctx->stream));
   API_END(ctx)
 }
 

@@ -2674,6 +2674,13 @@ void launch_sum(hipStream_t s, int64_t n, const double* x, double* parts) { LAUN
 void launch_sub_mean(hipStream_t s, int64_t n, int64_t count, const double* parts, double* x) {
   LAUNCH(k_sub_mean, vgrid(n), s, n, count, parts, x);
 }
+__global__ __launch_bounds__(256) void k_gather_diag(int n, const int32_t* __restrict__ diag, const double* __restrict__ vals,
+                                                     double* __restrict__ out) {
+  GRID_STRIDE(i, n) out[i] = diag[i] >= 0 ? vals[diag[i]] : 0.0;
+}
+void launch_gather_diag(hipStream_t s, int n, const int32_t* diag, const double* vals, double* out) {
+  LAUNCH(k_gather_diag, vgrid(n), s, n, diag, vals, out);
+}
 void launch_dot(hipStream_t s, int64_t n, const double* x, const double* y, double* parts) {
   LAUNCH(k_dot, kParts, s, n, x, y, parts);
 }

@@ -129,6 +129,13 @@ struct Pattern {
   std::vector<int32_t> h_rowptr, h_col;   // kept for export
 };
 void build_rowblocks(Pattern& p, hipStream_t s);
+// the same pattern, slot map and inverted index built on the device (pattern_device.hip); d_rowmap / d_colmap: SoA
+// device copies of the cell dof maps [nr][n_cells] / [nc][n_cells]
+void build_pattern_device(hipStream_t s, int n_rows, int n_cols, int n_cells, const int32_t* d_rowmap, int nr,
+                          const int32_t* d_colmap, int nc, bool want_diag, Pattern& out);
+// node-sorted layout of the element vectors (MeshDev::nptr, ndst) from the SoA device dof map [nl][n_cells]
+void build_node_index_device(hipStream_t s, int n_nodes, int n_cells, int nl, const int32_t* d_map, DevBuf<int32_t>& nptr,
+                             DevBuf<int32_t>& ndst);
 void build_sell(Pattern& p, hipStream_t s);
 // longest run of row blocks none of whose columns is flagged in `ghost_cols` ([n_cols] flags)
 void mark_interior_blocks(Pattern& p, const std::vector<uint8_t>& ghost_cols);
@@ -849,6 +856,7 @@ struct FastDiag : Precond {
 };
 // x -= sum(parts) / count on n entries (k_sum fills the slot: launch_sum)
 void launch_sum(hipStream_t s, int64_t n, const double* x, double* parts);
+void launch_gather_diag(hipStream_t s, int n, const int32_t* diag, const double* vals, double* out);   // out[i] = vals[diag[i]]
 void launch_sub_mean(hipStream_t s, int64_t n, int64_t count, const double* parts, double* x);
 
 // z[dofs] = r[dofs]

@@ -336,7 +336,7 @@ def attach_schur_laplacian(ctx, velocity_bc_dofs, part=None):
     import scipy.sparse as sp
     import _native as nat
     D = ctx.operator_csr(nat.OP_DIV)                                # n_p1 x (dim n_p2), CSR
-    m = ctx.operator_csr(nat.OP_MASS_P2).diagonal()
+    m = ctx.operator_diagonal(nat.OP_MASS_P2)                        # (the same values as the exported matrix's diagonal)
     width = D.shape[1] // m.size
     w = np.repeat(1.0 / m, width)                                   # node-interleaved components
     free = np.ones(D.shape[1], dtype=bool)

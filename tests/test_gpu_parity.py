@@ -1090,3 +1090,60 @@ def test_block_dictionaries_of_the_monolithic_scheme(dim, n, monkeypatch):
         assert a[0] == b[0] and abs(a[1] - b[1]) <= max(1, 0.05 * a[1])
     assert rel(u1, u0) < 1e-9
     assert rel(p1 - p1.mean(), p0 - p0.mean()) < 1e-7
+
+
+@pytest.mark.parametrize("kind", ["2d", "3d", "unstructured"])
+def test_device_built_patterns_equal_the_host_built_ones(kind, monkeypatch):
+    """Round 4: sparsity patterns, slot maps and inverted indices come from one radix sort per pattern on the device
+    (csrc/pattern_device.hip) instead of the threaded host construction (csrc/pattern.cpp; what dolfin's
+    SparsityPatternBuilder does inside the reference's variational solvers, source/ns_ipcs_solver.py:136-147).  The
+    two must agree array for array: every exported operator (pattern AND values: the values go through the slot map
+    and the inverted index) is bitwise the same, and so is an IPCS step."""
+    import fem_mesh as fm
+    if kind == "2d":
+        mesh, dm, marks = box(12, 9, p1=(1.0, 0.75))
+    elif kind == "3d":
+        mesh = fm.box_mesh((0.0, 0.0, 0.0), (1.0, 0.5, 0.75), 4, 3, 5)
+        dm = fm.TaylorHoodDofMap(mesh, reorder="parity")
+    else:
+        mesh, dm, marks = box(10, 10)
+        rng = np.random.default_rng(5)
+        inner = np.nonzero((np.abs(mesh.coords - 0.5) < 0.49).all(axis=1))[0]
+        coords = mesh.coords.copy()
+        coords[inner] += 0.02 * rng.standard_normal((inner.size, 2))
+        mesh = fm.Mesh(coords, mesh.cells)
+        dm = fm.TaylorHoodDofMap(mesh)
+    dim = mesh.coords.shape[1]
+    X = dm.p2_coords
+    wall = np.nonzero((np.abs(X - X.min(axis=0)) < 1e-12).any(axis=1) | (np.abs(X - X.max(axis=0)) < 1e-12).any(axis=1))[0]
+    lid = np.abs(X[wall, dim - 1] - X[:, dim - 1].max()) < 1e-12
+    bd = np.concatenate([dim * wall + a for a in range(dim)]).astype(np.int32)
+    bv = np.concatenate([np.where(lid, 1.0, 0.0)] + [np.zeros(wall.size)] * (dim - 1))
+    results = []
+    for host in (True, False):
+        if host:
+            monkeypatch.setenv("NSFEM_PATTERN_HOST", "1")
+        else:
+            monkeypatch.delenv("NSFEM_PATTERN_HOST", raising=False)
+        ctx = context(mesh, dm)
+        ops = {}
+        for name in ("OP_MASS_P2", "OP_STIFF_P2", "OP_STIFF_P1", "OP_MASS_P1", "OP_DIV", "OP_GRAD", "OP_DIVT"):
+            A = ctx.operator_csr(getattr(nat, name))
+            ops[name] = (A.indptr.copy(), A.indices.copy(), A.data.copy())
+        ctx.set_coeffs(1.0, 1.0, 0.01)
+        ctx.set_dirichlet(nat.VELOCITY, bd, bv)
+        ctx.set_dirichlet(nat.PRESSURE, np.zeros(0, np.int32), np.zeros(0))
+        o = ctx.default_step_opts()
+        o.matrix_free = 1                                   # the assembled Jacobian: slot map + inverted index at work
+        for step in range(2):
+            ctx.set_bdf(fo.bdf_alpha(step, 1.0), 0.01)
+            info = ctx.step_ipcs(o)
+            assert info.converged
+            ctx.advance(0)
+        results.append((ops, ctx.get_state(nat.U1), ctx.get_state(nat.P_OLD)))
+        ctx.close()
+    (ops_h, u_h, p_h), (ops_d, u_d, p_d) = results
+    for name in ops_h:
+        for a, b in zip(ops_h[name], ops_d[name]):
+            assert np.array_equal(a, b), name
+    assert np.array_equal(u_h, u_d) and np.array_equal(p_h, p_d)

@@ -1272,7 +1272,7 @@ def cavity_ipcs_bench(args):
         # round 4: the MEAN over the finest-level launches (largest grid of the kernel symbol) of 2 x FETCH_SIZE +
         # WRITE_SIZE -- the figure that pairs with the average `algorithmic_bytes_per_launch` over the same launch shapes
         c = json.load(open(pmc4)).get("by_grid", {})
-        keys = [k for k in c.get("fetch", {}) if k.startswith("void nsfem::k_cheb_lattice<2, 3, 4> @ grid")]
+        keys = [k for k in c.get("fetch", {}) if k.startswith("void nsfem::k_cheb_lattice<2, 3, 4") and " @ grid" in k]
         if keys:
             key = max(keys, key=lambda k: int(k.rsplit(" ", 1)[1]))
             if key in c.get("write", {}):

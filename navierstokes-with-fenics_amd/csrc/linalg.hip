@@ -1050,7 +1050,7 @@ struct LatticeSlots {
 
 // stages of a wave whose nodes share ONE dictionary entry: its LP values and LDS offsets (zero padded
 // tables, LP >= the entry's length) are scalar loads issued once, before the first stage
-template <int NV, int K, int LP, int WPC>
+template <int NV, int K, int LP, int WPC, bool GH>
 __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, LatticeSlots<NV, K, WPC>& st,
                                                        double* __restrict__ xs0, double* __restrict__ xs1,
                                                        const double* __restrict__ vp,
@@ -1114,8 +1114,8 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
             dn = c2 * di * (st.bq[q][c] - acc[c]);
             if (c1 != 0.0) dn += c1 * st.dq[q][c];
             xn = src[(size_t)st.self(q) * NV + c] + dn;
-          } else if ((a.ident && last) || (LAT_MK(q) & 4)) {    // identity row on the last step; ghost row of a
-            xn = st.bq[q][c];                                     // strip: frozen (its start value sits in bq)
+          } else if ((a.ident && last) || (GH && (LAT_MK(q) & 4))) {    // identity row on the last step; ghost row
+            xn = st.bq[q][c];                                             // of a strip: frozen (start value in bq)
           }
           st.dq[q][c] = dn;
           dst[(size_t)st.self(q) * NV + c] = xn;
@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
 }
 
 // the same for a wave whose nodes use several entries (tiles at the domain boundary): per-lane loads
-template <int NV, int K, int WPC>
+template <int NV, int K, int WPC, bool GH>
 __device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, LatticeSlots<NV, K, WPC>& st,
                                                        double* __restrict__ xs0, double* __restrict__ xs1,
                                                        const double* __restrict__ tval,
@@ -1181,8 +1181,8 @@ __device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, Lat
             dn = c2 * di * (st.bq[q][c] - acc[c]);
             if (c1 != 0.0) dn += c1 * st.dq[q][c];
             xn = src[(size_t)st.self(q) * NV + c] + dn;
-          } else if ((a.ident && last) || (LAT_MK(q) & 4)) {    // identity row on the last step; ghost row of a
-            xn = st.bq[q][c];                                     // strip: frozen (its start value sits in bq)
+          } else if ((a.ident && last) || (GH && (LAT_MK(q) & 4))) {    // identity row on the last step; ghost row
+            xn = st.bq[q][c];                                             // of a strip: frozen (start value in bq)
           }
           st.dq[q][c] = dn;
           dst[(size_t)st.self(q) * NV + c] = xn;
@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void lattice_stages_general(const LatticeArgs& a, Lat
 // the stencil's end), toff[(st * 4 + class) * lp + k] LDS offset of the k-th neighbour, tlen[st],
 // tdinv[st] = 1 / diagonal.  512 threads: waves 2c, 2c + 1 own class c; slot q of wave w covers the plane
 // rows 2 (2 q + (w & 1)) and the next.
-template <int NV, int K, int WPE, int WPC>
+template <int NV, int K, int WPE, int WPC, bool GH>
 __global__ __launch_bounds__(256 * WPC) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_t* __restrict__ toff,
                     const int32_t* __restrict__ tlen, const double* __restrict__ tdinv) {
@@ -1353,7 +1353,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
   for (int q = 0; q < K; ++q) {
     const int ring = ringq[q];
     const bool counts = ring <= need;
-    const int stq = counts ? (smq[q] & 63) : 0, mkq = counts ? ((smq[q] >> 6) | ((((smq[q] >> 6) & 1) && (gjcq[q] < a.gh_lo || gjcq[q] >= a.H - a.gh_hi)) ? 4 : 0)) : 0;
+    const int stq = counts ? (smq[q] & 63) : 0, mkq = counts ? ((smq[q] >> 6) | ((GH && ((smq[q] >> 6) & 1) && (gjcq[q] < a.gh_lo || gjcq[q] >= a.H - a.gh_hi)) ? 4 : 0)) : 0;
     // (bit 2: ghost row of a partitioned strip -- whole lattice lines at the bottom / top, flagged in the mask as well)
     double xv[NV];
 #pragma unroll
@@ -1368,7 +1368,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
       double v = 0.0;
       if (!a.from_zero && ring <= a.G) v = (a.xc && mk) ? 0.0 : xraw[q][c];
       xv[c] = v;
-      st.bq[q][c] = (mkq & 4) ? v : bv;        // (ghost rows carry their frozen iterate in place of b)
+      st.bq[q][c] = (GH && (mkq & 4)) ? v : bv;        // (ghost rows carry their frozen iterate in place of b)
     }
     st.info[q] = (ring << 16) | (mkq << 8) | stq;
     // do the wave's nodes share their dictionary entry?
@@ -1384,7 +1384,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
         double v = 0.0;
         if (counts) {
           if (!((mkq >> c) & 1)) v = a.c2[0] * di * st.bq[q][c];
-          else if (a.ident && a.S == 1 && !(mkq & 4)) v = st.bq[q][c];
+          else if (a.ident && a.S == 1 && !(GH && (mkq & 4))) v = st.bq[q][c];
         }
         xv[c] = v;
         st.dq[q][c] = (mkq >> c) & 1 ? 0.0 : v;
@@ -1400,12 +1400,12 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
       const double* __restrict__ vp = tval + (size_t)stu * a.lp;
       const int32_t* __restrict__ op = toff + ((size_t)stu * 4 + cls) * a.lp;
       const double di = tdinv[stu];
-      if (L <= 8 && a.lp >= 8) lattice_stages_uniform<NV, K, 8, WPC>(a, st, xs0, xs1, vp, op, di);
-      else if (L <= 12 && a.lp >= 12) lattice_stages_uniform<NV, K, 12, WPC>(a, st, xs0, xs1, vp, op, di);
-      else if (L <= 20 && a.lp >= 20) lattice_stages_uniform<NV, K, 20, WPC>(a, st, xs0, xs1, vp, op, di);
-      else lattice_stages_general<NV, K, WPC>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
+      if (L <= 8 && a.lp >= 8) lattice_stages_uniform<NV, K, 8, WPC, GH>(a, st, xs0, xs1, vp, op, di);
+      else if (L <= 12 && a.lp >= 12) lattice_stages_uniform<NV, K, 12, WPC, GH>(a, st, xs0, xs1, vp, op, di);
+      else if (L <= 20 && a.lp >= 20) lattice_stages_uniform<NV, K, 20, WPC, GH>(a, st, xs0, xs1, vp, op, di);
+      else lattice_stages_general<NV, K, WPC, GH>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
     } else {
-      lattice_stages_general<NV, K, WPC>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
+      lattice_stages_general<NV, K, WPC, GH>(a, st, xs0, xs1, tval, toff, tlen, tdinv, cls);
     }
   }
   // the newest iterate sits in the buffer the last smoothing stage wrote (stage m writes buffer m & 1)
@@ -1416,7 +1416,7 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
     if (LAT_RING(q) == 0) {
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
-        a.x_out[st.grow(q) * NV + c] = (a.gh_zero && (LAT_MK(q) & 4)) ? 0.0 : fin[(size_t)st.self(q) * NV + c];
+        a.x_out[st.grow(q) * NV + c] = (GH && a.gh_zero && (LAT_MK(q) & 4)) ? 0.0 : fin[(size_t)st.self(q) * NV + c];
         if (a.d_out) a.d_out[st.grow(q) * NV + c] = st.dq[q][c];
       }
     }
@@ -1553,34 +1553,39 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   // launch shape (tuning switch NSFEM_LATTICE_SHAPE): 0 = 4 waves per SIMD (<= 128 VGPRs: two workgroups per
   // CU), 1 = 2 waves per SIMD (no register cap: one workgroup per CU)
   static const int shape = [] { const char* e = std::getenv("NSFEM_LATTICE_SHAPE"); return e ? std::atoi(e) : 0; }();
-#define NSFEM_LAT(NV, KK, WPE, WPC)                                                                    \
+#define NSFEM_LAT(NV, KK, WPE, WPC, GH)                                                                \
   do {                                                                                                 \
     static bool attr_dev[64];                                                                          \
     int dev_ = 0;                                                                                      \
     NSFEM_HIP(hipGetDevice(&dev_));                                                                    \
     bool& attr_set = attr_dev[dev_ & 63];                                                              \
     if (!attr_set) {                                                                                   \
-      NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, KK, WPE, WPC>),  \
+      NSFEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cheb_lattice<NV, KK, WPE, WPC, GH>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));         \
       attr_set = true;                                                                                 \
     }                                                                                                  \
-    hipLaunchKernelGGL((k_cheb_lattice<NV, KK, WPE, WPC>), dim3(grid), dim3(256 * WPC), lds, s, a,     \
+    hipLaunchKernelGGL((k_cheb_lattice<NV, KK, WPE, WPC, GH>), dim3(grid), dim3(256 * WPC), lds, s, a, \
                        (const double*)A.lat_vals.p, toff, (const int32_t*)d.len.p,                     \
                        (const double*)A.dict_dinv.p);                                                  \
   } while (0)
-#define NSFEM_LAT_K(NV, WPE)                        \
-  do {                                              \
-    if (eh == 48) NSFEM_LAT(NV, 3, 4, 4);           \
-    else if (eh == 32) NSFEM_LAT(NV, 4, WPE, 2);    \
-    else if (eh == 24) NSFEM_LAT(NV, 3, WPE, 2);    \
-    else NSFEM_LAT(NV, 2, WPE, 2);                  \
+#define NSFEM_LAT_K(NV, WPE, GH)                        \
+  do {                                                  \
+    if (eh == 48) NSFEM_LAT(NV, 3, 4, 4, GH);           \
+    else if (eh == 32) NSFEM_LAT(NV, 4, WPE, 2, GH);    \
+    else if (eh == 24) NSFEM_LAT(NV, 3, WPE, 2, GH);    \
+    else NSFEM_LAT(NV, 2, WPE, 2, GH);                  \
   } while (0)
-  if (nv == 2 && shape == 1) NSFEM_LAT_K(2, 2);
-  else if (nv == 2 && shape == 2) NSFEM_LAT_K(2, 6);
-  else if (nv == 2) NSFEM_LAT_K(2, 4);
-  else if (shape == 1) NSFEM_LAT_K(1, 2);
-  else if (shape == 2) NSFEM_LAT_K(1, 6);
-  else NSFEM_LAT_K(1, 4);
+  // (the frozen ghost lines of partitioned strips are a template flag: the single-context launches do not pay for
+  // them -- 811 vs 758 VALU instructions per wave; strips always use the default launch shape)
+  const bool gh = gh_lo > 0 || gh_hi > 0;
+  if (gh && nv == 2) NSFEM_LAT_K(2, 4, true);
+  else if (gh) NSFEM_LAT_K(1, 4, true);
+  else if (nv == 2 && shape == 1) NSFEM_LAT_K(2, 2, false);
+  else if (nv == 2 && shape == 2) NSFEM_LAT_K(2, 6, false);
+  else if (nv == 2) NSFEM_LAT_K(2, 4, false);
+  else if (shape == 1) NSFEM_LAT_K(1, 2, false);
+  else if (shape == 2) NSFEM_LAT_K(1, 6, false);
+  else NSFEM_LAT_K(1, 4, false);
 #undef NSFEM_LAT_K
 #undef NSFEM_LAT
   NSFEM_HIP(hipGetLastError());

@@ -44,7 +44,7 @@ import ast, json, re
 vals = {}
 for line in open("$O/r04_cheb_lattice_sq_counters_n512.txt"):
     m = re.search(r"(\{.*\}) n (\d+)", line)
-    if m and "k_cheb_lattice<2, 3, 4>" in line:
+    if m and "k_cheb_lattice<2, 3, 4" in line:
         vals.update(ast.literal_eval(m.group(1)))
 json.dump(vals, open("$O/r04_cheb_lattice_sq_counters_n512.json", "w"), indent=1)
 print(vals)

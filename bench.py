@@ -1230,7 +1230,7 @@ def cavity_ipcs_bench(args):
                                        "order (bitwise equal to k_conv_cell + k_spmv_dict_w8 with node gather), y written once"),
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_application": nbytes_conv,
-                            "bytes_formula": "n_p2 (3 x 16 u, x, y + 1 dictionary id + 2 mask bytes) + n_cells x 48 vertex coordinates",
+                            "bytes_formula": "n_p2 (3 x 16 u, x, y + 1 dictionary id + 2 mask bytes) [+ n_cells x 48 vertex coordinates on non-uniform lattices: a uniform lattice takes the geometry of its two cell types from 10 scalar loads]",
                             "ms_per_application": ms_conv, "applications_timed": n_conv,
                             "bound_note": ("not HBM bound: 7 x 130 fp64 operations per cell put the VALU floor at 15 us of the "
                                            "launch; the rest is the latency chain of a wave (loads, 9 barriers, LDS phases) at "

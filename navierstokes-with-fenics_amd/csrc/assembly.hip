@@ -1121,7 +1121,8 @@ bool jacobian_lattice_available(const MeshDev& m, const BlockMat& L) {
          d.n_stencils <= 64 && jac_lattice_lds(d) <= (size_t)96 * 1024;
 }
 int64_t jacobian_lattice_bytes(const MeshDev& m) {
-  return (int64_t)m.n_p2 * (3 * 16 + 1 + 2) + (int64_t)m.n_cells * 48;
+  // (uniform lattices: the cell geometry comes from 10 scalar loads, no coordinate stream)
+  return (int64_t)m.n_p2 * (3 * 16 + 1 + 2) + ((g_jac_uniform_geo && m.cl.geo_uniform) ? 0 : (int64_t)m.n_cells * 48);
 }
 
 // lin: 0 residual (x, mask unused; gadd = g), 1 Newton action, 2 Picard action

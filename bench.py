@@ -61,6 +61,10 @@ def _spawn_ranks(argv, n):
     ranks are then terminated: they would wait in a barrier for ever)."""
     import socket
     import subprocess
+    # (the rendezvous port is picked by bind(0) / close: another process may take it before rank 0 listens -- a job
+    # that dies within its first seconds is started once more on a fresh port)
+    attempt = int(os.environ.get("NSFEM_SPAWN_ATTEMPT", "0"))
+    t_start = time.time()
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -100,6 +104,10 @@ def _spawn_ranks(argv, n):
                 p.kill()
     if failed is not None:
         sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+        if attempt == 0 and time.time() - t_start < 20.0 and not b"".join(chunks).strip():
+            sys.stderr.write("bench.py: the job died during start-up; one more attempt on a fresh rendezvous port\n")
+            os.environ["NSFEM_SPAWN_ATTEMPT"] = "1"
+            return _spawn_ranks(argv, n)
         return failed[1] if failed[1] > 0 else 1
     return 0
 

@@ -354,6 +354,7 @@ struct ShmHeader {
   std::atomic<int> attached;
   int size;
   int64_t slot_bytes;
+  std::atomic<int> aborted;      // a rank that throws inside a collective sets it: its peers leave their barriers
 };
 struct ShmSlotHead {        // start of every rank's slot
   int64_t kind;             // collective entered (mismatch check, as LocalComm)
@@ -383,6 +384,8 @@ struct ShmComm : Comm {
       int spins = 0;
       const auto t0 = std::chrono::steady_clock::now();
       while (hd->generation.load(std::memory_order_acquire) == g) {
+        if (hd->aborted.load(std::memory_order_acquire))
+          throw Error(NSFEM_ERR_COMM, "shared-memory communicator: another rank failed inside a collective");
         if (++spins > 2000) {
           std::this_thread::sleep_for(std::chrono::microseconds(50));
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300))
@@ -393,10 +396,12 @@ struct ShmComm : Comm {
   }
   void check_kind(int64_t mine) {
     for (int r = 0; r < size; ++r)
-      if (head(r)->kind != mine)
+      if (head(r)->kind != mine) {
+        hd->aborted.store(1, std::memory_order_release);       // (the peers would wait for this rank at the next barrier)
         throw Error(NSFEM_ERR_COMM, "collective mismatch: rank " + std::to_string(rank) + " entered kind " +
                                         std::to_string(mine) + ", rank " + std::to_string(r) + " kind " +
                                         std::to_string(head(r)->kind));
+      }
   }
   ~ShmComm() override {
     if (base) {
@@ -407,7 +412,10 @@ struct ShmComm : Comm {
   }
   void reduce(hipStream_t s, double* dev, int64_t count, int op) {
     count_allreduce(count);
-    NSFEM_REQUIRE(count <= capacity(), "all-reduce larger than the shared-memory slot");
+    if (count > capacity()) {
+      hd->aborted.store(1, std::memory_order_release);
+      throw Error(NSFEM_ERR_COMM, "all-reduce larger than the shared-memory slot");
+    }
     ShmSlotHead* me = head(rank);
     me->kind = 1 + op;
     NSFEM_HIP(hipMemcpyAsync(data(rank), dev, sizeof(double) * count, hipMemcpyDeviceToHost, s));
@@ -446,7 +454,10 @@ struct ShmComm : Comm {
     me->n_part = (int64_t)out.size();
     int64_t o = 0, need = 0;
     for (const Part& p : out) need += p.cnt;
-    NSFEM_REQUIRE(need <= capacity(), "halo larger than the shared-memory slot");
+    if (need > capacity()) {
+      hd->aborted.store(1, std::memory_order_release);
+      throw Error(NSFEM_ERR_COMM, "halo larger than the shared-memory slot");
+    }
     ensure_dstage(s, (size_t)need);
     for (size_t k = 0; k < out.size(); ++k) {
       const Part& p = out[k];

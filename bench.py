@@ -1089,7 +1089,9 @@ def cavity_ipcs_bench(args):
             if factors is not None:
                 ctx.poisson_set_fast_diag(factors)
                 fast_diag = True
-        elif ny_global <= 8192 and dm.n_p1 % (n + 1) == 0:
+        elif ny_global <= 2048 and dm.n_p1 % (n + 1) == 0:
+            # (taller global lattices -- weak scaling beyond 4 strips of 512 rows -- keep the multigrid-CG solve: the
+            # all-reduced array grows with the number of ranks, 16.8 MB per solve at 8 x 512 rows)
             # (the strip's vertices are the lattice lines first ... of the global lattice, vertex id = j (n + 1) + i)
             xs, ys = np.linspace(0.0, 1.0, n + 1), np.linspace(0.0, height, ny_global + 1)
             first = int(part.p1_global[0]) // (n + 1)

@@ -1505,7 +1505,8 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   const int64_t nn = (int64_t)a.W * a.H;
   // (measured, 2D cavity n = 512, 3 steps on the P2 lattice: 24 lines 43 us warm / 49 us cold, 32 lines
   // 48 / 56 us -- 21 spilled registers under the 128-VGPR cap and 1040 tiles on 512 workgroup slots)
-  int eh = nn >= 20000 ? 24 : 16;
+  static const int64_t eh24_from = [] { const char* e = std::getenv("NSFEM_LATTICE_EH24_FROM"); return e ? std::atoll(e) : 20000ll; }();
+  int eh = nn >= eh24_from ? 24 : 16;
   static const int force_eh = [] { const char* e = std::getenv("NSFEM_LATTICE_EH"); return e ? std::atoi(e) : 0; }();
   // 48 lines: ONE workgroup of 1024 threads per CU (four waves per parity class, the same three slots per thread and
   // the same 4 waves per SIMD as two 24-line workgroups): the halo is shared by twice the output lines -- 1.64

@@ -1029,6 +1029,11 @@ struct LatticeArgs {
   // iterate is FROZEN through the stages of the launch (block-Jacobi across the ranks, as the one-step kernels do
   // with SpmvArgs::ghost = 1); gh_zero: the launch ends a smoothing sequence, the ghost rows are stored as zeros
   int gh_lo, gh_hi, gh_zero;
+  // dictionary entries (bit e) whose stencil has the CANONICAL interior shape of the wave's parity class on a
+  // right-diagonal lattice -- 0: none known; the stages of such waves read their neighbours at compile-time LDS
+  // offsets (lattice_stages_fixed).  fixed_shape: 1 = P2 operator (19 / 9 / 9 / 9 entries), 2 = P1 (7-point)
+  int fixed_shape;
+  unsigned long long fixed_mask[4];
   double c1[8], c2[8];     // (up to 7 steps on reach-1 operators: 6 applications after the pointwise first step)
 };
 
@@ -1121,6 +1126,116 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
           dst[(size_t)st.self(q) * NV + c] = xn;
         }
       } else {                          // residual of the smoothed iterate (ring 0 only)
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          a.r_out[(size_t)st.grow(q) * NV + c] = ((LAT_MK(q) >> c) & 1) ? 0.0 : st.bq[q][c] - acc[c];
+      }
+    }
+    if (m < a.Mv) __syncthreads();
+  }
+}
+
+// Canonical interior stencils of the right-diagonal lattice in dictionary order (ascending column = ascending
+// (dj, di)): the P2 operator's four parity classes (pi, pj) = (0,0) vertex, (1,0), (0,1), (1,1) edge midpoints, and
+// the 7-point P1 stencil (the same shape for every class).
+template <int SHAPE, int CLS> struct LatShape;
+#define NSFEM_LAT_SHAPE(SH, CL, NN, ...)                                   \
+  template <> struct LatShape<SH, CL> {                                    \
+    static constexpr int N = NN;                                           \
+    static constexpr int d[NN][2] = {__VA_ARGS__};   /* (dj, di) */        \
+  };
+NSFEM_LAT_SHAPE(1, 0, 19, {-2, -2}, {-2, -1}, {-2, 0}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 0}, {0, 1},
+                {0, 2}, {1, -1}, {1, 0}, {1, 1}, {1, 2}, {2, 0}, {2, 1}, {2, 2})
+NSFEM_LAT_SHAPE(1, 1, 9, {-2, -1}, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1}, {2, 1})
+NSFEM_LAT_SHAPE(1, 2, 9, {-1, -2}, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1}, {1, 2})
+NSFEM_LAT_SHAPE(1, 3, 9, {-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 0}, {0, 1}, {1, -1}, {1, 0}, {1, 1})
+NSFEM_LAT_SHAPE(2, 0, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
+NSFEM_LAT_SHAPE(2, 1, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
+NSFEM_LAT_SHAPE(2, 2, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
+NSFEM_LAT_SHAPE(2, 3, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
+#undef NSFEM_LAT_SHAPE
+// LDS offset (in nodes) of the neighbour (dj, di) of a node of class cls in the class-split tile with planes of
+// 32 x ehh words -- the formula of lattice_offsets, at compile time
+__host__ __device__ constexpr int lat_fl2(int v) { return v >= 0 ? v / 2 : -((1 - v) / 2); }
+__host__ __device__ constexpr int lat_fixed_off(int cls, int dj, int di, int ehh) {
+  const int pi = cls & 1, pj = (cls >> 1) & 1;
+  const int c2 = ((pi + di) & 1) | (((pj + dj) & 1) << 1);
+  return (c2 - cls) * 32 * ehh + lat_fl2(pj + dj) * 32 + lat_fl2(pi + di);
+}
+
+// Stages of a wave whose nodes share ONE dictionary entry of canonical shape: the neighbour reads carry their LDS
+// offsets as instruction immediates (ds_read_b128 ... offset:) -- no address arithmetic and no offset table; the
+// values are scalar loads issued once, as in lattice_stages_uniform.  
+template <int NV, int K, int WPC, bool GH, int SHAPE, int CLS>
+__device__ __forceinline__ void lattice_stages_fixed(const LatticeArgs& a, LatticeSlots<NV, K, WPC>& st,
+                                                     double* __restrict__ xs0, double* __restrict__ xs1,
+                                                     const double* __restrict__ vp, double di) {
+  typedef double vec __attribute__((ext_vector_type(2)));
+  typedef LatShape<SHAPE, CLS> SH;
+  constexpr int N = SH::N, EHH = 2 * K * WPC;
+  double v[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = vp[k];
+  const int n_smooth = a.S - a.from_zero;
+  for (int m = 1; m <= a.Mv; ++m) {
+    const int lim = a.R * (a.Mv - m);
+    const bool smoothing = m <= n_smooth;
+    const int kstep = m - 1 + a.from_zero;
+    const double c1 = smoothing ? a.c1[kstep] : 0.0, c2 = smoothing ? a.c2[kstep] : 0.0;
+    const bool last = smoothing && kstep == a.S - 1;
+    const double* __restrict__ src = (m & 1) ? xs0 : xs1;
+    double* __restrict__ dst = (m & 1) ? xs1 : xs0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const bool on = LAT_RING(q) <= lim;
+      if (__ballot(on) == 0) continue;               // (wave-uniform)
+      if (!on) continue;
+      double acc[NV];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) acc[c] = 0.0;
+      if (NV == 2) {
+        const vec* __restrict__ xv = reinterpret_cast<const vec*>(src) + st.self(q);
+#pragma unroll
+        for (int k0 = 0; k0 < N; k0 += 4) {
+          vec x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < N) x[u] = xv[lat_fixed_off(CLS, SH::d[k0 + u < N ? k0 + u : 0][0], SH::d[k0 + u < N ? k0 + u : 0][1], EHH)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < N) {
+              acc[0] += v[k0 + u] * x[u].x;
+              acc[NV - 1] += v[k0 + u] * x[u].y;
+            }
+        }
+      } else {
+        const double* __restrict__ xv = src + st.self(q);
+#pragma unroll
+        for (int k0 = 0; k0 < N; k0 += 4) {
+          double x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < N) x[u] = xv[lat_fixed_off(CLS, SH::d[k0 + u < N ? k0 + u : 0][0], SH::d[k0 + u < N ? k0 + u : 0][1], EHH)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < N) acc[0] += v[k0 + u] * x[u];
+        }
+      }
+      if (smoothing) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          double dn = 0.0, xn = 0.0;
+          if (!((LAT_MK(q) >> c) & 1)) {
+            dn = c2 * di * (st.bq[q][c] - acc[c]);
+            if (c1 != 0.0) dn += c1 * st.dq[q][c];
+            xn = src[(size_t)st.self(q) * NV + c] + dn;
+          } else if ((a.ident && last) || (GH && (LAT_MK(q) & 4))) {
+            xn = st.bq[q][c];
+          }
+          st.dq[q][c] = dn;
+          dst[(size_t)st.self(q) * NV + c] = xn;
+        }
+      } else {
 #pragma unroll
         for (int c = 0; c < NV; ++c)
           a.r_out[(size_t)st.grow(q) * NV + c] = ((LAT_MK(q) >> c) & 1) ? 0.0 : st.bq[q][c] - acc[c];
@@ -1400,6 +1515,24 @@ void k_cheb_lattice(LatticeArgs a, const double* __restrict__ tval, const int32_
       const double* __restrict__ vp = tval + (size_t)stu * a.lp;
       const int32_t* __restrict__ op = toff + ((size_t)stu * 4 + cls) * a.lp;
       const double di = tdinv[stu];
+      bool done = false;
+      if (WPE == 4 && a.fixed_shape != 0 && ((a.fixed_mask[cls] >> stu) & 1ull)) {
+        // (cls is wave-uniform: one of the eight instantiations runs)
+        done = true;
+        switch (a.fixed_shape * 4 + cls) {
+          case 4: lattice_stages_fixed<NV, K, WPC, GH, 1, 0>(a, st, xs0, xs1, vp, di); break;
+          case 5: lattice_stages_fixed<NV, K, WPC, GH, 1, 1>(a, st, xs0, xs1, vp, di); break;
+          case 6: lattice_stages_fixed<NV, K, WPC, GH, 1, 2>(a, st, xs0, xs1, vp, di); break;
+          case 7: lattice_stages_fixed<NV, K, WPC, GH, 1, 3>(a, st, xs0, xs1, vp, di); break;
+          case 8: lattice_stages_fixed<NV, K, WPC, GH, 2, 0>(a, st, xs0, xs1, vp, di); break;
+          case 9: lattice_stages_fixed<NV, K, WPC, GH, 2, 1>(a, st, xs0, xs1, vp, di); break;
+          case 10: lattice_stages_fixed<NV, K, WPC, GH, 2, 2>(a, st, xs0, xs1, vp, di); break;
+          case 11: lattice_stages_fixed<NV, K, WPC, GH, 2, 3>(a, st, xs0, xs1, vp, di); break;
+          default: done = false;
+        }
+      }
+      if (done) {
+      } else
       if (L <= 8 && a.lp >= 8) lattice_stages_uniform<NV, K, 8, WPC, GH>(a, st, xs0, xs1, vp, op, di);
       else if (L <= 12 && a.lp >= 12) lattice_stages_uniform<NV, K, 12, WPC, GH>(a, st, xs0, xs1, vp, op, di);
       else if (L <= 20 && a.lp >= 20) lattice_stages_uniform<NV, K, 20, WPC, GH>(a, st, xs0, xs1, vp, op, di);
@@ -1495,6 +1628,36 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   a.from_zero = (x_in || xc) ? 0 : 1;
   a.xc = xc; a.rf = rf; a.b_out = b_out;
   a.gh_lo = gh_lo; a.gh_hi = gh_hi; a.gh_zero = gh_zero;
+  // entries of canonical interior shape (compile-time LDS offsets in the stages; NSFEM_LATTICE_FIXED=0: off)
+  if (d.fixed_shape == 0) {
+    d.fixed_shape = -1;
+    const int shape = d.lat_r == 2 ? 1 : (d.lat_r == 1 ? 2 : 0);
+    if (shape != 0 && (int)d.h_len.size() == d.n_stencils) {
+      bool any = false;
+      for (int c = 0; c < 4; ++c) {
+        d.fixed_mask[c] = 0;
+        int n = 0;
+        const int (*sh)[2] = nullptr;
+        if (shape == 1) {
+          if (c == 0) { n = LatShape<1, 0>::N; sh = LatShape<1, 0>::d; }
+          else if (c == 1) { n = LatShape<1, 1>::N; sh = LatShape<1, 1>::d; }
+          else if (c == 2) { n = LatShape<1, 2>::N; sh = LatShape<1, 2>::d; }
+          else { n = LatShape<1, 3>::N; sh = LatShape<1, 3>::d; }
+        } else { n = LatShape<2, 0>::N; sh = LatShape<2, 0>::d; }
+        for (int e = 0; e < d.n_stencils && e < 64; ++e) {
+          if (d.h_len[e] != n) continue;
+          bool same = true;
+          for (int k = 0; k < n && same; ++k)
+            same = d.h_pack[(size_t)e * d.lmax + k] == (sh[k][0] + 8) * 32 + (sh[k][1] + 8);
+          if (same) { d.fixed_mask[c] |= 1ull << e; any = true; }
+        }
+      }
+      if (any) d.fixed_shape = shape;
+    }
+  }
+  static const bool fixed_on = [] { const char* e = std::getenv("NSFEM_LATTICE_FIXED"); return e ? std::atoi(e) != 0 : true; }();
+  a.fixed_shape = (fixed_on && d.fixed_shape > 0) ? d.fixed_shape : 0;
+  for (int c = 0; c < 4; ++c) a.fixed_mask[c] = a.fixed_shape ? d.fixed_mask[c] : 0ull;
   a.Wc = (d.lat_w + 1) / 2; a.Wf = 2 * d.lat_w - 1; a.Hf = 2 * d.lat_h - 1;
   a.Mv = steps - a.from_zero + (r_out ? 1 : 0);
   NSFEM_REQUIRE(a.Mv >= 0 && a.Mv * a.R <= 8, "lattice smoother: halo too wide");

@@ -187,6 +187,10 @@ struct StencilDict {
   };
   mutable std::vector<LatticeOffsets> loff_cache;   // one table per tile shape in use (built on first use)
   mutable DevBuf<uint8_t> sidm_scratch;             // entry | mask bytes for callers that bring none (test hook, timing)
+  // entries with the canonical interior stencil shape of a parity class (launch_cheb_lattice: compile-time LDS
+  // offsets): shape 0 = not looked at yet, -1 = none, 1 = P2 right-diagonal lattice, 2 = P1 7-point
+  mutable int fixed_shape = 0;
+  mutable unsigned long long fixed_mask[4] = {0, 0, 0, 0};
 };
 // false: the rows do not repeat (unstructured mesh) -- no dictionary
 // min_rows > 0: patterns down to that many rows are accepted when they turn out to be 2D lattices (tables_only)

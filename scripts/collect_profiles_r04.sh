@@ -65,7 +65,7 @@ if has configs; then
   # functional rehearsal of the N-rank paths on ONE GPU (thread ranks, in-process communicator): message counts and the
   # kernel set of a strong-scaling step on 8 strips -- NOT a performance figure
   timeout -k 10 600 python3 bench.py --local-ranks 8 --scaling strong --cells 960 --steps 4 --warmup 2 --timed-only > $O/r04_bench_strong_960_thread_ranks_8.json 2> $O/bench_lr8.err
-  NSFEM_SETUP_PROFILE=1 NSFEM_DEBUG_SETUP=1 timeout -k 10 600 python3 scripts/r03_setup_profile.py 64 > $O/r04_setup.txt 2>&1
+  NSFEM_SETUP_PROFILE=1 NSFEM_DEBUG_SETUP=1 timeout -k 10 600 python3 scripts/r03_setup_profile.py 64 > $O/r04_setup_end_of_round.txt 2>&1      # (profiles/r04_setup.txt = this + the start-of-round run)
   for f in n1024 n333 tgv3d_n64 channel3d_n48 channel3d_n64 dfg strong_960_thread_ranks_8; do python3 scripts/show_bench.py $O/r04_bench_$f.json; done
 fi
 ls $O

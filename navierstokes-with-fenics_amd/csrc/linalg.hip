@@ -20,6 +20,7 @@
 //     consume the scalar re-reduce them in a fixed order (bitwise reproducible,
 //     no atomics, no extra launch, no host round trip for alpha/beta/omega).
 #include "nsfem_internal.hpp"
+#include "lattice_shapes.hpp"
 #include <unordered_map>
 
 namespace nsfem {
@@ -1135,34 +1136,6 @@ __device__ __forceinline__ void lattice_stages_uniform(const LatticeArgs& a, Lat
   }
 }
 
-// Canonical interior stencils of the right-diagonal lattice in dictionary order (ascending column = ascending
-// (dj, di)): the P2 operator's four parity classes (pi, pj) = (0,0) vertex, (1,0), (0,1), (1,1) edge midpoints, and
-// the 7-point P1 stencil (the same shape for every class).
-template <int SHAPE, int CLS> struct LatShape;
-#define NSFEM_LAT_SHAPE(SH, CL, NN, ...)                                   \
-  template <> struct LatShape<SH, CL> {                                    \
-    static constexpr int N = NN;                                           \
-    static constexpr int d[NN][2] = {__VA_ARGS__};   /* (dj, di) */        \
-  };
-NSFEM_LAT_SHAPE(1, 0, 19, {-2, -2}, {-2, -1}, {-2, 0}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 0}, {0, 1},
-                {0, 2}, {1, -1}, {1, 0}, {1, 1}, {1, 2}, {2, 0}, {2, 1}, {2, 2})
-NSFEM_LAT_SHAPE(1, 1, 9, {-2, -1}, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1}, {2, 1})
-NSFEM_LAT_SHAPE(1, 2, 9, {-1, -2}, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1}, {1, 2})
-NSFEM_LAT_SHAPE(1, 3, 9, {-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 0}, {0, 1}, {1, -1}, {1, 0}, {1, 1})
-NSFEM_LAT_SHAPE(2, 0, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
-NSFEM_LAT_SHAPE(2, 1, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
-NSFEM_LAT_SHAPE(2, 2, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
-NSFEM_LAT_SHAPE(2, 3, 7, {-1, -1}, {-1, 0}, {0, -1}, {0, 0}, {0, 1}, {1, 0}, {1, 1})
-#undef NSFEM_LAT_SHAPE
-// LDS offset (in nodes) of the neighbour (dj, di) of a node of class cls in the class-split tile with planes of
-// 32 x ehh words -- the formula of lattice_offsets, at compile time
-__host__ __device__ constexpr int lat_fl2(int v) { return v >= 0 ? v / 2 : -((1 - v) / 2); }
-__host__ __device__ constexpr int lat_fixed_off(int cls, int dj, int di, int ehh) {
-  const int pi = cls & 1, pj = (cls >> 1) & 1;
-  const int c2 = ((pi + di) & 1) | (((pj + dj) & 1) << 1);
-  return (c2 - cls) * 32 * ehh + lat_fl2(pj + dj) * 32 + lat_fl2(pi + di);
-}
-
 // Stages of a wave whose nodes share ONE dictionary entry of canonical shape: the neighbour reads carry their LDS
 // offsets as instruction immediates (ds_read_b128 ... offset:) -- no address arithmetic and no offset table; the
 // values are scalar loads issued once, as in lattice_stages_uniform.  
@@ -1610,6 +1583,34 @@ static const int32_t* lattice_offsets(hipStream_t s, const StencilDict& d, int e
   return e.buf.p;
 }
 
+// which dictionary entries have the canonical interior stencil shape of a parity class (StencilDict::fixed_mask)
+void ensure_fixed_masks(const StencilDict& d) {
+  if (d.fixed_shape != 0) return;
+  d.fixed_shape = -1;
+  const int shape = d.lat_r == 2 ? 1 : (d.lat_r == 1 ? 2 : 0);
+  if (shape == 0 || d.lat_w <= 0 || (int)d.h_len.size() != d.n_stencils) return;
+  bool any = false;
+  for (int c = 0; c < 4; ++c) {
+    d.fixed_mask[c] = 0;
+    int n = 0;
+    const int (*sh)[2] = nullptr;
+    if (shape == 1) {
+      if (c == 0) { n = LatShape<1, 0>::N; sh = LatShape<1, 0>::d; }
+      else if (c == 1) { n = LatShape<1, 1>::N; sh = LatShape<1, 1>::d; }
+      else if (c == 2) { n = LatShape<1, 2>::N; sh = LatShape<1, 2>::d; }
+      else { n = LatShape<1, 3>::N; sh = LatShape<1, 3>::d; }
+    } else { n = LatShape<2, 0>::N; sh = LatShape<2, 0>::d; }
+    for (int e = 0; e < d.n_stencils && e < 64; ++e) {
+      if (d.h_len[e] != n) continue;
+      bool same = true;
+      for (int k = 0; k < n && same; ++k)
+        same = d.h_pack[(size_t)e * d.lmax + k] == (sh[k][0] + 8) * 32 + (sh[k][1] + 8);
+      if (same) { d.fixed_mask[c] |= 1ull << e; any = true; }
+    }
+  }
+  if (any) d.fixed_shape = shape;
+}
+
 // `steps` (<= lattice_smoother_max_steps) Chebyshev-Jacobi steps with the coefficients c1[k], c2[k]
 // supplied by the caller; x_in == nullptr: zero start
 void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double* x_in, const double* b,
@@ -1629,32 +1630,7 @@ void launch_cheb_lattice(hipStream_t s, const BlockMat& A, int nv, const double*
   a.xc = xc; a.rf = rf; a.b_out = b_out;
   a.gh_lo = gh_lo; a.gh_hi = gh_hi; a.gh_zero = gh_zero;
   // entries of canonical interior shape (compile-time LDS offsets in the stages; NSFEM_LATTICE_FIXED=0: off)
-  if (d.fixed_shape == 0) {
-    d.fixed_shape = -1;
-    const int shape = d.lat_r == 2 ? 1 : (d.lat_r == 1 ? 2 : 0);
-    if (shape != 0 && (int)d.h_len.size() == d.n_stencils) {
-      bool any = false;
-      for (int c = 0; c < 4; ++c) {
-        d.fixed_mask[c] = 0;
-        int n = 0;
-        const int (*sh)[2] = nullptr;
-        if (shape == 1) {
-          if (c == 0) { n = LatShape<1, 0>::N; sh = LatShape<1, 0>::d; }
-          else if (c == 1) { n = LatShape<1, 1>::N; sh = LatShape<1, 1>::d; }
-          else if (c == 2) { n = LatShape<1, 2>::N; sh = LatShape<1, 2>::d; }
-          else { n = LatShape<1, 3>::N; sh = LatShape<1, 3>::d; }
-        } else { n = LatShape<2, 0>::N; sh = LatShape<2, 0>::d; }
-        for (int e = 0; e < d.n_stencils && e < 64; ++e) {
-          if (d.h_len[e] != n) continue;
-          bool same = true;
-          for (int k = 0; k < n && same; ++k)
-            same = d.h_pack[(size_t)e * d.lmax + k] == (sh[k][0] + 8) * 32 + (sh[k][1] + 8);
-          if (same) { d.fixed_mask[c] |= 1ull << e; any = true; }
-        }
-      }
-      if (any) d.fixed_shape = shape;
-    }
-  }
+  ensure_fixed_masks(d);
   static const bool fixed_on = [] { const char* e = std::getenv("NSFEM_LATTICE_FIXED"); return e ? std::atoi(e) != 0 : true; }();
   a.fixed_shape = (fixed_on && d.fixed_shape > 0) ? d.fixed_shape : 0;
   for (int c = 0; c < 4; ++c) a.fixed_mask[c] = a.fixed_shape ? d.fixed_mask[c] : 0ull;

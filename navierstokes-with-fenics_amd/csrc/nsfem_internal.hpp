@@ -194,6 +194,7 @@ struct StencilDict {
 };
 // false: the rows do not repeat (unstructured mesh) -- no dictionary
 // min_rows > 0: patterns down to that many rows are accepted when they turn out to be 2D lattices (tables_only)
+void ensure_fixed_masks(const StencilDict& d);   // fills d.fixed_shape / fixed_mask (entries of canonical interior shape)
 bool build_stencil_dict(hipStream_t s, const Pattern& p, const double* dev_a, const double* dev_b,
                         StencilDict& d, int bsz = 1, bool rect = false, int min_rows = 0);
 

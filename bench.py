@@ -956,7 +956,7 @@ def _other_configs(args):
             ("tgv3d-ipcs", ["--workload", "tgv3d-ipcs", "--cells", "64"]),
             ("channel3d-bdf", ["--workload", "channel3d-bdf", "--cells", "48"])]
     for name, extra in jobs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
